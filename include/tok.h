@@ -1,0 +1,186 @@
+/*
+ * tok.h — C ABI of libtok_gfx950.so: the MI355X (gfx950 / CDNA4) hot path behind the
+ * TorchOk vision-training step (backbone -> pooling -> head -> loss -> optimizer).
+ *
+ * The reference (eora-ai/torchok, pure Python) has no native boundary of its own: its hot
+ * path bottoms out in ATen ops called from nn.Modules.  Every entry point below replaces one
+ * of those ATen call sites; the citation on each declaration is the reference line
+ * (/root/reference/...) or the timm-0.6.13 / torch symbol whose arithmetic it takes over.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers
+ *    (HBM) unless a parameter says "host".  The caller owns every buffer; nothing is
+ *    allocated or freed here; kernels borrow pointers for the duration of the enqueue.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    null stream).  No call synchronises the device.
+ *  - Return value: 0 on success, negative tok_status otherwise; tok_last_error() returns
+ *    a thread-local message for the last failure on the calling thread.
+ *  - Activations: NHWC ("channels-last") bf16, channel count a multiple of 8 (the caller
+ *    pads).  Convolution weights: bf16 [K][R][S][C] ("KRSC") for fwd, bf16 [C][R][S][K]
+ *    spatially flipped for dgrad (tok_pack_weight_* produce both from the fp32 master).
+ *    Statistics, gradients of parameters, optimizer state: fp32.
+ *  - Thread-safety: all entry points are re-entrant (PyTorch calls backward from an
+ *    autograd worker thread); there is no global mutable state except the thread-local
+ *    error string.
+ */
+#ifndef TOK_H_
+#define TOK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tok_status {
+  TOK_OK = 0,
+  TOK_ERR_INVALID = -1,     /* bad descriptor / unsupported shape            */
+  TOK_ERR_LAUNCH = -2,      /* hipLaunchKernel failed                        */
+  TOK_ERR_WORKSPACE = -3    /* workspace too small                           */
+} tok_status;
+
+typedef enum tok_dtype { TOK_F32 = 0, TOK_F16 = 1, TOK_BF16 = 2 } tok_dtype;
+
+/* Convolution geometry.  c and k are the PADDED channel counts of the bf16 activation
+ * tensors (multiples of 8), except in "c4" stem mode (c == 4: 3 image channels padded to 4,
+ * filter taps along S padded to `s_pad`).  groups == 1, dilation == 1 only
+ * (resnet18/resnet50/hrnet use nothing else: resnet.py:472-490, [timm] Bottleneck).       */
+typedef struct tok_conv_desc {
+  int32_t n, h, w, c;   /* input  N, H, W, C                                  */
+  int32_t k;            /* output channels                                    */
+  int32_t r, s;         /* filter height, width                               */
+  int32_t p, q;         /* output height, width                               */
+  int32_t stride, pad;  /* same in both spatial dims                          */
+  int32_t s_pad;        /* filter width as stored (== s, or 8 in c4 mode)     */
+} tok_conv_desc;
+
+const char* tok_last_error(void);
+int tok_version(void);
+
+/* ---- layout / dtype plumbing ------------------------------------------------------- */
+
+/* image NCHW (f32|f16|bf16) -> NHWC bf16 with channels zero-padded to c_pad.
+ * Replaces the implicit dtype cast + layout handling of torch autocast in front of
+ * `backbone(input_data)` (tasks/classification.py:109).                                  */
+int tok_nchw_to_nhwc_bf16(const void* src, int src_dtype, int n, int c, int h, int w,
+                          void* dst, int c_pad, void* stream);
+/* fp32 -> bf16 elementwise cast (refreshing the bf16 weight shadow of the fp32 masters). */
+int tok_cast_f32_bf16(const float* src, void* dst, size_t count, void* stream);
+/* master fp32 [k][r][s][c] -> bf16 [k_pad][r][s_pad][c_pad] (zero padded)               */
+int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c,
+                        void* dst, int k_pad, int s_pad, int c_pad, void* stream);
+/* master fp32 [k][r][s][c] -> bf16 [c_pad][r][s][k_pad], taps flipped (dgrad operand)    */
+int tok_pack_weight_dgrad(const float* src, int k, int r, int s, int c,
+                          void* dst, int k_pad, int c_pad, void* stream);
+
+/* ---- convolution (implicit GEMM on MFMA) --------------------------------------------
+ * Replace aten::conv2d fwd/bwd reached from resnet.py:488 (stem), [timm] BasicBlock /
+ * Bottleneck conv1-3, downsample_conv (resnet.py:383-387), hrnet.py:64-69,122,133,156,
+ * convbnact.py:38-44, and aten::linear at linear_head.py:31 / poolings linear.py:18
+ * (a linear layer is the 1x1 case with h = w = 1).                                        */
+
+/* Rows of the per-channel partial-statistics buffer tok_conv_fwd fills: the buffer is
+ * float[2][rows][k] (sum, then sum of squares, of the bf16-rounded outputs).              */
+int tok_conv_fwd_stat_rows(const tok_conv_desc* d);
+/* y = conv(x, w) (+ bias[k] if bias != NULL).  stats may be NULL.                         */
+int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w, const float* bias,
+                 void* y, float* stats, void* stream);
+/* dx = conv_transpose(dy, w) using the flipped/transposed operand from
+ * tok_pack_weight_dgrad;  accumulate != 0 adds into the existing dx (residual fan-in).     */
+int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                   int accumulate, void* stream);
+size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
+/* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
+ * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */
+int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
+                   int k_real, int c_real, void* ws, size_t ws_bytes, int accumulate,
+                   void* stream);
+
+/* ---- batch norm (training mode, batch statistics) -------------------------------------
+ * Replace aten::batch_norm fwd/bwd + relu_ + residual add_ reached from resnet.py:489-490,
+ * [timm] blocks (bn1..3, act1..3, `x += shortcut`), hrnet.py:65-69, convbnact.py:45-53.    */
+
+/* Reduce tok_conv_fwd partials -> mean, rstd (biased var), scale = gamma*rstd,
+ * shift = beta - mean*scale; running_mean/var momentum update (unbiased var), and
+ * num_batches_tracked += 1 (int64) — the semantics of torch.nn.BatchNorm2d in training.
+ * running_* / nbt may be NULL (track_running_stats=False).                                 */
+int tok_bn_finalize(const float* stats, int rows, int64_t count, int c,
+                    const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* nbt,
+                    float momentum, float eps,
+                    float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics                                          */
+int tok_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, int c,
+                       float* scale, float* shift, void* stream);
+/* per-channel sum / sumsq partials of an NHWC bf16 tensor (BN after a non-conv producer)  */
+int tok_bn_stats_rows(int64_t m, int c);
+int tok_bn_stats(const void* y, int64_t m, int c, float* stats, void* stream);
+/* out = act(y*scale[c] + shift[c] (+ shortcut));  act = relu if relu != 0                 */
+int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
+                   const void* shortcut, int relu, void* out, int64_t m, int c,
+                   void* stream);
+int tok_bn_bwd_rows(int64_t m, int c);
+/* partial[2][rows][c]: sum(dz), sum(dz * xhat), dz = dout * relu_mask.
+ * out = the forward output (needed for the mask when a shortcut was added; may be NULL
+ * when shortcut-free: the mask is then recomputed from y).                                */
+int tok_bn_bwd_reduce(const void* dout, const void* y, const void* out,
+                      const float* scale, const float* shift,
+                      const float* mean, const float* rstd, int relu,
+                      int64_t m, int c, float* partial, void* stream);
+/* dgamma, dbeta (+= if accumulate) and the 3 per-channel coefficients of
+ * dy = a1*dz + a2*y + a3  ->  coef[3][c]                                                  */
+int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c,
+                        const float* gamma, const float* mean, const float* rstd,
+                        float* dgamma, float* dbeta, float* coef, int accumulate,
+                        void* stream);
+/* dy = a1*dz + a2*y + a3;  if dshortcut != NULL: dshortcut (=|+=) dz                       */
+int tok_bn_bwd_apply(const void* dout, const void* y, const void* out,
+                     const float* scale, const float* shift, const float* coef, int relu,
+                     void* dy, void* dshortcut, int dshortcut_accumulate,
+                     int64_t m, int c, void* stream);
+
+/* ---- pooling ----------------------------------------------------------------------------
+ * aten::max_pool2d(3, stride 2, pad 1) at resnet.py:510; adaptive avg pool + flatten at
+ * poolings/classification/pooling.py:7-12 ([timm] SelectAdaptivePool2d).                   */
+int tok_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int n, int h, int w, int c,
+                         void* stream);
+int tok_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int accumulate,
+                         int n, int h, int w, int c, void* stream);
+int tok_gap_fwd(const void* x, void* y, int n, int hw, int c, void* stream);
+int tok_gap_bwd(const void* dy, void* dx, int accumulate, int n, int hw, int c, void* stream);
+
+/* column sums of a bf16 [m][n] matrix -> fp32 (bias gradients of Linear / biased conv)     */
+int tok_colsum(const void* dy, int64_t m, int n_pad, int n_real, float* out, int accumulate,
+               void* stream);
+
+/* ---- loss -------------------------------------------------------------------------------
+ * torch.nn.CrossEntropyLoss(mean, ignore_index) registered at losses/__init__.py:26, called
+ * from JointLoss.forward (losses/base.py:78-79).  logits bf16 [rows][ld] (classes <= ld).  */
+int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
+                       int64_t ignore_index, float* lse, float* row_loss,
+                       float* loss /* [0]=mean loss, [1]=n_valid */, void* stream);
+/* dlogits = (softmax - onehot) * gscale[0] / n_valid  (0 for ignored rows / pad columns)   */
+int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* lse,
+                       const float* loss, const float* gscale, int rows, int classes, int ld,
+                       int64_t ignore_index, void* dlogits, void* stream);
+
+/* ---- optimizers (flat arenas) -------------------------------------------------------------
+ * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
+ * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch
+ * updates `count` contiguous fp32 parameters and rewrites their bf16 shadow.               */
+int tok_sgd_step(float* param, const float* grad, float* momentum_buf, void* shadow_bf16,
+                 size_t count, float lr, float momentum, float dampening, float weight_decay,
+                 int nesterov, int first_step, int maximize, void* stream);
+int tok_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  void* shadow_bf16, size_t count, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int decoupled /*AdamW*/, int64_t step,
+                  int maximize, void* stream);
+int tok_fill_f32(float* dst, float value, size_t count, void* stream);
+int tok_scale_f32(float* dst, float factor, size_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOK_H_ */

@@ -1,0 +1,362 @@
+"""TEST-ONLY stand-in for libtok_gfx950.so operating on HOST memory with plain PyTorch ops.
+
+It implements the C ABI of include/tok.h (same names, same argument order, same layouts and
+rounding points) so that the host logic of torchok_amd — tape, gradient fan-in, parameter
+arenas, optimizers, task wiring — can be exercised on a CPU-only box (`-m "not gpu"` tests).
+It is installed through torchok_amd._C._install_backend() by tests only; the product never
+routes through it (a missing native library raises).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as F
+
+BF16 = torch.bfloat16
+_SZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int64: 8, torch.uint8: 1}
+
+
+def _t(ptr, shape, dtype):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    if ptr is None or n == 0:
+        return None
+    buf = (ctypes.c_char * (n * _SZ[dtype])).from_address(int(ptr))
+    return torch.frombuffer(buf, dtype=dtype, count=n).view(*[int(s) for s in shape])
+
+
+def _desc(d):
+    return d._obj if hasattr(d, '_obj') else d
+
+
+def _bf(x):
+    return x.to(BF16)
+
+
+class FakeTok:
+    """Each method == one extern "C" entry point."""
+
+    def __init__(self):
+        self.calls = []
+        self._err = b''
+
+    def tok_last_error(self):
+        return self._err
+
+    def tok_version(self):
+        return 1
+
+    # ---- layout ---------------------------------------------------------------------------------
+    def tok_nchw_to_nhwc_bf16(self, src, dt, n, c, h, w, dst, c_pad, st):
+        dtype = {0: torch.float32, 1: torch.float16, 2: BF16}[dt]
+        s = _t(src, (n, c, h, w), dtype)
+        d = _t(dst, (n, h, w, c_pad), BF16)
+        d.zero_()
+        d[..., :c] = s.permute(0, 2, 3, 1).to(BF16)
+        return 0
+
+    def tok_cast_f32_bf16(self, src, dst, count, st):
+        _t(dst, (count,), BF16).copy_(_t(src, (count,), torch.float32))
+        return 0
+
+    def tok_pack_weight_fwd(self, src, k, r, s, c, dst, k_pad, s_pad, c_pad, st):
+        w = _t(src, (k, r, s, c), torch.float32)
+        d = _t(dst, (k_pad, r, s_pad, c_pad), BF16)
+        d.zero_()
+        d[:k, :, :s, :c] = w.to(BF16)
+        return 0
+
+    def tok_pack_weight_dgrad(self, src, k, r, s, c, dst, k_pad, c_pad, st):
+        w = _t(src, (k, r, s, c), torch.float32)
+        d = _t(dst, (c_pad, r, s, k_pad), BF16)
+        d.zero_()
+        d[:c, :, :, :k] = w.flip(1, 2).permute(3, 1, 2, 0).to(BF16)
+        return 0
+
+    # ---- conv -----------------------------------------------------------------------------------
+    def tok_conv_fwd_stat_rows(self, d):
+        d = _desc(d)
+        return (d.n * d.p * d.q + 127) // 128
+
+    def _weights(self, d, w):
+        wt = _t(w, (d.k, d.r, d.s_pad, d.c), BF16).float()[:, :, :d.s, :]
+        return wt.permute(0, 3, 1, 2).contiguous()  # K C R S
+
+    def tok_conv_fwd(self, d, x, w, bias, y, stats, st):
+        d = _desc(d)
+        self.calls.append('conv_fwd')
+        xin = _t(x, (d.n, d.h, d.w, d.c), BF16).float().permute(0, 3, 1, 2)
+        b = _t(bias, (d.k,), torch.float32)
+        out = F.conv2d(xin, self._weights(d, w), b, stride=d.stride, padding=d.pad)
+        out = out.permute(0, 2, 3, 1).to(BF16)
+        _t(y, (d.n, d.p, d.q, d.k), BF16).copy_(out)
+        if stats is not None:
+            rows = self.tok_conv_fwd_stat_rows(d)
+            s = _t(stats, (2, rows, d.k), torch.float32)
+            s.zero_()
+            f = out.float().reshape(-1, d.k)
+            s[0, 0] = f.sum(0)
+            s[1, 0] = (f * f).sum(0)
+        return 0
+
+    def tok_conv_dgrad(self, d, dy, wd, dx, accumulate, st):
+        d = _desc(d)
+        self.calls.append('conv_dgrad')
+        g = _t(dy, (d.n, d.p, d.q, d.k), BF16).float().permute(0, 3, 1, 2)
+        pack = _t(wd, (d.c, d.r, d.s, d.k), BF16).float()
+        wt = pack.flip(1, 2).permute(3, 0, 1, 2).contiguous()  # K C R S
+        gi = torch.nn.grad.conv2d_input((d.n, d.c, d.h, d.w), wt, g.contiguous(), stride=d.stride, padding=d.pad)
+        gi = gi.permute(0, 2, 3, 1)
+        out = _t(dx, (d.n, d.h, d.w, d.c), BF16)
+        if accumulate:
+            out.copy_((gi + out.float()).to(BF16))
+        else:
+            out.copy_(gi.to(BF16))
+        return 0
+
+    def tok_conv_wgrad_ws_bytes(self, d):
+        return 64
+
+    def tok_conv_wgrad(self, d, x, dy, dw, k_real, c_real, ws, ws_bytes, accumulate, st):
+        d = _desc(d)
+        self.calls.append('conv_wgrad')
+        xin = _t(x, (d.n, d.h, d.w, d.c), BF16).float().permute(0, 3, 1, 2).contiguous()
+        g = _t(dy, (d.n, d.p, d.q, d.k), BF16).float().permute(0, 3, 1, 2).contiguous()
+        gw = torch.nn.grad.conv2d_weight(xin, (d.k, d.c, d.r, d.s), g, stride=d.stride, padding=d.pad)
+        gw = gw[:k_real, :c_real].permute(0, 2, 3, 1)  # k r s c
+        out = _t(dw, (k_real, d.r, d.s, c_real), torch.float32)
+        if accumulate:
+            out.add_(gw)
+        else:
+            out.copy_(gw)
+        return 0
+
+    # ---- batch norm -------------------------------------------------------------------------------
+    def tok_bn_finalize(self, stats, rows, count, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd,
+                        scale, shift, st):
+        s = _t(stats, (2, rows, c), torch.float32).double().sum(1)
+        mu = s[0] / count
+        var = (s[1] / count - mu * mu).clamp_min(0)
+        g, b = _t(gamma, (c,), torch.float32), _t(beta, (c,), torch.float32)
+        muf = mu.float()
+        rs = (1.0 / torch.sqrt(var + eps)).float()
+        _t(mean, (c,), torch.float32).copy_(muf)
+        _t(rstd, (c,), torch.float32).copy_(rs)
+        sc = g * rs
+        _t(scale, (c,), torch.float32).copy_(sc)
+        _t(shift, (c,), torch.float32).copy_(b - muf * sc)
+        if rm is not None:
+            unb = count / (count - 1) if count > 1 else 1.0
+            m_, v_ = _t(rm, (c,), torch.float32), _t(rv, (c,), torch.float32)
+            m_.mul_(1 - momentum).add_(momentum * muf)
+            v_.mul_(1 - momentum).add_(momentum * (var * unb).float())
+        if nbt is not None:
+            _t(nbt, (1,), torch.int64).add_(1)
+        return 0
+
+    def tok_bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift, st):
+        g, b = _t(gamma, (c,), torch.float32), _t(beta, (c,), torch.float32)
+        m_, v_ = _t(rm, (c,), torch.float32), _t(rv, (c,), torch.float32)
+        sc = g / torch.sqrt(v_ + eps)
+        _t(scale, (c,), torch.float32).copy_(sc)
+        _t(shift, (c,), torch.float32).copy_(b - m_ * sc)
+        return 0
+
+    def tok_bn_stats_rows(self, m, c):
+        return 1
+
+    def tok_bn_stats(self, y, m, c, stats, st):
+        f = _t(y, (m, c), BF16).float()
+        s = _t(stats, (2, 1, c), torch.float32)
+        s[0, 0] = f.sum(0)
+        s[1, 0] = (f * f).sum(0)
+        return 0
+
+    def tok_bn_act_fwd(self, y, scale, shift, shortcut, relu, out, m, c, st):
+        self.calls.append('bn_act_fwd')
+        z = _t(y, (m, c), BF16).float() * _t(scale, (c,), torch.float32) + _t(shift, (c,), torch.float32)
+        if shortcut is not None:
+            z = z + _t(shortcut, (m, c), BF16).float()
+        if relu:
+            z = z.clamp_min(0)
+        _t(out, (m, c), BF16).copy_(z.to(BF16))
+        return 0
+
+    def tok_bn_bwd_rows(self, m, c):
+        return 1
+
+    def _dz(self, dout, y, out, scale, shift, relu, m, c):
+        g = _t(dout, (m, c), BF16).float()
+        if not relu:
+            return g
+        if out is not None:
+            mask = _t(out, (m, c), BF16).float() > 0
+        else:
+            mask = (_t(y, (m, c), BF16).float() * _t(scale, (c,), torch.float32) + _t(shift, (c,), torch.float32)) > 0
+        return g * mask
+
+    def tok_bn_bwd_reduce(self, dout, y, out, scale, shift, mean, rstd, relu, m, c, partial, st):
+        dz = self._dz(dout, y, out, scale, shift, relu, m, c)
+        xhat = (_t(y, (m, c), BF16).float() - _t(mean, (c,), torch.float32)) * _t(rstd, (c,), torch.float32)
+        p = _t(partial, (2, 1, c), torch.float32)
+        p[0, 0] = dz.sum(0)
+        p[1, 0] = (dz * xhat).sum(0)
+        return 0
+
+    def tok_bn_bwd_finalize(self, partial, rows, m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, st):
+        p = _t(partial, (2, rows, c), torch.float32).double().sum(1)
+        sdz, sdzx = p[0].float(), p[1].float()
+        for ptr_, val in ((dgamma, sdzx), (dbeta, sdz)):
+            if ptr_ is not None:
+                t = _t(ptr_, (c,), torch.float32)
+                if accumulate:
+                    t.add_(val)
+                else:
+                    t.copy_(val)
+        g, mu, rs = (_t(q, (c,), torch.float32) for q in (gamma, mean, rstd))
+        m1, m2 = (p[0] / m).float(), (p[1] / m).float()
+        c1 = g * rs
+        c2 = -c1 * rs * m2
+        co = _t(coef, (3, c), torch.float32)
+        co[0], co[1], co[2] = c1, c2, -c1 * m1 - c2 * mu
+        return 0
+
+    def tok_bn_bwd_apply(self, dout, y, out, scale, shift, coef, relu, dy, dshortcut, ds_acc, m, c, st):
+        self.calls.append('bn_bwd_apply')
+        dz = self._dz(dout, y, out, scale, shift, relu, m, c)
+        co = _t(coef, (3, c), torch.float32)
+        res = co[0] * dz + co[1] * _t(y, (m, c), BF16).float() + co[2]
+        _t(dy, (m, c), BF16).copy_(res.to(BF16))
+        if dshortcut is not None:
+            d = _t(dshortcut, (m, c), BF16)
+            d.copy_(((dz + d.float()) if ds_acc else dz).to(BF16))
+        return 0
+
+    # ---- pooling ----------------------------------------------------------------------------------
+    def tok_maxpool3x3s2_fwd(self, x, y, argmax, n, h, w, c, st):
+        xin = _t(x, (n, h, w, c), BF16).float().permute(0, 3, 1, 2)
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out, idx = F.max_pool2d(xin, 3, 2, 1, return_indices=True)
+        _t(y, (n, p, q, c), BF16).copy_(out.permute(0, 2, 3, 1).to(BF16))
+        # flat input index -> tap index r*3+s
+        ih, iw = idx // w, idx % w
+        pp = torch.arange(p).view(1, 1, p, 1)
+        qq = torch.arange(q).view(1, 1, 1, q)
+        tap = (ih - (2 * pp - 1)) * 3 + (iw - (2 * qq - 1))
+        _t(argmax, (n, p, q, c), torch.uint8).copy_(tap.permute(0, 2, 3, 1).to(torch.uint8))
+        return 0
+
+    def tok_maxpool3x3s2_bwd(self, dy, argmax, dx, accumulate, n, h, w, c, st):
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        g = _t(dy, (n, p, q, c), BF16).float()
+        tap = _t(argmax, (n, p, q, c), torch.uint8).long()
+        pp = torch.arange(p).view(1, p, 1, 1)
+        qq = torch.arange(q).view(1, 1, q, 1)
+        ih = 2 * pp - 1 + tap // 3
+        iw = 2 * qq - 1 + tap % 3
+        flat = (ih * w + iw)
+        res = torch.zeros(n, h * w, c)
+        res.scatter_add_(1, flat.view(n, p * q, c), g.view(n, p * q, c))
+        out = _t(dx, (n, h, w, c), BF16)
+        res = res.view(n, h, w, c)
+        out.copy_(((res + out.float()) if accumulate else res).to(BF16))
+        return 0
+
+    def tok_gap_fwd(self, x, y, n, hw, c, st):
+        _t(y, (n, c), BF16).copy_((_t(x, (n, hw, c), BF16).float().sum(1) * (1.0 / hw)).to(BF16))
+        return 0
+
+    def tok_gap_bwd(self, dy, dx, accumulate, n, hw, c, st):
+        g = (_t(dy, (n, c), BF16).float() * (1.0 / hw)).unsqueeze(1).expand(n, hw, c)
+        out = _t(dx, (n, hw, c), BF16)
+        out.copy_(((g + out.float()) if accumulate else g).to(BF16))
+        return 0
+
+    def tok_colsum(self, dy, m, n_pad, n_real, out, accumulate, st):
+        s = _t(dy, (m, n_pad), BF16).float().sum(0)[:n_real]
+        o = _t(out, (n_real,), torch.float32)
+        if accumulate:
+            o.add_(s)
+        else:
+            o.copy_(s)
+        return 0
+
+    # ---- loss -------------------------------------------------------------------------------------
+    def tok_softmax_ce_fwd(self, logits, target, rows, classes, ld, ignore_index, lse, row_loss, loss, st):
+        z = _t(logits, (rows, ld), BF16).float()[:, :classes]
+        t = _t(target, (rows,), torch.int64)
+        l = torch.logsumexp(z, 1)
+        valid = t != ignore_index
+        tt = t.clamp(0, classes - 1)
+        rl = torch.where(valid, l - z.gather(1, tt[:, None])[:, 0], torch.zeros(()))
+        _t(lse, (rows,), torch.float32).copy_(l)
+        _t(row_loss, (rows,), torch.float32).copy_(rl)
+        o = _t(loss, (2,), torch.float32)
+        nv = valid.sum().double()
+        o[0] = (rl.double().sum() / nv).float()
+        o[1] = nv.float()
+        return 0
+
+    def tok_softmax_ce_bwd(self, logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, dlogits, st):
+        z = _t(logits, (rows, ld), BF16).float()[:, :classes]
+        t = _t(target, (rows,), torch.int64)
+        l = _t(lse, (rows,), torch.float32)
+        nv = _t(loss, (2,), torch.float32)[1]
+        gs = _t(gscale, (1,), torch.float32)[0] if gscale is not None else 1.0
+        valid = (t != ignore_index)
+        p = torch.exp(z - l[:, None])
+        p[torch.arange(rows)[valid], t[valid]] -= 1.0
+        p = p * (gs / nv) * valid[:, None]
+        rows_out = classes + (-classes) % 8
+        d = _t(dlogits, (rows, rows_out), BF16)
+        d.zero_()
+        d[:, :classes] = p.to(BF16)
+        return 0
+
+    # ---- optimizers ---------------------------------------------------------------------------------
+    def tok_sgd_step(self, param, grad, mbuf, shadow, count, lr, momentum, dampening, wd, nesterov, first,
+                     maximize, st):
+        self.calls.append('sgd_step')
+        p, g = _t(param, (count,), torch.float32), _t(grad, (count,), torch.float32)
+        d = -g if maximize else g.clone()
+        if wd != 0:
+            d = d + wd * p
+        if momentum != 0:
+            b = _t(mbuf, (count,), torch.float32)
+            if first:
+                b.copy_(d)
+            else:
+                b.mul_(momentum).add_(d, alpha=1 - dampening)
+            d = d + momentum * b if nesterov else b
+        p.add_(d, alpha=-lr)
+        if shadow is not None:
+            _t(shadow, (count,), BF16).copy_(p)
+        return 0
+
+    def tok_adam_step(self, param, grad, m, v, shadow, count, lr, b1, b2, eps, wd, decoupled, step, maximize, st):
+        self.calls.append('adam_step')
+        p, g = _t(param, (count,), torch.float32), _t(grad, (count,), torch.float32)
+        m_, v_ = _t(m, (count,), torch.float32), _t(v, (count,), torch.float32)
+        d = -g if maximize else g.clone()
+        if wd != 0:
+            if decoupled:
+                p.mul_(1 - lr * wd)
+            else:
+                d = d + wd * p
+        m_.lerp_(d, 1 - b1)
+        v_.mul_(b2).addcmul_(d, d, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        denom = v_.sqrt() / math.sqrt(bc2) + eps
+        p.addcdiv_(m_, denom, value=-(lr / bc1))
+        if shadow is not None:
+            _t(shadow, (count,), BF16).copy_(p)
+        return 0
+
+    def tok_fill_f32(self, dst, value, count, st):
+        _t(dst, (count,), torch.float32).fill_(value)
+        return 0
+
+    def tok_scale_f32(self, dst, f, count, st):
+        _t(dst, (count,), torch.float32).mul_(f)
+        return 0

@@ -1,0 +1,51 @@
+"""Shared helpers of the parity tests: config building, weight transfer oracle <-> build, metrics."""
+import copy
+
+import torch
+
+from torchok_amd.constructor.config import apply_schema
+
+
+def cls_config(backbone='resnet18', num_classes=10, optimizer='SGD', opt_params=None, backbone_params=None,
+               inputs_shape=(3, 32, 32)):
+    cfg = {
+        'task': {'name': 'ClassificationTask',
+                 'params': {'backbone_name': backbone,
+                            'backbone_params': dict({'pretrained': False, 'in_channels': 3}, **(backbone_params or {})),
+                            'pooling_name': 'Pooling', 'head_name': 'ClassificationHead',
+                            'head_params': {'num_classes': num_classes},
+                            'inputs': [{'shape': list(inputs_shape), 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': optimizer,
+                                        'params': opt_params or {'lr': 0.1, 'momentum': 0.9, 'weight_decay': 1e-4}}}],
+        'data': {}, 'trainer': {'precision': 'bf16'},
+    }
+    return apply_schema(cfg)
+
+
+def perturb_(module, seed=0, scale=0.2):
+    """Fresh inits are degenerate (zero-gamma on the last BN of every block):
+    move every BN affine parameter and bias off its init so all branches carry signal."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn(p.shape, generator=g) * scale + (0.5 if name.endswith('bn3.weight') or
+                                                                     name.endswith('bn2.weight') else 0.0))
+
+
+def copy_state(src_module, dst_module):
+    """state_dict transfer restricted to the keys both sides own (the task also registers
+    input_tensors_* buffers)."""
+    sd = src_module.state_dict()
+    dsd = dst_module.state_dict()
+    missing = [k for k in sd if k not in dsd]
+    assert not missing, missing
+    with torch.no_grad():
+        for k, v in sd.items():
+            dsd[k].copy_(v)
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))

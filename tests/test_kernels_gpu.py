@@ -1,0 +1,380 @@
+"""Kernel-level parity (GPU): every C-ABI entry point of libtok_gfx950.so against a plain PyTorch
+fp32 restatement of the same op (tests/fake_backend.py, which mirrors the ABI on host memory) on
+identical bf16-rounded inputs.  Tolerances: bf16 outputs ≤ 1e-2 relative (north_star), fp32
+reductions ≤ 1e-3, index/mask ops bit-exact."""
+import ctypes
+
+import pytest
+import torch
+
+from torchok_amd import _C
+from fake_backend import FakeTok
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def libs():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return _C.load_library(), FakeTok()
+
+
+def both(libs, name, args_fn):
+    """Run entry point `name` natively on device copies and on the host stand-in.
+    args_fn(dev) returns the argument list for tensors placed by dev(t)."""
+    lib, fake = libs
+    host_args = args_fn(lambda t: t)
+    dev_tensors = {}
+
+    def to_dev(t):
+        d = t.to(DEV)
+        dev_tensors[id(t)] = d
+        return d
+    dev_args = args_fn(to_dev)
+
+    def ptrs(args):
+        return [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+    st = torch.cuda.current_stream().cuda_stream
+    rc = getattr(lib, name)(*ptrs(dev_args)[:-1], st)
+    assert rc == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    rc = getattr(fake, name)(*ptrs(host_args)[:-1], None)
+    assert rc == 0
+    return dev_tensors
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def maxrel(a, b, floor):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float(((a - b).abs() / (b.abs() + floor)).max())
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+CONV_CASES = [
+    # n, h, w, c, k, r, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (2, 16, 16, 64, 128, 1, 1, 0),
+    (2, 16, 16, 128, 64, 1, 1, 0),
+    (2, 15, 13, 32, 64, 3, 1, 1),      # ragged spatial, C < BK
+    (3, 14, 14, 64, 256, 1, 2, 0),     # downsample 1x1 s2
+    (2, 17, 19, 64, 128, 3, 2, 1),     # 3x3 s2 ragged
+    (2, 8, 8, 8, 24, 3, 1, 1),         # tiny channels, K not multiple of 64
+    (1, 7, 7, 512, 512, 3, 1, 1),      # deep K (4608)
+    (4, 1, 1, 2048, 1000, 1, 1, 0),    # linear 2048 -> 1000
+    (1, 20, 20, 48, 96, 3, 1, 1),      # HRNet-like widths (taps straddle BK)
+]
+
+
+def _desc(n, h, w, c, k, r, stride, pad, s_pad=None):
+    p = (h + 2 * pad - r) // stride + 1
+    q = (w + 2 * pad - r) // stride + 1
+    return _C.ConvDesc(n, h, w, c, k, r, r, p, q, stride, pad, s_pad or r)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd(libs, case):
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    x = rnd(n, h, w, c).to(BF16)
+    wt = rnd(k, r, r, c, scale=(r * r * c) ** -0.5).to(BF16)
+    bias = rnd(k)
+    y = torch.zeros(n, d.p, d.q, k, dtype=BF16)
+    rows = libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d))
+    assert rows == libs[1].tok_conv_fwd_stat_rows(d)
+    stats = torch.zeros(2, rows, k)
+    dv = both(libs, 'tok_conv_fwd', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                               f(x), f(wt), f(bias), f(y), f(stats), None])
+    yd, sd = dv[id(y)], dv[id(stats)]
+    assert relerr(yd.float(), y.float()) < 4e-3
+    assert maxrel(yd.float(), y.float(), 0.05) < 3e-2
+    # the partial sums are taken over the kernel's OWN rounded outputs
+    f = yd.float().reshape(-1, k)
+    assert relerr(sd[0].sum(0), f.sum(0)) < 1e-3 or float((sd[0].sum(0).cpu() - f.sum(0).cpu()).abs().max()) < 1e-2
+    assert relerr(sd[1].sum(0), (f * f).sum(0)) < 1e-3
+
+
+def test_conv_fwd_stem_c4(libs):
+    n, h, w, k = 2, 33, 35, 64
+    d = _desc(n, h, w, 4, k, 7, 2, 3, s_pad=8)
+    x = rnd(n, h, w, 4).to(BF16)
+    x[..., 3] = 0
+    wt = rnd(k, 7, 8, 4, scale=0.08).to(BF16)
+    wt[:, :, 7, :] = 0
+    wt[..., 3] = 0
+    y = torch.zeros(n, d.p, d.q, k, dtype=BF16)
+    rows = libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d))
+    stats = torch.zeros(2, rows, k)
+    dv = both(libs, 'tok_conv_fwd', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                               f(x), f(wt), None, f(y), f(stats), None])
+    assert relerr(dv[id(y)].float(), y.float()) < 4e-3
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[3] % 8 == 0])
+@pytest.mark.parametrize('accumulate', [0, 1])
+def test_conv_dgrad(libs, case, accumulate):
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    wd = rnd(c, r, r, k, scale=(r * r * k) ** -0.5).to(BF16)
+    dx = rnd(n, h, w, c, seed=5).to(BF16)
+    dv = both(libs, 'tok_conv_dgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                 f(dy), f(wd), f(dx), accumulate, None])
+    assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_wgrad(libs, case):
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    x = rnd(n, h, w, c).to(BF16)
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    dw = torch.zeros(k, r, r, c)
+    wsb = libs[0].tok_conv_wgrad_ws_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(wsb // 4, 16))
+    dv = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                 f(x), f(dy), f(dw), k, c, f(ws), wsb, 0, None])
+    assert relerr(dv[id(dw)], dw) < 2e-3
+    # determinism: a second run is bit-identical (fixed-order partial reduction, no atomics)
+    first = dv[id(dw)].clone()
+    dv2 = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                  f(x), f(dy), f(dw), k, c, f(ws), wsb, 0, None])
+    assert torch.equal(first, dv2[id(dw)])
+
+
+def test_conv_wgrad_stem_c4(libs):
+    n, h, w, k = 2, 33, 35, 64
+    d = _desc(n, h, w, 4, k, 7, 2, 3, s_pad=8)
+    x = rnd(n, h, w, 4).to(BF16)
+    x[..., 3] = 0
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    dw = torch.zeros(k, 7, 7, 3)
+    wsb = libs[0].tok_conv_wgrad_ws_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(wsb // 4, 16))
+    dv = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                 f(x), f(dy), f(dw), k, 3, f(ws), wsb, 0, None])
+    assert relerr(dv[id(dw)], dw) < 2e-3
+
+
+def test_pack_weights(libs):
+    k, r, s, c = 10, 3, 3, 3
+    src = rnd(k, r, s, c)
+    dst = torch.zeros(16, r, 8, 4, dtype=BF16)
+    dv = both(libs, 'tok_pack_weight_fwd', lambda f: [f(src), k, r, s, c, f(dst), 16, 8, 4, None])
+    assert torch.equal(dv[id(dst)].cpu(), dst)
+    dst2 = torch.zeros(8, r, s, 16, dtype=BF16)
+    dv = both(libs, 'tok_pack_weight_dgrad', lambda f: [f(src), k, r, s, c, f(dst2), 16, 8, None])
+    assert torch.equal(dv[id(dst2)].cpu(), dst2)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.float16, torch.bfloat16])
+def test_nchw_to_nhwc(libs, dt):
+    n, c, h, w = 2, 3, 9, 11
+    src = rnd(n, c, h, w).to(dt)
+    code = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dt]
+    for cp in (4, 8):
+        dst = torch.ones(n, h, w, cp, dtype=BF16)
+        dv = both(libs, 'tok_nchw_to_nhwc_bf16', lambda f: [f(src), code, n, c, h, w, f(dst), cp, None])
+        assert torch.equal(dv[id(dst)].cpu(), dst)
+
+
+@pytest.mark.parametrize('m,c', [(1000, 64), (4096 + 17, 256), (300, 2048), (777, 48)])
+@pytest.mark.parametrize('relu,with_sc', [(1, 0), (1, 1), (0, 0)])
+def test_bn_chain(libs, m, c, relu, with_sc):
+    """finalize -> act_fwd -> bwd_reduce -> bwd_finalize -> bwd_apply against the host restatement."""
+    lib, fake = libs
+    y = (rnd(m, c) * 1.5 + 0.3).to(BF16)
+    f = y.float()
+    rows = 3
+    stats = torch.zeros(2, rows, c)
+    stats[0, 0], stats[1, 0] = f[: m // 2].sum(0), (f[: m // 2] ** 2).sum(0)
+    stats[0, 2], stats[1, 2] = f[m // 2:].sum(0), (f[m // 2:] ** 2).sum(0)
+    gamma, beta = rnd(c, seed=1) * 0.5 + 1, rnd(c, seed=2) * 0.2
+    rm, rv, nbt = rnd(c, seed=3), rnd(c, seed=4).abs() + 0.5, torch.tensor([7])
+    mean, rstd, scale, shift = (torch.zeros(c) for _ in range(4))
+    dv = both(libs, 'tok_bn_finalize', lambda fn: [fn(stats), rows, m, c, fn(gamma), fn(beta), fn(rm), fn(rv),
+                                                   fn(nbt), 0.1, 1e-5, fn(mean), fn(rstd), fn(scale), fn(shift), None])
+    for t in (mean, rstd, scale, shift, rm, rv):
+        assert maxrel(dv[id(t)], t, 1e-3) < 1e-4
+    assert int(dv[id(nbt)].item()) == 8 == int(nbt.item())
+    # torch's own training BatchNorm as the independent check of the statistics semantics
+    bn = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn.weight.copy_(gamma), bn.bias.copy_(beta)
+    ref = bn(f.t().reshape(1, c, m, 1)).reshape(c, m).t()
+    assert relerr(f * scale + shift, ref) < 1e-4
+
+    sc = rnd(m, c, seed=9).to(BF16) if with_sc else None
+    out = torch.zeros(m, c, dtype=BF16)
+    dv = both(libs, 'tok_bn_act_fwd', lambda fn: [fn(y), fn(scale), fn(shift), fn(sc) if with_sc else None, relu,
+                                                  fn(out), m, c, None])
+    assert relerr(dv[id(out)].float(), out.float()) < 1e-3
+    assert (dv[id(out)].cpu() != out).float().mean() < 1e-3  # fma vs mul+add may flip a last bit
+
+    dout = rnd(m, c, seed=11).to(BF16)
+    rows_b = lib.tok_bn_bwd_rows(m, c)
+    part_d = torch.zeros(2, rows_b, c, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    args = dict(dout=dout, y=y, out=out if (relu and with_sc) else None)
+    dd = {k_: (v.to(DEV) if v is not None else None) for k_, v in args.items()}
+    cd = {k_: v.to(DEV) for k_, v in dict(scale=scale, shift=shift, mean=mean, rstd=rstd, gamma=gamma).items()}
+    P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    assert lib.tok_bn_bwd_reduce(P(dd['dout']), P(dd['y']), P(dd['out']), P(cd['scale']), P(cd['shift']),
+                                 P(cd['mean']), P(cd['rstd']), relu, m, c, P(part_d), st) == 0
+    part_h = torch.zeros(2, 1, c)
+    assert fake.tok_bn_bwd_reduce(P(dout), P(y), P(args['out']), P(scale), P(shift), P(mean), P(rstd), relu, m, c,
+                                  P(part_h), None) == 0
+    torch.cuda.synchronize()
+    assert relerr(part_d.sum(1), part_h.sum(1)) < 1e-3
+
+    dg_d, db_d, coef_d = (torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(3, c, device=DEV))
+    dg_h, db_h, coef_h = torch.zeros(c), torch.zeros(c), torch.zeros(3, c)
+    assert lib.tok_bn_bwd_finalize(P(part_d), rows_b, m, c, P(cd['gamma']), P(cd['mean']), P(cd['rstd']), P(dg_d),
+                                   P(db_d), P(coef_d), 0, st) == 0
+    assert fake.tok_bn_bwd_finalize(P(part_h), 1, m, c, P(gamma), P(mean), P(rstd), P(dg_h), P(db_h), P(coef_h), 0,
+                                    None) == 0
+    torch.cuda.synchronize()
+    assert relerr(dg_d, dg_h) < 1e-3 and relerr(db_d, db_h) < 1e-3 and relerr(coef_d, coef_h) < 1e-3
+
+    dy_d = torch.zeros(m, c, dtype=BF16, device=DEV)
+    ds_d = torch.zeros(m, c, dtype=BF16, device=DEV) if with_sc else None
+    dy_h = torch.zeros(m, c, dtype=BF16)
+    ds_h = torch.zeros(m, c, dtype=BF16) if with_sc else None
+    coef_same = coef_h.to(DEV)
+    assert lib.tok_bn_bwd_apply(P(dd['dout']), P(dd['y']), P(dd['out']), P(cd['scale']), P(cd['shift']), P(coef_same),
+                                relu, P(dy_d), P(ds_d), 0, m, c, st) == 0
+    assert fake.tok_bn_bwd_apply(P(dout), P(y), P(args['out']), P(scale), P(shift), P(coef_h), relu, P(dy_h), P(ds_h),
+                                 0, m, c, None) == 0
+    torch.cuda.synchronize()
+    assert relerr(dy_d.float(), dy_h.float()) < 2e-3
+    if with_sc:
+        assert torch.equal(ds_d.cpu(), ds_h)  # masked copy of the incoming gradient: exact
+    # independent check of the whole BN backward against autograd (fp32)
+    yy = f.clone().requires_grad_(True)
+    z = torch.nn.functional.batch_norm(yy, None, None, gamma, beta, True, 0.1, 1e-5)
+    if with_sc:
+        z = z + sc.float()
+    if relu:
+        z = z.relu()
+    z.backward(dout.float())
+    assert relerr(dy_h.float(), yy.grad) < 2e-2
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128)])
+def test_maxpool_exact(libs, shape):
+    n, h, w, c = shape
+    x = rnd(n, h, w, c).relu().to(BF16)   # post-ReLU input: many exact ties at 0
+    p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.zeros(n, p, q, c, dtype=BF16)
+    am = torch.zeros(n, p, q, c, dtype=torch.uint8)
+    dv = both(libs, 'tok_maxpool3x3s2_fwd', lambda f: [f(x), f(y), f(am), n, h, w, c, None])
+    assert torch.equal(dv[id(y)].cpu(), y)
+    assert torch.equal(dv[id(am)].cpu(), am)
+    dy = rnd(n, p, q, c, seed=3).to(BF16)
+    for acc in (0, 1):
+        dx = rnd(n, h, w, c, seed=4).to(BF16)
+        dv = both(libs, 'tok_maxpool3x3s2_bwd', lambda f: [f(dy), f(am), f(dx), acc, n, h, w, c, None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < 2e-3
+        if not acc:
+            assert torch.equal(dv[id(dx)].cpu() != 0, dx != 0)  # gradient routing is index-exact
+
+
+def test_gap_colsum(libs):
+    n, hw, c = 5, 49, 256
+    x = rnd(n, hw, c).to(BF16)
+    y = torch.zeros(n, c, dtype=BF16)
+    dv = both(libs, 'tok_gap_fwd', lambda f: [f(x), f(y), n, hw, c, None])
+    assert relerr(dv[id(y)].float(), y.float()) < 2e-3
+    dy = rnd(n, c, seed=1).to(BF16)
+    for acc in (0, 1):
+        dx = rnd(n, hw, c, seed=2).to(BF16)
+        dv = both(libs, 'tok_gap_bwd', lambda f: [f(dy), f(dx), acc, n, hw, c, None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < 2e-3
+    m, npad, nreal = 300, 16, 10
+    g = rnd(m, npad).to(BF16)
+    out = torch.ones(nreal)
+    dv = both(libs, 'tok_colsum', lambda f: [f(g), m, npad, nreal, f(out), 1, None])
+    assert relerr(dv[id(out)], out) < 1e-4
+
+
+@pytest.mark.parametrize('rows,classes', [(256, 1000), (7, 10), (64, 11318)])
+def test_softmax_ce(libs, rows, classes):
+    ld = (classes + 7) // 8 * 8
+    z = (rnd(rows, ld) * 3).to(BF16)
+    t = torch.randint(0, classes, (rows,), generator=torch.Generator().manual_seed(1))
+    t[::5] = -100
+    lse, rl, loss = torch.zeros(rows), torch.zeros(rows), torch.zeros(2)
+    dv = both(libs, 'tok_softmax_ce_fwd', lambda f: [f(z), f(t), rows, classes, ld, -100, f(lse), f(rl), f(loss), None])
+    assert maxrel(dv[id(lse)], lse, 1e-3) < 1e-4
+    assert maxrel(dv[id(loss)], loss, 1e-6) < 1e-5
+    ref = torch.nn.functional.cross_entropy(z.float()[:, :classes], t, ignore_index=-100)
+    assert abs(float(dv[id(loss)][0]) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    assert float(dv[id(loss)][1]) == float((t != -100).sum())
+    gs = torch.tensor([0.7])
+    dl = torch.ones(rows, ld, dtype=BF16)
+    dv = both(libs, 'tok_softmax_ce_bwd', lambda f: [f(z), f(t), f(lse), f(loss), f(gs), rows, classes, ld, -100,
+                                                     f(dl), None])
+    assert relerr(dv[id(dl)].float(), dl.float()) < 3e-3
+    assert torch.all(dv[id(dl)][:, classes:] == 0) and torch.all(dv[id(dl)][::5] == 0)
+
+
+def test_optimizers_match_torch(libs):
+    """tok_sgd_step / tok_adam_step against torch.optim (the optimizers the reference registers)."""
+    lib = libs[0]
+    n = 10007
+    st = torch.cuda.current_stream().cuda_stream
+    p0, grads = rnd(n), [rnd(n, seed=s) for s in range(1, 4)]
+    for nesterov, wd, damp in ((False, 1e-4, 0.0), (True, 0.0, 0.0), (False, 1e-2, 0.1)):
+        ref = torch.nn.Parameter(p0.clone())
+        opt = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=wd, nesterov=nesterov, dampening=damp)
+        p, m = p0.clone().to(DEV), torch.zeros(n, device=DEV)
+        sh = torch.zeros(n, dtype=BF16, device=DEV)
+        for i, g in enumerate(grads):
+            ref.grad = g.clone()
+            opt.step()
+            gd = g.to(DEV)
+            assert lib.tok_sgd_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), sh.data_ptr(), n, 0.1, 0.9, damp, wd,
+                                    int(nesterov), int(i == 0), 0, st) == 0
+        torch.cuda.synchronize()
+        assert maxrel(p, ref.data, 1e-3) < 1e-5
+        assert torch.equal(sh.cpu(), p.cpu().to(BF16))
+    for decoupled, cls in ((0, torch.optim.Adam), (1, torch.optim.AdamW)):
+        ref = torch.nn.Parameter(p0.clone())
+        opt = cls([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for i, g in enumerate(grads):
+            ref.grad = g.clone()
+            opt.step()
+            gd = g.to(DEV)
+            assert lib.tok_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, 1e-3, 0.9,
+                                     0.999, 1e-8, 1e-2, decoupled, i + 1, 0, st) == 0
+        torch.cuda.synchronize()
+        assert maxrel(p, ref.data, 1e-3) < 1e-5
+
+
+def test_tr_read_microbench(libs):
+    """The wgrad kernel rests on ds_read_b64_tr_b16; a 1x1 conv wgrad with one-hot operands makes
+    any lane-mapping mistake visible as a permuted dW."""
+    n, h, w, c, k = 1, 8, 8, 64, 64
+    d = _desc(n, h, w, c, k, 1, 1, 0)
+    x = torch.zeros(n, h, w, c, dtype=BF16)
+    dy = torch.zeros(n, h, w, k, dtype=BF16)
+    flat_x, flat_dy = x.view(-1, c), dy.view(-1, k)
+    for m in range(64):
+        flat_x[m, (m * 7) % c] = 1.0 + m / 64.0
+        flat_dy[m, (m * 5 + 3) % k] = 2.0
+    dw = torch.zeros(k, 1, 1, c)
+    wsb = libs[0].tok_conv_wgrad_ws_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(wsb // 4, 16))
+    dv = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                 f(x), f(dy), f(dw), k, c, f(ws), wsb, 0, None])
+    assert torch.allclose(dv[id(dw)].cpu(), dw, atol=1e-6)

@@ -1,0 +1,122 @@
+"""ctypes binding of libtok_gfx950.so (the C ABI declared in include/tok.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950) and
+lives next to this package (``torchok_amd/lib``).  There is NO fallback: if the shared object
+is missing, or a tensor is not on a HIP device, the product path raises.  (Unit tests may
+install a host-memory stand-in through :func:`_install_backend` to exercise the host logic on
+a CPU-only box; nothing in the package itself does.)
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtok_gfx950.so')
+
+TOK_F32, TOK_F16, TOK_BF16 = 0, 1, 2
+
+
+class ConvDesc(Structure):
+    """Mirror of ``tok_conv_desc`` (include/tok.h)."""
+    _fields_ = [('n', c_int32), ('h', c_int32), ('w', c_int32), ('c', c_int32),
+                ('k', c_int32), ('r', c_int32), ('s', c_int32),
+                ('p', c_int32), ('q', c_int32),
+                ('stride', c_int32), ('pad', c_int32), ('s_pad', c_int32)]
+
+
+_P = c_void_p
+_PD = POINTER(ConvDesc)
+
+# name -> (restype, argtypes); every symbol include/tok.h declares
+PROTOTYPES = {
+    'tok_last_error': (c_char_p, []),
+    'tok_version': (c_int, []),
+    'tok_nchw_to_nhwc_bf16': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'tok_cast_f32_bf16': (c_int, [_P, _P, c_size_t, _P]),
+    'tok_pack_weight_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
+    'tok_pack_weight_dgrad': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    'tok_conv_fwd_stat_rows': (c_int, [_PD]),
+    'tok_conv_fwd': (c_int, [_PD, _P, _P, _P, _P, _P, _P]),
+    'tok_conv_dgrad': (c_int, [_PD, _P, _P, _P, c_int, _P]),
+    'tok_conv_wgrad_ws_bytes': (c_size_t, [_PD]),
+    'tok_conv_wgrad': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float,
+                                _P, _P, _P, _P, _P]),
+    'tok_bn_eval_coeffs': (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
+    'tok_bn_stats_rows': (c_int, [c_int64, c_int]),
+    'tok_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, c_int64, c_int, _P]),
+    'tok_bn_bwd_rows': (c_int, [c_int64, c_int]),
+    'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
+    'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
+    'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_gap_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    'tok_gap_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
+    'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
+    'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
+    'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
+                             c_int, c_int, c_int, _P]),
+    'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
+                              c_float, c_int, c_int64, c_int, _P]),
+    'tok_fill_f32': (c_int, [_P, c_float, c_size_t, _P]),
+    'tok_scale_f32': (c_int, [_P, c_float, c_size_t, _P]),
+}
+
+
+class TokError(RuntimeError):
+    pass
+
+
+_lib = None
+_fake = False
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and attach prototypes.  Raises if it is not built."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise TokError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                       f'(hipcc --offload-arch=gfx950). torchok_amd has no CPU/eager fallback.')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib
+
+
+def is_fake():
+    return _fake
+
+
+def _install_backend(backend):
+    """TEST HOOK: replace the native library by an object exposing the same entry points
+    (operating on host memory).  Used by tests/ only; returns the previous backend."""
+    global _lib, _fake
+    prev = (_lib, _fake)
+    _lib = backend
+    _fake = backend is not None and not isinstance(backend, ctypes.CDLL)
+    return prev
+
+
+def _restore_backend(prev):
+    global _lib, _fake
+    _lib, _fake = prev
+
+
+def check(status, what=''):
+    if status != 0:
+        msg = lib().tok_last_error()
+        if isinstance(msg, bytes):
+            msg = msg.decode()
+        raise TokError(f'{what} failed ({status}): {msg}')

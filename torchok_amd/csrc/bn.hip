@@ -1,0 +1,421 @@
+// BatchNorm (training, batch statistics) + ReLU + residual add, NHWC bf16, fp32 statistics.
+// All passes are HBM-bound streaming kernels: 16-byte (8 x bf16) accesses per lane, a thread
+// keeps ONE 8-channel group for its whole life so scale/shift/coefficients live in registers.
+//
+// Forward :  conv epilogue partial sums -> tok_bn_finalize -> tok_bn_act_fwd
+// Backward:  tok_bn_bwd_reduce (partials) -> tok_bn_bwd_finalize -> tok_bn_bwd_apply
+//            dz = dout * mask ;  dy = a1*dz + a2*y + a3   (a* per channel)
+#include "tok_common.h"
+
+namespace {
+
+// Block geometry shared by the streaming kernels: CGE = min(C/8, 256) channel groups across
+// the block, RPB = 256 / CGE rows per block iteration.
+struct Geo {
+  int cg_total, cge, rpb;
+};
+inline Geo make_geo(int c) {
+  Geo g;
+  g.cg_total = c / 8;
+  g.cge = g.cg_total < 256 ? g.cg_total : 256;
+  g.rpb = 256 / g.cge;
+  return g;
+}
+inline int stream_blocks(int64_t m, const Geo& g, int cap) {
+  int64_t b = (m + g.rpb - 1) / g.rpb;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ void load8f(const float* p, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* __restrict__ y,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const bf16* __restrict__ shortcut, int relu,
+                                                         bf16* __restrict__ out, int64_t M, int C,
+                                                         int cge, int rpb) {
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  if (rl >= rpb) return;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float sc[8], sh[8];
+    load8f(scale + cg * 8, sc);
+    load8f(shift + cg * 8, sh);
+    for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+      const size_t off = (size_t)m * C + cg * 8;
+      const bf16x8 v = ldg16(y + off);
+      bf16x8 o;
+      if (shortcut != nullptr) {
+        const bf16x8 s = ldg16(shortcut + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = fmaf(bf2f(v[e]), sc[e], sh[e]) + bf2f(s[e]);
+          if (relu) z = fmaxf(z, 0.f);
+          o[e] = f2bf(z);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = fmaf(bf2f(v[e]), sc[e], sh[e]);
+          if (relu) z = fmaxf(z, 0.f);
+          o[e] = f2bf(z);
+        }
+      }
+      stg16(out + off, o);
+    }
+  }
+}
+
+// generic per-channel (sum, sumsq) partials of an NHWC tensor: partial[2][gridDim.x][C]
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ y, int64_t M, int C,
+                                                       int cge, int rpb, float* __restrict__ partial) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < rpb) {
+      for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+        const bf16x8 v = ldg16(y + (size_t)m * C + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = bf2f(v[e]); s1[e] += f; s2[e] += f * f; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < rpb; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += red[0][r * cge + cgl][e]; s2[e] += red[1][r * cge + cgl][e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        partial[((size_t)0 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s1[e];
+        partial[((size_t)1 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// 4 channels per block, 64 row-lanes each; fp64 accumulation across partial rows.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows,
+                                                          double inv_count, double unbias, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var,
+                                                          int64_t* nbt, float momentum, float eps,
+                                                          float* mean, float* rstd, float* scale,
+                                                          float* shift) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, rl = tid >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    for (int r = rl; r < rows; r += 64) {
+      a1 += (double)stats[(size_t)r * C + c];
+      a2 += (double)stats[((size_t)rows + r) * C + c];
+    }
+  }
+  red[0][tid] = a1;
+  red[1][tid] = a2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (rl < s) {
+      red[0][tid] += red[0][tid + s * 4];
+      red[1][tid] += red[1][tid + s * 4];
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && c < C) {
+    const double mu = red[0][tid] * inv_count;
+    double var = red[1][tid] * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float muf = (float)mu;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = muf;
+    rstd[c] = rs;
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = fmaf(-muf, sc, beta[c]);
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * muf;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * unbias);
+    }
+  }
+  if (nbt != nullptr && blockIdx.x == 0 && tid == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
+                                      const float* rv, float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float rs = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = fmaf(-rm[c], sc, beta[c]);
+  }
+}
+
+// partial[2][gridDim.x][C] = (sum dz, sum dz * xhat)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16* __restrict__ dout, const bf16* __restrict__ y, const bf16* __restrict__ out,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int relu, int64_t M, int C, int cge, int rpb,
+    float* __restrict__ partial) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < rpb) {
+      float sc[8], sh[8], mu[8], rs[8];
+      load8f(scale + cg * 8, sc);
+      load8f(shift + cg * 8, sh);
+      load8f(mean + cg * 8, mu);
+      load8f(rstd + cg * 8, rs);
+      for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+        const size_t off = (size_t)m * C + cg * 8;
+        const bf16x8 g = ldg16(dout + off);
+        const bf16x8 v = ldg16(y + off);
+        if (relu && out != nullptr) {
+          const bf16x8 o = ldg16(out + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yf = bf2f(v[e]);
+            const float dz = bf2f(o[e]) > 0.f ? bf2f(g[e]) : 0.f;
+            s1[e] += dz;
+            s2[e] += dz * ((yf - mu[e]) * rs[e]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float yf = bf2f(v[e]);
+            float dz = bf2f(g[e]);
+            if (relu && !(fmaf(yf, sc[e], sh[e]) > 0.f)) dz = 0.f;
+            s1[e] += dz;
+            s2[e] += dz * ((yf - mu[e]) * rs[e]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < rpb; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += red[0][r * cge + cgl][e]; s2[e] += red[1][r * cge + cgl][e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        partial[((size_t)0 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s1[e];
+        partial[((size_t)1 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int rows, double inv_m, int C, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* dgamma, float* dbeta,
+    float* coef, int accumulate) {
+  __shared__ double red[2][256];
+  const int tid = threadIdx.x;
+  const int cl = tid & 3, rl = tid >> 2;
+  const int c = blockIdx.x * 4 + cl;
+  double a1 = 0.0, a2 = 0.0;
+  if (c < C) {
+    for (int r = rl; r < rows; r += 64) {
+      a1 += (double)partial[(size_t)r * C + c];
+      a2 += (double)partial[((size_t)rows + r) * C + c];
+    }
+  }
+  red[0][tid] = a1;
+  red[1][tid] = a2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (rl < s) {
+      red[0][tid] += red[0][tid + s * 4];
+      red[1][tid] += red[1][tid + s * 4];
+    }
+    __syncthreads();
+  }
+  if (rl == 0 && c < C) {
+    const float sdz = (float)red[0][tid];
+    const float sdzx = (float)red[1][tid];
+    if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + sdzx : sdzx;
+    if (dbeta != nullptr) dbeta[c] = accumulate ? dbeta[c] + sdz : sdz;
+    const float m1 = (float)(red[0][tid] * inv_m);
+    const float m2 = (float)(red[1][tid] * inv_m);
+    const float g = gamma[c], rs = rstd[c], mu = mean[c];
+    const float c1 = g * rs;
+    const float c2 = -c1 * rs * m2;
+    coef[c] = c1;
+    coef[C + c] = c2;
+    coef[2 * C + c] = -c1 * m1 - c2 * mu;
+  }
+}
+
+// dout / dshortcut may alias (in-place masking of the incoming gradient): no restrict on them.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16* dout, const bf16* __restrict__ y, const bf16* __restrict__ out,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
+    int relu, bf16* __restrict__ dy, bf16* dshortcut, int ds_acc, int64_t M, int C, int cge, int rpb) {
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  if (rl >= rpb) return;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float sc[8], sh[8], c1[8], c2[8], c3[8];
+    load8f(scale + cg * 8, sc);
+    load8f(shift + cg * 8, sh);
+    load8f(coef + cg * 8, c1);
+    load8f(coef + C + cg * 8, c2);
+    load8f(coef + 2 * C + cg * 8, c3);
+    for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+      const size_t off = (size_t)m * C + cg * 8;
+      const bf16x8 g = ldg16(dout + off);
+      const bf16x8 v = ldg16(y + off);
+      float dz[8];
+      if (relu && out != nullptr) {
+        const bf16x8 o = ldg16(out + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dz[e] = bf2f(o[e]) > 0.f ? bf2f(g[e]) : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dz[e] = bf2f(g[e]);
+          if (relu && !(fmaf(bf2f(v[e]), sc[e], sh[e]) > 0.f)) dz[e] = 0.f;
+        }
+      }
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(c1[e], dz[e], fmaf(c2[e], bf2f(v[e]), c3[e])));
+      stg16(dy + off, o);
+      if (dshortcut != nullptr) {
+        bf16x8 d;
+        if (ds_acc) {
+          const bf16x8 old = ldg16(dshortcut + off);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = f2bf(dz[e] + bf2f(old[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) d[e] = f2bf(dz[e]);
+        }
+        stg16(dshortcut + off, d);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static const int kStreamCap = 2048;   // blocks of elementwise kernels (8 per CU)
+static const int kReduceCap = 1024;   // partial rows of the reducing kernels
+
+extern "C" int tok_bn_finalize(const float* stats, int rows, int64_t count, int c, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               int64_t* nbt, float momentum, float eps, float* mean, float* rstd,
+                               float* scale, float* shift, void* stream) {
+  TOK_CHECK_ARG(stats && gamma && beta && mean && rstd && scale && shift, "tok_bn_finalize: null pointer");
+  TOK_CHECK_ARG(rows > 0 && count > 0 && c > 0, "tok_bn_finalize: bad sizes");
+  TOK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "tok_bn_finalize: running stats");
+  const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), stats, rows,
+                     1.0 / (double)count, unbias, c, gamma, beta, running_mean, running_var, nbt,
+                     momentum, eps, mean, rstd, scale, shift);
+  TOK_CHECK_LAUNCH("tok_bn_finalize");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, int c, float* scale,
+                                  float* shift, void* stream) {
+  TOK_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "tok_bn_eval_coeffs: null");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, tok_stream(stream), gamma,
+                     beta, running_mean, running_var, eps, c, scale, shift);
+  TOK_CHECK_LAUNCH("tok_bn_eval_coeffs");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_stats_rows(int64_t m, int c) {
+  if (m <= 0 || c <= 0 || c % 8) return TOK_ERR_INVALID;
+  return stream_blocks(m, make_geo(c), kReduceCap);
+}
+
+extern "C" int tok_bn_stats(const void* y, int64_t m, int c, float* stats, void* stream) {
+  TOK_CHECK_ARG(y && stats && m > 0 && c > 0 && c % 8 == 0, "tok_bn_stats: bad args");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(stream_blocks(m, g, kReduceCap)), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)y, m, c, g.cge, g.rpb, stats);
+  TOK_CHECK_LAUNCH("tok_bn_stats");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
+                              const void* shortcut, int relu, void* out, int64_t m, int c,
+                              void* stream) {
+  TOK_CHECK_ARG(y && scale && shift && out && m > 0 && c > 0 && c % 8 == 0, "tok_bn_act_fwd: bad args");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)y, scale, shift, (const bf16*)shortcut, relu,
+                     (bf16*)out, m, c, g.cge, g.rpb);
+  TOK_CHECK_LAUNCH("tok_bn_act_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_bwd_rows(int64_t m, int c) { return tok_bn_stats_rows(m, c); }
+
+extern "C" int tok_bn_bwd_reduce(const void* dout, const void* y, const void* out, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, int relu,
+                                 int64_t m, int c, float* partial, void* stream) {
+  TOK_CHECK_ARG(dout && y && scale && shift && mean && rstd && partial, "tok_bn_bwd_reduce: null pointer");
+  TOK_CHECK_ARG(m > 0 && c > 0 && c % 8 == 0, "tok_bn_bwd_reduce: bad sizes");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(stream_blocks(m, g, kReduceCap)), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, (const bf16*)out, scale, shift,
+                     mean, rstd, relu, m, c, g.cge, g.rpb, partial);
+  TOK_CHECK_LAUNCH("tok_bn_bwd_reduce");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c, const float* gamma,
+                                   const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                   float* coef, int accumulate, void* stream) {
+  TOK_CHECK_ARG(partial && gamma && mean && rstd && coef, "tok_bn_bwd_finalize: null pointer");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), partial,
+                     rows, 1.0 / (double)m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate);
+  TOK_CHECK_LAUNCH("tok_bn_bwd_finalize");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const void* out, const float* scale,
+                                const float* shift, const float* coef, int relu, void* dy,
+                                void* dshortcut, int dshortcut_accumulate, int64_t m, int c,
+                                void* stream) {
+  TOK_CHECK_ARG(dout && y && scale && shift && coef && dy, "tok_bn_bwd_apply: null pointer");
+  TOK_CHECK_ARG(m > 0 && c > 0 && c % 8 == 0, "tok_bn_bwd_apply: bad sizes");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, (const bf16*)out, scale, shift,
+                     coef, relu, (bf16*)dy, (bf16*)dshortcut, dshortcut_accumulate, m, c, g.cge, g.rpb);
+  TOK_CHECK_LAUNCH("tok_bn_bwd_apply");
+  return TOK_OK;
+}

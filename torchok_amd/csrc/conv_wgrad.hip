@@ -1,0 +1,302 @@
+// Weight-gradient of the NHWC bf16 convolution on MFMA for gfx950.
+//
+//   dW[n][k] = sum_m dY[m][n] * A[m][k]      m = (b, p, q)   k = (r, s, c)
+//
+// The reduction index m is the SLOW (strided) index of both operands, so the MFMA fragments
+// (8 consecutive reduction elements per lane) are produced by the gfx950 LDS transpose read
+// ds_read_b64_tr_b16: tiles are staged row-major [m][n] / [m][k] exactly as they sit in HBM
+// (16-byte coalesced loads, 16-byte LDS stores) and each 16-lane group pulls a 4(m) x 16(col)
+// block out transposed.  The k-slot -> m mapping inside one MFMA is
+//   slot (g, j<4) -> m = 4g + j,  slot (g, j>=4) -> m = 16 + 4g + (j-4)      (g = lane>>4)
+// identically for both operands, which is all a reduction needs.
+//
+// Work split: output tile TN x TK (64 or 128 each), the M range is cut into `splitM` chunks
+// that run as independent workgroups and write fp32 partial tiles to a workspace; a second
+// kernel sums the partials in a fixed order (deterministic — no atomics) and un-pads into the
+// fp32 master-gradient layout [k][r][s][c].
+#include "tok_common.h"
+
+namespace {
+
+struct WgradArgs {
+  const bf16* x;
+  const bf16* dy;
+  float* ws;
+  int H, W, C, K, R, S, P, Q, stride, pad;
+  int M, PQ, HW, Ktot;
+  int tilesN, tilesK, splitM, mchunk;
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x4 tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+}
+
+template <int TN, int TK, bool C4>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int CN = TN / 8, CK = TK / 8;      // 16-byte chunks per tile row
+  constexpr int RPY = 256 / CN, RPX = 256 / CK;  // rows covered per pass
+  constexpr int YP = 32 / RPY, XP = 32 / RPX;    // passes per 32-row step
+  constexpr int YS = (TN + 16) * 2, XS = (TK + 16) * 2;  // padded row strides (bytes)
+  constexpr int YBYTES = 32 * YS, XBYTES = 32 * XS;
+  constexpr int NT = TN / 32, KTL = TK / 32;   // 16-wide tiles per wave (2x2 waves)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wn2 = wv & 1, wk2 = wv >> 1;
+
+  const int ntile = a.tilesN * a.tilesK;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / a.tilesK;
+  const int tk = t - tn * a.tilesK;
+
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + 31) >> 5;
+
+  // ---- staging assignment ---------------------------------------------------------------
+  const int ycol = tid % CN, yrow = tid / CN;
+  const int xcol = tid % CK, xrow = tid / CK;
+  const int yn = tn * TN + ycol * 8;
+  const bool yn_ok = yn < a.K;
+
+  // this thread's k-chunk never changes: tap (kr, ks), channel offset kc0
+  const int k0 = tk * TK + xcol * 8;
+  int kr, ks, kc0;
+  if (C4) { kr = k0 >> 5; ks = (k0 & 31) >> 2; kc0 = 0; }
+  else { const int tap = k0 / a.C; kc0 = k0 - tap * a.C; kr = tap / a.S; ks = tap - kr * a.S; }
+  const bool k_ok = kr < a.R;
+
+  int xm[XP], xq[XP], xp[XP], xpix[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int m = mstart + xrow + i * RPX;
+    xm[i] = m;
+    const int mm = min(m, a.M - 1);
+    const int b = mm / a.PQ;
+    const int rem = mm - b * a.PQ;
+    xp[i] = rem / a.Q;
+    xq[i] = rem - xp[i] * a.Q;
+    xpix[i] = b * a.HW;
+  }
+  int ym = mstart + yrow;
+
+  bf16x8 ry[YP], rx[XP];
+
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < YP; ++i) {
+      const int m = ym + i * RPY;
+      bf16x8 v = zero8();
+      if (yn_ok && m < mend) v = ldg16(a.dy + (size_t)m * a.K + yn);
+      ry[i] = v;
+    }
+    ym += 32;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int hh = xp[i] * a.stride - a.pad + kr;
+      const int ww = xq[i] * a.stride - a.pad + ks;
+      const bool ok = k_ok && xm[i] < mend && (unsigned)hh < (unsigned)a.H;
+      bf16x8 v = zero8();
+      if (C4) {
+        if (ok) {
+          const bf16* ptr = a.x + ((size_t)(xpix[i] + hh * a.W + ww)) * 4;
+          bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
+          if ((unsigned)ww < (unsigned)a.W) lo = *reinterpret_cast<const bf16x4*>(ptr);
+          if ((unsigned)(ww + 1) < (unsigned)a.W) hi = *reinterpret_cast<const bf16x4*>(ptr + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+        }
+      } else {
+        if (ok && (unsigned)ww < (unsigned)a.W)
+          v = ldg16(a.x + ((size_t)(xpix[i] + hh * a.W + ww)) * a.C + kc0);
+      }
+      rx[i] = v;
+      // advance this row cursor by 32 output pixels
+      xm[i] += 32;
+      xq[i] += 32;
+      while (xq[i] >= a.Q) {
+        xq[i] -= a.Q;
+        if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* Yb = smem + buf * (YBYTES + XBYTES);
+    char* Xb = Yb + YBYTES;
+#pragma unroll
+    for (int i = 0; i < YP; ++i)
+      *reinterpret_cast<bf16x8*>(Yb + (yrow + i * RPY) * YS + ycol * 16) = ry[i];
+#pragma unroll
+    for (int i = 0; i < XP; ++i)
+      *reinterpret_cast<bf16x8*>(Xb + (xrow + i * RPX) * XS + xcol * 16) = rx[i];
+  };
+
+  const int g = lane >> 4, li = lane & 15;
+  // transpose-read address of this lane inside a 16-column tile: row 4g + (li>>2), cols (li&3)*4..
+  const int yoff = (4 * g + (li >> 2)) * YS + (wn2 * (TN / 2) + (li & 3) * 4) * 2;
+  const int xoff = (4 * g + (li >> 2)) * XS + (wk2 * (TK / 2) + (li & 3) * 4) * 2;
+
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (steps > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int st = 0; st < steps; ++st) {
+    const bool more = (st + 1) < steps;
+    if (more) load_tile();
+    const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
+    const char* Xb = Yb + YBYTES;
+    bf16x8 af[NT], bfr[KTL];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bf16x4 lo = tr_read(Yb + yoff + i * 32);
+      const bf16x4 hi = tr_read(Yb + yoff + i * 32 + 16 * YS);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { af[i][e] = lo[e]; af[i][4 + e] = hi[e]; }
+    }
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      const bf16x4 lo = tr_read(Xb + xoff + j * 32);
+      const bf16x4 hi = tr_read(Xb + xoff + j * 32 + 16 * XS);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bfr[j][e] = lo[e]; bfr[j][4 + e] = hi[e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < KTL; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (more) store_tile((st + 1) & 1);
+    __syncthreads();
+  }
+
+  // D[i = n][j = kcol]: lane holds rows g*4+reg, column li
+  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      const int kcol = tk * TK + wk2 * (TK / 2) + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
+        if (n < a.K && kcol < a.Ktot) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splitM,
+                                    int k_real, int R, int S, int c_real, int K, int S_pad,
+                                    int C_pad, int accumulate) {
+  const size_t total = (size_t)k_real * R * S * c_real;
+  const size_t slab = (size_t)K * R * S_pad * C_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c_real);
+    size_t rest = i / c_real;
+    const int s = (int)(rest % S);
+    rest /= S;
+    const int r = (int)(rest % R);
+    const int k = (int)(rest / R);
+    const size_t src = (((size_t)k * R + r) * S_pad + s) * C_pad + c;
+    float t = 0.f;
+    for (int sp = 0; sp < splitM; ++sp) t += ws[(size_t)sp * slab + src];
+    dw[i] = accumulate ? dw[i] + t : t;
+  }
+}
+
+struct Plan {
+  int TN, TK, tilesN, tilesK, splitM, mchunk;
+};
+
+Plan make_plan(const tok_conv_desc* d) {
+  Plan p;
+  const int Ktot = d->r * d->s_pad * d->c;
+  const long long M = (long long)d->n * d->p * d->q;
+  p.TN = d->k >= 128 ? 128 : 64;
+  p.TK = Ktot >= 128 ? 128 : 64;
+  p.tilesN = tok_cdiv(d->k, p.TN);
+  p.tilesK = tok_cdiv(Ktot, p.TK);
+  const int tiles = p.tilesN * p.tilesK;
+  long long split = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+  const long long max_split = (M + 255) / 256;   // at least 8 steps of 32 rows per workgroup
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  long long chunk = (M + split - 1) / split;
+  chunk = ((chunk + 31) / 32) * 32;
+  p.mchunk = (int)chunk;
+  p.splitM = (int)((M + chunk - 1) / chunk);
+  return p;
+}
+
+template <int TN, int TK, bool C4>
+void launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * 32 * ((TN + 16) * 2 + (TK + 16) * 2);
+  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
+                     smem, st, a);
+}
+
+}  // namespace
+
+extern "C" size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d) {
+  if (d == nullptr) return 0;
+  const Plan p = make_plan(d);
+  return (size_t)p.splitM * d->k * d->r * d->s_pad * d->c * sizeof(float);
+}
+
+extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
+                              int k_real, int c_real, void* ws, size_t ws_bytes, int accumulate,
+                              void* stream) {
+  TOK_CHECK_ARG(d && x && dy && dw && ws, "tok_conv_wgrad: null pointer");
+  TOK_CHECK_ARG(d->k % 8 == 0 && (d->c % 8 == 0 || d->c == 4), "tok_conv_wgrad: bad channel padding");
+  TOK_CHECK_ARG(k_real <= d->k && c_real <= d->c, "tok_conv_wgrad: real dims exceed padded dims");
+  TOK_CHECK_ARG(d->c == 4 ? d->s_pad == 8 : d->s_pad == d->s, "tok_conv_wgrad: bad s_pad");
+  const Plan p = make_plan(d);
+  const size_t need = tok_conv_wgrad_ws_bytes(d);
+  if (ws_bytes < need) {
+    tok_set_error("tok_conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
+    return TOK_ERR_WORKSPACE;
+  }
+  WgradArgs a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.ws = (float*)ws;
+  a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad; a.P = d->p; a.Q = d->q;
+  a.stride = d->stride; a.pad = d->pad;
+  a.M = d->n * d->p * d->q; a.PQ = d->p * d->q; a.HW = d->h * d->w;
+  a.Ktot = d->r * d->s_pad * d->c;
+  a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
+  hipStream_t st = tok_stream(stream);
+  const bool c4 = d->c == 4;
+  if (p.TN == 128 && p.TK == 128) {
+    if (c4) launch_wgrad<128, 128, true>(a, st); else launch_wgrad<128, 128, false>(a, st);
+  } else if (p.TN == 128) {
+    if (c4) launch_wgrad<128, 64, true>(a, st); else launch_wgrad<128, 64, false>(a, st);
+  } else if (p.TK == 128) {
+    if (c4) launch_wgrad<64, 128, true>(a, st); else launch_wgrad<64, 128, false>(a, st);
+  } else {
+    if (c4) launch_wgrad<64, 64, true>(a, st); else launch_wgrad<64, 64, false>(a, st);
+  }
+  TOK_CHECK_LAUNCH("tok_conv_wgrad");
+  const size_t total = (size_t)k_real * d->r * d->s * c_real;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw,
+                     p.splitM, k_real, d->r, d->s, c_real, d->k, d->s_pad, d->c, accumulate);
+  TOK_CHECK_LAUNCH("tok_conv_wgrad(reduce)");
+  return TOK_OK;
+}

@@ -1,0 +1,143 @@
+// Layout / dtype plumbing kernels: image NCHW -> NHWC bf16, fp32 -> bf16 shadows, weight packs.
+#include "tok_common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+// thread = (pixel, group of up to 8 output channels); reads are coalesced along W per channel plane
+template <typename T, int G>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ src, bf16* __restrict__ dst,
+                                                           int N, int C, int HW, int c_pad) {
+  const int groups = c_pad / G;
+  const size_t total = (size_t)N * HW * groups;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const size_t pix = i % ((size_t)N * HW);   // pixel fastest: coalesced plane reads
+    const int gidx = (int)(i / ((size_t)N * HW));
+    const int n = (int)(pix / HW);
+    const int hw = (int)(pix - (size_t)n * HW);
+    bf16 o[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+      const int c = gidx * G + e;
+      o[e] = (c < C) ? f2bf(to_f32<T>(src[((size_t)n * C + c) * HW + hw])) : (bf16)0.f;
+    }
+    bf16* d = dst + pix * c_pad + gidx * G;
+    if (G == 8) {
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = o[e % G];
+      stg16(d, v);
+    } else {
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = o[e % G];
+      *reinterpret_cast<bf16x4*>(d) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = f2bf(src[i]);
+}
+
+__global__ __launch_bounds__(256) void pack_fwd_kernel(const float* __restrict__ src, int k, int r, int s, int c,
+                                                       bf16* __restrict__ dst, int k_pad, int s_pad, int c_pad) {
+  const size_t total = (size_t)k_pad * r * s_pad * c_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c_pad);
+    size_t rest = i / c_pad;
+    const int ss = (int)(rest % s_pad);
+    rest /= s_pad;
+    const int rr = (int)(rest % r);
+    const int kk = (int)(rest / r);
+    float v = 0.f;
+    if (kk < k && ss < s && cc < c) v = src[(((size_t)kk * r + rr) * s + ss) * c + cc];
+    dst[i] = f2bf(v);
+  }
+}
+
+// dst[c][r'][s'][k] = src[k][R-1-r'][S-1-s'][c]
+__global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict__ src, int k, int r, int s, int c,
+                                                         bf16* __restrict__ dst, int k_pad, int c_pad) {
+  const size_t total = (size_t)c_pad * r * s * k_pad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int kk = (int)(i % k_pad);
+    size_t rest = i / k_pad;
+    const int ss = (int)(rest % s);
+    rest /= s;
+    const int rr = (int)(rest % r);
+    const int cc = (int)(rest / r);
+    float v = 0.f;
+    if (kk < k && cc < c) v = src[(((size_t)kk * r + (r - 1 - rr)) * s + (s - 1 - ss)) * c + cc];
+    dst[i] = f2bf(v);
+  }
+}
+
+inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+template <typename T>
+void launch_nchw(const void* src, void* dst, int n, int c, int hw, int c_pad, hipStream_t st) {
+  if (c_pad % 8 == 0) {
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, 8>), dim3(grid_for((size_t)n * hw * (c_pad / 8))), dim3(256), 0,
+                       st, (const T*)src, (bf16*)dst, n, c, hw, c_pad);
+  } else {
+    hipLaunchKernelGGL((nchw_to_nhwc_kernel<T, 4>), dim3(grid_for((size_t)n * hw * (c_pad / 4))), dim3(256), 0,
+                       st, (const T*)src, (bf16*)dst, n, c, hw, c_pad);
+  }
+}
+
+}  // namespace
+
+extern "C" int tok_nchw_to_nhwc_bf16(const void* src, int src_dtype, int n, int c, int h, int w, void* dst,
+                                     int c_pad, void* stream) {
+  TOK_CHECK_ARG(src && dst && n > 0 && c > 0 && h > 0 && w > 0, "tok_nchw_to_nhwc_bf16: bad args");
+  TOK_CHECK_ARG(c_pad >= c && c_pad % 4 == 0, "tok_nchw_to_nhwc_bf16: c_pad=%d must be >= c and a multiple of 4", c_pad);
+  hipStream_t st = tok_stream(stream);
+  switch (src_dtype) {
+    case TOK_F32: launch_nchw<float>(src, dst, n, c, h * w, c_pad, st); break;
+    case TOK_F16: launch_nchw<__half>(src, dst, n, c, h * w, c_pad, st); break;
+    case TOK_BF16: launch_nchw<bf16>(src, dst, n, c, h * w, c_pad, st); break;
+    default: tok_set_error("tok_nchw_to_nhwc_bf16: unknown dtype %d", src_dtype); return TOK_ERR_INVALID;
+  }
+  TOK_CHECK_LAUNCH("tok_nchw_to_nhwc_bf16");
+  return TOK_OK;
+}
+
+extern "C" int tok_cast_f32_bf16(const float* src, void* dst, size_t count, void* stream) {
+  TOK_CHECK_ARG(src && dst && count > 0, "tok_cast_f32_bf16: bad args");
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(count)), dim3(256), 0, tok_stream(stream), src, (bf16*)dst, count);
+  TOK_CHECK_LAUNCH("tok_cast_f32_bf16");
+  return TOK_OK;
+}
+
+extern "C" int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c, void* dst, int k_pad,
+                                   int s_pad, int c_pad, void* stream) {
+  TOK_CHECK_ARG(src && dst && k > 0 && r > 0 && s > 0 && c > 0, "tok_pack_weight_fwd: bad args");
+  TOK_CHECK_ARG(k_pad >= k && s_pad >= s && c_pad >= c, "tok_pack_weight_fwd: pads smaller than dims");
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3(grid_for((size_t)k_pad * r * s_pad * c_pad)), dim3(256), 0,
+                     tok_stream(stream), src, k, r, s, c, (bf16*)dst, k_pad, s_pad, c_pad);
+  TOK_CHECK_LAUNCH("tok_pack_weight_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_pack_weight_dgrad(const float* src, int k, int r, int s, int c, void* dst, int k_pad,
+                                     int c_pad, void* stream) {
+  TOK_CHECK_ARG(src && dst && k > 0 && r > 0 && s > 0 && c > 0, "tok_pack_weight_dgrad: bad args");
+  TOK_CHECK_ARG(k_pad >= k && c_pad >= c, "tok_pack_weight_dgrad: pads smaller than dims");
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for((size_t)c_pad * r * s * k_pad)), dim3(256), 0,
+                     tok_stream(stream), src, k, r, s, c, (bf16*)dst, k_pad, c_pad);
+  TOK_CHECK_LAUNCH("tok_pack_weight_dgrad");
+  return TOK_OK;
+}

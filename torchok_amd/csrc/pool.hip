@@ -1,0 +1,232 @@
+// Pooling kernels, NHWC bf16: 3x3/s2/p1 max-pool (index-exact), global average pool, column sums.
+#include "tok_common.h"
+#include <math.h>
+
+namespace {
+
+// One thread = one output pixel x 8 channels.  argmax = tap index r*3+s of the FIRST maximum in
+// (r, s) scan order over the in-bounds taps; NaN wins (aten max_pool2d: `val > max || isnan(val)`).
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                          uint8_t* __restrict__ argmax, int N, int H,
+                                                          int W, int C, int P, int Q) {
+  const int cg_total = C >> 3;
+  const size_t total = (size_t)N * P * Q * cg_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    size_t pix = i / cg_total;
+    const int q = (int)(pix % Q);
+    pix /= Q;
+    const int p = (int)(pix % P);
+    const int n = (int)(pix / P);
+    float best[8];
+    int idx[8];
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * p - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = 2 * q - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const bf16x8 v = ldg16(x + (((size_t)n * H + h) * W + w) * C + cg * 8);
+        if (first) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; idx[e] = r * 3 + s; }
+          first = false;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(v[e]);
+          if (f > best[e] || f != f) { best[e] = f; idx[e] = r * 3 + s; }
+        }
+      }
+    }
+    bf16x8 o;
+    uint64_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = f2bf(best[e]);
+      packed |= (uint64_t)(idx[e] & 0xff) << (8 * e);
+    }
+    const size_t off = (((size_t)n * P + p) * Q + q) * C + cg * 8;
+    stg16(y + off, o);
+    *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+  }
+}
+
+// Gather formulation (no atomics): each input pixel visits the <= 4 windows that contain it.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict__ dy,
+                                                          const uint8_t* __restrict__ argmax,
+                                                          bf16* dx, int accumulate, int N, int H, int W,
+                                                          int C, int P, int Q) {
+  const int cg_total = C >> 3;
+  const size_t total = (size_t)N * H * W * cg_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    size_t pix = i / cg_total;
+    const int w = (int)(pix % W);
+    pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float g[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    // windows p with 2p-1 <= h <= 2p+1
+    const int p_lo = h >> 1, p_hi = (h + 1) >> 1;
+    const int q_lo = w >> 1, q_hi = (w + 1) >> 1;
+    for (int p = p_lo; p <= p_hi; ++p) {
+      if (p >= P) continue;
+      const int r = h - (2 * p - 1);
+      for (int q = q_lo; q <= q_hi; ++q) {
+        if (q >= Q) continue;
+        const int s = w - (2 * q - 1);
+        const int tap = r * 3 + s;
+        const size_t off = (((size_t)n * P + p) * Q + q) * C + cg * 8;
+        const uint64_t packed = *reinterpret_cast<const uint64_t*>(argmax + off);
+        const bf16x8 d = ldg16(dy + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if ((int)((packed >> (8 * e)) & 0xff) == tap) g[e] += bf2f(d[e]);
+      }
+    }
+    const size_t xoff = (((size_t)n * H + h) * W + w) * C + cg * 8;
+    bf16x8 o;
+    if (accumulate) {
+      const bf16x8 old = ldg16(dx + xoff);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e] + bf2f(old[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(g[e]);
+    }
+    stg16(dx + xoff, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                      int N, int HW, int C, float inv) {
+  const int cg_total = C >> 3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * cg_total) return;
+  const int cg = i % cg_total, n = i / cg_total;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  const bf16* p = x + (size_t)n * HW * C + cg * 8;
+  for (int j = 0; j < HW; ++j) {
+    const bf16x8 v = ldg16(p + (size_t)j * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv);
+  stg16(y + (size_t)n * C + cg * 8, o);
+}
+
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const bf16* __restrict__ dy, bf16* dx, int accumulate,
+                                                      int N, int HW, int C, float inv) {
+  const int cg_total = C >> 3;
+  const size_t total = (size_t)N * HW * cg_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const size_t pix = i / cg_total;
+    const int n = (int)(pix / HW);
+    const bf16x8 d = ldg16(dy + (size_t)n * C + cg * 8);
+    const size_t off = pix * C + cg * 8;
+    bf16x8 o;
+    if (accumulate) {
+      const bf16x8 old = ldg16(dx + off);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(d[e]) * inv + bf2f(old[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(d[e]) * inv);
+    }
+    stg16(dx + off, o);
+  }
+}
+
+// one block per 8-column group; 256 threads stride the rows; fixed-order LDS tree (deterministic)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ dy, int64_t M, int ld,
+                                                     int n_real, float* out, int accumulate) {
+  __shared__ float red[256][8];
+  const int cg = blockIdx.x, tid = threadIdx.x;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int64_t m = tid; m < M; m += 256) {
+    const bf16x8 v = ldg16(dy + (size_t)m * ld + cg * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[tid][e] = acc[e];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[tid][e] += red[tid + s][e];
+    __syncthreads();
+  }
+  if (tid < 8) {
+    const int c = cg * 8 + tid;
+    if (c < n_real) out[c] = accumulate ? out[c] + red[0][tid] : red[0][tid];
+  }
+}
+
+inline int grid_for(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int tok_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int n, int h, int w, int c,
+                                    void* stream) {
+  TOK_CHECK_ARG(x && y && argmax && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_maxpool3x3s2_fwd: bad args");
+  const int P = (h + 2 - 3) / 2 + 1, Q = (w + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)n * P * Q * (c / 8))), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)x, (bf16*)y, argmax, n, h, w, c, P, Q);
+  TOK_CHECK_LAUNCH("tok_maxpool3x3s2_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int accumulate, int n,
+                                    int h, int w, int c, void* stream) {
+  TOK_CHECK_ARG(dy && dx && argmax && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_maxpool3x3s2_bwd: bad args");
+  const int P = (h + 2 - 3) / 2 + 1, Q = (w + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)dy, argmax, (bf16*)dx, accumulate, n, h, w, c, P, Q);
+  TOK_CHECK_LAUNCH("tok_maxpool3x3s2_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_gap_fwd(const void* x, void* y, int n, int hw, int c, void* stream) {
+  TOK_CHECK_ARG(x && y && n > 0 && hw > 0 && c > 0 && c % 8 == 0, "tok_gap_fwd: bad args");
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3((n * (c / 8) + 255) / 256), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)x, (bf16*)y, n, hw, c, 1.0f / (float)hw);
+  TOK_CHECK_LAUNCH("tok_gap_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_gap_bwd(const void* dy, void* dx, int accumulate, int n, int hw, int c, void* stream) {
+  TOK_CHECK_ARG(dy && dx && n > 0 && hw > 0 && c > 0 && c % 8 == 0, "tok_gap_bwd: bad args");
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((size_t)n * hw * (c / 8))), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)dy, (bf16*)dx, accumulate, n, hw, c, 1.0f / (float)hw);
+  TOK_CHECK_LAUNCH("tok_gap_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_colsum(const void* dy, int64_t m, int n_pad, int n_real, float* out, int accumulate,
+                          void* stream) {
+  TOK_CHECK_ARG(dy && out && m > 0 && n_pad > 0 && n_pad % 8 == 0 && n_real <= n_pad, "tok_colsum: bad args");
+  hipLaunchKernelGGL(colsum_kernel, dim3(n_pad / 8), dim3(256), 0, tok_stream(stream), (const bf16*)dy, m,
+                     n_pad, n_real, out, accumulate);
+  TOK_CHECK_LAUNCH("tok_colsum");
+  return TOK_OK;
+}

@@ -1,0 +1,101 @@
+"""Flat parameter arenas.
+
+All parameters handed to a fused optimizer are re-homed into ONE fp32 buffer (`master`), with a
+gradient buffer and optimizer-state buffers of identical layout.  `param.data` / `param.grad`
+become strided views of those buffers, so:
+  * the optimizer step is one kernel launch per run of parameters (normally: one per group),
+  * the data-parallel gradient exchange is a handful of large contiguous RCCL all-reduces
+    (bucket = arena range, dist/ddp.py) instead of one per parameter,
+  * tok_conv_wgrad / tok_bn_bwd_finalize write parameter gradients straight into their final
+    place (engine.core.grad_slot).
+Layout order = optimizer order = module registration order (what the reference hands to
+torch.optim: ``list(modules.parameters())``, constructor/constructor.py:151-152), so gradients
+become ready from the END of the arena towards its start during backward.
+"""
+from typing import Dict, List
+
+import torch
+
+from . import core
+
+ALIGN = 64  # elements (256 B)
+
+
+def _dense(p: torch.Tensor) -> bool:
+    if p.numel() == 0:
+        return False
+    # non-overlapping & dense <=> sorted strides multiply out to numel
+    dims = sorted(zip(p.stride(), p.shape))
+    expect = 1
+    for st, sz in dims:
+        if sz == 1:
+            continue
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
+class ParamArena:
+    def __init__(self, params: List[torch.nn.Parameter], n_state: int = 0):
+        assert len(params) > 0
+        dev = params[0].device
+        self.params = list(params)
+        self.offsets: List[int] = []
+        off = 0
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError('ParamArena: all parameters must be fp32 on one device')
+            if p.dim() == 4 and not p.permute(0, 2, 3, 1).is_contiguous():
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+            if not _dense(p):
+                p.data = p.data.contiguous()
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.state = [torch.zeros(off, dtype=torch.float32, device=dev) for _ in range(n_state)]
+        self.index: Dict[int, int] = {}
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                view = torch.as_strided(self.master, p.shape, p.stride(), o)
+                view.copy_(p.data)
+                gview = torch.as_strided(self.grad, p.shape, p.stride(), o)
+                if p.grad is not None:
+                    gview.copy_(p.grad)
+                    p.grad = gview
+                p.data = view
+                core.register_grad_slot(p, gview)
+                self.index[id(p)] = i
+
+    def span(self, i: int):
+        p = self.params[i]
+        return self.offsets[i], p.numel()
+
+    def padded_end(self, i: int) -> int:
+        return self.offsets[i + 1] if i + 1 < len(self.params) else self.total
+
+    def state_view(self, k: int, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return torch.as_strided(self.state[k], p.shape, p.stride(), self.offsets[i])
+
+    def grad_view(self, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return torch.as_strided(self.grad, p.shape, p.stride(), self.offsets[i])
+
+    def owns_data(self, i: int) -> bool:
+        p = self.params[i]
+        return p.data_ptr() == self.master.data_ptr() + 4 * self.offsets[i]
+
+    def adopt_grad(self, i: int) -> bool:
+        """Make sure params[i].grad (if any) lives in the arena.  Returns False for grad None."""
+        p = self.params[i]
+        if p.grad is None:
+            return False
+        want = self.grad.data_ptr() + 4 * self.offsets[i]
+        if p.grad.data_ptr() != want:
+            gv = self.grad_view(i)
+            gv.copy_(p.grad)
+            p.grad = gv
+        return True

@@ -1,0 +1,311 @@
+"""Execution engine: NHWC-bf16 device tensors, a define-by-run tape per module region, and ONE
+torch.autograd node per region.
+
+Why a tape instead of one autograd.Function per op: the backward of a residual network is
+HBM-bound, and the fan-in of gradients at every residual junction (`x += shortcut` in [timm]
+Bottleneck/BasicBlock) is where an op-by-op autograd engine burns extra passes (a separate
+add kernel, 3 x |S| bytes per block).  The tape knows the consumers of every tensor, so the
+second gradient to arrive is accumulated by the producing kernel's epilogue (`accumulate=1`
+in tok_conv_dgrad / tok_bn_bwd_apply / tok_maxpool3x3s2_bwd), and the masked incoming
+gradient of a residual unit is handed to the shortcut branch without a copy.
+
+PyTorch is used for: device memory (torch.empty), the current HIP stream, the autograd graph
+between regions (backbone -> pooling -> head -> loss).  All arithmetic is in libtok_gfx950.so.
+"""
+import threading
+import weakref
+from typing import List, Optional, Sequence
+
+import torch
+
+from .. import _C
+
+BF16 = torch.bfloat16
+
+
+def pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def stream_ptr():
+    """The HIP stream every kernel of the calling thread is enqueued on (torch's current one)."""
+    if _C.is_fake():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t: torch.Tensor):
+    if t.device.type != 'cuda' and not _C.is_fake():
+        raise RuntimeError(
+            f'torchok_amd executes on MI355X (HIP) devices only, got a tensor on "{t.device}". '
+            f'There is no CPU path: move the task and the batch to cuda.')
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class TTensor:
+    """Engine tensor: bf16, channel-last, channels padded to a multiple of 8.
+
+    data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
+    __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', '__weakref__')
+
+    def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
+        self.data = data
+        self.c = c
+        self.node = node
+        self.grad: Optional[torch.Tensor] = None
+        self.grad_owned = True
+        self.requires_grad = requires_grad
+
+    @property
+    def cp(self) -> int:
+        return self.data.shape[-1]
+
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    def rows(self) -> int:
+        """M of the [M][Cp] matrix view."""
+        return self.data.numel() // self.data.shape[-1]
+
+    def torch_view(self) -> torch.Tensor:
+        """Logical NCHW (or (N, C)) view of the buffer — zero copy."""
+        d = self.data
+        if d.dim() == 4:
+            v = d.permute(0, 3, 1, 2)
+            return v if self.c == self.cp else v[:, :self.c]
+        return d if self.c == self.cp else d[:, :self.c]
+
+
+# ---- gradient fan-in protocol ---------------------------------------------------------------
+
+def grad_target(x: TTensor):
+    """Buffer to write a gradient contribution of `x` into, and whether to accumulate.
+
+    First arrival allocates (accumulate=0); later arrivals add in the producer's epilogue.
+    A gradient tensor that came from outside the region (autograd grad_output) is never
+    written in place: it is cloned first."""
+    if x.grad is None:
+        x.grad = torch.empty_like(x.data)
+        x.grad_owned = True
+        return x.grad, 0
+    if not x.grad_owned:
+        x.grad = x.grad.clone()
+        x.grad_owned = True
+    return x.grad, 1
+
+
+def donate_grad(x: TTensor, buf: torch.Tensor) -> bool:
+    """Hand an already-computed gradient buffer to `x` without a copy (first arrival only)."""
+    if x.grad is None:
+        x.grad = buf
+        x.grad_owned = True
+        return True
+    return False
+
+
+# ---- parameter gradient slots ------------------------------------------------------------------
+# id(param) -> fp32 tensor with the parameter's shape/strides.  A ParamArena (engine/arena.py)
+# pre-registers views of one flat buffer here so that optimizers / all-reduce see one range.
+_grad_slots = {}
+
+
+def register_grad_slot(p: torch.nn.Parameter, slot: torch.Tensor):
+    _grad_slots[id(p)] = (weakref.ref(p), slot)
+
+
+def grad_slot(p: torch.nn.Parameter) -> torch.Tensor:
+    ent = _grad_slots.get(id(p))
+    if ent is not None and ent[0]() is p and ent[1].shape == p.shape and ent[1].device == p.device \
+            and ent[1].stride() == p.stride():
+        return ent[1]
+    slot = torch.empty_like(p, dtype=torch.float32)
+    _grad_slots[id(p)] = (weakref.ref(p), slot)
+    return slot
+
+
+def param_grad_target(p: torch.nn.Parameter):
+    """(slot, accumulate): where the kernel writes dParam.  Call commit_param_grad afterwards."""
+    slot = grad_slot(p)
+    if p.grad is None:
+        return slot, 0
+    if p.grad.data_ptr() == slot.data_ptr():
+        return slot, 1
+    # a foreign .grad tensor (set by user code): compute into the slot, add afterwards
+    return slot, 2
+
+
+def commit_param_grad(p: torch.nn.Parameter, slot: torch.Tensor, mode: int):
+    if mode == 0:
+        p.grad = slot
+    elif mode == 2:
+        p.grad.add_(slot)
+
+
+# ---- regions -----------------------------------------------------------------------------------
+
+_anchors = {}
+_tls = threading.local()
+
+
+def _anchor(device) -> torch.Tensor:
+    a = _anchors.get(device)
+    if a is None:
+        a = torch.zeros(1, device=device, requires_grad=True)
+        _anchors[device] = a
+    return a
+
+
+# data_ptr -> row length of zero-padded 2-D gradient buffers produced by our own loss kernels
+_padded_rows = {}
+
+
+def mark_padded(buf: torch.Tensor):
+    _padded_rows[buf.data_ptr()] = buf.shape[-1]
+
+
+class Node:
+    """One fused unit on the tape."""
+    needs_backward = False
+
+    def backward(self):
+        raise NotImplementedError
+
+    def release(self):
+        pass
+
+
+class Region:
+    """A module-level execution scope: torch tensors in, torch tensors out, a tape in between."""
+
+    def __init__(self):
+        self.nodes: List[Node] = []
+        self.inputs = []  # (TTensor, torch.Tensor) pairs whose torch side requires grad
+        self.grad_mode = torch.is_grad_enabled()
+        self.device = None
+
+    # -- entry ---------------------------------------------------------------------------------
+    def input(self, x: torch.Tensor, c_pad_to: int = 8) -> TTensor:
+        require_device(x)
+        self.device = x.device
+        need = self.grad_mode and x.requires_grad
+        if x.dim() == 4:
+            n, c, h, w = x.shape
+            cp = (c + c_pad_to - 1) // c_pad_to * c_pad_to
+            if x.dtype == BF16 and cp == c and x.permute(0, 2, 3, 1).is_contiguous():
+                data = x.detach().permute(0, 2, 3, 1)
+            else:
+                if need:
+                    raise RuntimeError('torchok_amd: a 4-D region input that requires grad must already be '
+                                       'channels-last bf16 with channels % 8 == 0 (produced by torchok_amd modules)')
+                if x.dtype not in _DT:
+                    raise TypeError(f'unsupported image dtype {x.dtype}')
+                src = x.detach().contiguous()
+                data = torch.empty((n, h, w, cp), dtype=BF16, device=x.device)
+                _C.check(_C.lib().tok_nchw_to_nhwc_bf16(ptr(src), _DT[x.dtype], n, c, h, w, ptr(data), cp,
+                                                        stream_ptr()), 'tok_nchw_to_nhwc_bf16')
+            t = TTensor(data, c, requires_grad=need)
+        elif x.dim() == 2:
+            n, c = x.shape
+            cp = pad8(c)
+            if x.dtype == BF16 and x.stride(1) == 1 and (
+                    (cp == c and x.stride(0) == c) or
+                    (x.stride(0) == cp and _padded_rows.get(x.data_ptr()) == cp)):
+                data = x.detach() if cp == c else torch.as_strided(x.detach(), (n, cp), (cp, 1))
+            else:
+                data = torch.zeros((n, cp), dtype=BF16, device=x.device)
+                data[:, :c] = x.detach()
+            t = TTensor(data, c, requires_grad=need)
+        else:
+            raise ValueError(f'torchok_amd regions take (N,C,H,W) or (N,C) tensors, got {tuple(x.shape)}')
+        if need:
+            self.inputs.append((t, x))
+        return t
+
+    def add(self, node: Node):
+        self.nodes.append(node)
+
+    # -- exit ----------------------------------------------------------------------------------
+    def output(self, *outs: TTensor):
+        need = self.grad_mode and any(o.requires_grad for o in outs)
+        if not need:
+            for n in self.nodes:
+                n.release()
+            self.nodes = []
+            res = tuple(o.torch_view() for o in outs)
+        else:
+            tins = [x for _, x in self.inputs]
+            res = _RegionFn.apply(self, list(outs), _anchor(self.device), *tins)
+        return res[0] if len(res) == 1 else res
+
+    def run_backward(self):
+        for node in reversed(self.nodes):
+            if node.needs_backward:
+                node.backward()
+            node.release()
+        self.nodes = []
+
+
+_DT = {torch.float32: _C.TOK_F32, torch.float16: _C.TOK_F16, torch.bfloat16: _C.TOK_BF16}
+
+
+def _grad_to_engine(t: TTensor, g: torch.Tensor) -> torch.Tensor:
+    """Bring an autograd grad_output into the engine layout of `t` (zero copy when it already is)."""
+    if g.dim() == 4:
+        gp = g.permute(0, 2, 3, 1)
+        if g.dtype == BF16 and t.c == t.cp and gp.is_contiguous():
+            return gp
+        buf = torch.zeros_like(t.data)
+        buf[..., :t.c] = gp
+        return buf
+    n, c = g.shape
+    if g.dtype == BF16 and g.stride(1) == 1:
+        if t.c == t.cp and g.stride(0) == c:
+            return g
+        if g.stride(0) == t.cp and _padded_rows.pop(g.data_ptr(), None) == t.cp:
+            return torch.as_strided(g, (n, t.cp), (t.cp, 1))
+    buf = torch.zeros_like(t.data)
+    buf[:, :t.c] = g
+    return buf
+
+
+class _RegionFn(torch.autograd.Function):
+    """The single autograd node of a region.  Parameter gradients are written straight into
+    their fp32 slots (and `.grad` is pointed at them), so only activation inputs are returned."""
+
+    @staticmethod
+    def forward(ctx, region: Region, outs: Sequence[TTensor], anchor, *tins):
+        ctx.region = region
+        ctx.outs = outs
+        ctx.set_materialize_grads(False)
+        return tuple(o.torch_view() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        region: Region = ctx.region
+        for o, g in zip(ctx.outs, gouts):
+            if g is None:
+                continue
+            ge = _grad_to_engine(o, g)
+            if o.grad is None:
+                o.grad = ge
+                o.grad_owned = False
+            else:  # same tensor returned twice from the region
+                tgt, _ = grad_target(o)
+                tgt.add_(ge)
+        region.run_backward()
+        gins = []
+        for t, x in region.inputs:
+            if t.grad is None:
+                gins.append(None)
+            else:
+                gt = TTensor(t.grad, t.c)
+                gins.append(gt.torch_view())
+                if x.dim() == 2 and t.c != t.cp:
+                    mark_padded(t.grad)
+        ctx.region = None
+        ctx.outs = None
+        return (None, None, None, *gins)

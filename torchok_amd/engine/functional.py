@@ -1,0 +1,378 @@
+"""Fused units recorded on the engine tape.  Each function launches the forward kernels through
+the C ABI and (in grad mode) appends a Node whose ``backward`` launches the backward kernels.
+
+Unit                      replaces (reference / [timm] / ATen)
+------------------------  -------------------------------------------------------------------
+conv_bn_act               conv2d -> batch_norm -> (+ shortcut) -> relu   ([timm] Bottleneck /
+                          BasicBlock / downsample_conv; resnet.py:488-490; convbnact.py:48-53)
+max_pool_3x3_s2           nn.MaxPool2d(3, 2, 1)                          (resnet.py:510)
+global_avg_pool           SelectAdaptivePool2d('avg', flatten=True)      (pooling.py:7-12)
+linear                    nn.Linear                                      (linear_head.py:31)
+"""
+import weakref
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .. import _C
+from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target, pad8,
+                   param_grad_target, ptr, stream_ptr)
+
+F32 = torch.float32
+
+
+# ---- packed bf16 operands of the fp32 master weights ------------------------------------------------
+
+class _Packs:
+    """bf16 MFMA operands derived from one fp32 master weight: the forward pack [Kp][R][Sp][Cp]
+    and the dgrad pack [Cp][R][S][Kp] (flipped taps).  Re-derived whenever `refresh` is asked
+    (every training forward: the optimizer has moved the master since)."""
+    __slots__ = ('fwd', 'dgrad', 'bias', 'key')
+
+    def __init__(self):
+        self.fwd = None
+        self.dgrad = None
+        self.bias = None
+        self.key = None
+
+
+_packs = {}  # id(weight) -> (weakref(weight), _Packs); Tensor.__eq__ rules out a WeakKeyDictionary
+
+
+def _packs_for(weight) -> _Packs:
+    ent = _packs.get(id(weight))
+    if ent is not None and ent[0]() is weight:
+        return ent[1]
+    pk = _Packs()
+    key = id(weight)
+    _packs[key] = (weakref.ref(weight, lambda _r, key=key: _packs.pop(key, None)), pk)
+    return pk
+
+
+def _krsc(weight: torch.Tensor):
+    """(K, R, S, C) of a conv (K,C,R,S) or linear (K,C) master and a guarantee that its
+    physical layout is [k][r][s][c]."""
+    if weight.dim() == 2:
+        if not weight.is_contiguous():
+            raise RuntimeError('linear weight must be contiguous')
+        return weight.shape[0], 1, 1, weight.shape[1]
+    k, c, r, s = weight.shape
+    if not weight.permute(0, 2, 3, 1).is_contiguous():
+        # re-home the master in channels-last order once (logical shape / state_dict unchanged)
+        weight.data = weight.data.contiguous(memory_format=torch.channels_last)
+        if not weight.permute(0, 2, 3, 1).is_contiguous():  # degenerate dims: force strides
+            weight.data = torch.as_strided(weight.data.permute(0, 2, 3, 1).contiguous().view(-1),
+                                           (k, c, r, s), (r * s * c, 1, s * c, c))
+    return k, r, s, c
+
+
+def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: int, cp: int,
+              want_dgrad: bool, refresh: bool) -> _Packs:
+    pk = _packs_for(weight)
+    k, r, s, c = _krsc(weight)
+    key = (weight.data_ptr(), kp, sp, cp, weight.device)
+    lib = _C.lib()
+    st = stream_ptr()
+    stale = refresh or pk.key != key
+    if pk.fwd is None or stale:
+        if pk.fwd is None or pk.key != key:
+            pk.fwd = torch.empty((kp, r, sp, cp), dtype=BF16, device=weight.device)
+        _C.check(lib.tok_pack_weight_fwd(ptr(weight), k, r, s, c, ptr(pk.fwd), kp, sp, cp, st),
+                 'tok_pack_weight_fwd')
+    if want_dgrad and (pk.dgrad is None or stale):
+        if pk.dgrad is None or pk.key != key:
+            pk.dgrad = torch.empty((cp, r, s, kp), dtype=BF16, device=weight.device)
+        _C.check(lib.tok_pack_weight_dgrad(ptr(weight), k, r, s, c, ptr(pk.dgrad), kp, cp, st),
+                 'tok_pack_weight_dgrad')
+    if bias is not None:
+        if kp == k:
+            pk.bias = bias.detach()
+        else:
+            if pk.bias is None or pk.bias.shape[0] != kp:
+                pk.bias = torch.zeros(kp, dtype=F32, device=weight.device)
+            pk.bias[:k] = bias.detach()
+    else:
+        pk.bias = None
+    pk.key = key
+    return pk
+
+
+def _conv_desc(x: TTensor, k_pad: int, r: int, s: int, stride: int, pad: int) -> _C.ConvDesc:
+    if x.data.dim() == 2:      # (N, Cp) rows: the 1x1 / h = w = 1 case (Linear)
+        n, cp = x.shape
+        h = w = 1
+    else:
+        n, h, w, cp = x.shape
+    p = (h + 2 * pad - r) // stride + 1
+    q = (w + 2 * pad - s) // stride + 1
+    return _C.ConvDesc(n, h, w, cp, k_pad, r, s, p, q, stride, pad, 8 if cp == 4 else s)
+
+
+def _check_conv(conv: nn.Conv2d):
+    if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
+        raise NotImplementedError('torchok_amd conv: groups == 1 and dilation == 1 only')
+    if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] \
+            or conv.padding[0] != conv.padding[1] or isinstance(conv.padding, str):
+        raise NotImplementedError('torchok_amd conv: square kernel / stride / padding only')
+    if conv.padding_mode != 'zeros':
+        raise NotImplementedError('torchok_amd conv: zero padding only')
+
+
+# ---- conv + bn + (add) + relu ------------------------------------------------------------------------
+
+class _ConvBnActNode(Node):
+    needs_backward = True
+
+    def __init__(self):
+        self.x = self.out = self.shortcut = None
+        self.y = None
+
+    def release(self):
+        self.x = self.out = self.shortcut = None
+        self.y = self.pk = None
+        self.mean = self.rstd = self.scale = self.shift = None
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        out: TTensor = self.out
+        g = out.grad
+        if g is None:
+            return
+        conv, bn, d = self.conv, self.bn, self.desc
+        m, kp = self.y.numel() // self.y.shape[-1], self.y.shape[-1]
+        x: TTensor = self.x
+        w_need = conv.weight.requires_grad
+        x_need = x.requires_grad
+        bias_need = conv.bias is not None and conv.bias.requires_grad
+        sc: Optional[TTensor] = self.shortcut
+
+        if bn is not None:
+            g_need = bn.weight.requires_grad
+            b_need = bn.bias.requires_grad
+            sc_need = sc is not None and sc.requires_grad
+            out_for_mask = out.data if (self.relu and sc is not None) else None
+            if self.batch_stats:
+                rows = lib.tok_bn_bwd_rows(m, kp)
+                partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
+                _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(out_for_mask), ptr(self.scale),
+                                               ptr(self.shift), ptr(self.mean), ptr(self.rstd),
+                                               int(self.relu), m, kp, ptr(partial), st), 'tok_bn_bwd_reduce')
+                coef = torch.empty((3, kp), dtype=F32, device=g.device)
+                gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
+                bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
+                if gm == 2 or bm == 2 or (gm != bm and g_need and b_need):
+                    # rare mixed state: run the accumulate-free form and fix up on the host side
+                    gacc = torch.empty_like(gs) if g_need else None
+                    bacc = torch.empty_like(bs) if b_need else None
+                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
+                                                     ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, st),
+                             'tok_bn_bwd_finalize')
+                    for p_, acc_ in ((bn.weight, gacc), (bn.bias, bacc)):
+                        if acc_ is not None:
+                            if p_.grad is None:
+                                p_.grad = acc_
+                            else:
+                                p_.grad.add_(acc_)
+                else:
+                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
+                                                     ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
+                                                     1 if (gm == 1 or bm == 1) else 0, st), 'tok_bn_bwd_finalize')
+                    if g_need:
+                        commit_param_grad(bn.weight, gs, gm)
+                    if b_need:
+                        commit_param_grad(bn.bias, bs, bm)
+            else:
+                # eval-mode BN: y -> out is a fixed affine map: dy = scale * dz, dgamma/dbeta unsupported
+                if g_need or b_need:
+                    raise NotImplementedError('gradients of BatchNorm affine parameters in eval mode')
+                coef = torch.zeros((3, kp), dtype=F32, device=g.device)
+                coef[0] = self.scale
+            need_dy = w_need or x_need or bias_need
+            if need_dy or sc_need:
+                dy = torch.empty_like(self.y)
+                ds_ptr, ds_acc = None, 0
+                if sc_need:
+                    if sc.grad is None and out.grad_owned:
+                        # in-place mask of the incoming gradient, then donate it to the shortcut
+                        ds_ptr = ptr(g)
+                        donate_grad(sc, g)
+                    else:
+                        tgt, ds_acc = grad_target(sc)
+                        ds_ptr = ptr(tgt)
+                _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(out_for_mask), ptr(self.scale),
+                                              ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
+                                              ds_acc, m, kp, st), 'tok_bn_bwd_apply')
+            else:
+                dy = None
+        else:
+            dy = g  # plain conv (+bias): the output gradient IS dy
+        out.grad = None
+        if dy is None:
+            return
+        if bias_need:
+            bs, bm = param_grad_target(conv.bias)
+            _C.check(lib.tok_colsum(ptr(dy), m, kp, conv.bias.shape[0], ptr(bs), 1 if bm == 1 else 0, st),
+                     'tok_colsum')
+            commit_param_grad(conv.bias, bs, bm)
+        if w_need:
+            k, r, s, c = _krsc(conv.weight)
+            ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
+            slot, mode = param_grad_target(conv.weight)
+            _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                        1 if mode == 1 else 0, st), 'tok_conv_wgrad')
+            commit_param_grad(conv.weight, slot, mode)
+        if x_need:
+            tgt, acc = grad_target(x)
+            _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+
+
+def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None,
+                relu: bool = False, shortcut: Optional[TTensor] = None) -> TTensor:
+    """out = act(bn(conv(x)) (+ shortcut)).  `conv` is an nn.Conv2d or nn.Linear used purely as
+    the parameter container (state_dict names stay those of the reference)."""
+    lib, st = _C.lib(), stream_ptr()
+    if isinstance(conv, nn.Linear):
+        r = s = 1
+        stride, pad = 1, 0
+        k_real = conv.out_features
+    else:
+        _check_conv(conv)
+        r, s = conv.kernel_size
+        stride, pad = conv.stride[0], conv.padding[0]
+        k_real = conv.out_channels
+    x4 = x
+    kp = pad8(k_real)
+    if bn is not None and kp != k_real:
+        raise NotImplementedError('BatchNorm over a channel count that is not a multiple of 8')
+    d = _conv_desc(x4, kp, r, s, stride, pad)
+    training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or
+                                     (bn is not None and bn.weight.requires_grad))
+    pk = get_packs(conv.weight, conv.bias, kp, d.s_pad, x4.cp, want_dgrad=region.grad_mode and x.requires_grad,
+                   refresh=True)
+    dev = x.data.device
+    y = torch.empty((d.n, d.p, d.q, kp), dtype=BF16, device=dev)
+    m = d.n * d.p * d.q
+    batch_stats = bn is not None and (bn.training or bn.running_mean is None)
+    stats = None
+    if batch_stats:
+        rows = lib.tok_conv_fwd_stat_rows(d)
+        stats = torch.empty((2, rows, kp), dtype=F32, device=dev)
+    _C.check(lib.tok_conv_fwd(d, ptr(x4.data), ptr(pk.fwd), ptr(pk.bias), ptr(y), ptr(stats), st), 'tok_conv_fwd')
+
+    node = _ConvBnActNode()
+    if bn is not None:
+        scale = torch.empty(kp, dtype=F32, device=dev)
+        shift = torch.empty(kp, dtype=F32, device=dev)
+        mean = rstd = None
+        if batch_stats:
+            if bn.momentum is None:
+                raise NotImplementedError('BatchNorm momentum=None (cumulative average)')
+            mean = torch.empty(kp, dtype=F32, device=dev)
+            rstd = torch.empty(kp, dtype=F32, device=dev)
+            track = bn.training and bn.track_running_stats and bn.running_mean is not None
+            _C.check(lib.tok_bn_finalize(ptr(stats), rows, m, kp, ptr(bn.weight), ptr(bn.bias),
+                                         ptr(bn.running_mean) if track else None,
+                                         ptr(bn.running_var) if track else None,
+                                         ptr(bn.num_batches_tracked) if track else None,
+                                         float(bn.momentum), float(bn.eps), ptr(mean), ptr(rstd),
+                                         ptr(scale), ptr(shift), st), 'tok_bn_finalize')
+        else:
+            _C.check(lib.tok_bn_eval_coeffs(ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                            ptr(bn.running_var), float(bn.eps), kp, ptr(scale), ptr(shift), st),
+                     'tok_bn_eval_coeffs')
+        out_data = torch.empty_like(y)
+        _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
+                                    int(relu), ptr(out_data), m, kp, st), 'tok_bn_act_fwd')
+        node.mean, node.rstd, node.scale, node.shift = mean, rstd, scale, shift
+    else:
+        if relu or shortcut is not None:
+            raise NotImplementedError('relu / shortcut without BatchNorm')
+        out_data = y
+    if x.data.dim() == 2:
+        y = y.view(d.n, kp)
+        out_data = out_data.view(d.n, kp)
+
+    req = bool(training or (shortcut is not None and shortcut.requires_grad and region.grad_mode))
+    out = TTensor(out_data, k_real, requires_grad=req)
+    if req:
+        node.x, node.out, node.shortcut, node.y = x, out, shortcut, y
+        node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
+        node.relu, node.batch_stats = relu, batch_stats
+        out.node = node
+        region.add(node)
+    return out
+
+
+def linear(region: Region, x: TTensor, fc: nn.Linear) -> TTensor:
+    """y = x W^T + b on the MFMA conv kernel (1x1, h = w = 1)."""
+    return conv_bn_act(region, x, fc, None, False, None)
+
+
+# ---- max pool ----------------------------------------------------------------------------------------
+
+class _MaxPoolNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        n, h, w, c = self.x.shape
+        tgt, acc = grad_target(self.x)
+        _C.check(_C.lib().tok_maxpool3x3s2_bwd(ptr(g), ptr(self.argmax), ptr(tgt), acc, n, h, w, c, stream_ptr()),
+                 'tok_maxpool3x3s2_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = self.argmax = None
+
+
+def max_pool_3x3_s2(region: Region, x: TTensor) -> TTensor:
+    n, h, w, c = x.shape
+    p, q = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    y = torch.empty((n, p, q, c), dtype=BF16, device=x.data.device)
+    argmax = torch.empty((n, p, q, c), dtype=torch.uint8, device=x.data.device)
+    _C.check(_C.lib().tok_maxpool3x3s2_fwd(ptr(x.data), ptr(y), ptr(argmax), n, h, w, c, stream_ptr()),
+             'tok_maxpool3x3s2_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, x.c, requires_grad=req)
+    if req:
+        node = _MaxPoolNode()
+        node.x, node.out, node.argmax = x, out, argmax
+        out.node = node
+        region.add(node)
+    return out
+
+
+# ---- global average pool --------------------------------------------------------------------------------
+
+class _GapNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        n, h, w, c = self.x.shape
+        tgt, acc = grad_target(self.x)
+        _C.check(_C.lib().tok_gap_bwd(ptr(g), ptr(tgt), acc, n, h * w, c, stream_ptr()), 'tok_gap_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def global_avg_pool(region: Region, x: TTensor) -> TTensor:
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=BF16, device=x.data.device)
+    _C.check(_C.lib().tok_gap_fwd(ptr(x.data), ptr(y), n, h * w, c, stream_ptr()), 'tok_gap_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, x.c, requires_grad=req)
+    if req:
+        node = _GapNode()
+        node.x, node.out = x, out
+        out.node = node
+        region.add(node)
+    return out

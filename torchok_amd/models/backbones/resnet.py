@@ -1,0 +1,252 @@
+"""ResNet backbones on the MI355X engine.
+
+Mirrors the reference wiring ``torchok/models/backbones/resnet.py``: ``make_blocks`` (:363-405),
+``ResNet.__init__`` (:462-526), ``init_weights`` (:529-539), ``forward`` (:541-551), ``get_stages``
+(:553-563) and the ``resnet18/34/50/101/152`` entrypoints (:589-594, :648-653 ...), with the
+[timm 0.6.13] ``BasicBlock`` / ``Bottleneck`` / ``downsample_conv`` semantics restated here
+(SURVEY.md App. A.1).  Module / parameter names are those of timm, so reference checkpoints load.
+
+Execution differs completely: each ``conv -> bn -> (+shortcut) -> relu`` group is ONE engine unit
+(implicit-GEMM MFMA conv with BatchNorm statistics in its epilogue, one fused normalise/add/ReLU
+pass), activations stay NHWC bf16 in HBM between units, and the whole backbone is a single
+autograd node.  The nn.Conv2d / nn.BatchNorm2d children are parameter containers only.
+
+Only the plain (v1.5) family is built: no SE / anti-aliasing / drop-block / avg-down / deep stem
+(the other 84 registered variants of the reference are outside the hot-path scope).
+"""
+import math
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from ... import engine
+from ...constructor import BACKBONES
+from ...engine import functional as EF
+from ..base import BaseBackbone
+
+
+def get_padding(kernel_size: int, stride: int, dilation: int = 1) -> int:
+    return ((stride - 1) + dilation * (kernel_size - 1)) // 2
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, cardinality=1, base_width=64,
+                 reduce_first=1, dilation=1, first_dilation=None, act_layer=nn.ReLU, norm_layer=nn.BatchNorm2d,
+                 attn_layer=None, aa_layer=None, drop_block=None, drop_path=None):
+        super().__init__()
+        assert cardinality == 1 and base_width == 64, 'BasicBlock only supports cardinality=1, base_width=64'
+        _unsupported(dilation=dilation != 1, attn_layer=attn_layer, aa_layer=aa_layer, drop_block=drop_block,
+                     drop_path=drop_path)
+        first_planes = planes // reduce_first
+        outplanes = planes * self.expansion
+        self.conv1 = nn.Conv2d(inplanes, first_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = norm_layer(first_planes)
+        self.act1 = act_layer(inplace=True)
+        self.conv2 = nn.Conv2d(first_planes, outplanes, kernel_size=3, padding=1, bias=False)
+        self.bn2 = norm_layer(outplanes)
+        self.act2 = act_layer(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def zero_init_last(self):
+        nn.init.zeros_(self.bn2.weight)
+
+    def forward(self, x):
+        r = engine.current_region()
+        shortcut = x
+        y = EF.conv_bn_act(r, x, self.conv1, self.bn1, relu=True)
+        if self.downsample is not None:
+            shortcut = EF.conv_bn_act(r, x, self.downsample[0], self.downsample[1], relu=False)
+        return EF.conv_bn_act(r, y, self.conv2, self.bn2, relu=True, shortcut=shortcut)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, cardinality=1, base_width=64,
+                 reduce_first=1, dilation=1, first_dilation=None, act_layer=nn.ReLU, norm_layer=nn.BatchNorm2d,
+                 attn_layer=None, aa_layer=None, drop_block=None, drop_path=None):
+        super().__init__()
+        _unsupported(cardinality=cardinality != 1, dilation=dilation != 1, attn_layer=attn_layer,
+                     aa_layer=aa_layer, drop_block=drop_block, drop_path=drop_path)
+        width = int(math.floor(planes * (base_width / 64)) * cardinality)
+        first_planes = width // reduce_first
+        outplanes = planes * self.expansion
+        self.conv1 = nn.Conv2d(inplanes, first_planes, kernel_size=1, bias=False)
+        self.bn1 = norm_layer(first_planes)
+        self.act1 = act_layer(inplace=True)
+        self.conv2 = nn.Conv2d(first_planes, width, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(width)
+        self.act2 = act_layer(inplace=True)
+        self.conv3 = nn.Conv2d(width, outplanes, kernel_size=1, bias=False)
+        self.bn3 = norm_layer(outplanes)
+        self.act3 = act_layer(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def zero_init_last(self):
+        nn.init.zeros_(self.bn3.weight)
+
+    def forward(self, x):
+        r = engine.current_region()
+        shortcut = x
+        y = EF.conv_bn_act(r, x, self.conv1, self.bn1, relu=True)
+        y = EF.conv_bn_act(r, y, self.conv2, self.bn2, relu=True)
+        if self.downsample is not None:
+            shortcut = EF.conv_bn_act(r, x, self.downsample[0], self.downsample[1], relu=False)
+        return EF.conv_bn_act(r, y, self.conv3, self.bn3, relu=True, shortcut=shortcut)
+
+
+def _unsupported(**flags):
+    bad = [k for k, v in flags.items() if v]
+    if bad:
+        raise NotImplementedError(f'torchok_amd ResNet: {bad} not built (plain v1.5 ResNets only)')
+
+
+def downsample_conv(in_channels, out_channels, kernel_size, stride=1, dilation=1, first_dilation=None,
+                    norm_layer=None):
+    norm_layer = norm_layer or nn.BatchNorm2d
+    kernel_size = 1 if stride == 1 and dilation == 1 else kernel_size
+    first_dilation = (first_dilation or dilation) if kernel_size > 1 else 1
+    p = get_padding(kernel_size, stride, first_dilation)
+    return nn.Sequential(
+        nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=p, dilation=first_dilation,
+                  bias=False),
+        norm_layer(out_channels))
+
+
+def make_blocks(block_fn, channels, block_repeats, inplanes, reduce_first=1, output_stride=32,
+                down_kernel_size=1, avg_down=False, drop_block_rate=0., drop_path_rate=0., **kwargs):
+    _unsupported(avg_down=avg_down, drop_block_rate=drop_block_rate, drop_path_rate=drop_path_rate,
+                 output_stride=output_stride != 32)
+    no_downsample_stages = kwargs.pop('no_downsample_stages', [0])
+    stages, feature_info = [], []
+    net_stride = 4
+    for stage_idx, (planes, num_blocks) in enumerate(zip(channels, block_repeats)):
+        stage_name = f'layer{stage_idx + 1}'
+        stride = 1 if stage_idx in no_downsample_stages else 2
+        net_stride *= stride
+        downsample = None
+        if stride != 1 or inplanes != planes * block_fn.expansion:
+            downsample = downsample_conv(inplanes, planes * block_fn.expansion, kernel_size=down_kernel_size,
+                                         stride=stride, norm_layer=kwargs.get('norm_layer'))
+        blocks = []
+        for block_idx in range(num_blocks):
+            blocks.append(block_fn(inplanes, planes, stride if block_idx == 0 else 1,
+                                   downsample if block_idx == 0 else None, reduce_first=reduce_first, **kwargs))
+            inplanes = planes * block_fn.expansion
+        stages.append((stage_name, nn.Sequential(*blocks)))
+        feature_info.append(dict(num_chs=inplanes, reduction=net_stride, module=stage_name))
+    return stages, feature_info
+
+
+class ResNet(BaseBackbone):
+    def __init__(self, block, layers, in_channels=3, output_stride=32, cardinality=1, base_width=64,
+                 stem_width=64, stem_type='', replace_stem_pool=False, block_reduce_first=1, down_kernel_size=1,
+                 avg_down=False, act_layer=nn.ReLU, norm_layer=nn.BatchNorm2d, aa_layer=None, drop_path_rate=0.,
+                 drop_block_rate=0., zero_init_last=True, block_args=None):
+        super().__init__(in_channels=in_channels)
+        block_args = block_args or dict()
+        if output_stride not in (8, 16, 32):
+            raise ValueError('`output_stride` must be in (8, 16, 32)')
+        _unsupported(stem_type=bool(stem_type), replace_stem_pool=replace_stem_pool, aa_layer=aa_layer,
+                     act_layer=act_layer is not nn.ReLU, norm_layer=norm_layer is not nn.BatchNorm2d)
+        inplanes = 64
+        self.conv1 = nn.Conv2d(in_channels, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(inplanes)
+        self.act1 = act_layer(inplace=True)
+        self.feature_info = [dict(num_chs=inplanes, reduction=2, module='act1')]
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+        channels = [64, 128, 256, 512]
+        stage_modules, stage_feature_info = make_blocks(
+            block, channels, layers, inplanes, cardinality=cardinality, base_width=base_width,
+            output_stride=output_stride, reduce_first=block_reduce_first, avg_down=avg_down,
+            down_kernel_size=down_kernel_size, act_layer=act_layer, norm_layer=norm_layer, aa_layer=aa_layer,
+            drop_block_rate=drop_block_rate, drop_path_rate=drop_path_rate, **block_args)
+        for stage in stage_modules:
+            self.add_module(*stage)
+        self.feature_info.extend(stage_feature_info)
+        self._out_channels = 512 * block.expansion
+        self.create_hooks()
+        self.init_weights(zero_init_last=zero_init_last)
+        # masters live in [k][r][s][c] order (what the MFMA packs and the wgrad kernel use);
+        # logical shapes / state_dict are unchanged
+        self.to(memory_format=torch.channels_last)
+
+    def init_weights(self, zero_init_last=True):
+        for n, m in self.named_modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if zero_init_last:
+            for m in self.modules():
+                if hasattr(m, 'zero_init_last'):
+                    m.zero_init_last()
+
+    def _run(self, r, x: torch.Tensor):
+        t = r.input(x, c_pad_to=4 if x.shape[1] <= 4 else 8)
+        feats = []
+        t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True)
+        feats.append(t)
+        t = EF.max_pool_3x3_s2(r, t)
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            t = layer(t)
+            feats.append(t)
+        return feats
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        with engine.region() as r:
+            feats = self._run(r, x)
+            return r.output(feats[-1])
+
+    def forward_features(self, x: torch.Tensor) -> List[torch.Tensor]:
+        with engine.region() as r:
+            feats = self._run(r, x)
+            outs = r.output(*feats)
+        return [x] + list(outs)
+
+    def get_stages(self, stage: int) -> nn.Module:
+        output = [self.conv1, self.bn1, self.act1, self.maxpool]
+        layers = [self.layer1, self.layer2, self.layer3, self.layer4]
+        return nn.ModuleList(output + layers[:stage])
+
+
+def _create_resnet(variant, pretrained=False, **kwargs):
+    # [timm] build_model_with_cfg: drops kwargs_filter keys, instantiates, loads weights iff pretrained
+    for k in ('num_classes', 'global_pool', 'in_chans'):
+        kwargs.pop(k, None)
+    if pretrained:
+        raise RuntimeError(f'{variant}: pretrained weights need a download (no network here); pass '
+                           f'pretrained=false and use task.load_checkpoint for local checkpoints')
+    return ResNet(**kwargs)
+
+
+@BACKBONES.register_class
+def resnet18(pretrained=False, **kwargs):
+    return _create_resnet('resnet18', pretrained, **dict(block=BasicBlock, layers=[2, 2, 2, 2], **kwargs))
+
+
+@BACKBONES.register_class
+def resnet34(pretrained=False, **kwargs):
+    return _create_resnet('resnet34', pretrained, **dict(block=BasicBlock, layers=[3, 4, 6, 3], **kwargs))
+
+
+@BACKBONES.register_class
+def resnet50(pretrained=False, **kwargs):
+    return _create_resnet('resnet50', pretrained, **dict(block=Bottleneck, layers=[3, 4, 6, 3], **kwargs))
+
+
+@BACKBONES.register_class
+def resnet101(pretrained=False, **kwargs):
+    return _create_resnet('resnet101', pretrained, **dict(block=Bottleneck, layers=[3, 4, 23, 3], **kwargs))
+
+
+@BACKBONES.register_class
+def resnet152(pretrained=False, **kwargs):
+    return _create_resnet('resnet152', pretrained, **dict(block=Bottleneck, layers=[3, 8, 36, 3], **kwargs))

@@ -1,0 +1,211 @@
+"""Fused flat-arena optimizers registered under the reference's names
+(``torchok/optim/optimizers/__init__.py:11,13,18``: SGD, Adam, AdamW) with the constructor
+signatures of torch.optim, so ``Constructor.create_optimizer`` (constructor.py:151-158) drives them
+unchanged: ``OPTIMIZERS.get(name)(parameters, **optimizer_cfg)``.
+
+One tok_sgd_step / tok_adam_step launch updates a whole run of consecutive parameters in the
+arena (engine/arena.py).  Semantics follow torch: parameters whose ``.grad`` is None are skipped,
+momentum buffers start as a copy of the first gradient, Adam keeps a per-parameter step count.
+"""
+from typing import List
+
+import torch
+from torch.optim import Optimizer
+
+from .. import _C
+from ..constructor import OPTIMIZERS
+from ..engine.arena import ParamArena
+from ..engine.core import ptr, require_device, stream_ptr
+
+
+class _ArenaOptimizer(Optimizer):
+    _n_state = 0
+
+    def _build(self):
+        self._arenas: List[ParamArena] = []
+        for group in self.param_groups:
+            params = [p for p in group['params']]
+            if not params:
+                self._arenas.append(None)
+                continue
+            for p in params:
+                require_device(p)
+            self._arenas.append(ParamArena(params, self._n_state))
+        self._built = True
+
+    def _ensure_built(self):
+        if not getattr(self, '_built', False):
+            self._build()
+            return
+        # a module.to()/load that replaced .data detaches parameters from the arena: rebuild
+        for g, a in zip(self.param_groups, self._arenas):
+            if a is not None and (len(a.params) != len(g['params']) or
+                                  any(not a.owns_data(i) for i in range(len(a.params)))):
+                self._rebuild()
+                return
+
+    def _rebuild(self):
+        old_state = {id(p): dict(s) for p, s in self.state.items()}
+        self._build()
+        self._restore_state(old_state)
+
+    def _restore_state(self, old_state):
+        pass
+
+    def _runs(self, arena: ParamArena, key_fn):
+        """Maximal runs of consecutive parameters that have a gradient and share key_fn(i)."""
+        runs = []
+        cur = None
+        for i in range(len(arena.params)):
+            if not arena.adopt_grad(i):
+                cur = None
+                continue
+            k = key_fn(i)
+            if cur is not None and cur[2] == k:
+                cur[1] = i
+            else:
+                cur = [i, i, k]
+                runs.append(cur)
+        return [(a, b, k) for a, b, k in runs]
+
+    def zero_grad(self, set_to_none: bool = True):
+        # keeps torch semantics (default: grads become None; the arena slots are simply rewritten
+        # by the next backward — no memset pass over the gradient arena)
+        super().zero_grad(set_to_none=set_to_none)
+
+
+@OPTIMIZERS.register_class
+class SGD(_ArenaOptimizer):
+    _n_state = 1
+
+    def __init__(self, params, lr=1e-3, momentum=0., dampening=0., weight_decay=0., nesterov=False, *,
+                 maximize: bool = False, foreach=None, differentiable: bool = False, fused=None):
+        if lr < 0.0:
+            raise ValueError(f'Invalid learning rate: {lr}')
+        if momentum < 0.0:
+            raise ValueError(f'Invalid momentum value: {momentum}')
+        if weight_decay < 0.0:
+            raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError('Nesterov momentum requires a momentum and zero dampening')
+        if differentiable:
+            raise NotImplementedError('differentiable optimizers are not supported')
+        defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                        nesterov=nesterov, maximize=maximize)
+        super().__init__(params, defaults)
+
+    def _restore_state(self, old_state):
+        for a in self._arenas:
+            if a is None:
+                continue
+            for i, p in enumerate(a.params):
+                s = old_state.get(id(p))
+                if s and 'momentum_buffer' in s and s['momentum_buffer'] is not None:
+                    a.state_view(0, i).copy_(s['momentum_buffer'])
+                    self.state[p]['momentum_buffer'] = a.state_view(0, i)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._ensure_built()
+        lib, st = _C.lib(), stream_ptr()
+        for group, arena in zip(self.param_groups, self._arenas):
+            if arena is None:
+                continue
+            mom = float(group['momentum'])
+
+            def has_buf(i, arena=arena):
+                return self.state[arena.params[i]].get('momentum_buffer') is not None
+            for a, b, inited in self._runs(arena, has_buf):
+                off = arena.offsets[a]
+                count = arena.padded_end(b) - off
+                _C.check(lib.tok_sgd_step(ptr(arena.master) + 4 * off, ptr(arena.grad) + 4 * off,
+                                          ptr(arena.state[0]) + 4 * off, None, count,
+                                          float(group['lr']), mom, float(group['dampening']),
+                                          float(group['weight_decay']), int(group['nesterov']),
+                                          0 if inited else 1, int(group['maximize']), st), 'tok_sgd_step')
+                if mom != 0 and not inited:
+                    for i in range(a, b + 1):
+                        self.state[arena.params[i]]['momentum_buffer'] = arena.state_view(0, i)
+        return loss
+
+
+class _AdamBase(_ArenaOptimizer):
+    _n_state = 2
+    _decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0., amsgrad=False, *,
+                 foreach=None, maximize: bool = False, capturable: bool = False, differentiable: bool = False,
+                 fused=None):
+        if lr < 0.0:
+            raise ValueError(f'Invalid learning rate: {lr}')
+        if eps < 0.0:
+            raise ValueError(f'Invalid epsilon value: {eps}')
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f'Invalid beta parameters: {betas}')
+        if weight_decay < 0.0:
+            raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        if amsgrad or differentiable or capturable:
+            raise NotImplementedError('amsgrad / differentiable / capturable are not supported')
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize)
+        super().__init__(params, defaults)
+
+    def _restore_state(self, old_state):
+        for a in self._arenas:
+            if a is None:
+                continue
+            for i, p in enumerate(a.params):
+                s = old_state.get(id(p))
+                if s and 'exp_avg' in s:
+                    a.state_view(0, i).copy_(s['exp_avg'])
+                    a.state_view(1, i).copy_(s['exp_avg_sq'])
+                    self.state[p].update(step=s['step'], exp_avg=a.state_view(0, i),
+                                         exp_avg_sq=a.state_view(1, i))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._ensure_built()
+        lib, st = _C.lib(), stream_ptr()
+        for group, arena in zip(self.param_groups, self._arenas):
+            if arena is None:
+                continue
+            b1, b2 = group['betas']
+
+            def step_of(i, arena=arena):
+                return int(self.state[arena.params[i]].get('step', 0))
+            for a, b, t in self._runs(arena, step_of):
+                off = arena.offsets[a]
+                count = arena.padded_end(b) - off
+                _C.check(lib.tok_adam_step(ptr(arena.master) + 4 * off, ptr(arena.grad) + 4 * off,
+                                           ptr(arena.state[0]) + 4 * off, ptr(arena.state[1]) + 4 * off,
+                                           None, count, float(group['lr']), float(b1), float(b2),
+                                           float(group['eps']), float(group['weight_decay']),
+                                           int(self._decoupled), t + 1, int(group['maximize']), st),
+                         'tok_adam_step')
+                for i in range(a, b + 1):
+                    s = self.state[arena.params[i]]
+                    if 'exp_avg' not in s:
+                        s['exp_avg'] = arena.state_view(0, i)
+                        s['exp_avg_sq'] = arena.state_view(1, i)
+                    s['step'] = t + 1
+        return loss
+
+
+@OPTIMIZERS.register_class
+class Adam(_AdamBase):
+    _decoupled = False
+
+
+@OPTIMIZERS.register_class
+class AdamW(_AdamBase):
+    _decoupled = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)

@@ -1,0 +1,2 @@
+from .base import BaseTask  # noqa: F401
+from .classification import ClassificationTask  # noqa: F401

@@ -1,0 +1,88 @@
+"""BaseTask: the Lightning-module surface of the reference (``torchok/tasks/base.py:17-204``)
+without the lightning dependency (absent here).  Same per-step API — ``training_step`` /
+``validation_step`` / ``test_step`` / ``predict_step`` / ``configure_optimizers`` /
+``forward_with_gt`` / ``as_module`` — same return dicts, same example-input buffers
+(``input_tensors_{i}``, :37-43).  ``self.log`` is a cheap recorder (no host sync)."""
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ..constructor.config import Phase
+from ..constructor.constructor import Constructor
+
+
+class BaseTask(nn.Module, ABC):
+    def __init__(self, hparams, inputs=None, **kwargs):
+        super().__init__()
+        self._hparams = hparams
+        self._constructor = Constructor(hparams)
+        self.input_tensor_names = []
+        self.losses = self._constructor.configure_losses() if hparams.get('joint_loss') is not None else None
+        self.metrics_manager = self._constructor.configure_metrics_manager()
+        self.example_input_array = []
+        self.logged: Dict[str, Tensor] = {}
+        self.current_epoch = 0
+        if inputs is not None:
+            for i, input_params in enumerate(inputs):
+                name = f'input_tensors_{i}'
+                self.input_tensor_names.append(name)
+                t = torch.rand(1, *input_params['shape']).type(torch.__dict__[input_params['dtype']])
+                self.example_input_array.append(t)
+                self.register_buffer(name, t)
+
+    @property
+    def hparams(self):
+        return self._hparams
+
+    def log(self, name: str, value, **kwargs) -> None:
+        self.logged[name] = value.detach() if isinstance(value, Tensor) else value
+
+    def log_dict(self, d: Dict[str, Any], **kwargs) -> None:
+        for k, v in d.items():
+            self.log(k, v)
+
+    @abstractmethod
+    def forward(self, *args, **kwargs) -> torch.Tensor:
+        pass
+
+    @abstractmethod
+    def forward_with_gt(self, batch: Dict[str, Any]) -> Dict[str, torch.Tensor]:
+        pass
+
+    @abstractmethod
+    def as_module(self) -> nn.Sequential:
+        pass
+
+    def configure_optimizers(self) -> List[Dict[str, Any]]:
+        return self._constructor.configure_optimizers(list(self.children()))
+
+    def training_step(self, batch: Dict[str, Union[Tensor, int]], batch_idx: int) -> Dict[str, Tensor]:
+        output = self.forward_with_gt(batch)
+        total_loss, tagged_loss_values = self.losses(**output)
+        self.log('loss', total_loss, prog_bar=True, on_step=True)
+        self.metrics_manager.update(Phase.TRAIN, **output)
+        output_dict = {'loss': total_loss}
+        output_dict.update(tagged_loss_values)
+        return output_dict
+
+    def validation_step(self, batch, batch_idx: int, dataloader_idx: int = 0) -> Dict[str, Tensor]:
+        output = self.forward_with_gt(batch)
+        self.metrics_manager.update(Phase.VALID, dataloader_idx, **output)
+        if self._hparams.task.compute_loss_on_valid:
+            total_loss, tagged_loss_values = self.losses(**output)
+            output_dict = {'loss': total_loss}
+            self.log('loss', total_loss, prog_bar=True, on_step=True)
+            output_dict.update(tagged_loss_values)
+        else:
+            output_dict = {}
+        return output_dict
+
+    def test_step(self, batch, batch_idx: int, dataloader_idx: int = 0) -> None:
+        output = self.forward_with_gt(batch)
+        self.metrics_manager.update(Phase.TEST, dataloader_idx, **output)
+
+    def predict_step(self, batch, batch_idx: int, dataloader_idx: int = 0) -> Dict[str, Tensor]:
+        return self.forward_with_gt(batch)
