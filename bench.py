@@ -1,0 +1,199 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): images/sec of the ResNet-50 ClassificationTask training step
+(forward, loss, backward, SGD step, + RCCL gradient all-reduce for N > 1) at 224x224, bf16,
+batch 256 per GPU, synthetic data resident in HBM.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = images all ranks processed / max-over-ranks wall time of
+exactly K steps (barrier + device sync on both sides).  `roofline`: the step is HBM-bound
+(SURVEY.md §8(d)): achieved = algorithmic bytes of one step (309.7 MB/img x per-GPU batch) / the
+average step duration measured with HIP events on the launch stream; peak = 8.0 TB/s.
+`cpu_baseline`: the CPU oracle (oracle/torchok_ref.py, fp32, same step) timed on this box's host
+cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+ALG_BYTES_PER_IMG = {'resnet50': 309.7e6, 'resnet18': 70.6e6}   # SURVEY.md App. C (Model F + weights @B=256)
+HBM_PEAK = 8.0e12
+
+
+def build_task(backbone: str, num_classes: int):
+    import torchok_amd as T
+    from torchok_amd.constructor.config import apply_schema
+    cfg = apply_schema({
+        'task': {'name': 'ClassificationTask',
+                 'params': {'backbone_name': backbone,
+                            'backbone_params': {'pretrained': False, 'in_channels': 3, 'zero_init_last': False},
+                            'pooling_name': 'Pooling', 'head_name': 'ClassificationHead',
+                            'head_params': {'num_classes': num_classes},
+                            'inputs': [{'shape': [3, 224, 224], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        # examples/configs/classification_imagenet.yaml:29-35
+        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.1, 'weight_decay': 1e-4, 'momentum': 0.9}}}],
+        'data': {}, 'trainer': {'precision': 'bf16', 'strategy': 'ddp'},
+    })
+    return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+
+
+def _usable_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a box can
+    show 256 logical CPUs under a much smaller quota; oversubscribing them makes torch crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(backbone: str, num_classes: int, res: int, batch: int = 16, steps: int = 2):
+    """The oracle's training step on the host cores (reported baseline, not the target)."""
+    import oracle.torchok_ref as R
+    threads = _usable_cores()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    ref = R.ClassificationModel(backbone, num_classes, zero_init_last=False).train()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    x = torch.randn(batch, 3, res, res)
+    y = torch.randint(0, num_classes, (batch,))
+    t0 = time.perf_counter()
+    R.training_step(ref, {'image': x, 'target': y}, opt)  # warm-up
+    warm = time.perf_counter() - t0
+    if warm > 15.0:   # keep the default run within minutes on a slow host
+        steps = 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.training_step(ref, {'image': x, 'target': y}, opt)
+    dt = time.perf_counter() - t0
+    return {'value': batch * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'{steps} fp32 steps of the same {backbone} {res}x{res} training step at batch {batch} '
+                      f'(1 warm-up), torch {torch.__version__} CPU'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--backbone', default='resnet50')
+    ap.add_argument('--res', type=int, default=224)
+    ap.add_argument('--classes', type=int, default=1000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    import __graft_entry__ as ge
+    if not os.path.exists(ge.LIB):
+        ge.build()
+
+    torch.manual_seed(1234)
+    task = build_task(args.backbone, args.classes).cuda().train()
+    opt = task.configure_optimizers()[0]['optimizer']
+    reducer = None
+    if world > 1:
+        from torchok_amd.dist import GradientAllReducer
+        reducer = GradientAllReducer(opt)
+
+    g = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    image = torch.randn(args.batch, 3, args.res, args.res, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
+    target = torch.randint(0, args.classes, (args.batch,), generator=g, device='cuda')
+    batch = {'image': image, 'target': target}
+
+    def step(i):
+        out = task.training_step(batch, i)
+        opt.zero_grad(set_to_none=True)
+        if reducer is not None:
+            reducer.begin_step()
+        out['loss'].backward()
+        if reducer is not None:
+            reducer.finish_step()
+        opt.step()
+        return out['loss']
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = args.batch * world * args.steps / dt
+        alg = ALG_BYTES_PER_IMG.get(args.backbone)
+        ev_ms = sum(step_ms) / len(step_ms)
+        roofline = None
+        if alg is not None and args.res == 224:
+            achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                        'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
+                        'launch': 'one training step (all kernels of fwd+bwd+optimizer on the step stream), '
+                                  f'HIP-event avg {ev_ms:.3f} ms'}
+        line = {
+            'metric': 'images/sec (node) ResNet-50 224px bs256/GPU; step p50 ms' if args.backbone == 'resnet50'
+                      else f'images/sec (node) {args.backbone} {args.res}px',
+            'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'step_p50_ms': round(statistics.median(step_ms), 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
+            'data': 'synthetic', 'final_loss': round(final_loss, 4),
+            'config': {'workload': f'{args.backbone} + ClassificationTask(Pooling, ClassificationHead {args.classes}) '
+                                   f'+ CrossEntropyLoss + SGD(momentum 0.9, wd 1e-4), synthetic 3x{args.res}x{args.res} '
+                                   f'bf16, batch {args.batch}/GPU', 'global_batch': args.batch * world,
+                       'parallelism': f'dp{world}'},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

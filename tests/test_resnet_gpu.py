@@ -64,7 +64,7 @@ def test_training_step_vs_oracle(backbone, size, batch, classes):
         if n.endswith('num_batches_tracked'):
             assert int(b) == int(rb[n]) == 1
         else:
-            assert rel_err(b, rb[n]) < 2e-2, n
+            assert rel_err(b, rb[n]) < 5e-2, n   # bf16 conv outputs feed the batch variance
     # optimizer step on the arena == torch.optim.SGD given the same gradients
     with torch.no_grad():
         for n, p in ref.named_parameters():
@@ -82,8 +82,9 @@ def test_training_step_vs_oracle(backbone, size, batch, classes):
     out2['loss'].backward()
     opt.step()
     torch.cuda.synchronize()
+    ref_loss2, _ = R.training_step(ref, {'image': x, 'target': y}, None)   # oracle after the same update
     assert torch.isfinite(out2['loss'])
-    assert float(out2['loss']) < float(out['loss']) + 0.5
+    assert abs(float(out2['loss']) - float(ref_loss2)) < 0.15 * max(1.0, abs(float(ref_loss2)))
 
 
 def test_forward_features_shapes():

@@ -138,11 +138,18 @@ def param_grad_target(p: torch.nn.Parameter):
     return slot, 2
 
 
+# callbacks fired when a parameter's gradient for this backward pass has been enqueued
+# (dist/ddp.py uses them to launch a bucket's all-reduce as soon as its last gradient exists)
+param_grad_hooks = []
+
+
 def commit_param_grad(p: torch.nn.Parameter, slot: torch.Tensor, mode: int):
     if mode == 0:
         p.grad = slot
     elif mode == 2:
         p.grad.add_(slot)
+    for h in param_grad_hooks:
+        h(p)
 
 
 # ---- regions -----------------------------------------------------------------------------------

@@ -22,6 +22,11 @@ from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, 
 F32 = torch.float32
 
 
+def core_hooks():
+    from . import core
+    return core.param_grad_hooks
+
+
 # ---- packed bf16 operands of the fp32 master weights ------------------------------------------------
 
 class _Packs:
@@ -174,6 +179,8 @@ class _ConvBnActNode(Node):
                                 p_.grad = acc_
                             else:
                                 p_.grad.add_(acc_)
+                            for h_ in core_hooks():
+                                h_(p_)
                 else:
                     _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
                                                      ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
