@@ -1,0 +1,169 @@
+"""Host-logic tests (CPU): registries and YAML config — the drop-in boundary of
+reference torchok/constructor/registry.py:10-138, constructor/__init__.py:4-17, config_structure.py."""
+import os
+import textwrap
+
+import pytest
+
+import torchok_amd as T
+from torchok_amd.constructor import registry as reg_mod
+from torchok_amd.constructor.config import load_config
+from torchok_amd.constructor.registry import Registry
+
+
+def test_fourteen_registries_exist():
+    import torchok_amd.constructor as C
+    names = ['DATASETS', 'TRANSFORMS', 'OPTIMIZERS', 'SCHEDULERS', 'LOSSES', 'METRICS', 'CALLBACKS', 'TASKS',
+             'BACKBONES', 'POOLINGS', 'HEADS', 'NECKS', 'DETECTION_NECKS', 'SAMPLERS']
+    for n in names:
+        assert isinstance(getattr(C, n), Registry)
+
+
+def test_registry_semantics():
+    r = Registry('things')
+
+    @r.register_class
+    class Foo:
+        pass
+
+    assert r.get('Foo') is Foo and r['Foo'] is Foo and 'Foo' in r
+    with pytest.raises(KeyError):          # reference registry.py:57-58
+        r.get('Bar')
+    with pytest.raises(KeyError):          # duplicate, :80-81
+        r.register_class(Foo)
+    with pytest.raises(TypeError):         # non-callable, :76-77
+        r.register_class(3)
+    assert 'Foo' in __import__(Foo.__module__, fromlist=['x']).__all__
+
+
+def test_list_models_natural_order_and_filters():
+    names = T.BACKBONES.list_models('resnet*')
+    assert names == ['resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152']  # natural, not lexical
+    assert T.BACKBONES.list_models('resnet*', exclude_filters='resnet1*') == ['resnet34', 'resnet50']
+    assert reg_mod._natural_key('resnet101') == ['resnet', 101, '']
+
+
+def test_hot_path_names_registered():
+    for reg, names in ((T.BACKBONES, ['resnet18', 'resnet50']), (T.POOLINGS, ['Pooling', 'PoolingLinear']),
+                       (T.HEADS, ['LinearHead', 'ClassificationHead']), (T.LOSSES, ['CrossEntropyLoss']),
+                       (T.OPTIMIZERS, ['SGD', 'Adam', 'AdamW']), (T.TASKS, ['ClassificationTask']),
+                       (T.SCHEDULERS, ['ExponentialLR', 'ReduceLROnPlateau'])):
+        for n in names:
+            assert n in reg, n
+
+
+CIFAR_LIKE = textwrap.dedent('''
+    task:
+      name: ClassificationTask
+      params:
+        backbone_name: resnet18
+        backbone_params:
+          pretrained: false
+          in_channels: 3
+        pooling_name: Pooling
+        head_name: ClassificationHead
+        head_params:
+          num_classes: &num_classes 10
+        inputs:
+          - shape: [3, &height 32, &width 32]
+            dtype: &input_dtype float16
+    joint_loss:
+      losses:
+        - name: CrossEntropyLoss
+          mapping:
+              input: prediction
+              target: target
+    optimization:
+      - optimizer:
+          name: Adam
+          params:
+            lr: 0.0001
+        scheduler:
+          name: ExponentialLR
+          params:
+            gamma: 0.97
+    data:
+      TRAIN:
+        - dataloader:
+            batch_size: 128
+          dataset:
+            name: CIFAR10
+            params:
+              data_folder: &data_folder ${oc.env:HOME}/.cache/torchok/cifar10/data
+    trainer:
+      accelerator: 'gpu'
+      precision: 16
+    logger:
+      log_dir: '${oc.env:HOME}/.cache/torchok/cifar10/logs'
+      experiment_name: resnet18
+      timestamp: '${now:%Y-%m-%d}'
+      name: TensorBoardLogger
+    hydra:
+      run:
+        dir: &logs_dir '${logger.log_dir}/${logger.experiment_name}/${logger.timestamp}'
+    callbacks:
+      - name: ModelCheckpoint
+        params:
+          dirpath: *logs_dir
+''')
+
+
+def test_yaml_config_drives_the_task(tmp_path):
+    """The keys/anchors/interpolations of examples/configs/classification_cifar10.yaml."""
+    p = tmp_path / 'cfg.yaml'
+    p.write_text(CIFAR_LIKE)
+    cfg = load_config(str(p))
+    home = os.environ['HOME']
+    assert cfg.data['TRAIN'][0]['dataset']['params']['data_folder'] == f'{home}/.cache/torchok/cifar10/data'
+    assert cfg.callbacks[0].params.dirpath.startswith(f'{home}/.cache/torchok/cifar10/logs/resnet18/20')
+    assert cfg.task.compute_loss_on_valid is True and cfg.task.load_checkpoint is None   # schema defaults
+    assert cfg.optimization[0].scheduler.pl_params.interval == 'epoch'
+    assert cfg.joint_loss.normalize_weights is True and cfg.joint_loss.losses[0].tag is None
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    assert type(task).__name__ == 'ClassificationTask'
+    assert task.input_tensors_0.shape == (1, 3, 32, 32) and str(task.input_tensors_0.dtype) == 'torch.float16'
+    osl = task.configure_optimizers()
+    assert type(osl[0]['optimizer']).__name__ == 'Adam' and len(osl[0]['optimizer'].param_groups) == 1
+    assert type(osl[0]['lr_scheduler']['scheduler']).__name__ == 'ExponentialLR'
+    assert osl[0]['lr_scheduler']['interval'] == 'epoch' and osl[0]['lr_scheduler']['monitor'] == 'val_loss'
+    n_params = sum(p.numel() for p in task.parameters())
+    assert n_params == 11_181_642           # ResNet-18 with a 10-way fc
+
+
+def test_unknown_top_level_key_is_an_error(tmp_path):
+    p = tmp_path / 'cfg.yaml'
+    p.write_text(CIFAR_LIKE + '\nnonsense: 1\n')
+    with pytest.raises(KeyError):
+        load_config(str(p))
+
+
+def test_state_dict_names_match_timm_layout():
+    m = T.BACKBONES.get('resnet50')(pretrained=False)
+    keys = set(m.state_dict())
+    for k in ['conv1.weight', 'bn1.running_mean', 'bn1.num_batches_tracked', 'layer1.0.conv3.weight',
+              'layer1.0.downsample.0.weight', 'layer1.0.downsample.1.running_var', 'layer4.2.bn3.bias']:
+        assert k in keys, k
+    assert sum(p.numel() for p in m.parameters()) == 23_508_032
+    assert m.conv1.weight.shape == (64, 3, 7, 7)          # logical OIHW kept (checkpoint interchange)
+    assert m.out_channels == 2048 and m.out_encoder_channels == (64, 256, 512, 1024, 2048)
+    assert all(float(b.bn3.weight.abs().sum()) == 0 for b in m.layer1)   # zero_init_last default (resnet.py:536-539)
+    with pytest.raises(RuntimeError):
+        T.BACKBONES.get('resnet18')(pretrained=True)
+    with pytest.raises(KeyError):
+        T.BACKBONES.get('resnet18_does_not_exist')
+
+
+def test_paramwise_cfg_groups():
+    """mmcv-style rules of reference constructor.py:163-251."""
+    from torchok_amd.constructor.constructor import Constructor
+    from torchok_amd.constructor.config import to_config
+    m = T.BACKBONES.get('resnet18')(pretrained=False)
+    opt = Constructor.create_optimizer([m], to_config({'name': 'SGD', 'params': {'lr': 0.1, 'weight_decay': 1e-2},
+                                                       'paramwise_cfg': {'norm_decay_mult': 0.0,
+                                                                         'custom_keys': {'layer4': {'lr_mult': 0.1}}}}))
+    groups = opt.param_groups
+    assert len(groups) == len(list(m.parameters()))
+    names = [n for n, _ in m.named_parameters()]
+    by_name = dict(zip(names, groups))
+    assert by_name['bn1.weight']['weight_decay'] == 0.0 and by_name['conv1.weight']['weight_decay'] == 1e-2
+    assert abs(by_name['layer4.0.conv1.weight']['lr'] - 0.01) < 1e-12 and by_name['layer3.0.conv1.weight']['lr'] == 0.1

@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the REFERENCE's own code (runs only where /root/reference
+exists, i.e. in the build container; the fixtures it writes are small data files that travel).
+
+What is executed here is the reference itself, imported through a shim:
+  * `torchok` is registered as a bare package pointing at /root/reference/torchok so that
+    torchok/__init__.py (which imports lightning, albumentations, ...) is NOT executed;
+  * the reference's own files are loaded unmodified: constructor/registry.py, constructor/__init__.py,
+    models/base.py, models/backbones/base_backbone.py, models/backbones/resnet.py (its ResNet class,
+    make_blocks, init_weights, forward), models/poolings/classification/pooling.py,
+    models/heads/representation/linear_head.py, models/heads/classification/classification_head.py,
+    losses/base.py (JointLoss);
+  * the third-party `timm` 0.6.13 (absent offline) is stubbed by oracle/timm_min.py — the
+    restated block semantics; this is the part the reference's tests do not pin.
+The run also asserts that oracle/torchok_ref.py reproduces the reference wiring bit-for-bit on the
+same parameters, i.e. the restatement == reference-files-on-stub-timm.
+
+Parameters are a deterministic function of their state_dict NAME (tests/helpers.py:
+deterministic_state), so any box can rebuild the exact same model without the reference.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+REF = '/root/reference/torchok'
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+from oracle import timm_min  # noqa: E402
+import oracle.torchok_ref as R  # noqa: E402
+from helpers import deterministic_state  # noqa: E402
+
+
+def _fake_pkg(name, path=None):
+    m = types.ModuleType(name)
+    m.__path__ = [path] if path else []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, file, pkg_dir=None):
+    spec = importlib.util.spec_from_file_location(name, file, submodule_search_locations=[pkg_dir] if pkg_dir else None)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def install_shim():
+    # ---- timm stub (restated subset) -------------------------------------------------------
+    import re
+    _fake_pkg('timm')
+    d = _fake_pkg('timm.data')
+    d.IMAGENET_DEFAULT_MEAN, d.IMAGENET_DEFAULT_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    _fake_pkg('timm.models')
+    h = _fake_pkg('timm.models.helpers')
+    h.build_model_with_cfg = timm_min.build_model_with_cfg
+    lay = _fake_pkg('timm.models.layers')
+    lay.BlurPool2d, lay.DropPath, lay.get_attn, lay.GroupNorm = None, timm_min.DropPath, (lambda *a, **k: None), nn.GroupNorm
+    ap = _fake_pkg('timm.models.layers.adaptive_avgmax_pool')
+    ap.SelectAdaptivePool2d = timm_min.SelectAdaptivePool2d
+    rn = _fake_pkg('timm.models.resnet')
+    for n in ('BasicBlock', 'Bottleneck', 'create_aa', 'drop_blocks', 'downsample_avg', 'downsample_conv'):
+        setattr(rn, n, getattr(timm_min, n))
+    ft = _fake_pkg('timm.models.features')
+    ft.FeatureHooks = timm_min.FeatureHooks
+    rg = _fake_pkg('timm.models.registry')
+    rg._natural_key = lambda s: [int(p) if p.isdigit() else p for p in re.split(r'(\d+)', s.lower())]
+    # ---- reference files -------------------------------------------------------------------------
+    _fake_pkg('torchok', REF)
+    _load('torchok.constructor', f'{REF}/constructor/__init__.py', f'{REF}/constructor')
+    _fake_pkg('torchok.models', f'{REF}/models')
+    _load('torchok.models.base', f'{REF}/models/base.py')
+    bb = _fake_pkg('torchok.models.backbones', f'{REF}/models/backbones')
+    bb.BaseBackbone = _load('torchok.models.backbones.base_backbone', f'{REF}/models/backbones/base_backbone.py').BaseBackbone
+    resnet = _load('torchok.models.backbones.resnet', f'{REF}/models/backbones/resnet.py')
+    _fake_pkg('torchok.models.poolings', f'{REF}/models/poolings')
+    _fake_pkg('torchok.models.poolings.classification', f'{REF}/models/poolings/classification')
+    pooling = _load('torchok.models.poolings.classification.pooling', f'{REF}/models/poolings/classification/pooling.py')
+    _fake_pkg('torchok.models.heads', f'{REF}/models/heads')
+    _fake_pkg('torchok.models.heads.representation', f'{REF}/models/heads/representation')
+    _load('torchok.models.heads.representation.linear_head', f'{REF}/models/heads/representation/linear_head.py')
+    _fake_pkg('torchok.models.heads.classification', f'{REF}/models/heads/classification')
+    head = _load('torchok.models.heads.classification.classification_head',
+                 f'{REF}/models/heads/classification/classification_head.py')
+    _fake_pkg('torchok.losses', f'{REF}/losses')
+    losses = _load('torchok.losses.base', f'{REF}/losses/base.py')
+    return resnet, pooling, head, losses
+
+
+class RefTask(nn.Module):
+    """The wiring of reference tasks/classification.py:45-73,90-119 over the reference's own modules."""
+
+    def __init__(self, mods, backbone, num_classes):
+        super().__init__()
+        resnet, pooling, head, _ = mods
+        self.backbone = getattr(resnet, backbone)(pretrained=False, in_channels=3)
+        self.pooling = pooling.Pooling(in_channels=self.backbone.out_channels)
+        self.head = head.ClassificationHead(in_channels=self.pooling.out_channels, num_classes=num_classes)
+
+    def forward_with_gt(self, batch):
+        features = self.backbone(batch['image'])
+        embeddings = self.pooling(features)
+        prediction = self.head(embeddings, batch['target'])
+        return {'embeddings': embeddings, 'prediction': prediction, 'target': batch['target']}
+
+
+def golden_step(mods, backbone, num_classes, batch, size, seed, out_path):
+    torch.manual_seed(seed)
+    task = RefTask(mods, backbone, num_classes).train()
+    task.load_state_dict(deterministic_state(task.state_dict(), seed))
+    ora = R.ClassificationModel(backbone, num_classes).train()
+    ora.load_state_dict(deterministic_state(ora.state_dict(), seed))
+    assert set(ora.state_dict()) == set(task.state_dict()), 'state_dict keys differ: restated wiring != reference'
+
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, num_classes, (batch,), generator=g)
+    JointLoss = mods[3].JointLoss
+    jl = JointLoss([nn.CrossEntropyLoss()], [dict(input='prediction', target='target')], [None], [None])
+    opt = torch.optim.SGD(task.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+
+    feats = task.backbone.forward_features(x)
+    out = task.forward_with_gt({'image': x, 'target': y})
+    total, tagged = jl(**out)
+    total.backward()
+    grads = {n: p.grad.clone() for n, p in task.named_parameters()}
+    opt.step()
+
+    # the restatement must agree with the reference files bit-for-bit (same ATen ops, same order)
+    ofeats = ora.backbone.forward_features(x)
+    oloss, oout = R.training_step(ora, {'image': x, 'target': y},
+                                  torch.optim.SGD(ora.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4))
+    assert all(torch.equal(a, b) for a, b in zip(feats, ofeats))
+    assert torch.equal(out['prediction'], oout['prediction']) and torch.equal(total.detach(), oloss)
+    for (n, p), (n2, p2) in zip(task.named_parameters(), ora.named_parameters()):
+        assert n == n2 and torch.equal(p, p2), n
+    for (n, b), (n2, b2) in zip(task.named_buffers(), ora.named_buffers()):
+        assert n == n2 and torch.equal(b, b2), n
+
+    names = [n for n, _ in task.named_parameters()]
+    small = [n for n in names if task.get_parameter(n).numel() <= 2048]
+    np.savez_compressed(
+        out_path,
+        backbone=backbone, num_classes=num_classes, seed=seed,
+        x=x.numpy(), y=y.numpy(),
+        feat_shapes=np.array([list(f.shape) for f in feats]),
+        feat_sum=np.array([float(f.double().sum()) for f in feats]),
+        feat_sumsq=np.array([float((f.double() ** 2).sum()) for f in feats]),
+        embeddings=out['embeddings'].detach().numpy(), prediction=out['prediction'].detach().numpy(),
+        loss=float(total),
+        param_names=np.array(names),
+        grad_norm=np.array([float(grads[n].double().norm()) for n in names]),
+        post_step_norm=np.array([float(task.get_parameter(n).double().norm()) for n in names]),
+        small_names=np.array(small),
+        **{f'grad__{n}': grads[n].numpy() for n in small},
+        **{f'post__{n}': task.get_parameter(n).detach().numpy() for n in small},
+        bn1_running_mean=task.backbone.bn1.running_mean.numpy(), bn1_running_var=task.backbone.bn1.running_var.numpy(),
+        bn1_nbt=int(task.backbone.bn1.num_batches_tracked),
+    )
+    print(f'wrote {out_path}: loss {float(total):.6f}, {len(names)} params, restatement == reference files: OK')
+
+
+def golden_heads(mods, out_path):
+    _, _, head, losses = mods
+    torch.manual_seed(3)
+    h = head.ClassificationHead(in_channels=32, num_classes=7)
+    h.load_state_dict(deterministic_state(h.state_dict(), 3))
+    x = torch.randn(5, 32, generator=torch.Generator().manual_seed(4))
+    np.savez_compressed(out_path, x=x.numpy(), y=h(x).detach().numpy(),
+                        binary=head.ClassificationHead(in_channels=32, num_classes=1)(x).shape)
+    print('wrote', out_path)
+
+
+def main():
+    mods = install_shim()
+    gd = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(gd, exist_ok=True)
+    golden_step(mods, 'resnet18', 10, 4, 64, 11, os.path.join(gd, 'resnet18_cls_step.npz'))
+    golden_step(mods, 'resnet50', 16, 2, 64, 12, os.path.join(gd, 'resnet50_cls_step.npz'))
+    golden_heads(mods, os.path.join(gd, 'classification_head.npz'))
+
+
+if __name__ == '__main__':
+    main()
