@@ -5,22 +5,46 @@
 // One kernel serves both directions:
 //   fwd   : A gathered from x at (p*stride - pad + r, q*stride - pad + s)
 //   dgrad : "x" is dY, the weights are the flipped/transposed pack ([C][R][S][K]), the gather
-//           runs at stride 1 / pad R-1-pad with an input divisor IN_DIV = conv stride: a tap
-//           contributes only where (h - pad' + r') is divisible by the stride.
+//           runs at stride 1 / pad R-1-pad.  For stride-2 convolutions (IN_DIV = 2) a tap
+//           contributes only where (h - pad' + r') is even: output pixels are enumerated per
+//           PARITY CLASS (h&1, w&1) so that a whole tile shares the parity and K steps whose tap
+//           cannot contribute are skipped outright (no loads, no MFMAs) instead of multiplying
+//           zeros — a 1x1/s2 dgrad touches 1 class in 4, a 3x3/s2 one runs 1+2+2+4 of 36 taps.
 //
 // Tile: BM=128 output pixels x BN in {64,128} channels x BK=64, 256 threads (4 waves),
 // mfma_f32_16x16x32_bf16.  The MFMA "A" operand is the WEIGHT tile and the "B" operand the
-// activation tile, so D[i=channel][j=pixel]: each lane ends up holding 16 CONSECUTIVE output
-// channels of one pixel (rows of the weight tile are fed in the order
-// n = (i>>2)*16 + t*4 + (i&3)), i.e. the epilogue is two 16-byte NHWC stores per pixel and the
-// per-channel BatchNorm partial sums are a 16-lane butterfly.
+// activation tile, so D[i=channel][j=pixel].  Weight rows are fed in the order
+//   n = (t>>1)*32 + (i>>2)*8 + (t&1)*4 + (i&3)          (t = 16-row MFMA tile, i = MFMA row)
+// which leaves lane (g = lane>>4) with channels {h*32 + g*8 + e}: the epilogue is two 16-byte
+// stores per pixel and the four g-lanes of a pixel cover 64 contiguous bytes per instruction.
+// BatchNorm partial sums: recursive-halving butterfly over the 16 pixel-lanes (15 shuffles per
+// quantity; lane li ends up owning channel li of its group).
 //
-// Staging: global -> registers (next tile in flight during the MFMAs of the current one)
-// -> LDS (two buffers, one barrier per K step), 16-byte XOR-swizzled slots so every
-// ds_read_b128 of a fragment is bank-conflict free (see swizzle notes at the reads).
+// Persistent workgroups: each workgroup walks tiles b, b+G, ...; the first K-step loads of the
+// NEXT tile are issued before the epilogue of the current one, so HBM loads stay in flight while
+// the stores drain (the small-K layers of ResNet are a streaming problem, not a GEMM problem).
+// Staging: global -> registers -> LDS (two buffers, one barrier per K step), 16-byte
+// XOR-swizzled slots so every ds_read_b128 of a fragment is bank-conflict free.
 #include "tok_common.h"
+#include <stdlib.h>
 
 namespace {
+
+struct FastDiv {
+  uint32_t mul, shift;
+};
+FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d <= 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+  return (uint32_t)(((uint64_t)__umulhi(n, f.mul) + n) >> f.shift);
+}
 
 struct ConvArgs {
   const bf16* x;
@@ -35,79 +59,155 @@ struct ConvArgs {
   int stride, pad;
   int M, PQ, Ktot, KT;
   int gridM, gridN;
-  int accumulate;
+  int accumulate, uniform_taps;
+  FastDiv fd_pq, fd_q;
+  int stat_rows;   // workgroups per channel tile = rows of the partial-statistics buffer
+  // IN_DIV == 2: per parity class (ph*2 + pw); m-tile index = 4 * (tile inside class) + class
+  int cls_M[4], cls_nw[4], cls_hw[4];
+  FastDiv cls_fd_hw[4], cls_fd_w[4];
 };
 
 constexpr int BK = 64;
 
 __device__ __forceinline__ int fw_swz(int n) {
-  // weight-tile slot swizzle: rows read together by one ds_read_b128 lane group are
-  // n = q*16 + t*4 + i (q,i in 0..3).  h = [0,2,3,1] separates the q's that share a lane
-  // group, bit 2 separates i>>1; (i&1) already lands in the other half of the 256-B row.
-  return ((0x78 >> (((n >> 4) & 3) << 1)) & 3) | (((n >> 1) & 1) << 2);
+  // weight-tile slot swizzle.  One ds_read_b128 lane group reads rows n = c0 + 8q + i (q,i in
+  // 0..3): h = [0,2,3,1] separates the q's that share a lane group, bit 2 separates i>>1, and
+  // (i&1) lands in the other half of the 256-byte bank row.
+  return ((0x78 >> (((n >> 3) & 3) << 1)) & 3) | (((n >> 1) & 1) << 2);
 }
 
 template <int BM, int BN, int IN_DIV, bool C4>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+  // 4 waves.  128x64 tile (the streaming layers): 4 waves along m, a wave owns 32 pixels x 64
+  // channels (8 accumulator tiles), <= 168 registers -> 3 workgroups per CU.  128x128 tile (the
+  // deep-K, MFMA-bound layers): 2 x 2 waves, a wave owns 64 x 64 (16 accumulator tiles: 16 MFMAs
+  // per 8 fragment reads), 2 workgroups per CU.
+  constexpr int NT = 256;
   constexpr int WGN = BN / 64;
-  constexpr int WGM = 4 / WGN;
+  constexpr int WGM = (NT / 64) / WGN;
   constexpr int MT = BM / (WGM * 16);
-  constexpr int AROWS = BM / 32;  // A rows staged per thread
-  constexpr int WROWS = BN / 32;  // W rows staged per thread
+  constexpr int RSTEP = NT / 8;             // rows covered by one staging pass
+  constexpr int AROWS = BM / RSTEP;
+  constexpr int WROWS = BN / RSTEP;
   constexpr int TILE_BYTES = (BM + BN) * BK * 2;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // [2][WGM][BN]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
   const int wn = wv % WGN;
   const int wm = wv / WGN;
-
-  const int tile = tok_xcd_remap(blockIdx.x, a.gridM * a.gridN);
-  const int bm = tile / a.gridN;
-  const int bn = tile - bm * a.gridN;
-  const int m0 = bm * BM;
-  const int n0 = bn * BN;
-
-  // ---- staging assignment: thread -> (16-byte k-chunk kc, rows lrow + 32*i) -----------------
   const int kc = tid & 7;
   const int lrow = tid >> 3;
 
+  // ---- loader state (belongs to the tile whose loads are being issued) ----------------------
   int h0[AROWS], w0[AROWS], pix[AROWS];
-#pragma unroll
-  for (int i = 0; i < AROWS; ++i) {
-    const int m = m0 + lrow + 32 * i;
-    if (m < a.M) {
-      const int b = m / a.PQ;
-      const int rem = m - b * a.PQ;
-      const int p = rem / a.Q;
-      const int q = rem - p * a.Q;
-      h0[i] = p * a.stride - a.pad;
-      w0[i] = q * a.stride - a.pad;
-      pix[i] = b * a.H * a.W;
-    } else {
-      h0[i] = -0x40000000;
-      w0[i] = 0;
-      pix[i] = 0;
-    }
-  }
-  // k-chunk cursor (tap r,s and channel offset c0 of this thread's 8 elements)
-  int kr, ks, kc0;
-  if (C4) {
-    kr = kc >> 2;            // k0 = kc*8 ; r = k0 / 32
-    ks = (kc & 3) << 1;      // s = (k0 % 32) / 4
-    kc0 = 0;
-  } else {
-    const int k0 = kc * 8;
-    const int tap = k0 / a.C;
-    kc0 = k0 - tap * a.C;
-    kr = tap / a.S;
-    ks = tap - kr * a.S;
-  }
-  size_t wk = (size_t)kc * 8;  // offset of this thread's chunk inside a weight row
-
+  int kr, ks, kc0, kt;
+  size_t wk;
+  int par_h = 0, par_w = 0;  // (ph - pad), (pw - pad) of the loader's tile (IN_DIV == 2)
   bf16x8 ra[AROWS], rw[WROWS];
+
+  struct Ctx { int m0, n0, bm, cls; };
+
+  // Tile ownership: workgroup b sits on XCD b % 8.  Inside an XCD the index j = b / 8 splits into
+  // (channel tile bn = j % gridN, m-slot jm = j / gridN); in sweep i the XCD owns the S8 consecutive
+  // m-tiles [i*S + xcd*S8, +S8): neighbouring pixel tiles (3x3 halos) share that XCD's L2, all
+  // channel tiles of one pixel tile run together, and bn never changes for a workgroup (its
+  // BatchNorm partial sums stay in registers across tiles).
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int bn_fixed = jx % a.gridN, jm = jx / a.gridN;
+  const int S8 = (gridDim.x >> 3) / a.gridN;
+  const int sweep = 8 * S8;
+
+  auto setup = [&](int bm) -> Ctx {
+    Ctx c;
+    c.bm = bm;
+    c.n0 = bn_fixed * BN;
+    c.cls = 0;
+    if (IN_DIV == 2) {
+      // class of m-tile bm, rotated per sweep so no workgroup keeps drawing the heavy class
+      c.cls = ((bm & 3) + (bm >> 2) / (sweep >> 2)) & 3;
+      c.m0 = (bm >> 2) * BM;
+      const int ph = c.cls >> 1, pw = c.cls & 1;
+      par_h = ph - a.pad;
+      par_w = pw - a.pad;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int ml = c.m0 + lrow + RSTEP * i;
+        if (ml < a.cls_M[c.cls]) {
+          const uint32_t b = fdiv(ml, a.cls_fd_hw[c.cls]);
+          const uint32_t rem = ml - b * a.cls_hw[c.cls];
+          const uint32_t h2 = fdiv(rem, a.cls_fd_w[c.cls]);
+          const uint32_t w2 = rem - h2 * a.cls_nw[c.cls];
+          h0[i] = 2 * (int)h2 + par_h;
+          w0[i] = 2 * (int)w2 + par_w;
+          pix[i] = b * a.H * a.W;
+        } else {
+          h0[i] = -0x40000000; w0[i] = 0; pix[i] = 0;
+        }
+      }
+    } else {
+      c.m0 = c.bm * BM;
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) {
+        const int m = c.m0 + lrow + RSTEP * i;
+        if (m < a.M) {
+          const uint32_t b = fdiv(m, a.fd_pq);
+          const uint32_t rem = m - b * a.PQ;
+          const uint32_t p = fdiv(rem, a.fd_q);
+          const uint32_t q = rem - p * a.Q;
+          h0[i] = (int)p * a.stride - a.pad;
+          w0[i] = (int)q * a.stride - a.pad;
+          pix[i] = b * a.H * a.W;
+        } else {
+          h0[i] = -0x40000000; w0[i] = 0; pix[i] = 0;
+        }
+      }
+    }
+    // k-chunk cursor of this thread at K step 0
+    if (C4) {
+      kr = kc >> 2; ks = (kc & 3) << 1; kc0 = 0;
+    } else {
+      const int k0 = kc * 8;
+      const int tap = k0 / a.C;   // kc*8 < 64: at most a handful of taps
+      kc0 = k0 - tap * a.C;
+      kr = tap / a.S;
+      ks = tap - kr * a.S;
+    }
+    wk = (size_t)kc * 8;
+    kt = 0;
+    return c;
+  };
+
+  auto advance = [&]() {
+    wk += BK;
+    if (C4) {
+      kr += 2;
+    } else {
+      kc0 += BK;
+      while (kc0 >= a.C) {
+        kc0 -= a.C;
+        if (++ks == a.S) { ks = 0; ++kr; }
+      }
+    }
+  };
+
+  // stride-2 dgrad: skip K steps whose (uniform) tap has the wrong parity for this tile
+  auto seek = [&]() {
+    if (IN_DIV == 2) {
+      if (a.uniform_taps) {
+        while (kt < a.KT) {
+          const int tap = (kt * BK) / a.C;
+          const int r = tap / a.S, s = tap - r * a.S;
+          if ((((par_h + r) | (par_w + s)) & 1) == 0) break;
+          advance();
+          ++kt;
+        }
+      }
+    }
+  };
 
   auto load_tile = [&]() {
     const bool kvalid = kr < a.R;
@@ -123,12 +223,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
       ok = ok && ((unsigned)hh < (unsigned)a.H);
       if (C4) {
-        const bf16* ptr = a.x + ((size_t)(pix[i] + hh * a.W + ww)) * 4;
-        const bool ok0 = ok && ((unsigned)ww < (unsigned)a.W);
-        const bool ok1 = ok && ((unsigned)(ww + 1) < (unsigned)a.W);
         bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
-        if (ok0) lo = *reinterpret_cast<const bf16x4*>(ptr);
-        if (ok1) hi = *reinterpret_cast<const bf16x4*>(ptr + 4);
+        if (ok) {
+          const bf16* ptr = a.x + ((size_t)(pix[i] + hh * a.W + ww)) * 4;
+          if ((unsigned)ww < (unsigned)a.W) lo = *reinterpret_cast<const bf16x4*>(ptr);
+          if ((unsigned)(ww + 1) < (unsigned)a.W) hi = *reinterpret_cast<const bf16x4*>(ptr + 4);
+        }
         bf16x8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
@@ -142,21 +242,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-      const int n = n0 + lrow + 32 * j;
+      const int n = bn_fixed * BN + lrow + RSTEP * j;
       bf16x8 v = zero8();
       if (kvalid && n < a.K) v = ldg16(a.w + (size_t)n * a.Ktot + wk);
       rw[j] = v;
-    }
-    // advance the cursor by BK
-    wk += BK;
-    if (C4) {
-      kr += 2;
-    } else {
-      kc0 += BK;
-      while (kc0 >= a.C) {
-        kc0 -= a.C;
-        if (++ks == a.S) { ks = 0; ++kr; }
-      }
     }
   };
 
@@ -165,39 +254,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     char* Wb = Ab + BM * BK * 2;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
-      const int row = lrow + 32 * i;
+      const int row = lrow + RSTEP * i;
       *reinterpret_cast<bf16x8*>(Ab + row * 128 + ((kc ^ (row & 7)) << 4)) = ra[i];
     }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-      const int row = lrow + 32 * j;
+      const int row = lrow + RSTEP * j;
       *reinterpret_cast<bf16x8*>(Wb + row * 128 + ((kc ^ fw_swz(row)) << 4)) = rw[j];
     }
   };
 
-  // ---- fragment addressing ------------------------------------------------------------------
+  // ---- fragment addressing (lane constants) -------------------------------------------------------
   const int sl = lane >> 4;
   const int li = lane & 15;
-  // weight rows fed to MFMA row i (= li): n = (li>>2)*16 + t*4 + (li&3)
-  const int wrow0 = wn * 64 + (li >> 2) * 16 + (li & 3);
+  // weight row of MFMA tile t fed by this lane: wn*64 + (t>>1)*32 + (li>>2)*8 + (t&1)*4 + (li&3)
+  const int wrow0 = wn * 64 + (li >> 2) * 8 + (li & 3);
   const int wswz = fw_swz(wrow0);
   const int arow0 = wm * (MT * 16) + li;
   const int aswz = li & 7;
 
+  float s1[16], s2[16];   // per-lane BatchNorm partial sums of this workgroup's channel tile
+#pragma unroll
+  for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+
   f32x4 acc[4][MT];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
 
-  load_tile();
-  store_tile(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < a.KT; ++kt) {
-    const bool more = (kt + 1) < a.KT;
-    if (more) load_tile();
-    const char* Ab = smem + (kt & 1) * TILE_BYTES;
+  auto compute = [&](int buf) {
+    const char* Ab = smem + buf * TILE_BYTES;
     const char* Wb = Ab + BM * BK * 2;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -205,7 +294,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int s = sl + 4 * kk;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        wf[t] = *reinterpret_cast<const bf16x8*>(Wb + (wrow0 + t * 4) * 128 + ((s ^ wswz) << 4));
+        wf[t] = *reinterpret_cast<const bf16x8*>(Wb + (wrow0 + (t >> 1) * 32 + (t & 1) * 4) * 128 +
+                                                 ((s ^ wswz) << 4));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
         af[mt] = *reinterpret_cast<const bf16x8*>(Ab + (arow0 + mt * 16) * 128 + ((s ^ aswz) << 4));
@@ -215,96 +305,193 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], af[mt], acc[t][mt], 0, 0, 0);
     }
-    if (more) store_tile((kt + 1) & 1);
-    __syncthreads();
-  }
+  };
 
-  // ---- epilogue: lane (sl, li) holds channels nb..nb+15 of pixels m0 + arow0 + mt*16 ----------
-  const int nb = n0 + wn * 64 + sl * 16;
-  float bias_v[16];
+  // epilogue of one finished tile: lane (sl, li) holds channels nb + {0..7} and nb + 32 + {0..7}
+  auto epilogue = [&](const Ctx& ctx) {
+    const int nb = ctx.n0 + wn * 64 + sl * 8;
+    if (a.bias != nullptr) {
 #pragma unroll
-  for (int c = 0; c < 16; ++c) bias_v[c] = (a.bias != nullptr && nb + c < a.K) ? a.bias[nb + c] : 0.f;
-
-  float s1[16], s2[16];
+      for (int c = 0; c < 16; ++c) {
+        const int n = nb + (c >> 3) * 32 + (c & 7);
+        const float bv = n < a.K ? a.bias[n] : 0.f;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-
+        for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
+      }
+    }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = m0 + arow0 + mt * 16;
-    if (m < a.M) {
-      bf16* yp = a.y + (size_t)m * a.K + nb;
-      float v[16];
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ml = ctx.m0 + arow0 + mt * 16;
+      size_t opix;
+      bool rowok;
+      if (IN_DIV == 2) {
+        rowok = ml < a.cls_M[ctx.cls];
+        const uint32_t mm = rowok ? ml : 0;
+        const uint32_t b = fdiv(mm, a.cls_fd_hw[ctx.cls]);
+        const uint32_t rem = mm - b * a.cls_hw[ctx.cls];
+        const uint32_t h2 = fdiv(rem, a.cls_fd_w[ctx.cls]);
+        const uint32_t w2 = rem - h2 * a.cls_nw[ctx.cls];
+        opix = ((size_t)b * a.P + (2 * h2 + (ctx.cls >> 1))) * a.Q + (2 * w2 + (ctx.cls & 1));
+      } else {
+        rowok = ml < a.M;
+        opix = (size_t)ml;
+      }
+      if (rowok) {
+        bf16* yp = a.y + opix * a.K + nb;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int half = 0; half < 2; ++half) {
+          if (nb + half * 32 + 8 <= a.K) {
+            bf16x8 o;
+            if (a.accumulate) {
+              const bf16x8 old = ldg16(yp + half * 32);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[t * 4 + r] = acc[t][mt][r] + bias_v[t * 4 + r];
+              for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[half * 2 + (e >> 2)][mt][e & 3] + bf2f(old[e]));
+            } else {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (nb + half * 8 + 8 <= a.K) {
-          bf16x8 o;
-          if (a.accumulate) {
-            const bf16x8 old = ldg16(yp + half * 8);
+              for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[half * 2 + (e >> 2)][mt][e & 3]);
+            }
+            stg16(yp + half * 32, o);
+            if (a.stats != nullptr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[half * 8 + e] + bf2f(old[e]));
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[half * 8 + e]);
-          }
-          stg16(yp + half * 8, o);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float f = bf2f(o[e]);
-            s1[half * 8 + e] += f;
-            s2[half * 8 + e] += f * f;
+              for (int e = 0; e < 8; ++e) {
+                const float f = bf2f(o[e]);
+                s1[half * 8 + e] += f;
+                s2[half * 8 + e] += f * f;
+              }
+            }
           }
         }
       }
     }
+  };
+
+  // ---- one software pipeline over the flattened (tile, K step) sequence of this workgroup ----------
+  // iteration: issue the loads of the NEXT stage (next K step, or the first K step of the next
+  // tile), run the MFMAs of the current stage out of LDS, drain a finished tile through the epilogue,
+  // then park the landed registers in the other LDS buffer.  The next stage's HBM latency is hidden
+  // behind compute + epilogue of the current one, also across tile seams.  (Single call site per
+  // phase on purpose: duplicated bodies push hipcc into spilling inside the loop, and a scratch
+  // reload's vmcnt(0) would drain the prefetch.)
+  int it = xcd * S8 + jm;
+  bool any = it < a.gridM;   // a workgroup without tiles still owns a (zero) statistics row
+  Ctx cur = {0, bn_fixed * BN, 0, 0};
+  bool cur_has = false;
+  if (any) {
+    cur = setup(it);
+    seek();
+    cur_has = kt < a.KT;
+    if (cur_has) { load_tile(); store_tile(0); }
+  }
+  __syncthreads();
+  zero_acc();
+  int buf = 0;
+  while (any) {
+    bool tile_done, nxt_has, any_next = true;
+    Ctx nxt = cur;
+    if (cur_has) { advance(); ++kt; seek(); }
+    if (kt < a.KT) {
+      tile_done = false;
+      nxt_has = true;
+    } else {
+      tile_done = true;
+      it += sweep;
+      any_next = it < a.gridM;
+      nxt_has = false;
+      if (any_next) {
+        nxt = setup(it);
+        seek();
+        nxt_has = kt < a.KT;
+      }
+    }
+    if (nxt_has) load_tile();
+    if (cur_has) compute(buf);
+    if (tile_done) {
+      epilogue(cur);
+      zero_acc();
+    }
+    if (nxt_has) store_tile(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    any = !(tile_done && !any_next);
+    cur = nxt;
+    cur_has = nxt_has;
   }
 
+  // ---- BatchNorm partial sums of everything this workgroup produced -> one row per workgroup ----
   if (a.stats != nullptr) {
-    // butterfly over the 16 pixel-lanes that share this lane's channel group
+    // recursive halving over the 16 pixel-lanes: after the 4 steps lane li owns channel li
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int step = 0; step < 4; ++step) {
+      const int off = 8 >> step;
+      const int cnt = 8 >> step;
+      const bool up = (li & off) != 0;
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        s1[c] += __shfl_xor(s1[c], off, 64);
-        s2[c] += __shfl_xor(s2[c], off, 64);
+      for (int j = 0; j < cnt; ++j) {
+        const float send1 = up ? s1[j] : s1[j + cnt];
+        const float send2 = up ? s2[j] : s2[j + cnt];
+        const float keep1 = up ? s1[j + cnt] : s1[j];
+        const float keep2 = up ? s2[j + cnt] : s2[j];
+        s1[j] = keep1 + __shfl_xor(send1, off, 64);
+        s2[j] = keep2 + __shfl_xor(send2, off, 64);
       }
     }
-    float* red = reinterpret_cast<float*>(smem);  // [2][WGM][BN]; tiles are dead (barrier above)
-    if (li == 0) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        red[(0 * WGM + wm) * BN + wn * 64 + sl * 16 + c] = s1[c];
-        red[(1 * WGM + wm) * BN + wn * 64 + sl * 16 + c] = s2[c];
-      }
-    }
+    const int nl = wn * 64 + (li >> 3) * 32 + sl * 8 + (li & 7);
+    red[(0 * WGM + wm) * BN + nl] = s1[0];
+    red[(1 * WGM + wm) * BN + nl] = s2[0];
     __syncthreads();
-    if (tid < 2 * BN) {
+    if (tid < 2 * BN) {   // NT >= 2*BN
       const int which = tid / BN;
       const int c = tid - which * BN;
       float t = 0.f;
 #pragma unroll
       for (int w_ = 0; w_ < WGM; ++w_) t += red[(which * WGM + w_) * BN + c];
-      if (n0 + c < a.K) a.stats[((size_t)which * a.gridM + bm) * a.K + n0 + c] = t;
+      const int row = xcd * S8 + jm;
+      const int n = bn_fixed * BN + c;
+      if (n < a.K) a.stats[((size_t)which * a.stat_rows + row) * a.K + n] = t;
     }
   }
 }
 
+// Persistent grid: 2 (128x128 tile) or 3 (128x64) workgroups per CU, rounded to a multiple of
+// 8 * gridN so every XCD holds whole (channel tile, m-slot) groups; never more than the tiles need.
+int plan_grid(int bn_tile, int gridM, int gridN) {
+  const int unit = 8 * gridN;
+  int G = 256 * (bn_tile == 64 ? 3 : 2);
+  const long long need = (long long)gridM * gridN;
+  if (need < G) G = (int)((need + unit - 1) / unit) * unit;
+  G = G / unit * unit;
+  if (G < unit) G = unit;
+  return G;
+}
+
 template <int BM, int BN, int IN_DIV, bool C4>
-int launch(const ConvArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * BK * 2;
+int launch(ConvArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * (BM + BN) * BK * 2 + 2 * 4 * BN * 4;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, IN_DIV, C4>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, IN_DIV, C4>), dim3(a.gridM * a.gridN), dim3(256),
-                     smem, st, a);
+  const int grid = plan_grid(BN, a.gridM, a.gridN);
+  a.stat_rows = grid / a.gridN;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, IN_DIV, C4>), dim3(grid), dim3(256), smem, st, a);
   return 0;
+}
+
+// experiment knob: TOK_BN64=1 forces the 128x64 tile for every layer
+static int force_bn64() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_BN64"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v;
+}
+
+// Channel-tile width.  Short-K layers are HBM-streaming problems: the 128x64 tile (4 waves, 3
+// workgroups per CU) keeps more loads/stores in flight; deep-K layers are MFMA-bound and want the
+// 128x128 tile's operand reuse.  (Measured on the ResNet-50 shapes, tools/bench_conv.py.)
+int pick_bn(int n_out, int ktot) {
+  if (n_out <= 64 || force_bn64()) return 64;
+  return ktot <= 768 ? 64 : 128;
 }
 
 int check_desc(const tok_conv_desc* d, const char* who) {
@@ -327,25 +514,28 @@ int check_desc(const tok_conv_desc* d, const char* who) {
 
 extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   if (check_desc(d, "tok_conv_fwd_stat_rows")) return TOK_ERR_INVALID;
-  return tok_cdiv((long long)d->n * d->p * d->q, 128);
+  const int gridM = tok_cdiv((long long)d->n * d->p * d->q, 128);
+  const int bn_tile = pick_bn(d->k, d->r * d->s_pad * d->c);
+  const int gridN = tok_cdiv(d->k, bn_tile);
+  return plan_grid(bn_tile, gridM, gridN) / gridN;
 }
 
 extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w,
                             const float* bias, void* y, float* stats, void* stream) {
   if (int e = check_desc(d, "tok_conv_fwd")) return e;
   TOK_CHECK_ARG(x && w && y, "tok_conv_fwd: null pointer");
-  ConvArgs a;
+  ConvArgs a = {};
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.bias = bias; a.stats = stats;
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad;
   a.P = d->p; a.Q = d->q; a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q;
   a.Ktot = d->r * d->s_pad * d->c; a.KT = tok_cdiv(a.Ktot, BK);
   a.gridM = tok_cdiv(a.M, 128);
-  a.accumulate = 0;
+  a.fd_pq = make_fastdiv(a.PQ); a.fd_q = make_fastdiv(a.Q);
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (d->k <= 64) {
-    a.gridN = 1;
+  if (pick_bn(d->k, a.Ktot) == 64) {
+    a.gridN = tok_cdiv(d->k, 64);
     if (c4) launch<128, 64, 1, true>(a, st); else launch<128, 64, 1, false>(a, st);
   } else {
     a.gridN = tok_cdiv(d->k, 128);
@@ -362,19 +552,37 @@ extern "C" int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void
   TOK_CHECK_ARG(d->c % 8 == 0, "tok_conv_dgrad: c4 (stem) input needs no data gradient");
   TOK_CHECK_ARG(d->stride == 1 || d->stride == 2, "tok_conv_dgrad: stride %d unsupported", d->stride);
   TOK_CHECK_ARG(d->r - 1 - d->pad >= 0, "tok_conv_dgrad: pad > r-1 unsupported");
-  ConvArgs a;
+  TOK_CHECK_ARG(d->r == d->s, "tok_conv_dgrad: square filters only");
+  ConvArgs a = {};
   a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr; a.stats = nullptr;
   // gathered tensor = dY (P x Q x K), output = dX (H x W x C)
   a.H = d->p; a.W = d->q; a.C = d->k; a.K = d->c; a.R = d->r; a.S = d->s;
   a.P = d->h; a.Q = d->w; a.stride = 1; a.pad = d->r - 1 - d->pad;
-  TOK_CHECK_ARG(d->s - 1 - d->pad == a.pad, "tok_conv_dgrad: square filters only");
   a.M = d->n * d->h * d->w; a.PQ = d->h * d->w;
   a.Ktot = d->r * d->s * d->k; a.KT = tok_cdiv(a.Ktot, BK);
-  a.gridM = tok_cdiv(a.M, 128);
+  a.fd_pq = make_fastdiv(a.PQ); a.fd_q = make_fastdiv(a.Q);
   a.accumulate = accumulate;
+  a.uniform_taps = (d->k % BK == 0) ? 1 : 0;
+  if (d->stride == 1) {
+    a.gridM = tok_cdiv(a.M, 128);
+  } else {
+    int tmax = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      const int nh = (d->h - ph + 1) / 2, nw = (d->w - pw + 1) / 2;
+      a.cls_M[cls] = d->n * nh * nw;
+      a.cls_nw[cls] = nw;
+      a.cls_hw[cls] = nh * nw;
+      a.cls_fd_hw[cls] = make_fastdiv(nh * nw > 0 ? nh * nw : 1);
+      a.cls_fd_w[cls] = make_fastdiv(nw > 0 ? nw : 1);
+      const int t = tok_cdiv(a.cls_M[cls], 128);
+      if (t > tmax) tmax = t;
+    }
+    a.gridM = 4 * tmax;   // classes interleaved (m-tile & 3) so heavy and light tiles mix on every XCD
+  }
   hipStream_t st = tok_stream(stream);
-  if (d->c <= 64) {
-    a.gridN = 1;
+  if (pick_bn(d->c, a.Ktot) == 64) {
+    a.gridN = tok_cdiv(d->c, 64);
     if (d->stride == 1) launch<128, 64, 1, false>(a, st); else launch<128, 64, 2, false>(a, st);
   } else {
     a.gridN = tok_cdiv(d->c, 128);

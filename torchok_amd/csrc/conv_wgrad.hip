@@ -222,6 +222,47 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// no padding anywhere: dw and the partial slabs share one flat index space.  A block owns 64
+// consecutive floats (16 float4 columns); its 16 thread-rows stride the split dimension so the
+// partial slabs are read with independent, coalesced 256-byte segments; fixed-order LDS tree.
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int splitM, size_t slab, int accumulate) {
+  __shared__ float4 red[16][16];
+  const int col = threadIdx.x & 15, row = threadIdx.x >> 4;
+  const size_t n4 = slab >> 2;
+  for (size_t base = (size_t)blockIdx.x * 16; base < n4; base += (size_t)gridDim.x * 16) {
+    const size_t i = base + col;
+    float4 t = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4) {
+#pragma unroll 4
+      for (int sp = row; sp < splitM; sp += 16) {
+        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)sp * slab)[i];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+    }
+    red[row][col] = t;
+    __syncthreads();
+    for (int s_ = 8; s_ > 0; s_ >>= 1) {
+      if (row < s_) {
+        const float4 o = red[row + s_][col];
+        float4 m = red[row][col];
+        m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
+        red[row][col] = m;
+      }
+      __syncthreads();
+    }
+    if (row == 0 && i < n4) {
+      float4 r = red[0][col];
+      if (accumulate) {
+        const float4 o = reinterpret_cast<const float4*>(dw)[i];
+        r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+      }
+      reinterpret_cast<float4*>(dw)[i] = r;
+    }
+    __syncthreads();
+  }
+}
+
 struct Plan {
   int TN, TK, tilesN, tilesK, splitM, mchunk;
 };
@@ -238,6 +279,7 @@ Plan make_plan(const tok_conv_desc* d) {
   long long split = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
   const long long max_split = (M + 255) / 256;   // at least 8 steps of 32 rows per workgroup
   if (split > max_split) split = max_split;
+  if (split > 256) split = 256;
   if (split < 1) split = 1;
   long long chunk = (M + split - 1) / split;
   chunk = ((chunk + 31) / 32) * 32;
@@ -274,8 +316,11 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
     tok_set_error("tok_conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     return TOK_ERR_WORKSPACE;
   }
+  const bool flat = (k_real == d->k) && (c_real == d->c) && (d->s_pad == d->s) &&
+                    (((size_t)d->k * d->r * d->s * d->c) % 4 == 0) && (((uintptr_t)dw & 15) == 0);
+  const bool direct = flat && p.splitM == 1 && !accumulate;   // single chunk: write dW in place
   WgradArgs a;
-  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.ws = (float*)ws;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.ws = direct ? dw : (float*)ws;
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad; a.P = d->p; a.Q = d->q;
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q; a.HW = d->h * d->w;
@@ -293,6 +338,15 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
     if (c4) launch_wgrad<64, 64, true>(a, st); else launch_wgrad<64, 64, false>(a, st);
   }
   TOK_CHECK_LAUNCH("tok_conv_wgrad");
+  if (direct) return TOK_OK;
+  if (flat) {
+    const size_t slab = (size_t)d->k * d->r * d->s * d->c;
+    const size_t nb = (slab / 4 + 15) / 16;
+    hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, st,
+                       (const float*)ws, dw, p.splitM, slab, accumulate);
+    TOK_CHECK_LAUNCH("tok_conv_wgrad(reduce)");
+    return TOK_OK;
+  }
   const size_t total = (size_t)k_real * d->r * d->s * c_real;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw,
