@@ -71,7 +71,10 @@ def deterministic_state(state_dict, seed: int):
         elif v.dim() == 2:
             out[k] = torch.randn(v.shape, generator=g) * 0.05
         elif k.endswith('.weight'):       # BN gamma
-            out[k] = 1.0 + torch.randn(v.shape, generator=g) * 0.1
+            last = k.endswith('bn3.weight') or (k.endswith('bn2.weight') and k.replace('bn2', 'bn3') not in state_dict)
+            # the residual branch's last gamma is kept small (the reference initialises it to 0,
+            # resnet.py:536-539): non-degenerate, yet as well conditioned as a real network
+            out[k] = (0.25 if last else 1.0) + torch.randn(v.shape, generator=g) * (0.05 if last else 0.1)
         elif k.startswith('input_tensors'):
             out[k] = v.clone()
         else:                             # BN beta / linear bias

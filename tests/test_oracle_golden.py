@@ -21,7 +21,7 @@ def test_oracle_reproduces_reference_golden(name):
     backbone, classes, seed = str(g['backbone']), int(g['num_classes']), int(g['seed'])
     m = R.ClassificationModel(backbone, classes).train()
     m.load_state_dict(deterministic_state(m.state_dict(), seed))
-    x, y = torch.from_numpy(g['x']), torch.from_numpy(g['y'])
+    x, y = torch.from_numpy(g['x'].astype(np.float32)), torch.from_numpy(g['y'])
     feats = m.backbone.forward_features(x)
     assert [list(f.shape) for f in feats] == g['feat_shapes'].tolist()
     np.testing.assert_allclose([float(f.double().sum()) for f in feats], g['feat_sum'], rtol=1e-5, atol=1e-3)
@@ -64,6 +64,6 @@ def test_classification_head_golden():
     import torch.nn as nn
     fc = nn.Linear(32, 7)
     sd = deterministic_state({'fc.weight': fc.weight, 'fc.bias': fc.bias}, 3)
-    y = torch.nn.functional.linear(torch.from_numpy(g['x']), sd['fc.weight'], sd['fc.bias'])
+    y = torch.nn.functional.linear(torch.from_numpy(g['x'].astype(np.float32)), sd['fc.weight'], sd['fc.bias'])
     np.testing.assert_allclose(y.numpy(), g['y'], rtol=1e-5, atol=1e-6)
     assert tuple(g['binary']) == (5,)      # num_classes == 1 squeezes the channel dim (classification_head.py:37-38)

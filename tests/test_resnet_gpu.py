@@ -13,7 +13,7 @@ import torch
 
 import oracle.torchok_ref as R
 import torchok_amd as T
-from helpers import cls_config, copy_state, perturb_, rel_err
+from helpers import cls_config, copy_state, deterministic_state, perturb_, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +33,7 @@ def test_training_step_vs_oracle(backbone, size, batch, classes):
     cfg = cls_config(backbone, classes, backbone_params={'zero_init_last': False})
     task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
     ref = R.ClassificationModel(backbone, classes, zero_init_last=False)
-    perturb_(ref, scale=0.1)
+    ref.load_state_dict(deterministic_state(ref.state_dict(), 21))
     copy_state(ref, task)
     task.cuda().train()
     ref.train()
