@@ -35,7 +35,7 @@ def test_bad_descriptor_is_reported_not_launched():
     assert b'multiple of 8' in lib.tok_last_error()
     assert lib.tok_conv_fwd_stat_rows(ctypes.byref(d)) == -1
     d2 = _C.ConvDesc(2, 8, 8, 8, 8, 3, 3, 8, 8, 1, 1, 3)
-    assert lib.tok_conv_fwd_stat_rows(ctypes.byref(d2)) == 1
+    assert lib.tok_conv_fwd_stat_rows(ctypes.byref(d2)) >= 1
     assert lib.tok_conv_wgrad_ws_bytes(ctypes.byref(d2)) > 0
     assert lib.tok_bn_bwd_rows(1000, 64) > 0 and lib.tok_bn_stats_rows(10, 7) == -1
 
