@@ -90,6 +90,16 @@ int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w, const flo
  * tok_pack_weight_dgrad;  accumulate != 0 adds into the existing dx (residual fan-in).     */
 int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                    int accumulate, void* stream);
+/* dgrad fused with the BatchNorm-backward reduction of the unit that PRODUCED x (the tensor
+ * whose gradient dx this call completes): the epilogue, holding the final dx tile in
+ * registers, also loads that unit's raw conv output bn_y (same NHWC shape as dx) and its ReLU
+ * bit mask (nullable = no ReLU) and accumulates sum(dz), sum(dz*y), dz = dx*mask, into
+ * partial[2][tok_conv_dgrad_stat_rows(d)][c] — replacing a separate tok_bn_bwd_reduce pass over
+ * dx and y (feed the result to tok_bn_bwd_finalize with dzy_form = 1).                     */
+int tok_conv_dgrad_stat_rows(const tok_conv_desc* d);
+int tok_conv_dgrad_bnstats(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                           int accumulate, const void* bn_y, const uint8_t* bn_mask, float* partial,
+                           void* stream);
 size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 /* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
  * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */
@@ -117,26 +127,29 @@ int tok_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 /* per-channel sum / sumsq partials of an NHWC bf16 tensor (BN after a non-conv producer)  */
 int tok_bn_stats_rows(int64_t m, int c);
 int tok_bn_stats(const void* y, int64_t m, int c, float* stats, void* stream);
-/* out = act(y*scale[c] + shift[c] (+ shortcut));  act = relu if relu != 0                 */
+/* out = act(y*scale[c] + shift[c] (+ shortcut));  act = relu if relu != 0.
+ * mask (nullable): uint8 [m][c/8], bit e of byte (row, g) = (out[row][8g+e] > 0) — the ReLU mask
+ * the backward kernels read instead of `out` (1/16 of its bytes).                            */
 int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
-                   const void* shortcut, int relu, void* out, int64_t m, int c,
+                   const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m, int c,
                    void* stream);
 int tok_bn_bwd_rows(int64_t m, int c);
 /* partial[2][rows][c]: sum(dz), sum(dz * xhat), dz = dout * relu_mask.
- * out = the forward output (needed for the mask when a shortcut was added; may be NULL
- * when shortcut-free: the mask is then recomputed from y).                                */
-int tok_bn_bwd_reduce(const void* dout, const void* y, const void* out,
+ * mask = the bit mask tok_bn_act_fwd wrote (may be NULL when no shortcut was added: the mask
+ * is then recomputed from y, scale, shift).                                                */
+int tok_bn_bwd_reduce(const void* dout, const void* y, const uint8_t* mask,
                       const float* scale, const float* shift,
                       const float* mean, const float* rstd, int relu,
                       int64_t m, int c, float* partial, void* stream);
 /* dgamma, dbeta (+= if accumulate) and the 3 per-channel coefficients of
- * dy = a1*dz + a2*y + a3  ->  coef[3][c]                                                  */
+ * dy = a1*dz + a2*y + a3  ->  coef[3][c].  dzy_form != 0: the second partial is sum(dz * y)
+ * (what tok_conv_dgrad_bnstats accumulates) instead of sum(dz * xhat).                     */
 int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c,
                         const float* gamma, const float* mean, const float* rstd,
-                        float* dgamma, float* dbeta, float* coef, int accumulate,
+                        float* dgamma, float* dbeta, float* coef, int accumulate, int dzy_form,
                         void* stream);
 /* dy = a1*dz + a2*y + a3;  if dshortcut != NULL: dshortcut (=|+=) dz                       */
-int tok_bn_bwd_apply(const void* dout, const void* y, const void* out,
+int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* mask,
                      const float* scale, const float* shift, const float* coef, int relu,
                      void* dy, void* dshortcut, int dshortcut_accumulate,
                      int64_t m, int c, void* stream);

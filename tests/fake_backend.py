@@ -115,6 +115,28 @@ class FakeTok:
             out.copy_(gi.to(BF16))
         return 0
 
+    def tok_conv_dgrad_stat_rows(self, d):
+        return 2
+
+    def tok_conv_dgrad_bnstats(self, d, dy, wd, dx, accumulate, bn_y, bn_mask, partial, st):
+        rc = self.tok_conv_dgrad(d, dy, wd, dx, accumulate, st)
+        d = _desc(d)
+        self.calls.append('dgrad_bnstats')
+        m = d.n * d.h * d.w
+        g = _t(dx, (m, d.c), BF16).float()
+        yv = _t(bn_y, (m, d.c), BF16).float()
+        dz = g * self._bits(bn_mask, m, d.c) if bn_mask is not None else g
+        p = _t(partial, (2, 2, d.c), torch.float32)
+        p.zero_()
+        p[0, 1] = dz.sum(0)
+        p[1, 1] = (dz * yv).sum(0)
+        return rc
+
+    @staticmethod
+    def _bits(mask, m, c):
+        b = _t(mask, (m, c // 8), torch.uint8).long()
+        return ((b.unsqueeze(-1) >> torch.arange(8)) & 1).reshape(m, c).float()
+
     def tok_conv_wgrad_ws_bytes(self, d):
         return 64
 
@@ -173,14 +195,18 @@ class FakeTok:
         s[1, 0] = (f * f).sum(0)
         return 0
 
-    def tok_bn_act_fwd(self, y, scale, shift, shortcut, relu, out, m, c, st):
+    def tok_bn_act_fwd(self, y, scale, shift, shortcut, relu, out, mask, m, c, st):
         self.calls.append('bn_act_fwd')
         z = _t(y, (m, c), BF16).float() * _t(scale, (c,), torch.float32) + _t(shift, (c,), torch.float32)
         if shortcut is not None:
             z = z + _t(shortcut, (m, c), BF16).float()
         if relu:
             z = z.clamp_min(0)
-        _t(out, (m, c), BF16).copy_(z.to(BF16))
+        o = z.to(BF16)
+        _t(out, (m, c), BF16).copy_(o)
+        if mask is not None:
+            bits = (o.float() > 0).long().reshape(m, c // 8, 8)
+            _t(mask, (m, c // 8), torch.uint8).copy_((bits << torch.arange(8)).sum(-1).to(torch.uint8))
         return 0
 
     def tok_bn_bwd_rows(self, m, c):
@@ -190,8 +216,8 @@ class FakeTok:
         g = _t(dout, (m, c), BF16).float()
         if not relu:
             return g
-        if out is not None:
-            mask = _t(out, (m, c), BF16).float() > 0
+        if out is not None:     # `out` = the uint8 bit mask written by tok_bn_act_fwd
+            mask = self._bits(out, m, c) > 0
         else:
             mask = (_t(y, (m, c), BF16).float() * _t(scale, (c,), torch.float32) + _t(shift, (c,), torch.float32)) > 0
         return g * mask
@@ -204,8 +230,10 @@ class FakeTok:
         p[1, 0] = (dz * xhat).sum(0)
         return 0
 
-    def tok_bn_bwd_finalize(self, partial, rows, m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, st):
+    def tok_bn_bwd_finalize(self, partial, rows, m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, st):
         p = _t(partial, (2, rows, c), torch.float32).double().sum(1)
+        if dzy:
+            p[1] = _t(rstd, (c,), torch.float32).double() * (p[1] - _t(mean, (c,), torch.float32).double() * p[0])
         sdz, sdzx = p[0].float(), p[1].float()
         for ptr_, val in ((dgamma, sdzx), (dbeta, sdz)):
             if ptr_ is not None:

@@ -214,16 +214,20 @@ def test_bn_chain(libs, m, c, relu, with_sc):
 
     sc = rnd(m, c, seed=9).to(BF16) if with_sc else None
     out = torch.zeros(m, c, dtype=BF16)
+    mask = torch.zeros(m, c // 8, dtype=torch.uint8)
     dv = both(libs, 'tok_bn_act_fwd', lambda fn: [fn(y), fn(scale), fn(shift), fn(sc) if with_sc else None, relu,
-                                                  fn(out), m, c, None])
+                                                  fn(out), fn(mask), m, c, None])
     assert relerr(dv[id(out)].float(), out.float()) < 1e-3
     assert (dv[id(out)].cpu() != out).float().mean() < 1e-3  # fma vs mul+add may flip a last bit
+    # the bit mask is exactly (out > 0) of the kernel's own output
+    got_bits = ((dv[id(mask)].cpu().long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(m, c).bool()
+    assert torch.equal(got_bits, dv[id(out)].cpu().float() > 0)
 
     dout = rnd(m, c, seed=11).to(BF16)
     rows_b = lib.tok_bn_bwd_rows(m, c)
     part_d = torch.zeros(2, rows_b, c, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    args = dict(dout=dout, y=y, out=out if (relu and with_sc) else None)
+    args = dict(dout=dout, y=y, out=mask if (relu and with_sc) else None)   # `out` slot = ReLU bit mask
     dd = {k_: (v.to(DEV) if v is not None else None) for k_, v in args.items()}
     cd = {k_: v.to(DEV) for k_, v in dict(scale=scale, shift=shift, mean=mean, rstd=rstd, gamma=gamma).items()}
     P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
@@ -238,9 +242,9 @@ def test_bn_chain(libs, m, c, relu, with_sc):
     dg_d, db_d, coef_d = (torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(3, c, device=DEV))
     dg_h, db_h, coef_h = torch.zeros(c), torch.zeros(c), torch.zeros(3, c)
     assert lib.tok_bn_bwd_finalize(P(part_d), rows_b, m, c, P(cd['gamma']), P(cd['mean']), P(cd['rstd']), P(dg_d),
-                                   P(db_d), P(coef_d), 0, st) == 0
+                                   P(db_d), P(coef_d), 0, 0, st) == 0
     assert fake.tok_bn_bwd_finalize(P(part_h), 1, m, c, P(gamma), P(mean), P(rstd), P(dg_h), P(db_h), P(coef_h), 0,
-                                    None) == 0
+                                    0, None) == 0
     torch.cuda.synchronize()
     assert relerr(dg_d, dg_h) < 1e-3 and relerr(db_d, db_h) < 1e-3 and relerr(coef_d, coef_h) < 1e-3
 
@@ -358,6 +362,59 @@ def test_optimizers_match_torch(libs):
                                      0.999, 1e-8, 1e-2, decoupled, i + 1, 0, st) == 0
         torch.cuda.synchronize()
         assert maxrel(p, ref.data, 1e-3) < 1e-4
+
+
+@pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 256, 64, 1, 1, 0),
+                                  (3, 14, 14, 64, 256, 1, 2, 0), (2, 17, 19, 64, 128, 3, 2, 1),
+                                  (1, 7, 7, 512, 512, 3, 1, 1)])
+@pytest.mark.parametrize('with_mask', [0, 1])
+def test_conv_dgrad_bnstats(libs, case, with_mask):
+    """dgrad whose epilogue also reduces sum(dz), sum(dz*y) of the unit that produced x."""
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    lib, fake = libs
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    wd = rnd(c, r, r, k, scale=(r * r * k) ** -0.5).to(BF16)
+    dx = rnd(n, h, w, c, seed=5).to(BF16)
+    bn_y = rnd(n, h, w, c, seed=6).to(BF16)
+    mask = torch.randint(0, 256, (n * h * w, c // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    rows = lib.tok_conv_dgrad_stat_rows(ctypes.byref(d))
+    assert rows > 0
+    part_d = torch.zeros(2, rows, c)
+    part_h = torch.zeros(2, 2, c)
+    dv = both(libs, 'tok_conv_dgrad_bnstats',
+              lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d, f(dy), f(wd), f(dx), 1, f(bn_y),
+                         f(mask) if with_mask else None, f(part_d) if f.__name__ == 'to_dev' else f(part_h), None])
+    assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
+    # statistics are taken over the kernel's OWN rounded dx
+    g = dv[id(dx)].float().cpu().reshape(-1, c)
+    bits = ((mask.long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(-1, c).float() if with_mask else 1.0
+    dz = g * bits
+    got = dv[id(part_d)].cpu().sum(1)
+    assert relerr(got[0], dz.sum(0)) < 1e-3
+    assert relerr(got[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 1e-3
+    # and the dz*y form finalises to the same dgamma/dbeta/coefficients as the xhat form
+    m = n * h * w
+    mean, rstd, gamma = rnd(c, seed=8) * 0.3, rnd(c, seed=9).abs() + 0.5, rnd(c, seed=10) + 1
+    xhat = (bn_y.float().reshape(-1, c) - mean) * rstd
+    ph = torch.stack([dz.sum(0), (dz * xhat).sum(0)]).reshape(2, 1, c).contiguous()
+    outs = []
+    for partial, nrows, form in ((got.reshape(2, 1, c).contiguous(), 1, 1), (ph, 1, 0)):
+        dg, db, coef = torch.zeros(c), torch.zeros(c), torch.zeros(3, c)
+        assert fake.tok_bn_bwd_finalize(partial.data_ptr(), nrows, m, c, gamma.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, form,
+                                        None) == 0
+        outs.append((dg, db, coef))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert relerr(a_, b_) < 2e-3
+    st = torch.cuda.current_stream().cuda_stream
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    dgd, dbd, cod = dev(torch.zeros(c)), dev(torch.zeros(c)), dev(torch.zeros(3, c))
+    pd, gd, md, rd = dev(got.reshape(2, 1, c).contiguous()), dev(gamma), dev(mean), dev(rstd)
+    assert lib.tok_bn_bwd_finalize(pd.data_ptr(), 1, m, c, gd.data_ptr(), md.data_ptr(), rd.data_ptr(), dgd.data_ptr(),
+                                   dbd.data_ptr(), cod.data_ptr(), 0, 1, st) == 0
+    torch.cuda.synchronize()
+    assert relerr(dgd, outs[0][0]) < 1e-3 and relerr(cod, outs[0][2]) < 1e-3
 
 
 def test_tr_read_microbench(libs):

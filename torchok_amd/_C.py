@@ -38,6 +38,8 @@ PROTOTYPES = {
     'tok_conv_fwd_stat_rows': (c_int, [_PD]),
     'tok_conv_fwd': (c_int, [_PD, _P, _P, _P, _P, _P, _P]),
     'tok_conv_dgrad': (c_int, [_PD, _P, _P, _P, c_int, _P]),
+    'tok_conv_dgrad_stat_rows': (c_int, [_PD]),
+    'tok_conv_dgrad_bnstats': (c_int, [_PD, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'tok_conv_wgrad_ws_bytes': (c_size_t, [_PD]),
     'tok_conv_wgrad': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float,
@@ -45,10 +47,10 @@ PROTOTYPES = {
     'tok_bn_eval_coeffs': (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
     'tok_bn_stats_rows': (c_int, [c_int64, c_int]),
     'tok_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P]),
-    'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, c_int64, c_int, _P]),
+    'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P]),
     'tok_bn_bwd_rows': (c_int, [c_int64, c_int]),
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
-    'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, _P]),
+    'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
     'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

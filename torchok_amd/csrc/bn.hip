@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* __restrict_
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const bf16* __restrict__ shortcut, int relu,
-                                                         bf16* __restrict__ out, int64_t M, int C,
-                                                         int cge, int rpb) {
+                                                         bf16* __restrict__ out, uint8_t* __restrict__ mask,
+                                                         int64_t M, int C, int cge, int rpb) {
   const int tid = threadIdx.x;
   const int cgl = tid % cge, rl = tid / cge;
   if (rl >= rpb) return;
@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* __restrict_
         }
       }
       stg16(out + off, o);
+      if (mask != nullptr) {   // bit e = (out[e] > 0): the ReLU mask the backward kernels read (1/16 of `out`)
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
+        mask[(size_t)m * cg_total + cg] = (uint8_t)bits;
+      }
     }
   }
 }
@@ -172,7 +178,7 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // partial[2][gridDim.x][C] = (sum dz, sum dz * xhat)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const bf16* __restrict__ dout, const bf16* __restrict__ y, const bf16* __restrict__ out,
+    const bf16* __restrict__ dout, const bf16* __restrict__ y, const uint8_t* __restrict__ mask,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int relu, int64_t M, int C, int cge, int rpb,
     float* __restrict__ partial) {
@@ -194,12 +200,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const size_t off = (size_t)m * C + cg * 8;
         const bf16x8 g = ldg16(dout + off);
         const bf16x8 v = ldg16(y + off);
-        if (relu && out != nullptr) {
-          const bf16x8 o = ldg16(out + off);
+        if (relu && mask != nullptr) {
+          const unsigned bits = mask[(size_t)m * cg_total + cg];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float yf = bf2f(v[e]);
-            const float dz = bf2f(o[e]) > 0.f ? bf2f(g[e]) : 0.f;
+            const float dz = ((bits >> e) & 1u) ? bf2f(g[e]) : 0.f;
             s1[e] += dz;
             s2[e] += dz * ((yf - mu[e]) * rs[e]);
           }
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int rows, double inv_m, int C, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* dgamma, float* dbeta,
-    float* coef, int accumulate) {
+    float* coef, int accumulate, int dzy_form) {
   __shared__ double red[2][256];
   const int tid = threadIdx.x;
   const int cl = tid & 3, rl = tid >> 2;
@@ -258,6 +264,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     __syncthreads();
   }
   if (rl == 0 && c < C) {
+    if (dzy_form) {   // second sum is sum(dz * y): sum(dz * xhat) = rstd * (sum(dz*y) - mean * sum(dz))
+      red[1][tid] = (double)rstd[c] * (red[1][tid] - (double)mean[c] * red[0][tid]);
+    }
     const float sdz = (float)red[0][tid];
     const float sdzx = (float)red[1][tid];
     if (dgamma != nullptr) dgamma[c] = accumulate ? dgamma[c] + sdzx : sdzx;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 
 // dout / dshortcut may alias (in-place masking of the incoming gradient): no restrict on them.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const bf16* dout, const bf16* __restrict__ y, const bf16* __restrict__ out,
+    const bf16* dout, const bf16* __restrict__ y, const uint8_t* __restrict__ mask,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ coef,
     int relu, bf16* __restrict__ dy, bf16* dshortcut, int ds_acc, int64_t M, int C, int cge, int rpb) {
   const int tid = threadIdx.x;
@@ -294,10 +303,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       const bf16x8 g = ldg16(dout + off);
       const bf16x8 v = ldg16(y + off);
       float dz[8];
-      if (relu && out != nullptr) {
-        const bf16x8 o = ldg16(out + off);
+      if (relu && mask != nullptr) {
+        const unsigned bits = mask[(size_t)m * cg_total + cg];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dz[e] = bf2f(o[e]) > 0.f ? bf2f(g[e]) : 0.f;
+        for (int e = 0; e < 8; ++e) dz[e] = ((bits >> e) & 1u) ? bf2f(g[e]) : 0.f;
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -370,27 +379,27 @@ extern "C" int tok_bn_stats(const void* y, int64_t m, int c, float* stats, void*
 }
 
 extern "C" int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
-                              const void* shortcut, int relu, void* out, int64_t m, int c,
+                              const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m, int c,
                               void* stream) {
   TOK_CHECK_ARG(y && scale && shift && out && m > 0 && c > 0 && c % 8 == 0, "tok_bn_act_fwd: bad args");
   const Geo g = make_geo(c);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
                      tok_stream(stream), (const bf16*)y, scale, shift, (const bf16*)shortcut, relu,
-                     (bf16*)out, m, c, g.cge, g.rpb);
+                     (bf16*)out, mask, m, c, g.cge, g.rpb);
   TOK_CHECK_LAUNCH("tok_bn_act_fwd");
   return TOK_OK;
 }
 
 extern "C" int tok_bn_bwd_rows(int64_t m, int c) { return tok_bn_stats_rows(m, c); }
 
-extern "C" int tok_bn_bwd_reduce(const void* dout, const void* y, const void* out, const float* scale,
+extern "C" int tok_bn_bwd_reduce(const void* dout, const void* y, const uint8_t* mask, const float* scale,
                                  const float* shift, const float* mean, const float* rstd, int relu,
                                  int64_t m, int c, float* partial, void* stream) {
   TOK_CHECK_ARG(dout && y && scale && shift && mean && rstd && partial, "tok_bn_bwd_reduce: null pointer");
   TOK_CHECK_ARG(m > 0 && c > 0 && c % 8 == 0, "tok_bn_bwd_reduce: bad sizes");
   const Geo g = make_geo(c);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(stream_blocks(m, g, kReduceCap)), dim3(256), 0,
-                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, (const bf16*)out, scale, shift,
+                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, mask, scale, shift,
                      mean, rstd, relu, m, c, g.cge, g.rpb, partial);
   TOK_CHECK_LAUNCH("tok_bn_bwd_reduce");
   return TOK_OK;
@@ -398,15 +407,15 @@ extern "C" int tok_bn_bwd_reduce(const void* dout, const void* y, const void* ou
 
 extern "C" int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c, const float* gamma,
                                    const float* mean, const float* rstd, float* dgamma, float* dbeta,
-                                   float* coef, int accumulate, void* stream) {
+                                   float* coef, int accumulate, int dzy_form, void* stream) {
   TOK_CHECK_ARG(partial && gamma && mean && rstd && coef, "tok_bn_bwd_finalize: null pointer");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), partial,
-                     rows, 1.0 / (double)m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate);
+                     rows, 1.0 / (double)m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
   TOK_CHECK_LAUNCH("tok_bn_bwd_finalize");
   return TOK_OK;
 }
 
-extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const void* out, const float* scale,
+extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* mask, const float* scale,
                                 const float* shift, const float* coef, int relu, void* dy,
                                 void* dshortcut, int dshortcut_accumulate, int64_t m, int c,
                                 void* stream) {
@@ -414,7 +423,7 @@ extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const void* out
   TOK_CHECK_ARG(m > 0 && c > 0 && c % 8 == 0, "tok_bn_bwd_apply: bad sizes");
   const Geo g = make_geo(c);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
-                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, (const bf16*)out, scale, shift,
+                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, mask, scale, shift,
                      coef, relu, (bf16*)dy, (bf16*)dshortcut, dshortcut_accumulate, m, c, g.cge, g.rpb);
   TOK_CHECK_LAUNCH("tok_bn_bwd_apply");
   return TOK_OK;

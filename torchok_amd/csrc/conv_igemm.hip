@@ -51,7 +51,9 @@ struct ConvArgs {
   const bf16* w;
   bf16* y;
   const float* bias;
-  float* stats;  // [2][gridM][K] or null
+  float* stats;  // [2][stat_rows][K] or null
+  const bf16* bn_y;        // dgrad + BatchNorm-backward statistics: raw conv output of the unit that
+  const uint8_t* bn_mask;  // produced the tensor whose gradient this launch completes, and its ReLU bits
   int H, W, C;   // gathered tensor
   int K;         // output channels (padded count of y)
   int R, S;      // S = stored filter width (s_pad)
@@ -352,11 +354,24 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
             }
             stg16(yp + half * 32, o);
             if (a.stats != nullptr) {
+              if (a.bn_y != nullptr) {
+                // backward statistics of the producing BatchNorm: dz = dx * relu_mask, sum dz, sum dz*y
+                const size_t eoff = opix * a.K + nb + half * 32;
+                const bf16x8 yv = ldg16(a.bn_y + eoff);
+                const unsigned bits = a.bn_mask != nullptr ? a.bn_mask[eoff >> 3] : 0xffu;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float f = bf2f(o[e]);
-                s1[half * 8 + e] += f;
-                s2[half * 8 + e] += f * f;
+                for (int e = 0; e < 8; ++e) {
+                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
+                  s1[half * 8 + e] += dz;
+                  s2[half * 8 + e] += dz * bf2f(yv[e]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = bf2f(o[e]);
+                  s1[half * 8 + e] += f;
+                  s2[half * 8 + e] += f * f;
+                }
               }
             }
           }
@@ -545,23 +560,21 @@ extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w
   return TOK_OK;
 }
 
-extern "C" int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                              int accumulate, void* stream) {
-  if (int e = check_desc(d, "tok_conv_dgrad")) return e;
-  TOK_CHECK_ARG(dy && w_dgrad && dx, "tok_conv_dgrad: null pointer");
+namespace {
+
+struct DgradPlan { int bn_tile, gridM, gridN; };
+
+int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
   TOK_CHECK_ARG(d->c % 8 == 0, "tok_conv_dgrad: c4 (stem) input needs no data gradient");
   TOK_CHECK_ARG(d->stride == 1 || d->stride == 2, "tok_conv_dgrad: stride %d unsupported", d->stride);
   TOK_CHECK_ARG(d->r - 1 - d->pad >= 0, "tok_conv_dgrad: pad > r-1 unsupported");
   TOK_CHECK_ARG(d->r == d->s, "tok_conv_dgrad: square filters only");
-  ConvArgs a = {};
-  a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr; a.stats = nullptr;
   // gathered tensor = dY (P x Q x K), output = dX (H x W x C)
   a.H = d->p; a.W = d->q; a.C = d->k; a.K = d->c; a.R = d->r; a.S = d->s;
   a.P = d->h; a.Q = d->w; a.stride = 1; a.pad = d->r - 1 - d->pad;
   a.M = d->n * d->h * d->w; a.PQ = d->h * d->w;
   a.Ktot = d->r * d->s * d->k; a.KT = tok_cdiv(a.Ktot, BK);
   a.fd_pq = make_fastdiv(a.PQ); a.fd_q = make_fastdiv(a.Q);
-  a.accumulate = accumulate;
   a.uniform_taps = (d->k % BK == 0) ? 1 : 0;
   if (d->stride == 1) {
     a.gridM = tok_cdiv(a.M, 128);
@@ -580,14 +593,50 @@ extern "C" int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void
     }
     a.gridM = 4 * tmax;   // classes interleaved (m-tile & 3) so heavy and light tiles mix on every XCD
   }
+  pl.bn_tile = pick_bn(d->c, a.Ktot);
+  a.gridN = tok_cdiv(d->c, pl.bn_tile);
+  pl.gridM = a.gridM; pl.gridN = a.gridN;
+  return 0;
+}
+
+int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+               const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who) {
+  if (int e = check_desc(d, who)) return e;
+  TOK_CHECK_ARG(dy && w_dgrad && dx, "%s: null pointer", who);
+  ConvArgs a = {};
+  DgradPlan pl;
+  if (int e = dgrad_fill(d, a, pl)) return e;
+  a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr;
+  a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask;
+  a.accumulate = accumulate;
   hipStream_t st = tok_stream(stream);
-  if (pick_bn(d->c, a.Ktot) == 64) {
-    a.gridN = tok_cdiv(d->c, 64);
+  if (pl.bn_tile == 64) {
     if (d->stride == 1) launch<128, 64, 1, false>(a, st); else launch<128, 64, 2, false>(a, st);
   } else {
-    a.gridN = tok_cdiv(d->c, 128);
     if (d->stride == 1) launch<128, 128, 1, false>(a, st); else launch<128, 128, 2, false>(a, st);
   }
-  TOK_CHECK_LAUNCH("tok_conv_dgrad");
+  TOK_CHECK_LAUNCH(who);
   return TOK_OK;
+}
+
+}  // namespace
+
+extern "C" int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                              int accumulate, void* stream) {
+  return dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, nullptr, stream, "tok_conv_dgrad");
+}
+
+extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
+  if (check_desc(d, "tok_conv_dgrad_stat_rows")) return TOK_ERR_INVALID;
+  ConvArgs a = {};
+  DgradPlan pl;
+  if (dgrad_fill(d, a, pl)) return TOK_ERR_INVALID;
+  return plan_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;
+}
+
+extern "C" int tok_conv_dgrad_bnstats(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                      int accumulate, const void* bn_y, const uint8_t* bn_mask,
+                                      float* partial, void* stream) {
+  TOK_CHECK_ARG(bn_y && partial, "tok_conv_dgrad_bnstats: bn_y / partial must not be null");
+  return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bnstats");
 }

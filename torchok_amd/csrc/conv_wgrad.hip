@@ -33,13 +33,13 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
 }
 
-template <int TN, int TK, bool C4>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+template <int TN, int TK, bool C4, int MS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {              // reduction rows staged per barrier (2 MFMA k-steps of 32)
   constexpr int CN = TN / 8, CK = TK / 8;      // 16-byte chunks per tile row
   constexpr int RPY = 256 / CN, RPX = 256 / CK;  // rows covered per pass
-  constexpr int YP = 32 / RPY, XP = 32 / RPX;    // passes per 32-row step
+  constexpr int YP = MS / RPY, XP = MS / RPX;    // passes per step
   constexpr int YS = (TN + 16) * 2, XS = (TK + 16) * 2;  // padded row strides (bytes)
-  constexpr int YBYTES = 32 * YS, XBYTES = 32 * XS;
+  constexpr int YBYTES = MS * YS, XBYTES = MS * XS;
   constexpr int NT = TN / 32, KTL = TK / 32;   // 16-wide tiles per wave (2x2 waves)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 
   const int mstart = split * a.mchunk;
   const int mend = min(a.M, mstart + a.mchunk);
-  const int steps = (mend - mstart + 31) >> 5;
+  const int steps = (mend - mstart + MS - 1) / MS;
 
   // ---- staging assignment ---------------------------------------------------------------
   const int ycol = tid % CN, yrow = tid / CN;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       if (yn_ok && m < mend) v = ldg16(a.dy + (size_t)m * a.K + yn);
       ry[i] = v;
     }
-    ym += 32;
+    ym += MS;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int hh = xp[i] * a.stride - a.pad + kr;
@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
           v = ldg16(a.x + ((size_t)(xpix[i] + hh * a.W + ww)) * a.C + kc0);
       }
       rx[i] = v;
-      // advance this row cursor by 32 output pixels
-      xm[i] += 32;
-      xq[i] += 32;
+      // advance this row cursor by MS output pixels
+      xm[i] += MS;
+      xq[i] += MS;
       while (xq[i] >= a.Q) {
         xq[i] -= a.Q;
         if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
@@ -161,26 +161,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     if (more) load_tile();
     const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
     const char* Xb = Yb + YBYTES;
-    bf16x8 af[NT], bfr[KTL];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const bf16x4 lo = tr_read(Yb + yoff + i * 32);
-      const bf16x4 hi = tr_read(Yb + yoff + i * 32 + 16 * YS);
+    for (int ks = 0; ks < MS / 32; ++ks) {
+      bf16x8 af[NT], bfr[KTL];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { af[i][e] = lo[e]; af[i][4 + e] = hi[e]; }
+      for (int i = 0; i < NT; ++i) {
+        const bf16x4 lo = tr_read(Yb + yoff + i * 32 + ks * 32 * YS);
+        const bf16x4 hi = tr_read(Yb + yoff + i * 32 + (ks * 32 + 16) * YS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { af[i][e] = lo[e]; af[i][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int j = 0; j < KTL; ++j) {
+        const bf16x4 lo = tr_read(Xb + xoff + j * 32 + ks * 32 * XS);
+        const bf16x4 hi = tr_read(Xb + xoff + j * 32 + (ks * 32 + 16) * XS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bfr[j][e] = lo[e]; bfr[j][4 + e] = hi[e]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < KTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < KTL; ++j) {
-      const bf16x4 lo = tr_read(Xb + xoff + j * 32);
-      const bf16x4 hi = tr_read(Xb + xoff + j * 32 + 16 * XS);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bfr[j][e] = lo[e]; bfr[j][4 + e] = hi[e]; }
-    }
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int j = 0; j < KTL; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     if (more) store_tile((st + 1) & 1);
     __syncthreads();
   }
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 }
 
 struct Plan {
-  int TN, TK, tilesN, tilesK, splitM, mchunk;
+  int TN, TK, tilesN, tilesK, splitM, mchunk, MS;
 };
 
 Plan make_plan(const tok_conv_desc* d) {
@@ -277,22 +280,37 @@ Plan make_plan(const tok_conv_desc* d) {
   p.tilesK = tok_cdiv(Ktot, p.TK);
   const int tiles = p.tilesN * p.tilesK;
   long long split = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
-  const long long max_split = (M + 255) / 256;   // at least 8 steps of 32 rows per workgroup
+  // reduction rows per barrier: 64 on the long-M layers (twice the MFMAs per barrier), 32 where M is
+  // short and occupancy (4 workgroups per CU instead of 2) matters more
+  p.MS = (M >= 100000 && p.TN == 128 && p.TK == 128) ? 64 : 32;
+  const long long max_split = (M + 8 * p.MS - 1) / (8 * p.MS);   // at least 8 steps per workgroup
   if (split > max_split) split = max_split;
   if (split > 256) split = 256;
   if (split < 1) split = 1;
   long long chunk = (M + split - 1) / split;
-  chunk = ((chunk + 31) / 32) * 32;
+  chunk = ((chunk + p.MS - 1) / p.MS) * p.MS;
   p.mchunk = (int)chunk;
   p.splitM = (int)((M + chunk - 1) / chunk);
   return p;
 }
 
-template <int TN, int TK, bool C4>
-void launch_wgrad(const WgradArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * 32 * ((TN + 16) * 2 + (TK + 16) * 2);
-  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
+template <int TN, int TK, bool C4, int MS>
+void launch_wgrad_ms(const WgradArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
                      smem, st, a);
+}
+
+template <int TN, int TK, bool C4>
+void launch_wgrad(const WgradArgs& a, hipStream_t st, int ms) {
+  if (ms == 64) launch_wgrad_ms<TN, TK, C4, 64>(a, st);
+  else launch_wgrad_ms<TN, TK, C4, 32>(a, st);
 }
 
 }  // namespace
@@ -329,13 +347,13 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
   if (p.TN == 128 && p.TK == 128) {
-    if (c4) launch_wgrad<128, 128, true>(a, st); else launch_wgrad<128, 128, false>(a, st);
+    if (c4) launch_wgrad<128, 128, true>(a, st, p.MS); else launch_wgrad<128, 128, false>(a, st, p.MS);
   } else if (p.TN == 128) {
-    if (c4) launch_wgrad<128, 64, true>(a, st); else launch_wgrad<128, 64, false>(a, st);
+    if (c4) launch_wgrad<128, 64, true>(a, st, p.MS); else launch_wgrad<128, 64, false>(a, st, p.MS);
   } else if (p.TK == 128) {
-    if (c4) launch_wgrad<64, 128, true>(a, st); else launch_wgrad<64, 128, false>(a, st);
+    if (c4) launch_wgrad<64, 128, true>(a, st, p.MS); else launch_wgrad<64, 128, false>(a, st, p.MS);
   } else {
-    if (c4) launch_wgrad<64, 64, true>(a, st); else launch_wgrad<64, 64, false>(a, st);
+    if (c4) launch_wgrad<64, 64, true>(a, st, p.MS); else launch_wgrad<64, 64, false>(a, st, p.MS);
   }
   TOK_CHECK_LAUNCH("tok_conv_wgrad");
   if (direct) return TOK_OK;

@@ -49,7 +49,7 @@ class TTensor:
     """Engine tensor: bf16, channel-last, channels padded to a multiple of 8.
 
     data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
-    __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', '__weakref__')
+    __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', '__weakref__')
 
     def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
         self.data = data
@@ -58,6 +58,8 @@ class TTensor:
         self.grad: Optional[torch.Tensor] = None
         self.grad_owned = True
         self.requires_grad = requires_grad
+        self.uses = 0       # in-region consumers that will send a gradient (counted in forward)
+        self.arrived = 0    # gradient contributions received so far (backward)
 
     @property
     def cp(self) -> int:
@@ -88,6 +90,7 @@ def grad_target(x: TTensor):
     First arrival allocates (accumulate=0); later arrivals add in the producer's epilogue.
     A gradient tensor that came from outside the region (autograd grad_output) is never
     written in place: it is cloned first."""
+    x.arrived += 1
     if x.grad is None:
         x.grad = torch.empty_like(x.data)
         x.grad_owned = True
@@ -101,10 +104,17 @@ def grad_target(x: TTensor):
 def donate_grad(x: TTensor, buf: torch.Tensor) -> bool:
     """Hand an already-computed gradient buffer to `x` without a copy (first arrival only)."""
     if x.grad is None:
+        x.arrived += 1
         x.grad = buf
         x.grad_owned = True
         return True
     return False
+
+
+def is_last_contribution(x: TTensor) -> bool:
+    """True when the NEXT gradient contribution to `x` completes its gradient (all in-region
+    consumers counted in forward have reported)."""
+    return x.uses > 0 and x.arrived + 1 == x.uses
 
 
 # ---- parameter gradient slots ------------------------------------------------------------------

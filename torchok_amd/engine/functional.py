@@ -16,8 +16,8 @@ import torch
 from torch import nn
 
 from .. import _C
-from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target, pad8,
-                   param_grad_target, ptr, stream_ptr)
+from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target,
+                   is_last_contribution, pad8, param_grad_target, ptr, stream_ptr)
 
 F32 = torch.float32
 
@@ -131,12 +131,17 @@ class _ConvBnActNode(Node):
 
     def __init__(self):
         self.x = self.out = self.shortcut = None
-        self.y = None
+        self.y = self.mask = None
+        self.fused_partial = None   # (partial, rows) when a consumer's dgrad epilogue did our BN-bwd reduce
 
     def release(self):
         self.x = self.out = self.shortcut = None
-        self.y = self.pk = None
+        self.y = self.pk = self.mask = self.fused_partial = None
         self.mean = self.rstd = self.scale = self.shift = None
+
+    def wants_fused_bwd_stats(self) -> bool:
+        """Can the kernel that completes d(out) also reduce sum(dz), sum(dz*y) for this unit?"""
+        return self.bn is not None and self.batch_stats and (not self.relu or self.mask is not None)
 
     def backward(self):
         lib, st = _C.lib(), stream_ptr()
@@ -156,13 +161,18 @@ class _ConvBnActNode(Node):
             g_need = bn.weight.requires_grad
             b_need = bn.bias.requires_grad
             sc_need = sc is not None and sc.requires_grad
-            out_for_mask = out.data if (self.relu and sc is not None) else None
+            mask = self.mask if self.relu else None
             if self.batch_stats:
-                rows = lib.tok_bn_bwd_rows(m, kp)
-                partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
-                _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(out_for_mask), ptr(self.scale),
-                                               ptr(self.shift), ptr(self.mean), ptr(self.rstd),
-                                               int(self.relu), m, kp, ptr(partial), st), 'tok_bn_bwd_reduce')
+                dzy = 0
+                if self.fused_partial is not None:
+                    partial, rows = self.fused_partial   # reduced by the dgrad that completed d(out)
+                    dzy = 1
+                else:
+                    rows = lib.tok_bn_bwd_rows(m, kp)
+                    partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
+                    _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
+                                                   ptr(self.shift), ptr(self.mean), ptr(self.rstd),
+                                                   int(self.relu), m, kp, ptr(partial), st), 'tok_bn_bwd_reduce')
                 coef = torch.empty((3, kp), dtype=F32, device=g.device)
                 gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
                 bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
@@ -171,7 +181,7 @@ class _ConvBnActNode(Node):
                     gacc = torch.empty_like(gs) if g_need else None
                     bacc = torch.empty_like(bs) if b_need else None
                     _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
-                                                     ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, st),
+                                                     ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, dzy, st),
                              'tok_bn_bwd_finalize')
                     for p_, acc_ in ((bn.weight, gacc), (bn.bias, bacc)):
                         if acc_ is not None:
@@ -184,7 +194,7 @@ class _ConvBnActNode(Node):
                 else:
                     _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
                                                      ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
-                                                     1 if (gm == 1 or bm == 1) else 0, st), 'tok_bn_bwd_finalize')
+                                                     1 if (gm == 1 or bm == 1) else 0, dzy, st), 'tok_bn_bwd_finalize')
                     if g_need:
                         commit_param_grad(bn.weight, gs, gm)
                     if b_need:
@@ -207,7 +217,7 @@ class _ConvBnActNode(Node):
                     else:
                         tgt, ds_acc = grad_target(sc)
                         ds_ptr = ptr(tgt)
-                _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(out_for_mask), ptr(self.scale),
+                _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
                                               ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
                                               ds_acc, m, kp, st), 'tok_bn_bwd_apply')
             else:
@@ -231,8 +241,21 @@ class _ConvBnActNode(Node):
                                         1 if mode == 1 else 0, st), 'tok_conv_wgrad')
             commit_param_grad(conv.weight, slot, mode)
         if x_need:
+            prod = x.node
+            fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
+                    and prod.fused_partial is None)
             tgt, acc = grad_target(x)
-            _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+            if fuse:
+                # this dgrad completes d(x): its epilogue also reduces the BatchNorm-backward sums of the
+                # unit that produced x (saves that unit a full pass over d(x) and y)
+                rows = lib.tok_conv_dgrad_stat_rows(d)
+                partial = torch.empty((2, rows, x.cp), dtype=F32, device=g.device)
+                _C.check(lib.tok_conv_dgrad_bnstats(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, ptr(prod.y),
+                                                    ptr(prod.mask) if prod.relu else None, ptr(partial), st),
+                         'tok_conv_dgrad_bnstats')
+                prod.fused_partial = (partial, rows)
+            else:
+                _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
 
 
 def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None,
@@ -290,8 +313,12 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
                                             ptr(bn.running_var), float(bn.eps), kp, ptr(scale), ptr(shift), st),
                      'tok_bn_eval_coeffs')
         out_data = torch.empty_like(y)
+        mask = None
+        if relu and region.grad_mode and batch_stats:
+            mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev)   # ReLU bits for the backward pass
         _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
-                                    int(relu), ptr(out_data), m, kp, st), 'tok_bn_act_fwd')
+                                    int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
+        node.mask = mask
         node.mean, node.rstd, node.scale, node.shift = mean, rstd, scale, shift
     else:
         if relu or shortcut is not None:
@@ -308,6 +335,10 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
         node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
         node.relu, node.batch_stats = relu, batch_stats
         out.node = node
+        if x.requires_grad:
+            x.uses += 1
+        if shortcut is not None and shortcut.requires_grad:
+            shortcut.uses += 1
         region.add(node)
     return out
 
@@ -349,6 +380,7 @@ def max_pool_3x3_s2(region: Region, x: TTensor) -> TTensor:
         node = _MaxPoolNode()
         node.x, node.out, node.argmax = x, out, argmax
         out.node = node
+        x.uses += 1
         region.add(node)
     return out
 
@@ -381,5 +413,6 @@ def global_avg_pool(region: Region, x: TTensor) -> TTensor:
         node = _GapNode()
         node.x, node.out = x, out
         out.node = node
+        x.uses += 1
         region.add(node)
     return out
