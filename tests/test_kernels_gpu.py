@@ -96,10 +96,11 @@ def test_conv_fwd(libs, case):
     yd, sd = dv[id(y)], dv[id(stats)]
     assert relerr(yd.float(), y.float()) < 4e-3
     assert maxrel(yd.float(), y.float(), 0.05) < 3e-2
-    # the partial sums are taken over the kernel's OWN rounded outputs
+    # the partial sums are taken over the fp32 accumulators (before the bf16 store): against the
+    # sums of the stored values they may differ by the rounding noise, <= 2^-8 relative per element
     f = yd.float().reshape(-1, k)
-    assert relerr(sd[0].sum(0), f.sum(0)) < 1e-3 or float((sd[0].sum(0).cpu() - f.sum(0).cpu()).abs().max()) < 1e-2
-    assert relerr(sd[1].sum(0), (f * f).sum(0)) < 1e-3
+    assert relerr(sd[0].sum(0), f.sum(0)) < 4e-3 or float((sd[0].sum(0).cpu() - f.sum(0).cpu()).abs().max()) < 2e-2
+    assert relerr(sd[1].sum(0), (f * f).sum(0)) < 4e-3
 
 
 def test_conv_fwd_stem_c4(libs):
@@ -386,13 +387,13 @@ def test_conv_dgrad_bnstats(libs, case, with_mask):
               lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d, f(dy), f(wd), f(dx), 1, f(bn_y),
                          f(mask) if with_mask else None, f(part_d) if f.__name__ == 'to_dev' else f(part_h), None])
     assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
-    # statistics are taken over the kernel's OWN rounded dx
+    # statistics are taken over the fp32 dx (before the bf16 store): compare with rounding slack
     g = dv[id(dx)].float().cpu().reshape(-1, c)
     bits = ((mask.long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(-1, c).float() if with_mask else 1.0
     dz = g * bits
     got = dv[id(part_d)].cpu().sum(1)
-    assert relerr(got[0], dz.sum(0)) < 1e-3
-    assert relerr(got[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 1e-3
+    assert relerr(got[0], dz.sum(0)) < 4e-3
+    assert relerr(got[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 4e-3
     # and the dz*y form finalises to the same dgamma/dbeta/coefficients as the xhat form
     m = n * h * w
     mean, rstd, gamma = rnd(c, seed=8) * 0.3, rnd(c, seed=9).abs() + 0.5, rnd(c, seed=10) + 1
@@ -406,7 +407,7 @@ def test_conv_dgrad_bnstats(libs, case, with_mask):
                                         None) == 0
         outs.append((dg, db, coef))
     for a_, b_ in zip(outs[0], outs[1]):
-        assert relerr(a_, b_) < 2e-3
+        assert relerr(a_, b_) < 6e-3   # fp32-sum vs rounded-dx sums, amplified by the mean subtraction
     st = torch.cuda.current_stream().cuda_stream
     dev = lambda t: t.to(DEV)  # noqa: E731
     dgd, dbd, cod = dev(torch.zeros(c)), dev(torch.zeros(c)), dev(torch.zeros(3, c))

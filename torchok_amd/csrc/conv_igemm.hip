@@ -62,7 +62,9 @@ struct ConvArgs {
   int M, PQ, Ktot, KT;
   int gridM, gridN;
   int accumulate, uniform_taps;
+  uint32_t x_bytes, w_bytes;   // extents of x / w for the buffer descriptors (< 4 GiB)
   FastDiv fd_pq, fd_q;
+  unsigned long long* timing;   // TOK_TIMING builds only: per-phase cycle totals of wave 0
   int stat_rows;   // workgroups per channel tile = rows of the partial-statistics buffer
   // IN_DIV == 2: per parity class (ph*2 + pw); m-tile index = 4 * (tile inside class) + class
   int cls_M[4], cls_nw[4], cls_hw[4];
@@ -78,8 +80,11 @@ __device__ __forceinline__ int fw_swz(int n) {
   return ((0x78 >> (((n >> 3) & 3) << 1)) & 3) | (((n >> 1) & 1) << 2);
 }
 
-template <int BM, int BN, int IN_DIV, bool C4>
+template <int BM, int BN, int IN_DIV, bool C4, bool PW>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+  // PW: pointwise fast path (1x1, stride 1, no padding, forward or dgrad): a pixel row of the A
+  // matrix is simply x[m][:], so the per-tile / per-K-step address arithmetic collapses (these
+  // layers are VALU-issue bound, not HBM bound, when done the general way).
   // 4 waves.  128x64 tile (the streaming layers): 4 waves along m, a wave owns 32 pixels x 64
   // channels (8 accumulator tiles), <= 168 registers -> 3 workgroups per CU.  128x128 tile (the
   // deep-K, MFMA-bound layers): 2 x 2 waves, a wave owns 64 x 64 (16 accumulator tiles: 16 MFMAs
@@ -104,8 +109,11 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   const int kc = tid & 7;
   const int lrow = tid >> 3;
 
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
   // ---- loader state (belongs to the tile whose loads are being issued) ----------------------
-  int h0[AROWS], w0[AROWS], pix[AROWS];
+  int h0[AROWS], w0[AROWS], pix[AROWS];   // pix: pixel base (C4 / IN_DIV 2) or ELEMENT base of tap (0,0)
   int kr, ks, kc0, kt;
   size_t wk;
   int par_h = 0, par_w = 0;  // (ph - pad), (pw - pad) of the loader's tile (IN_DIV == 2)
@@ -155,14 +163,18 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const int m = c.m0 + lrow + RSTEP * i;
-        if (m < a.M) {
+        if (PW) {
+          h0[i] = m < a.M ? 0 : -1;
+          w0[i] = 0;
+          pix[i] = m * a.C;
+        } else if (m < a.M) {
           const uint32_t b = fdiv(m, a.fd_pq);
           const uint32_t rem = m - b * a.PQ;
           const uint32_t p = fdiv(rem, a.fd_q);
           const uint32_t q = rem - p * a.Q;
           h0[i] = (int)p * a.stride - a.pad;
           w0[i] = (int)q * a.stride - a.pad;
-          pix[i] = b * a.H * a.W;
+          pix[i] = C4 ? (int)(b * a.H * a.W) : (int)(((b * a.H + h0[i]) * a.W + w0[i]) * a.C);
         } else {
           h0[i] = -0x40000000; w0[i] = 0; pix[i] = 0;
         }
@@ -171,6 +183,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     // k-chunk cursor of this thread at K step 0
     if (C4) {
       kr = kc >> 2; ks = (kc & 3) << 1; kc0 = 0;
+    } else if (PW) {
+      kc0 = kc * 8; kr = kc0 >= a.C ? 1 : 0; ks = 0;   // C >= 8; a chunk past C is past the K extent
     } else {
       const int k0 = kc * 8;
       const int tap = k0 / a.C;   // kc*8 < 64: at most a handful of taps
@@ -187,6 +201,9 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     wk += BK;
     if (C4) {
       kr += 2;
+    } else if (PW) {
+      kc0 += BK;
+      kr = kc0 >= a.C ? 1 : 0;
     } else {
       kc0 += BK;
       while (kc0 >= a.C) {
@@ -211,8 +228,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     }
   };
 
+  bool ld_on = true;   // false: issue the same loads with out-of-range offsets (zeros, no traffic)
   auto load_tile = [&]() {
-    const bool kvalid = kr < a.R;
+    const bool kvalid = ld_on && kr < a.R;
+    const int tap_delta = (kr * a.W + ks) * a.C + kc0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       int hh = h0[i] + kr;
@@ -236,18 +255,29 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         ra[i] = v;
       } else {
-        ok = ok && ((unsigned)ww < (unsigned)a.W);
-        bf16x8 v = zero8();
-        if (ok) v = ldg16(a.x + ((size_t)(pix[i] + hh * a.W + ww)) * a.C + kc0);
-        ra[i] = v;
+        // buffer load: padding taps / rows past M / K tail use an out-of-range offset, which the
+        // buffer unit answers with zeros — one unconditional instruction per row, no zero-fill VALU
+        // write for hipcc to fence with a vmcnt(0) (that fence used to serialise these loads behind
+        // the previous tile's stores)
+        uint32_t off;
+        if (IN_DIV == 2) {
+          ok = ok && ((unsigned)ww < (unsigned)a.W);
+          off = ok ? (uint32_t)((pix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
+        } else if (PW) {
+          off = (kvalid && h0[i] == 0) ? (uint32_t)(pix[i] + kc0) * 2u : 0xFFFFFFF0u;
+        } else {
+          // pix[i] = element offset of tap (0,0); the tap displacement is the same for all rows
+          ok = ok && ((unsigned)ww < (unsigned)a.W);
+          off = ok ? (uint32_t)(pix[i] + tap_delta) * 2u : 0xFFFFFFF0u;
+        }
+        ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
     }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       const int n = bn_fixed * BN + lrow + RSTEP * j;
-      bf16x8 v = zero8();
-      if (kvalid && n < a.K) v = ldg16(a.w + (size_t)n * a.Ktot + wk);
-      rw[j] = v;
+      const uint32_t off = (kvalid && n < a.K) ? (uint32_t)(n * a.Ktot + (int)wk) * 2u : 0xFFFFFFF0u;
+      rw[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0));
     }
   };
 
@@ -344,14 +374,16 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
         for (int half = 0; half < 2; ++half) {
           if (nb + half * 32 + 8 <= a.K) {
             bf16x8 o;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[half * 2 + (e >> 2)][mt][e & 3];
             if (a.accumulate) {
               const bf16x8 old = ldg16(yp + half * 32);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[half * 2 + (e >> 2)][mt][e & 3] + bf2f(old[e]));
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[half * 2 + (e >> 2)][mt][e & 3]);
+              for (int e = 0; e < 8; ++e) v[e] += bf2f(old[e]);
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
             stg16(yp + half * 32, o);
             if (a.stats != nullptr) {
               if (a.bn_y != nullptr) {
@@ -359,18 +391,19 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
                 const size_t eoff = opix * a.K + nb + half * 32;
                 const bf16x8 yv = ldg16(a.bn_y + eoff);
                 const unsigned bits = a.bn_mask != nullptr ? a.bn_mask[eoff >> 3] : 0xffu;
+                // (sums are taken over the fp32 values: the bf16 rounding of dx is zero-mean noise of
+                //  relative size 2^-9 / sqrt(M) in a sum over M pixels)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
+                  const float dz = ((bits >> e) & 1u) ? v[e] : 0.f;
                   s1[half * 8 + e] += dz;
-                  s2[half * 8 + e] += dz * bf2f(yv[e]);
+                  s2[half * 8 + e] = fmaf(dz, bf2f(yv[e]), s2[half * 8 + e]);
                 }
               } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float f = bf2f(o[e]);
-                  s1[half * 8 + e] += f;
-                  s2[half * 8 + e] += f * f;
+                  s1[half * 8 + e] += v[e];
+                  s2[half * 8 + e] = fmaf(v[e], v[e], s2[half * 8 + e]);
                 }
               }
             }
@@ -400,6 +433,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   __syncthreads();
   zero_acc();
   int buf = 0;
+#ifdef TOK_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+#endif
   while (any) {
     bool tile_done, nxt_has, any_next = true;
     Ctx nxt = cur;
@@ -418,20 +455,58 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
         nxt_has = kt < a.KT;
       }
     }
-    if (nxt_has) load_tile();
+#ifdef TOK_TIMING
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
+    // load / LDS-store run unconditionally (an idle last stage loads zeros): with every iteration
+    // issuing and retiring the same loads, hipcc's wait-count bookkeeping stays exact across the
+    // back edge instead of falling back to "wait for everything" before the next loads
+    ld_on = nxt_has;
+    load_tile();
+#ifdef TOK_TIMING
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
     if (cur_has) compute(buf);
+#ifdef TOK_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+#endif
     if (tile_done) {
       epilogue(cur);
       zero_acc();
     }
-    if (nxt_has) store_tile(buf ^ 1);
+#ifdef TOK_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#endif
+    store_tile(buf ^ 1);
+#ifdef TOK_TIMING
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef TOK_TIMING
+    const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+    tacc[0] += t1 - t0;   // issue loads
+    tacc[1] += t2 - t1;   // LDS fragment reads + MFMAs
+    tacc[2] += t3 - t2;   // epilogue
+    tacc[3] += t4 - t3;   // wait for the loads + LDS store
+    tacc[4] += t5 - t4;   // barrier
+    tacc[5] += 1;
+#endif
     buf ^= 1;
     any = !(tile_done && !any_next);
     cur = nxt;
     cur_has = nxt_has;
   }
 
+#ifdef TOK_TIMING
+  if (tid == 0 && a.timing != nullptr) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&a.timing[i], tacc[i]);
+    atomicAdd(&a.timing[6], __builtin_amdgcn_s_memtime() - tk0);
+  }
+#endif
   // ---- BatchNorm partial sums of everything this workgroup produced -> one row per workgroup ----
   if (a.stats != nullptr) {
     // recursive halving over the 16 pixel-lanes: after the 4 steps lane li owns channel li
@@ -479,19 +554,45 @@ int plan_grid(int bn_tile, int gridM, int gridN) {
   return G;
 }
 
-template <int BM, int BN, int IN_DIV, bool C4>
-int launch(ConvArgs& a, hipStream_t st) {
+template <int BM, int BN, int IN_DIV, bool C4, bool PW>
+int launch_pw(ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * BK * 2 + 2 * 4 * BN * 4;
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, IN_DIV, C4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, IN_DIV, C4, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   const int grid = plan_grid(BN, a.gridM, a.gridN);
   a.stat_rows = grid / a.gridN;
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, IN_DIV, C4>), dim3(grid), dim3(256), smem, st, a);
+#ifdef TOK_TIMING
+  {
+    static unsigned long long* tbuf = nullptr;
+    if (!tbuf) { (void)hipMalloc(&tbuf, 64); }
+    (void)hipMemsetAsync(tbuf, 0, 64, st);
+    a.timing = tbuf;
+  }
+#endif
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, IN_DIV, C4, PW>), dim3(grid), dim3(256), smem, st, a);
+#ifdef TOK_TIMING
+  {
+    unsigned long long h[8];
+    (void)hipMemcpyAsync(h, a.timing, 64, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double n = h[5] ? (double)h[5] : 1.0;
+    fprintf(stderr, "[timing BN=%d grid=%d M=%d K=%d N=%d] iters/WG %.1f  ticks/iter: issue %.0f  mfma %.0f  epilogue %.0f  wait+lds %.0f  barrier %.0f | loop ticks/WG %.0f\n",
+            BN, grid, a.M, a.Ktot, a.K, n / grid, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, (double)h[6] / grid);
+  }
+#endif
   return 0;
+}
+
+template <int BM, int BN, int IN_DIV, bool C4>
+int launch(ConvArgs& a, hipStream_t st) {
+  if constexpr (IN_DIV == 1 && !C4) {
+    if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) return launch_pw<BM, BN, 1, false, true>(a, st);
+  }
+  return launch_pw<BM, BN, IN_DIV, C4, false>(a, st);
 }
 
 // experiment knob: TOK_BN64=1 forces the 128x64 tile for every layer
@@ -547,6 +648,9 @@ extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w
   a.Ktot = d->r * d->s_pad * d->c; a.KT = tok_cdiv(a.Ktot, BK);
   a.gridM = tok_cdiv(a.M, 128);
   a.fd_pq = make_fastdiv(a.PQ); a.fd_q = make_fastdiv(a.Q);
+  const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->c * 2, wb = (unsigned long long)d->k * a.Ktot * 2;
+  TOK_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "tok_conv_fwd: tensors of 4 GiB or more are not supported");
+  a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
   if (pick_bn(d->k, a.Ktot) == 64) {
@@ -576,6 +680,9 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
   a.Ktot = d->r * d->s * d->k; a.KT = tok_cdiv(a.Ktot, BK);
   a.fd_pq = make_fastdiv(a.PQ); a.fd_q = make_fastdiv(a.Q);
   a.uniform_taps = (d->k % BK == 0) ? 1 : 0;
+  const unsigned long long xb = (unsigned long long)d->n * d->p * d->q * d->k * 2, wb = (unsigned long long)d->c * a.Ktot * 2;
+  TOK_CHECK_ARG(xb < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "tok_conv_dgrad: tensors of 4 GiB or more are not supported");
+  a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
   if (d->stride == 1) {
     a.gridM = tok_cdiv(a.M, 128);
   } else {
