@@ -74,6 +74,10 @@ int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c,
 int tok_pack_weight_dgrad(const float* src, int k, int r, int s, int c,
                           void* dst, int k_pad, int c_pad, void* stream);
 
+/* both packs in one launch (what a training forward needs)                                */
+int tok_pack_weight_both(const float* src, int k, int r, int s, int c, void* dst_fwd, int k_pad,
+                         int s_pad, int c_pad, void* dst_dgrad, void* stream);
+
 /* ---- convolution (implicit GEMM on MFMA) --------------------------------------------
  * Replace aten::conv2d fwd/bwd reached from resnet.py:488 (stem), [timm] BasicBlock /
  * Bottleneck conv1-3, downsample_conv (resnet.py:383-387), hrnet.py:64-69,122,133,156,

@@ -74,6 +74,10 @@ class FakeTok:
         d[:c, :, :, :k] = w.flip(1, 2).permute(3, 1, 2, 0).to(BF16)
         return 0
 
+    def tok_pack_weight_both(self, src, k, r, s, c, dst_f, k_pad, s_pad, c_pad, dst_d, st):
+        self.tok_pack_weight_fwd(src, k, r, s, c, dst_f, k_pad, s_pad, c_pad, st)
+        return self.tok_pack_weight_dgrad(src, k, r, s, c, dst_d, k_pad, c_pad, st)
+
     # ---- conv -----------------------------------------------------------------------------------
     def tok_conv_fwd_stat_rows(self, d):
         d = _desc(d)

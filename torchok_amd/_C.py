@@ -35,6 +35,7 @@ PROTOTYPES = {
     'tok_cast_f32_bf16': (c_int, [_P, _P, c_size_t, _P]),
     'tok_pack_weight_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     'tok_pack_weight_dgrad': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    'tok_pack_weight_both': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
     'tok_conv_fwd_stat_rows': (c_int, [_PD]),
     'tok_conv_fwd': (c_int, [_PD, _P, _P, _P, _P, _P, _P]),
     'tok_conv_dgrad': (c_int, [_PD, _P, _P, _P, c_int, _P]),

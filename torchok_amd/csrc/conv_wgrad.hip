@@ -25,6 +25,7 @@ struct WgradArgs {
   int H, W, C, K, R, S, P, Q, stride, pad;
   int M, PQ, HW, Ktot;
   int tilesN, tilesK, splitM, mchunk;
+  uint32_t x_bytes, dy_bytes;
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -89,13 +90,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
 
   bf16x8 ry[YP], rx[XP];
 
+  // buffer loads: rows past the chunk end, padding taps and the K tail use an out-of-range offset
+  // (answered with zeros): unconditional instructions, exact wait counts, no zero-fill writes
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   auto load_tile = [&]() {
 #pragma unroll
     for (int i = 0; i < YP; ++i) {
       const int m = ym + i * RPY;
-      bf16x8 v = zero8();
-      if (yn_ok && m < mend) v = ldg16(a.dy + (size_t)m * a.K + yn);
-      ry[i] = v;
+      const uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
+      ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ysrd, off, 0, 0));
     }
     ym += MS;
 #pragma unroll
@@ -114,8 +118,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
           for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         }
       } else {
-        if (ok && (unsigned)ww < (unsigned)a.W)
-          v = ldg16(a.x + ((size_t)(xpix[i] + hh * a.W + ww)) * a.C + kc0);
+        const uint32_t off = (ok && (unsigned)ww < (unsigned)a.W)
+                                 ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
+        v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
       rx[i] = v;
       // advance this row cursor by MS output pixels
@@ -157,8 +162,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   __syncthreads();
 
   for (int st = 0; st < steps; ++st) {
-    const bool more = (st + 1) < steps;
-    if (more) load_tile();
+    // past the last step the cursors point beyond `mend`: the loads return zeros without traffic
+    load_tile();
     const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
     const char* Xb = Yb + YBYTES;
 #pragma unroll
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
         for (int j = 0; j < KTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tile((st + 1) & 1);
+    store_tile((st + 1) & 1);
     __syncthreads();
   }
 
@@ -344,6 +349,12 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q; a.HW = d->h * d->w;
   a.Ktot = d->r * d->s_pad * d->c;
   a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
+  {
+    const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->c * 2;
+    const unsigned long long yb = (unsigned long long)a.M * d->k * 2;
+    TOK_CHECK_ARG(xb < 0xFFFFFFF0ull && yb < 0xFFFFFFF0ull, "tok_conv_wgrad: tensors of 4 GiB or more are not supported");
+    a.x_bytes = (uint32_t)xb; a.dy_bytes = (uint32_t)yb;
+  }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
   if (p.TN == 128 && p.TK == 128) {

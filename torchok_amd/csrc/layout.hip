@@ -82,6 +82,40 @@ __global__ __launch_bounds__(256) void pack_dgrad_kernel(const float* __restrict
   }
 }
 
+// both MFMA operand packs of one fp32 master in ONE launch (grid covers max of the two index spaces)
+__global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict__ src, int k, int r, int s, int c,
+                                                        bf16* __restrict__ fwd, int k_pad, int s_pad, int c_pad,
+                                                        bf16* __restrict__ dgr) {
+  const size_t total_f = (size_t)k_pad * r * s_pad * c_pad;
+  const size_t total_d = (size_t)c_pad * r * s * k_pad;
+  const size_t total = total_f > total_d ? total_f : total_d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    if (i < total_f) {
+      const int cc = (int)(i % c_pad);
+      size_t rest = i / c_pad;
+      const int ss = (int)(rest % s_pad);
+      rest /= s_pad;
+      const int rr = (int)(rest % r);
+      const int kk = (int)(rest / r);
+      float v = 0.f;
+      if (kk < k && ss < s && cc < c) v = src[(((size_t)kk * r + rr) * s + ss) * c + cc];
+      fwd[i] = f2bf(v);
+    }
+    if (i < total_d) {
+      const int kk = (int)(i % k_pad);
+      size_t rest = i / k_pad;
+      const int ss = (int)(rest % s);
+      rest /= s;
+      const int rr = (int)(rest % r);
+      const int cc = (int)(rest / r);
+      float v = 0.f;
+      if (kk < k && cc < c) v = src[(((size_t)kk * r + (r - 1 - rr)) * s + (s - 1 - ss)) * c + cc];
+      dgr[i] = f2bf(v);
+    }
+  }
+}
+
 inline int grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -139,5 +173,16 @@ extern "C" int tok_pack_weight_dgrad(const float* src, int k, int r, int s, int 
   hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for((size_t)c_pad * r * s * k_pad)), dim3(256), 0,
                      tok_stream(stream), src, k, r, s, c, (bf16*)dst, k_pad, c_pad);
   TOK_CHECK_LAUNCH("tok_pack_weight_dgrad");
+  return TOK_OK;
+}
+
+extern "C" int tok_pack_weight_both(const float* src, int k, int r, int s, int c, void* dst_fwd, int k_pad,
+                                    int s_pad, int c_pad, void* dst_dgrad, void* stream) {
+  TOK_CHECK_ARG(src && dst_fwd && dst_dgrad && k > 0 && r > 0 && s > 0 && c > 0, "tok_pack_weight_both: bad args");
+  TOK_CHECK_ARG(k_pad >= k && s_pad >= s && c_pad >= c, "tok_pack_weight_both: pads smaller than dims");
+  const size_t tf = (size_t)k_pad * r * s_pad * c_pad, td = (size_t)c_pad * r * s * k_pad;
+  hipLaunchKernelGGL(pack_both_kernel, dim3(grid_for(tf > td ? tf : td)), dim3(256), 0, tok_stream(stream), src, k,
+                     r, s, c, (bf16*)dst_fwd, k_pad, s_pad, c_pad, (bf16*)dst_dgrad);
+  TOK_CHECK_LAUNCH("tok_pack_weight_both");
   return TOK_OK;
 }

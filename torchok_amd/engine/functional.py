@@ -80,16 +80,18 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
     lib = _C.lib()
     st = stream_ptr()
     stale = refresh or pk.key != key
-    if pk.fwd is None or stale:
+    if want_dgrad and (pk.fwd is None or pk.dgrad is None or stale):
+        if pk.fwd is None or pk.key != key:
+            pk.fwd = torch.empty((kp, r, sp, cp), dtype=BF16, device=weight.device)
+        if pk.dgrad is None or pk.key != key:
+            pk.dgrad = torch.empty((cp, r, s, kp), dtype=BF16, device=weight.device)
+        _C.check(lib.tok_pack_weight_both(ptr(weight), k, r, s, c, ptr(pk.fwd), kp, sp, cp, ptr(pk.dgrad), st),
+                 'tok_pack_weight_both')
+    elif pk.fwd is None or stale:
         if pk.fwd is None or pk.key != key:
             pk.fwd = torch.empty((kp, r, sp, cp), dtype=BF16, device=weight.device)
         _C.check(lib.tok_pack_weight_fwd(ptr(weight), k, r, s, c, ptr(pk.fwd), kp, sp, cp, st),
                  'tok_pack_weight_fwd')
-    if want_dgrad and (pk.dgrad is None or stale):
-        if pk.dgrad is None or pk.key != key:
-            pk.dgrad = torch.empty((cp, r, s, kp), dtype=BF16, device=weight.device)
-        _C.check(lib.tok_pack_weight_dgrad(ptr(weight), k, r, s, c, ptr(pk.dgrad), kp, cp, st),
-                 'tok_pack_weight_dgrad')
     if bias is not None:
         if kp == k:
             pk.bias = bias.detach()
