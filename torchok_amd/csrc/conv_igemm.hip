@@ -72,6 +72,11 @@ struct ConvArgs {
 };
 
 constexpr int BK = 64;
+#ifdef TOK_NO_DMA
+constexpr bool DMA_ENABLED = false;
+#else
+constexpr bool DMA_ENABLED = true;
+#endif
 
 __device__ __forceinline__ int fw_swz(int n) {
   // weight-tile slot swizzle.  One ds_read_b128 lane group reads rows n = c0 + 8q + i (q,i in
@@ -84,6 +89,11 @@ template <int BM, int BN, int IN_DIV, bool C4, int PWM>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool PW = PWM != 0;    // PWM 1: pointwise; 2: pointwise with streaming (non-temporal) stores
   constexpr bool NTS = PWM == 2;
+  // DMA: global -> LDS directly (buffer_load ... lds), no staging registers and no ds_write pass
+  // (LDS stores run at ~80 B/clk/CU: the register-staged loop was LDS-write bound on deep-K layers).
+  // The LDS image of a wave instruction is lane-linear, so the XOR swizzle is applied to the SOURCE:
+  // the lane sitting at slot kc fetches logical chunk kc ^ swz(row).
+  constexpr bool DMA = !C4 && DMA_ENABLED;
   // PW: pointwise fast path (1x1, stride 1, no padding, forward or dgrad): a pixel row of the A
   // matrix is simply x[m][:], so the per-tile / per-K-step address arithmetic collapses (these
   // layers are VALU-issue bound, not HBM bound, when done the general way).
@@ -110,6 +120,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   const int wm = wv / WGN;
   const int kc = tid & 7;
   const int lrow = tid >> 3;
+  // logical 16-byte k-chunk this thread fetches for the activation / weight tile
+  const int kcA = DMA ? (kc ^ (lrow & 7)) : kc;
+  const int kcW = DMA ? (kc ^ fw_swz(lrow)) : kc;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
@@ -186,15 +200,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     if (C4) {
       kr = kc >> 2; ks = (kc & 3) << 1; kc0 = 0;
     } else if (PW) {
-      kc0 = kc * 8; kr = kc0 >= a.C ? 1 : 0; ks = 0;   // C >= 8; a chunk past C is past the K extent
+      kc0 = kcA * 8; kr = kc0 >= a.C ? 1 : 0; ks = 0;   // C >= 8; a chunk past C is past the K extent
     } else {
-      const int k0 = kc * 8;
-      const int tap = k0 / a.C;   // kc*8 < 64: at most a handful of taps
+      const int k0 = kcA * 8;
+      const int tap = k0 / a.C;   // k0 < 64: at most a handful of taps
       kc0 = k0 - tap * a.C;
       kr = tap / a.S;
       ks = tap - kr * a.S;
     }
-    wk = (size_t)kc * 8;
+    wk = (size_t)kcW * 8;
     kt = 0;
     return c;
   };
@@ -231,8 +245,11 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   };
 
   bool ld_on = true;   // false: issue the same loads with out-of-range offsets (zeros, no traffic)
-  auto load_tile = [&]() {
+  auto load_tile = [&](int dbuf) {
     const bool kvalid = ld_on && kr < a.R;
+    typedef __attribute__((address_space(3))) void lds_void;
+    char* Adst = smem + dbuf * TILE_BYTES + wave_u * 1024;
+    char* Wdst = Adst + BM * BK * 2;
     const int tap_delta = (kr * a.W + ks) * a.C + kc0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -272,18 +289,22 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
           ok = ok && ((unsigned)ww < (unsigned)a.W);
           off = ok ? (uint32_t)(pix[i] + tap_delta) * 2u : 0xFFFFFFF0u;
         }
-        ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
+        if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
+        else ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
     }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       const int n = bn_fixed * BN + lrow + RSTEP * j;
-      const uint32_t off = (kvalid && n < a.K) ? (uint32_t)(n * a.Ktot + (int)wk) * 2u : 0xFFFFFFF0u;
-      rw[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0));
+      const bool wvalid = DMA ? (ld_on && (int)wk < a.Ktot) : kvalid;
+      const uint32_t off = (wvalid && n < a.K) ? (uint32_t)(n * a.Ktot + (int)wk) * 2u : 0xFFFFFFF0u;
+      if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
+      else rw[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0));
     }
   };
 
   auto store_tile = [&](int buf) {
+    if (DMA) return;   // the data is already on its way into LDS; hipcc drains vmcnt before the barrier
     char* Ab = smem + buf * TILE_BYTES;
     char* Wb = Ab + BM * BK * 2;
 #pragma unroll
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     cur = setup(it);
     seek();
     cur_has = kt < a.KT;
-    if (cur_has) { load_tile(); store_tile(0); }
+    if (cur_has) { load_tile(0); store_tile(0); }
   }
   __syncthreads();
   zero_acc();
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     // issuing and retiring the same loads, hipcc's wait-count bookkeeping stays exact across the
     // back edge instead of falling back to "wait for everything" before the next loads
     ld_on = nxt_has;
-    load_tile();
+    load_tile(buf ^ 1);
 #ifdef TOK_TIMING
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif

@@ -281,6 +281,7 @@ Plan make_plan(const tok_conv_desc* d) {
   const long long M = (long long)d->n * d->p * d->q;
   p.TN = d->k >= 128 ? 128 : 64;
   p.TK = Ktot >= 128 ? 128 : 64;
+  // (a 128 x 256 tile for deep filters was measured: no gain — the loop is LDS-write bound, not barrier bound)
   p.tilesN = tok_cdiv(d->k, p.TN);
   p.tilesK = tok_cdiv(Ktot, p.TK);
   const int tiles = p.tilesN * p.tilesK;
@@ -357,7 +358,9 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (p.TN == 128 && p.TK == 128) {
+  if (p.TN == 128 && p.TK == 256) {
+    launch_wgrad_ms<128, 256, false, 32>(a, st);
+  } else if (p.TN == 128 && p.TK == 128) {
     if (c4) launch_wgrad<128, 128, true>(a, st, p.MS); else launch_wgrad<128, 128, false>(a, st, p.MS);
   } else if (p.TN == 128) {
     if (c4) launch_wgrad<128, 64, true>(a, st, p.MS); else launch_wgrad<128, 64, false>(a, st, p.MS);
