@@ -39,8 +39,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   constexpr int CN = TN / 8, CK = TK / 8;      // 16-byte chunks per tile row
   constexpr int RPY = 256 / CN, RPX = 256 / CK;  // rows covered per pass
   constexpr int YP = MS / RPY, XP = MS / RPX;    // passes per step
-  constexpr int YS = (TN + 16) * 2, XS = (TK + 16) * 2;  // padded row strides (bytes)
+  // DMA (all but the c4 stem): tiles go global -> LDS directly (buffer_load ... lds): no staging
+  // registers, no ds_write pass (LDS stores run at ~80 B/clk/CU and bounded this loop).  The LDS
+  // image of a wave instruction is lane-linear, so rows are unpadded and the transpose reads are
+  // kept conflict-free by an XOR swizzle of the 16-byte chunk index with the row, applied on the
+  // SOURCE side (the lane at slot c fetches logical chunk c ^ swz(row)) and on the reads.
+  constexpr bool DMA = !C4;
+  constexpr int YS = DMA ? TN * 2 : (TN + 16) * 2, XS = DMA ? TK * 2 : (TK + 16) * 2;  // row strides (bytes)
   constexpr int YBYTES = MS * YS, XBYTES = MS * XS;
+  constexpr int SWY = CN / 2 - 1, SWX = CK / 2 - 1;   // swz(row) = (row & SW) << 1
   constexpr int NT = TN / 32, KTL = TK / 32;   // 16-wide tiles per wave (2x2 waves)
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,11 +71,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   // ---- staging assignment ---------------------------------------------------------------
   const int ycol = tid % CN, yrow = tid / CN;
   const int xcol = tid % CK, xrow = tid / CK;
-  const int yn = tn * TN + ycol * 8;
+  // logical chunk fetched by this thread (slot ^ swz(row); the row's low bits are pass-invariant)
+  const int ylog = DMA ? (ycol ^ ((yrow & SWY) << 1)) : ycol;
+  const int xlog = DMA ? (xcol ^ ((xrow & SWX) << 1)) : xcol;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int yn = tn * TN + ylog * 8;
   const bool yn_ok = yn < a.K;
 
   // this thread's k-chunk never changes: tap (kr, ks), channel offset kc0
-  const int k0 = tk * TK + xcol * 8;
+  const int k0 = tk * TK + xlog * 8;
   int kr, ks, kc0;
   if (C4) { kr = k0 >> 5; ks = (k0 & 31) >> 2; kc0 = 0; }
   else { const int tap = k0 / a.C; kc0 = k0 - tap * a.C; kr = tap / a.S; ks = tap - kr * a.S; }
@@ -94,12 +105,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   // (answered with zeros): unconditional instructions, exact wait counts, no zero-fill writes
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  auto load_tile = [&]() {
+  typedef __attribute__((address_space(3))) void lds_void;
+  auto load_tile = [&](int dbuf) {
+    char* Ydst = smem + dbuf * (YBYTES + XBYTES) + wave_u * 1024;
+    char* Xdst = smem + dbuf * (YBYTES + XBYTES) + YBYTES + wave_u * 1024;
 #pragma unroll
     for (int i = 0; i < YP; ++i) {
       const int m = ym + i * RPY;
       const uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
-      ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ysrd, off, 0, 0));
+      if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(Ydst + i * RPY * YS), 16, off, 0, 0, 0);
+      else ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ysrd, off, 0, 0));
     }
     ym += MS;
 #pragma unroll
@@ -120,7 +135,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
       } else {
         const uint32_t off = (ok && (unsigned)ww < (unsigned)a.W)
                                  ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
-        v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
+        if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
+        else v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
       rx[i] = v;
       // advance this row cursor by MS output pixels
@@ -134,6 +150,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   };
 
   auto store_tile = [&](int buf) {
+    if (DMA) return;   // already in flight into LDS; hipcc drains vmcnt before the barrier
     char* Yb = smem + buf * (YBYTES + XBYTES);
     char* Xb = Yb + YBYTES;
 #pragma unroll
@@ -146,8 +163,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
 
   const int g = lane >> 4, li = lane & 15;
   // transpose-read address of this lane inside a 16-column tile: row 4g + (li>>2), cols (li&3)*4..
-  const int yoff = (4 * g + (li >> 2)) * YS + (wn2 * (TN / 2) + (li & 3) * 4) * 2;
-  const int xoff = (4 * g + (li >> 2)) * XS + (wk2 * (TK / 2) + (li & 3) * 4) * 2;
+  const int rrow = 4 * g + (li >> 2);                       // row inside a 16-row half step
+  const int yoff = rrow * YS + (wn2 * (TN / 2) + (li & 3) * 4) * 2;
+  const int xoff = rrow * XS + (wk2 * (TK / 2) + (li & 3) * 4) * 2;
+  // DMA layout: byte column -> ((chunk ^ swz(row)) << 4) | (byte & 15); rows +16/+32 keep row & 7
+  const int yswz = ((rrow & SWY) << 1) << 4, xswz = ((rrow & SWX) << 1) << 4;
+  auto ycolb = [&](int i) { const int b = (wn2 * (TN / 2) + i * 16 + (li & 3) * 4) * 2; return DMA ? (b ^ yswz) : b; };
+  auto xcolb = [&](int j) { const int b = (wk2 * (TK / 2) + j * 16 + (li & 3) * 4) * 2; return DMA ? (b ^ xswz) : b; };
 
   f32x4 acc[NT][KTL];
 #pragma unroll
@@ -156,14 +178,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
     for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (steps > 0) {
-    load_tile();
+    load_tile(0);
     store_tile(0);
   }
   __syncthreads();
 
   for (int st = 0; st < steps; ++st) {
     // past the last step the cursors point beyond `mend`: the loads return zeros without traffic
-    load_tile();
+    load_tile((st + 1) & 1);
     const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
     const char* Xb = Yb + YBYTES;
 #pragma unroll
@@ -171,15 +193,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
       bf16x8 af[NT], bfr[KTL];
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const bf16x4 lo = tr_read(Yb + yoff + i * 32 + ks * 32 * YS);
-        const bf16x4 hi = tr_read(Yb + yoff + i * 32 + (ks * 32 + 16) * YS);
+        const bf16x4 lo = tr_read(Yb + (rrow + ks * 32) * YS + ycolb(i));
+        const bf16x4 hi = tr_read(Yb + (rrow + ks * 32 + 16) * YS + ycolb(i));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { af[i][e] = lo[e]; af[i][4 + e] = hi[e]; }
       }
 #pragma unroll
       for (int j = 0; j < KTL; ++j) {
-        const bf16x4 lo = tr_read(Xb + xoff + j * 32 + ks * 32 * XS);
-        const bf16x4 hi = tr_read(Xb + xoff + j * 32 + (ks * 32 + 16) * XS);
+        const bf16x4 lo = tr_read(Xb + (rrow + ks * 32) * XS + xcolb(j));
+        const bf16x4 hi = tr_read(Xb + (rrow + ks * 32 + 16) * XS + xcolb(j));
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bfr[j][e] = lo[e]; bfr[j][4 + e] = hi[e]; }
       }
@@ -302,7 +324,7 @@ Plan make_plan(const tok_conv_desc* d) {
 
 template <int TN, int TK, bool C4, int MS>
 void launch_wgrad_ms(const WgradArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);
+  constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);   // (the unpadded DMA layout needs less)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS>),
