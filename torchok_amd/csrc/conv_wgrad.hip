@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
 }
 
-template <int TN, int TK, bool C4, int MS>
+template <int TN, int TK, bool C4, int MS, bool DMA_T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {              // reduction rows staged per barrier (2 MFMA k-steps of 32)
   constexpr int CN = TN / 8, CK = TK / 8;      // 16-byte chunks per tile row
   constexpr int RPY = 256 / CN, RPX = 256 / CK;  // rows covered per pass
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   // image of a wave instruction is lane-linear, so rows are unpadded and the transpose reads are
   // kept conflict-free by an XOR swizzle of the 16-byte chunk index with the row, applied on the
   // SOURCE side (the lane at slot c fetches logical chunk c ^ swz(row)) and on the reads.
-  constexpr bool DMA = !C4;
+  // Measured per layer (tools/bench_conv.py + whole-step bench): DMA wins on the short-M layers
+  // (14x14, 7x7: -18 %), register staging with its longer prefetch distance on the long-M ones.
+  constexpr bool DMA = !C4 && DMA_T;
   constexpr int YS = DMA ? TN * 2 : (TN + 16) * 2, XS = DMA ? TK * 2 : (TK + 16) * 2;  // row strides (bytes)
   constexpr int YBYTES = MS * YS, XBYTES = MS * XS;
   constexpr int SWY = CN / 2 - 1, SWX = CK / 2 - 1;   // swz(row) = (row & SW) << 1
@@ -322,17 +324,25 @@ Plan make_plan(const tok_conv_desc* d) {
   return p;
 }
 
-template <int TN, int TK, bool C4, int MS>
-void launch_wgrad_ms(const WgradArgs& a, hipStream_t st) {
+template <int TN, int TK, bool C4, int MS, bool DMA_T>
+void launch_wgrad_dma(const WgradArgs& a, hipStream_t st) {
   constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);   // (the unpadded DMA layout needs less)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS, DMA_T>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
+  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS, DMA_T>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
                      smem, st, a);
+}
+
+template <int TN, int TK, bool C4, int MS>
+void launch_wgrad_ms(const WgradArgs& a, hipStream_t st) {
+  if constexpr (!C4 && MS == 32) {
+    if (a.M < 100000) { launch_wgrad_dma<TN, TK, C4, MS, true>(a, st); return; }
+  }
+  launch_wgrad_dma<TN, TK, C4, MS, false>(a, st);
 }
 
 template <int TN, int TK, bool C4>
@@ -380,9 +390,7 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (p.TN == 128 && p.TK == 256) {
-    launch_wgrad_ms<128, 256, false, 32>(a, st);
-  } else if (p.TN == 128 && p.TK == 128) {
+  if (p.TN == 128 && p.TK == 128) {
     if (c4) launch_wgrad<128, 128, true>(a, st, p.MS); else launch_wgrad<128, 128, false>(a, st, p.MS);
   } else if (p.TN == 128) {
     if (c4) launch_wgrad<128, 64, true>(a, st, p.MS); else launch_wgrad<128, 64, false>(a, st, p.MS);
