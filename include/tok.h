@@ -183,6 +183,32 @@ int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* l
                        const float* loss, const float* gscale, int rows, int classes, int ld,
                        int64_t ignore_index, void* dlogits, void* stream);
 
+/* ---- metric-learning head and loss -----------------------------------------------------------
+ * F.normalize (arcface_head.py:125-126, linear_head.py:33-34): y = x / max(||x||_2, eps) per row;
+ * is_f32 selects fp32 rows (class-weight matrix) instead of bf16 activations.               */
+int tok_l2norm_fwd(const void* x, void* y, float* inv_norm, int rows, int c, int ld, int is_f32,
+                   float eps, void* stream);
+int tok_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int accumulate,
+                   int rows, int c, int ld, int is_f32, void* stream);
+/* ArcFaceHead.__add_margin (arcface_head.py:95-108) on the bf16 cosine matrix [rows][ld]:
+ * the target column becomes phi (or its easy/hard fallback), everything is scaled.          */
+int tok_arcface_margin_fwd(const void* cosine, const int64_t* target, int rows, int classes, int ld,
+                           float cos_m, float sin_m, float th, float mm, int easy_margin, float scale,
+                           void* out, void* stream);
+int tok_arcface_margin_bwd(const void* cosine, const int64_t* target, const void* dout, int rows,
+                           int classes, int ld, float cos_m, float sin_m, float th, float mm,
+                           int easy_margin, float scale, void* dcos, void* stream);
+/* PairwiseLearnTask.calc_relevance_matrix for 1-D labels (pairwise_task.py:87-107): exact.   */
+int tok_relevance_matrix(const int64_t* labels_a, const int64_t* labels_b, int na, int nb, float* R,
+                         void* stream);
+/* ContrastiveLoss (losses/representation/pairwise.py:126-136, mean reduction, no regulariser):
+ * S = cdist(e1, e2) [n1][n2] (saved), loss[0] = mean_i sum_j (1-R)relu(mu-S)^2 + R S^2.      */
+int tok_contrastive_fwd(const void* e1, const void* e2, const float* R, int n1, int n2, int d, int ld,
+                        float margin, float* S, float* row_loss, float* loss, void* stream);
+int tok_contrastive_bwd(const void* e1, const void* e2, const float* R, const float* S,
+                        const float* gscale, int n1, int n2, int d, int ld, float margin, void* de1,
+                        void* de2, int same_tensor, void* stream);
+
 /* ---- optimizers (flat arenas) -------------------------------------------------------------
  * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
  * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch

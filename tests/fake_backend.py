@@ -346,6 +346,96 @@ class FakeTok:
         d[:, :classes] = p.to(BF16)
         return 0
 
+    # ---- metric-learning head / loss ---------------------------------------------------------------
+    def tok_l2norm_fwd(self, x, y, inv_norm, rows, c, ld, is_f32, eps, st):
+        dt = torch.float32 if is_f32 else BF16
+        xs = _t(x, (rows, ld), dt)[:, :c].float()
+        inv = 1.0 / xs.pow(2).sum(1).sqrt().clamp_min(eps)
+        _t(inv_norm, (rows,), torch.float32).copy_(inv)
+        out = _t(y, (rows, ld), dt)
+        out.zero_()
+        out[:, :c] = (xs * inv[:, None]).to(dt)
+        return 0
+
+    def tok_l2norm_bwd(self, dy, y, inv_norm, dx, accumulate, rows, c, ld, is_f32, st):
+        dt = torch.float32 if is_f32 else BF16
+        g = _t(dy, (rows, ld), dt)[:, :c].float()
+        yy = _t(y, (rows, ld), dt)[:, :c].float()
+        inv = _t(inv_norm, (rows,), torch.float32)
+        v = (g - yy * (g * yy).sum(1, keepdim=True)) * inv[:, None]
+        out = _t(dx, (rows, ld), dt)
+        if accumulate:
+            out[:, :c] = (out[:, :c].float() + v).to(dt)
+        else:
+            out.zero_()
+            out[:, :c] = v.to(dt)
+        return 0
+
+    def tok_arcface_margin_fwd(self, cosine, target, rows, classes, ld, cos_m, sin_m, th, mm, easy, scale, out, st):
+        cs = _t(cosine, (rows, ld), BF16)[:, :classes].float()
+        t = _t(target, (rows,), torch.int64)
+        sn = (1.0 - cs * cs).clamp(0, 1).sqrt()
+        phi = _bf(cs * cos_m - sn * sin_m).float()
+        phi = torch.where(cs > 0, phi, cs) if easy else torch.where(cs > th, phi, cs - mm)
+        oh = F.one_hot(t, classes).bool()
+        o = _t(out, (rows, ld), BF16)
+        o.zero_()
+        o[:, :classes] = _bf(torch.where(oh, phi, cs) * scale)
+        return 0
+
+    def tok_arcface_margin_bwd(self, cosine, target, dout, rows, classes, ld, cos_m, sin_m, th, mm, easy, scale,
+                               dcos, st):
+        cs = _t(cosine, (rows, ld), BF16)[:, :classes].float()
+        t = _t(target, (rows,), torch.int64)
+        g = _t(dout, (rows, ld), BF16)[:, :classes].float()
+        q = 1.0 - cs * cs
+        dsn = torch.where((q > 0) & (q < 1), -cs / q.clamp_min(1e-30).sqrt(), torch.zeros_like(cs))
+        use_phi = (cs > 0) if easy else (cs > th)
+        d = torch.where(use_phi, cos_m - dsn * sin_m, torch.ones_like(cs))
+        d = torch.where(F.one_hot(t, classes).bool(), d, torch.ones_like(cs))
+        o = _t(dcos, (rows, ld), BF16)
+        o.zero_()
+        o[:, :classes] = _bf(g * scale * d)
+        return 0
+
+    def tok_relevance_matrix(self, la, lb, na, nb, R, st):
+        a, b = _t(la, (na,), torch.int64), _t(lb, (nb,), torch.int64)
+        _t(R, (na, nb), torch.float32).copy_((a[:, None] == b[None, :]).float())
+        return 0
+
+    def tok_contrastive_fwd(self, e1, e2, R, n1, n2, d, ld, margin, S, row_loss, loss, st):
+        a = _t(e1, (n1, ld), BF16)[:, :d].float()
+        b = _t(e2, (n2, ld), BF16)[:, :d].float()
+        r = _t(R, (n1, n2), torch.float32)
+        ss = (a[:, None, :] - b[None, :, :]).pow(2).sum(-1)
+        s = ss.sqrt()
+        _t(S, (n1, n2), torch.float32).copy_(s)
+        rl = ((1 - r) * (margin - s).clamp_min(0).pow(2) + r * ss).sum(1)
+        _t(row_loss, (n1,), torch.float32).copy_(rl)
+        _t(loss, (1,), torch.float32).copy_(rl.double().mean().float().reshape(1))
+        return 0
+
+    def tok_contrastive_bwd(self, e1, e2, R, S, gscale, n1, n2, d, ld, margin, de1, de2, same, st):
+        a = _t(e1, (n1, ld), BF16)[:, :d].float()
+        b = _t(e2, (n2, ld), BF16)[:, :d].float()
+        r, s = _t(R, (n1, n2), torch.float32), _t(S, (n1, n2), torch.float32)
+        g = (_t(gscale, (1,), torch.float32)[0] if gscale else 1.0) / n1
+        dls = -2 * (1 - r) * (margin - s).clamp_min(0) + 2 * r * s
+        w = torch.where(s > 0, dls / s.clamp_min(1e-30), torch.zeros_like(s))
+        diff = a[:, None, :] - b[None, :, :]
+        g1 = (w[:, :, None] * diff).sum(1) * g
+        g2 = -(w[:, :, None] * diff).sum(0) * g
+        o1 = _t(de1, (n1, ld), BF16)
+        o1.zero_()
+        o1[:, :d] = _bf(g1)
+        if same:
+            o1[:, :d] = _bf(o1[:, :d].float() + g2)
+        else:
+            o2 = _t(de2, (n2, ld), BF16)
+            o2.zero_()
+            o2[:, :d] = _bf(g2)
+        return 0
+
     # ---- optimizers ---------------------------------------------------------------------------------
     def tok_sgd_step(self, param, grad, mbuf, shadow, count, lr, momentum, dampening, wd, nesterov, first,
                      maximize, st):

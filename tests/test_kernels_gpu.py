@@ -435,3 +435,85 @@ def test_tr_read_microbench(libs):
     dv = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
                                                  f(x), f(dy), f(dw), k, c, f(ws), wsb, 0, None])
     assert torch.allclose(dv[id(dw)].cpu(), dw, atol=1e-6)
+
+
+# ---- metric-learning kernels (metric.hip) -------------------------------------------------------------------
+@pytest.mark.parametrize('rows,c,ld,f32', [(37, 64, 64, 0), (16, 20, 24, 0), (1000, 512, 512, 0), (10, 64, 64, 1),
+                                          (1003, 2048, 2048, 1)])
+def test_l2norm(libs, rows, c, ld, f32):
+    dt = torch.float32 if f32 else BF16
+    x = torch.zeros(rows, ld)
+    x[:, :c] = rnd(rows, c, scale=3.0)
+    x = x.to(dt)
+    y, inv = torch.empty(rows, ld, dtype=dt), torch.empty(rows)
+    dv = both(libs, 'tok_l2norm_fwd', lambda d: [d(x), d(y), d(inv), rows, c, ld, f32, 1e-12, None])
+    assert relerr(dv[id(inv)], inv) < 1e-5
+    assert relerr(dv[id(y)].float(), y.float()) < (1e-6 if f32 else 4e-3)
+    g = torch.zeros(rows, ld)
+    g[:, :c] = rnd(rows, c, seed=3)
+    g = g.to(dt)
+    for acc in (0, 1):
+        dx = (rnd(rows, ld, seed=9) if acc else torch.empty(rows, ld)).to(dt)
+        if acc:
+            dx[:, c:] = 0
+        dv = both(libs, 'tok_l2norm_bwd', lambda d: [d(g), d(y), d(inv), d(dx), acc, rows, c, ld, f32, None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < (1e-5 if f32 else 6e-3)
+
+
+@pytest.mark.parametrize('rows,classes,ld,easy', [(16, 10, 16, 0), (16, 10, 16, 1), (256, 1000, 1000, 0),
+                                                  (33, 11003, 11008, 0)])
+def test_arcface_margin(libs, rows, classes, ld, easy):
+    import math
+    m, scale = 0.5, 30.0
+    consts = [math.cos(m), math.sin(m), math.cos(math.pi - m), math.sin(math.pi - m) * m, easy, scale]
+    cs = torch.zeros(rows, ld)
+    cs[:, :classes] = torch.rand(rows, classes, generator=torch.Generator().manual_seed(rows)) * 2 - 1
+    tg = torch.randint(0, classes, (rows,), generator=torch.Generator().manual_seed(1))
+    cs[0, tg[0]] = 1.0           # sine clamp edge
+    cs[1, tg[1]] = -1.0
+    cs[2, tg[2]] = 0.0
+    cs = cs.to(BF16)
+    out = torch.empty(rows, ld, dtype=BF16)
+    dv = both(libs, 'tok_arcface_margin_fwd', lambda d: [d(cs), d(tg), rows, classes, ld, *consts, d(out), None])
+    assert relerr(dv[id(out)].float(), out.float()) < 4e-3
+    g = rnd(rows, ld, seed=4).to(BF16)
+    dc = torch.empty(rows, ld, dtype=BF16)
+    dv = both(libs, 'tok_arcface_margin_bwd', lambda d: [d(cs), d(tg), d(g), rows, classes, ld, *consts, d(dc), None])
+    assert relerr(dv[id(dc)].float(), dc.float()) < 4e-3
+    assert float(dv[id(dc)][:, classes:].abs().max().item() if ld > classes else 0.0) == 0.0
+
+
+@pytest.mark.parametrize('na,nb', [(16, 16), (256, 256), (7, 130)])
+def test_relevance_matrix_exact(libs, na, nb):
+    a = torch.randint(0, 9, (na,), generator=torch.Generator().manual_seed(na))
+    b = torch.randint(0, 9, (nb,), generator=torch.Generator().manual_seed(nb + 1))
+    R = torch.empty(na, nb)
+    dv = both(libs, 'tok_relevance_matrix', lambda d: [d(a), d(b), na, nb, d(R), None])
+    assert torch.equal(dv[id(R)].cpu(), R)
+
+
+@pytest.mark.parametrize('n1,n2,dim,ld,same', [(16, 16, 24, 24, 1), (16, 12, 24, 24, 0), (256, 256, 512, 512, 1),
+                                               (33, 65, 20, 24, 0)])
+def test_contrastive(libs, n1, n2, dim, ld, same):
+    e1 = torch.zeros(n1, ld)
+    e1[:, :dim] = rnd(n1, dim, scale=1.0 / dim ** 0.5)
+    e1 = e1.to(BF16)
+    if same:
+        e2 = e1
+    else:
+        e2 = torch.zeros(n2, ld)
+        e2[:, :dim] = rnd(n2, dim, scale=1.0 / dim ** 0.5, seed=5)
+        e2 = e2.to(BF16)
+    R = (torch.rand(n1, n2, generator=torch.Generator().manual_seed(2)) < 0.2).float()
+    S, rl, loss = torch.empty(n1, n2), torch.empty(n1), torch.empty(1)
+    dv = both(libs, 'tok_contrastive_fwd', lambda d: [d(e1), d(e2), d(R), n1, n2, dim, ld, 1.2, d(S), d(rl), d(loss),
+                                                        None])
+    assert relerr(dv[id(S)], S) < 1e-5 and relerr(dv[id(rl)], rl) < 1e-5 and relerr(dv[id(loss)], loss) < 1e-5
+    gs = torch.tensor([0.7])
+    de1 = torch.empty(n1, ld, dtype=BF16)
+    de2 = torch.empty(n2, ld, dtype=BF16)
+    dv = both(libs, 'tok_contrastive_bwd', lambda d: [d(e1), d(e1) if same else d(e2), d(R), d(S), d(gs), n1, n2, dim,
+                                                        ld, 1.2, d(de1), None if same else d(de2), same, None])
+    assert relerr(dv[id(de1)].float(), de1.float()) < 6e-3
+    if not same:
+        assert relerr(dv[id(de2)].float(), de2.float()) < 6e-3

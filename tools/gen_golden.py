@@ -95,6 +95,80 @@ def install_shim():
     return resnet, pooling, head, losses
 
 
+def golden_metric(out_path):
+    """ArcFaceHead / LinearHead(normalize) / ContrastiveLoss / calc_relevance_matrix from the reference's
+    own files; asserts oracle/metric_ref.py == reference bit-for-bit on the same inputs."""
+    import ast
+    import oracle.metric_ref as M
+    arc = _load('torchok.models.heads.classification.arcface_head',
+                f'{REF}/models/heads/classification/arcface_head.py')
+    lin = sys.modules['torchok.models.heads.representation.linear_head']
+    _fake_pkg('torchok.losses.representation', f'{REF}/losses/representation')
+    pw = _load('torchok.losses.representation.pairwise', f'{REF}/losses/representation/pairwise.py')
+    # calc_relevance_matrix: tasks/pairwise_task.py cannot be imported (its base class pulls in lightning), so
+    # the method's own source lines are compiled out of the reference file and bound to a stub `self`
+    src = open(f'{REF}/tasks/pairwise_task.py').read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == 'calc_relevance_matrix')
+    ns = {'torch': torch, 'Tensor': torch.Tensor}
+    exec(compile(ast.Module([fn], []), f'{REF}/tasks/pairwise_task.py', 'exec'), ns)
+    calc_rel = ns['calc_relevance_matrix']
+
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    # ---- ArcFaceHead: default + easy margin, train + eval, gradients of CE(output, target) -------
+    n, c, k = 16, 64, 10
+    x = torch.randn(n, c, generator=g)
+    t = torch.randint(0, k, (n,), generator=g)
+    for tag, easy in (('arc', False), ('arc_easy', True)):
+        h = arc.ArcFaceHead(c, k, easy_margin=easy).train()
+        h.load_state_dict(deterministic_state(h.state_dict(), 21))
+        with torch.no_grad():
+            h.weight.mul_(4.0)        # rows far from unit norm: exercises the weight normalisation backward
+        xi = x.clone().requires_grad_(True)
+        y = h(xi, t)
+        F_ce = torch.nn.functional.cross_entropy(y, t)
+        F_ce.backward()
+        yo = M.arcface_forward(x, h.weight.detach(), t, h.margin, h.scale, easy)
+        assert torch.equal(y.detach(), yo), 'arcface restatement != reference'
+        sc, mg = M.arcface_defaults(c, k)
+        assert sc == h.scale and mg == h.margin
+        out.update({f'{tag}_out': y.detach().numpy(), f'{tag}_dx': xi.grad.numpy(), f'{tag}_dw': h.weight.grad.numpy(),
+                    f'{tag}_loss': float(F_ce), f'{tag}_eval': h.eval()(x).detach().numpy(),
+                    f'{tag}_scale': h.scale, f'{tag}_margin': h.margin})
+    out.update(arc_x=x.numpy(), arc_t=t.numpy(), arc_w=h.weight.detach().numpy())
+    # ---- LinearHead(normalize=True) -----------------------------------------------------------------
+    lh = lin.LinearHead(c, 24, normalize=True)
+    lh.load_state_dict(deterministic_state(lh.state_dict(), 22))
+    xi = x.clone().requires_grad_(True)
+    y = lh(xi)
+    (y * torch.linspace(-1, 1, 24)).sum().backward()
+    assert torch.equal(y.detach(), M.linear_head_forward(x, lh.fc.weight.detach(), lh.fc.bias.detach(), True))
+    out.update(lin_out=y.detach().numpy(), lin_dx=xi.grad.numpy(), lin_dw=lh.fc.weight.grad.numpy(),
+               lin_db=lh.fc.bias.grad.numpy())
+    # ---- relevance matrix + ContrastiveLoss (emb1 is emb2, as PairwiseLearnTask hands them over) -------
+    class _Self:
+        num_classes = 6
+    lab = torch.randint(0, 6, (n,), generator=g)
+    R = calc_rel(_Self(), lab)
+    assert torch.equal(R, M.relevance_matrix(lab, 6))
+    e = (0.6 * torch.randn(n, 24, generator=g)).requires_grad_(True)
+    cl = pw.ContrastiveLoss(margin=1.0)
+    L = cl(emb1=e, emb2=e, R=R)
+    L.backward()
+    assert torch.equal(L.detach(), M.contrastive_loss(e.detach(), e.detach(), R, 1.0))
+    e2 = (0.6 * torch.randn(12, 24, generator=g)).requires_grad_(True)
+    e1 = e.detach().clone().requires_grad_(True)
+    lab2 = torch.randint(0, 6, (12,), generator=g)
+    R2 = (lab[:, None] == lab2[None, :]).float()
+    L2 = cl(emb1=e1, emb2=e2, R=R2)
+    L2.backward()
+    out.update(con_lab=lab.numpy(), con_R=R.numpy(), con_e=e.detach().numpy(), con_loss=float(L), con_de=e.grad.numpy(),
+               con_e2=e2.detach().numpy(), con_R2=R2.numpy(), con_loss2=float(L2), con_de1=e1.grad.numpy(),
+               con_de2=e2.grad.numpy())
+    np.savez_compressed(out_path, **out)
+    print(f'wrote {out_path}: restatement == reference files: OK')
+
+
 class RefTask(nn.Module):
     """The wiring of reference tasks/classification.py:45-73,90-119 over the reference's own modules."""
 
@@ -185,9 +259,12 @@ def main():
     os.makedirs(gd, exist_ok=True)
     # batch/size chosen so that the deepest BatchNorm still sees >= 32 samples per channel (bf16 parity
     # of the HIP path is checked against these same vectors)
+    if '--metric-only' in sys.argv:
+        return golden_metric(os.path.join(gd, 'metric_heads.npz'))
     golden_step(mods, 'resnet18', 10, 8, 96, 11, os.path.join(gd, 'resnet18_cls_step.npz'))
     golden_step(mods, 'resnet50', 16, 8, 128, 12, os.path.join(gd, 'resnet50_cls_step.npz'))
     golden_heads(mods, os.path.join(gd, 'classification_head.npz'))
+    golden_metric(os.path.join(gd, 'metric_heads.npz'))
 
 
 if __name__ == '__main__':

@@ -60,6 +60,13 @@ PROTOTYPES = {
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
     'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
+    'tok_l2norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
+    'tok_l2norm_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_arcface_margin_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P]),
+    'tok_arcface_margin_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, c_float, _P, _P]),
+    'tok_relevance_matrix': (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    'tok_contrastive_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'tok_contrastive_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
     'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,

@@ -1,2 +1,3 @@
 from .base import JointLoss  # noqa: F401
 from .cross_entropy import CrossEntropyLoss  # noqa: F401
+from .contrastive import ContrastiveLoss  # noqa: F401

@@ -1,1 +1,2 @@
 from .linear_head import ClassificationHead, LinearHead  # noqa: F401
+from .arcface_head import ArcFaceHead  # noqa: F401

@@ -9,6 +9,7 @@ from torch import Tensor
 from ... import engine
 from ...constructor import HEADS
 from ...engine import functional as EF
+from ...engine import metric as EM
 from ..base import BaseModel
 
 
@@ -23,10 +24,11 @@ class LinearHead(BaseModel):
     def forward(self, x: Tensor, targets: Optional[Tensor] = None) -> Tensor:
         if self.drop_rate > 0. and self.training:
             raise NotImplementedError('torchok_amd LinearHead: dropout is not built (p = 0 in all hot-path configs)')
-        if self.normalize:
-            raise NotImplementedError('torchok_amd LinearHead: normalize=True is not built yet')
         with engine.region() as r:
-            return r.output(EF.linear(r, r.input(x), self.fc))
+            y = EF.linear(r, r.input(x), self.fc)
+            if self.normalize:
+                y = EM.l2_normalize(r, y)
+            return r.output(y)
 
 
 @HEADS.register_class

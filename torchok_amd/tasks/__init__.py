@@ -1,2 +1,3 @@
 from .base import BaseTask  # noqa: F401
 from .classification import ClassificationTask  # noqa: F401
+from .pairwise_task import PairwiseLearnTask  # noqa: F401
