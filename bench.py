@@ -28,6 +28,16 @@ import torch  # noqa: E402
 
 ALG_BYTES_PER_IMG = {'resnet50': 309.7e6, 'resnet18': 70.6e6}   # SURVEY.md App. C (Model F + weights @B=256)
 HBM_PEAK = 8.0e12
+# PMC-measured HBM bytes of ONE step of the default workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes of this same command, summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01_resnet50_bs256_pmc_traffic.json')
+
+
+def measured_traffic(backbone: str, res: int, batch: int):
+    if (backbone, res, batch) != ('resnet50', 224, 256) or not os.path.exists(PMC_TRAFFIC):
+        return None
+    with open(PMC_TRAFFIC) as f:
+        return round(json.load(f)['hbm_bytes_per_step'] / 1e9, 2)
 
 
 def build_task(backbone: str, num_classes: int):
@@ -171,7 +181,10 @@ def main():
         if alg is not None and args.res == 224:
             achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                        'frac': round(achieved * 1e9 / HBM_PEAK, 4), 'traffic': None,
+                        'frac': round(achieved * 1e9 / HBM_PEAK, 4),
+                        'traffic': measured_traffic(args.backbone, args.res, args.batch), 'traffic_unit': 'GB/step '
+                        '(PMC, profiles/r01_resnet50_bs256_pmc_traffic.json)',
+                        'algorithmic': round(alg * args.batch / 1e9, 2), 'algorithmic_unit': 'GB/step',
                         'launch': 'one training step (all kernels of fwd+bwd+optimizer on the step stream), '
                                   f'HIP-event avg {ev_ms:.3f} ms'}
         line = {
