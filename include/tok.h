@@ -209,6 +209,26 @@ int tok_contrastive_bwd(const void* e1, const void* e2, const float* R, const fl
                         const float* gscale, int n1, int n2, int d, int ld, float margin, void* de1,
                         void* de2, int same_tensor, void* stream);
 
+/* ---- multi-resolution glue (HRNet) ------------------------------------------------------------
+ * [timm 0.6.13] HighResolutionModule.forward: out = relu(sum_j up_j(t_j)), where term j is an NHWC
+ * bf16 tensor at (h >> s_j, w >> s_j) and up_j the nearest-neighbour nn.Upsample(scale_factor=2^s_j)
+ * of its fuse layer (s_j = 0: same resolution).  Unused terms are NULL.  `mask` (may be NULL)
+ * receives the ReLU bits [n*h*w][c/8].  Backward, once per term: dterm (+)= block-sum of the masked
+ * output gradient (mask NULL: no ReLU).                                                          */
+int tok_fuse_sum_relu_fwd(const void* t0, int s0, const void* t1, int s1, const void* t2, int s2,
+                          const void* t3, int s3, int n, int h, int w, int c, int relu, void* out,
+                          uint8_t* mask, void* stream);
+int tok_fuse_sum_relu_bwd(const void* dout, const uint8_t* mask, int n, int h, int w, int c, int shift,
+                          void* dterm, int accumulate, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) (necks/segmentation/hrnet.py:36-39,
+ * heads/segmentation/base.py:37): src [n][hs][ws][ld_src] (first c channels) -> channels
+ * [ch_off, ch_off + c) of dst [n][hd][wd][ld_dst] — i.e. torch.cat (hrnet.py:41) costs nothing.
+ * hs == hd && ws == wd is an exact strided copy.  Backward = exact transpose, gather form.        */
+int tok_bilinear_fwd(const void* src, int n, int hs, int ws, int c, int ld_src, void* dst, int hd,
+                     int wd, int ld_dst, int ch_off, void* stream);
+int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_dst, int ch_off, void* dsrc,
+                     int hs, int ws, int c, int ld_src, int accumulate, void* stream);
+
 /* ---- optimizers (flat arenas) -------------------------------------------------------------
  * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
  * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch

@@ -162,4 +162,6 @@ def build_model_with_cfg(model_cls, variant, pretrained, pretrained_strict=False
     for k in kwargs_filter or ():
         kwargs.pop(k, None)
     assert not pretrained
+    if 'model_cfg' in kwargs:          # timm: model_cls(cfg=model_cfg, **kwargs)
+        kwargs['cfg'] = kwargs.pop('model_cfg')
     return model_cls(**kwargs)

@@ -436,6 +436,59 @@ class FakeTok:
             o2[:, :d] = _bf(g2)
         return 0
 
+    # ---- multi-resolution glue (HRNet) ----------------------------------------------------------------
+    def tok_fuse_sum_relu_fwd(self, t0, s0, t1, s1, t2, s2, t3, s3, n, h, w, c, relu, out, mask, st):
+        self.calls.append('fuse_sum_relu_fwd')
+        acc = torch.zeros(n, h, w, c)
+        for tp, sh in ((t0, s0), (t1, s1), (t2, s2), (t3, s3)):
+            if tp is None:
+                continue
+            v = _t(tp, (n, h >> sh, w >> sh, c), BF16).float()
+            if sh:
+                v = v.repeat_interleave(1 << sh, dim=1).repeat_interleave(1 << sh, dim=2)
+            acc = acc + v
+        if relu:
+            acc = acc.clamp_min(0)
+        o = acc.to(BF16)
+        _t(out, (n, h, w, c), BF16).copy_(o)
+        if mask is not None:
+            m = n * h * w
+            bits = (o.float() > 0).long().reshape(m, c // 8, 8)
+            _t(mask, (m, c // 8), torch.uint8).copy_((bits << torch.arange(8)).sum(-1).to(torch.uint8))
+        return 0
+
+    def tok_fuse_sum_relu_bwd(self, dout, mask, n, h, w, c, shift, dterm, accumulate, st):
+        self.calls.append('fuse_sum_relu_bwd')
+        g = _t(dout, (n, h, w, c), BF16).float()
+        if mask is not None:
+            g = g * self._bits(mask, n * h * w, c).reshape(n, h, w, c)
+        f = 1 << shift
+        g = g.reshape(n, h // f, f, w // f, f, c).sum((2, 4))
+        d = _t(dterm, (n, h // f, w // f, c), BF16)
+        d.copy_(_bf(g + d.float()) if accumulate else _bf(g))
+        return 0
+
+    def tok_bilinear_fwd(self, src, n, hs, ws, c, ld_src, dst, hd, wd, ld_dst, ch_off, st):
+        self.calls.append('bilinear_fwd')
+        x = _t(src, (n, hs, ws, ld_src), BF16)[..., :c].float().permute(0, 3, 1, 2)
+        y = F.interpolate(x, size=(hd, wd), mode='bilinear', align_corners=False)
+        _t(dst, (n, hd, wd, ld_dst), BF16)[..., ch_off:ch_off + c] = _bf(y.permute(0, 2, 3, 1))
+        return 0
+
+    def tok_bilinear_bwd(self, ddst, n, hd, wd, ld_dst, ch_off, dsrc, hs, ws, c, ld_src, accumulate, st):
+        self.calls.append('bilinear_bwd')
+        g = _t(ddst, (n, hd, wd, ld_dst), BF16)[..., ch_off:ch_off + c].float().permute(0, 3, 1, 2)
+        with torch.enable_grad():      # called from inside an autograd backward
+            x = torch.zeros(n, c, hs, ws, requires_grad=True)
+            gx, = torch.autograd.grad(F.interpolate(x, size=(hd, wd), mode='bilinear', align_corners=False), x, g)
+        gx = gx.permute(0, 2, 3, 1)
+        d = _t(dsrc, (n, hs, ws, ld_src), BF16)
+        if accumulate:
+            d[..., :c] = _bf(d[..., :c].float() + gx)
+        else:
+            d[..., :c] = _bf(gx)
+        return 0
+
     # ---- optimizers ---------------------------------------------------------------------------------
     def tok_sgd_step(self, param, grad, mbuf, shadow, count, lr, momentum, dampening, wd, nesterov, first,
                      maximize, st):

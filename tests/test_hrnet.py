@@ -1,0 +1,131 @@
+"""HRNet segmentation rows (SURVEY.md §8 a12-a14 + a10 on (N,C,H,W) logits): HighResolutionNet,
+HRNetSegmentationNeck, SegmentationHead, SegmentationTask against tests/golden/hrnet_seg_step.npz (one training
+step of the reference's own hrnet.py / neck / head, tools/gen_golden.py) and oracle/hrnet_ref.py.
+Each test runs on the host stand-in and, marked gpu, through libtok_gfx950.so."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.hrnet_ref as H
+import torchok_amd as T
+from helpers import deterministic_state, rel_err
+from torchok_amd.constructor.config import apply_schema
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'hrnet_seg_step.npz'))
+
+
+@pytest.fixture(params=['host', pytest.param('hip', marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == 'host':
+        request.getfixturevalue('fake_backend')
+        return 'cpu'
+    assert torch.cuda.is_available()
+    return 'cuda'
+
+
+def seg_config(backbone='hrnet_w18_small', classes=19, size=128):
+    return apply_schema({
+        'task': {'name': 'SegmentationTask',
+                 'params': {'backbone_name': backbone, 'backbone_params': {'pretrained': False, 'in_channels': 3},
+                            'neck_name': 'HRNetSegmentationNeck', 'head_name': 'SegmentationHead',
+                            'head_params': {'num_classes': classes},
+                            'inputs': [{'shape': [3, size, size], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'params': {'ignore_index': 255},
+                                   'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.01, 'momentum': 0.9, 'weight_decay': 5e-4}}}],
+        'data': {}, 'trainer': {'precision': 'bf16'}})
+
+
+def _inputs():
+    return torch.from_numpy(GOLD['x'].astype(np.float32)), torch.from_numpy(GOLD['y'].astype(np.int64))
+
+
+def test_oracle_reproduces_reference_step():
+    x, y = _inputs()
+    ora = H.SegmentationModel(str(GOLD['variant']), int(GOLD['num_classes'])).train()
+    ora.load_state_dict(deterministic_state(ora.state_dict(), int(GOLD['seed'])))
+    assert [n for n, _ in ora.named_parameters()] == [str(n) for n in GOLD['param_names']]
+    out = ora.forward_with_gt({'image': x, 'target': y})
+    loss = torch.nn.functional.cross_entropy(out['prediction'], y, ignore_index=255)
+    assert float(loss) == float(GOLD['loss'])
+    assert np.array_equal(out['prediction'].detach().half().numpy(), GOLD['prediction'])
+    loss.backward()
+    gn = np.array([float(p.grad.double().norm()) for p in ora.parameters()])
+    assert np.allclose(gn, GOLD['grad_norm'], rtol=1e-6)
+    assert sum(p.numel() for p in H.SegmentationModel('hrnet_w48', 19).parameters()) == 65858659
+
+
+def test_reference_shape_tests(dev):
+    """tests/additional_tests/models/backbones/test_backbone.py:75-89 (hrnet_w18_small on 2x3x64x64)."""
+    m = T.BACKBONES.get('hrnet_w18_small')(pretrained=False).to(dev)
+    x = torch.rand(2, 3, 64, 64).to(dev)
+    with torch.no_grad():
+        out = m(x)
+    assert [tuple(f.shape) for f in out] == [(2, 16, 16, 16), (2, 32, 8, 8), (2, 64, 4, 4), (2, 128, 2, 2)]
+    feats = m.forward_features(x)
+    assert [tuple(f.shape) for f in feats] == [(2, 3, 64, 64), (2, 16, 16, 16), (2, 32, 8, 8), (2, 64, 4, 4),
+                                               (2, 128, 2, 2)]
+    assert m.out_encoder_channels == (16, 32, 64, 128)
+    assert T.NECKS.get('HRNetSegmentationNeck')((18, 36, 72, 144)).out_channels == 270    # necks/test_hrnet.py:26
+    assert len(m.get_stages(4)) == 6 + 1 + 2 + 2 + 2
+    # state_dict layout = reference layout (timm names)
+    ref = H.HRNet('hrnet_w18_small')
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    with pytest.raises(ValueError, match='divisible by 32'):
+        m(torch.rand(1, 3, 72, 72).to(dev))
+
+
+def test_segmentation_step_vs_reference_golden(dev):
+    cfg = seg_config()
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')},
+                             int(GOLD['seed']))
+    task.load_state_dict(sd, strict=False)
+    task.to(dev).train()
+    x, y = _inputs()
+    feats = task.backbone.forward_features(x.to(dev))
+    assert [list(f.shape) for f in feats[1:]] == GOLD['feat_shapes'].tolist()
+    for f, ss in zip(feats[1:], GOLD['feat_sumsq']):
+        assert abs(float((f.detach().double() ** 2).sum()) / float(ss) - 1) < 3e-2
+    out = task.training_step({'image': x.to(dev), 'target': y.to(dev)}, 0)
+    fw = task.forward_with_gt({'image': x.to(dev), 'target': y.to(dev)})
+    assert set(fw) == {'prediction', 'target'} and fw['prediction'].shape == (4, 19, 128, 128)
+    pred = fw['prediction'].detach().float().cpu()
+    assert rel_err(pred, torch.from_numpy(GOLD['prediction'].astype(np.float32))) < 3e-2
+    assert abs(float(out['loss'].detach()) - float(GOLD['loss'])) < 2e-2 * float(GOLD['loss'])
+    out['loss'].backward()
+    names = [str(n) for n in GOLD['param_names']]
+    assert names == [n for n, _ in task.named_parameters()]
+
+    # bf16 yardstick: torch's bf16-autocast CPU run of the oracle on the same weights
+    ora = H.SegmentationModel(str(GOLD['variant']), 19).train()
+    ora.load_state_dict(sd)
+    ref32 = copy.deepcopy(ora)
+    torch.nn.functional.cross_entropy(ref32.forward_with_gt({'image': x, 'target': y})['prediction'], y,
+                                      ignore_index=255).backward()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        o = ora.forward_with_gt({'image': x, 'target': y})
+    torch.nn.functional.cross_entropy(o['prediction'].float(), y, ignore_index=255).backward()
+    g32 = {n: p.grad for n, p in ref32.named_parameters()}
+    yard = np.array([rel_err(p.grad, g32[n]) for n, p in ora.named_parameters()])
+    errs = np.array([rel_err(p.grad, g32[n]) for n, p in task.named_parameters()])
+    assert np.median(errs) < 1.5 * np.median(yard) + 1e-2, (np.median(errs), np.median(yard))
+    assert (errs < 1.5 * yard + 0.1).mean() > 0.9, np.sort(errs - 1.5 * yard)[-5:]
+    gn = np.array([float(p.grad.detach().double().norm()) for _, p in task.named_parameters()])
+    assert np.median(np.abs(gn / GOLD['grad_norm'] - 1)) < 0.1
+    opt = task.configure_optimizers()[0]['optimizer']
+    before = {n: p.detach().clone() for n, p in task.named_parameters()}
+    opt.step()
+    assert all(not torch.equal(before[n], p.detach()) for n, p in task.named_parameters())
+
+
+def test_eval_forward_and_single_class(dev):
+    cfg = seg_config(classes=1, size=64)
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).to(dev).eval()
+    with torch.no_grad():
+        y = task(torch.rand(2, 3, 64, 64).to(dev))
+    assert y.shape == (2, 64, 64)                    # heads/segmentation/base.py:38-39 squeeze
+    assert len(task.as_module()) == 3

@@ -517,3 +517,64 @@ def test_contrastive(libs, n1, n2, dim, ld, same):
     assert relerr(dv[id(de1)].float(), de1.float()) < 6e-3
     if not same:
         assert relerr(dv[id(de2)].float(), de2.float()) < 6e-3
+
+
+# ---- multi-resolution glue (resample.hip) ------------------------------------------------------------------
+@pytest.mark.parametrize('n,h,w,c,shifts,relu', [(2, 16, 16, 16, (0, 1, 2, 3), 1), (2, 8, 24, 48, (0, 0, 1), 1),
+                                               (1, 32, 32, 32, (0, 0), 1), (3, 8, 8, 64, (0, 2), 0)])
+def test_fuse_sum_relu(libs, n, h, w, c, shifts, relu):
+    terms = [rnd(n, h >> s, w >> s, c, seed=7 + i).to(BF16) for i, s in enumerate(shifts)]
+    out = torch.empty(n, h, w, c, dtype=BF16)
+    mask = torch.empty(n * h * w, c // 8, dtype=torch.uint8)
+
+    def args(d):
+        a = []
+        for i in range(4):
+            a += [d(terms[i]), shifts[i]] if i < len(terms) else [None, 0]
+        return a + [n, h, w, c, relu, d(out), d(mask), None]
+    dv = both(libs, 'tok_fuse_sum_relu_fwd', args)
+    assert relerr(dv[id(out)].float(), out.float()) < 4e-3
+    # mask bits may differ only where the sum rounds to +-0 in one of the two implementations
+    assert (dv[id(mask)].cpu() != mask).float().mean() < 1e-3
+    g = rnd(n, h, w, c, seed=3).to(BF16)
+    for s in sorted(set(shifts)):
+        for acc in (0, 1):
+            dt = (rnd(n, h >> s, w >> s, c, seed=11) if acc else torch.zeros(n, h >> s, w >> s, c)).to(BF16)
+            dv = both(libs, 'tok_fuse_sum_relu_bwd', lambda d: [d(g), d(mask) if relu else None, n, h, w, c, s, d(dt),
+                                                                  acc, None])
+            assert relerr(dv[id(dt)].float(), dt.float()) < 6e-3
+
+
+@pytest.mark.parametrize('n,hs,ws,c,hd,wd,ld,off', [(2, 8, 8, 16, 16, 16, 16, 0), (2, 4, 8, 32, 32, 64, 96, 32),
+                                                    (1, 16, 16, 24, 64, 64, 24, 0), (2, 16, 16, 16, 16, 16, 48, 16),
+                                                    (1, 5, 7, 8, 13, 20, 8, 0), (1, 9, 9, 8, 4, 5, 8, 0)])
+def test_bilinear(libs, n, hs, ws, c, hd, wd, ld, off):
+    src = rnd(n, hs, ws, c).to(BF16)
+    dst = rnd(n, hd, wd, ld, seed=2).to(BF16)       # other slices must stay untouched
+    before = dst.clone()
+    dv = both(libs, 'tok_bilinear_fwd', lambda d: [d(src), n, hs, ws, c, c, d(dst), hd, wd, ld, off, None])
+    assert relerr(dv[id(dst)].float(), dst.float()) < 4e-3
+    keep = torch.ones(ld, dtype=torch.bool)
+    keep[off:off + c] = False
+    assert torch.equal(dv[id(dst)].cpu()[..., keep], before[..., keep])
+    g = rnd(n, hd, wd, ld, seed=5).to(BF16)
+    for acc in (0, 1):
+        ds = (rnd(n, hs, ws, c, seed=6) if acc else torch.zeros(n, hs, ws, c)).to(BF16)
+        dv = both(libs, 'tok_bilinear_bwd', lambda d: [d(g), n, hd, wd, ld, off, d(ds), hs, ws, c, c, acc, None])
+        assert relerr(dv[id(ds)].float(), ds.float()) < 6e-3
+
+
+def test_bilinear_adjoint_property(libs):
+    """<up(x), g> == <x, up^T(g)> at a size no oracle run is needed for (size-independent property)."""
+    lib, _ = libs
+    n, hs, ws, c, hd, wd = 2, 32, 64, 64, 128, 256
+    x = rnd(n, hs, ws, c).to(BF16).cuda()
+    g = rnd(n, hd, wd, c, seed=1).to(BF16).cuda()
+    up = torch.empty(n, hd, wd, c, dtype=BF16, device='cuda')
+    gx = torch.empty(n, hs, ws, c, dtype=BF16, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tok_bilinear_fwd(x.data_ptr(), n, hs, ws, c, c, up.data_ptr(), hd, wd, c, 0, st) == 0
+    assert lib.tok_bilinear_bwd(g.data_ptr(), n, hd, wd, c, 0, gx.data_ptr(), hs, ws, c, c, 0, st) == 0
+    a = float((up.double() * g.double()).sum())
+    b = float((x.double() * gx.double()).sum())
+    assert abs(a - b) < 2e-2 * (up.double().norm() * g.double().norm()).item() ** 0.5 + 1e-2 * abs(a)

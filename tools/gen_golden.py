@@ -95,6 +95,69 @@ def install_shim():
     return resnet, pooling, head, losses
 
 
+def golden_hrnet(out_path, variant='hrnet_w18_small', classes=19, batch=4, size=128, seed=41):
+    """SegmentationTask wiring (tasks/segmentation.py:60-93) over the reference's OWN hrnet.py, segmentation neck
+    and head (timm.models.hrnet stubbed by oracle/hrnet_ref.py); asserts the restatement is bit-identical."""
+    import oracle.hrnet_ref as H
+    hr = _fake_pkg('timm.models.hrnet')
+    for n in ('_BN_MOMENTUM', 'BasicBlock', 'blocks_dict', 'Bottleneck', 'cfg_cls', 'HighResolutionModule'):
+        setattr(hr, n, getattr(H, n))
+    hrnet = _load('torchok.models.backbones.hrnet', f'{REF}/models/backbones/hrnet.py')
+    _fake_pkg('torchok.models.modules', f'{REF}/models/modules')
+    _fake_pkg('torchok.models.modules.bricks', f'{REF}/models/modules/bricks')
+    _load('torchok.models.modules.bricks.convbnact', f'{REF}/models/modules/bricks/convbnact.py')
+    _fake_pkg('torchok.models.necks', f'{REF}/models/necks')
+    _fake_pkg('torchok.models.necks.segmentation', f'{REF}/models/necks/segmentation')
+    neck = _load('torchok.models.necks.segmentation.hrnet', f'{REF}/models/necks/segmentation/hrnet.py')
+    _fake_pkg('torchok.models.heads.segmentation', f'{REF}/models/heads/segmentation')
+    head = _load('torchok.models.heads.segmentation.base', f'{REF}/models/heads/segmentation/base.py')
+
+    class RefSeg(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = getattr(hrnet, variant)(pretrained=False, in_channels=3)
+            self.neck = neck.HRNetSegmentationNeck(in_channels=self.backbone.out_encoder_channels)
+            self.head = head.SegmentationHead(in_channels=self.neck.out_channels, num_classes=classes)
+
+        def forward_with_gt(self, batch):
+            feats = self.backbone.forward_features(batch['image'])
+            return {'prediction': self.head(self.neck(feats)), 'target': batch['target']}
+
+    torch.manual_seed(seed)
+    task = RefSeg().train()
+    task.load_state_dict(deterministic_state(task.state_dict(), seed))
+    ora = H.SegmentationModel(variant, classes).train()
+    assert set(ora.state_dict()) == set(task.state_dict()), 'state_dict keys differ: restated wiring != reference'
+    ora.load_state_dict(deterministic_state(ora.state_dict(), seed))
+
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, size, size, generator=g).half().float()
+    y = torch.randint(0, classes, (batch, size, size), generator=g)
+    y[:, :4, :] = 255                                    # ignored border, as segmentation datasets have
+    ce = nn.CrossEntropyLoss(ignore_index=255)
+    feats = task.backbone.forward_features(x)
+    out = task.forward_with_gt({'image': x, 'target': y})
+    loss = ce(out['prediction'], y)
+    loss.backward()
+    oout = ora.forward_with_gt({'image': x, 'target': y})
+    oloss = ce(oout['prediction'], y)
+    oloss.backward()
+    assert torch.equal(out['prediction'], oout['prediction']) and torch.equal(loss, oloss)
+    for (n1, p1), (n2, p2) in zip(task.named_parameters(), ora.named_parameters()):
+        assert n1 == n2 and torch.equal(p1.grad, p2.grad), n1
+    names = [n for n, _ in task.named_parameters()]
+    grads = {n: p.grad for n, p in task.named_parameters()}
+    small = [n for n in names if grads[n].numel() <= 1024][:60]
+    np.savez_compressed(
+        out_path, variant=variant, num_classes=classes, seed=seed, x=x.half().numpy(), y=y.numpy().astype(np.uint8),
+        feat_shapes=np.array([list(f.shape) for f in feats[1:]]),
+        feat_sumsq=np.array([float((f.double() ** 2).sum()) for f in feats[1:]]),
+        prediction=out['prediction'].detach().half().numpy(), loss=float(loss.detach()),
+        param_names=np.array(names), grad_norm=np.array([float(grads[n].double().norm()) for n in names]),
+        small_names=np.array(small), **{f'grad__{n}': grads[n].numpy() for n in small})
+    print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params, restatement == reference files: OK')
+
+
 def golden_metric(out_path):
     """ArcFaceHead / LinearHead(normalize) / ContrastiveLoss / calc_relevance_matrix from the reference's
     own files; asserts oracle/metric_ref.py == reference bit-for-bit on the same inputs."""
@@ -261,10 +324,13 @@ def main():
     # of the HIP path is checked against these same vectors)
     if '--metric-only' in sys.argv:
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
+    if '--hrnet-only' in sys.argv:
+        return golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_step(mods, 'resnet18', 10, 8, 96, 11, os.path.join(gd, 'resnet18_cls_step.npz'))
     golden_step(mods, 'resnet50', 16, 8, 128, 12, os.path.join(gd, 'resnet50_cls_step.npz'))
     golden_heads(mods, os.path.join(gd, 'classification_head.npz'))
     golden_metric(os.path.join(gd, 'metric_heads.npz'))
+    golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
 
 
 if __name__ == '__main__':

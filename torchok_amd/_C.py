@@ -67,6 +67,10 @@ PROTOTYPES = {
     'tok_relevance_matrix': (c_int, [_P, _P, c_int, c_int, _P, _P]),
     'tok_contrastive_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'tok_contrastive_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
+    'tok_fuse_sum_relu_fwd': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'tok_fuse_sum_relu_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'tok_bilinear_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    'tok_bilinear_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,

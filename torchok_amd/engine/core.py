@@ -275,6 +275,10 @@ def _grad_to_engine(t: TTensor, g: torch.Tensor) -> torch.Tensor:
         gp = g.permute(0, 2, 3, 1)
         if g.dtype == BF16 and t.c == t.cp and gp.is_contiguous():
             return gp
+        n, h, w, cp = t.data.shape
+        if g.dtype == BF16 and gp.stride() == (h * w * cp, w * cp, cp, 1) \
+                and _padded_rows.pop(g.data_ptr(), None) == cp:
+            return torch.as_strided(g, (n, h, w, cp), (h * w * cp, w * cp, cp, 1))   # our own zero-padded rows
         buf = torch.zeros_like(t.data)
         buf[..., :t.c] = gp
         return buf

@@ -14,10 +14,24 @@ class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, target: Tensor, ignore_index: int):
         require_device(logits)
-        rows, classes = logits.shape
-        z = logits.detach()
-        if z.dtype != BF16 or z.stride(1) != 1:
-            z = z.to(BF16).contiguous()
+        ctx.spatial = None
+        if logits.dim() == 4:
+            # (N, C, H, W) logits vs (N, H, W) targets: every pixel is a row of the channel-last buffer
+            n, classes, h, w = logits.shape
+            zp = logits.detach().permute(0, 2, 3, 1)
+            ld = zp.stride(2)
+            if zp.dtype == BF16 and zp.stride(3) == 1 and ld >= classes and zp.stride(1) == w * ld \
+                    and zp.stride(0) == h * w * ld:
+                z = torch.as_strided(zp, (n * h * w, classes), (ld, 1))      # zero copy (segmentation head output)
+            else:
+                z = zp.to(BF16).contiguous().view(n * h * w, classes)
+            ctx.spatial = (n, h, w)
+            target = target.reshape(-1)
+        else:
+            z = logits.detach()
+            if z.dtype != BF16 or z.stride(1) != 1:
+                z = z.to(BF16).contiguous()
+        rows, classes = z.shape
         if target.dtype != torch.int64 or not target.is_contiguous():
             target = target.to(torch.int64).contiguous()
         dev = z.device
@@ -35,15 +49,21 @@ class _SoftmaxCE(torch.autograd.Function):
     def backward(ctx, g):
         z, target = ctx.z, ctx.target
         rows, classes = z.shape
-        ld = pad8(classes)
+        ld = z.stride(0)          # the kernel writes d(logits) in the row pitch of the logits
         gs = g.detach().to(torch.float32).reshape(1).contiguous()
         d = torch.empty((rows, ld), dtype=BF16, device=z.device)
         _C.check(_C.lib().tok_softmax_ce_bwd(ptr(z), ptr(target), ptr(ctx.lse), ptr(ctx.loss), ptr(gs), rows,
                                              classes, z.stride(0), ctx.ignore_index, ptr(d), stream_ptr()),
                  'tok_softmax_ce_bwd')
         ctx.z = ctx.target = ctx.lse = ctx.loss = None
-        if ld != classes:
-            mark_padded(d)
+        if ctx.spatial is not None:
+            n, h, w = ctx.spatial
+            if ld == pad8(classes) != classes:
+                mark_padded(d)
+            d = d.view(n, h, w, ld)[..., :classes].permute(0, 3, 1, 2)
+        elif ld != classes:
+            if ld == pad8(classes):
+                mark_padded(d)
             d = d[:, :classes]
         if ctx.in_dtype != BF16:
             d = d.to(ctx.in_dtype)
@@ -62,6 +82,8 @@ class CrossEntropyLoss(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
-        if input.dim() != 2:
-            raise NotImplementedError('torchok_amd CrossEntropyLoss: (N, C) logits only (for now)')
+        if input.dim() not in (2, 4):
+            raise NotImplementedError('torchok_amd CrossEntropyLoss: (N, C) or (N, C, H, W) logits')
+        if input.dim() == 4 and target.shape != (input.shape[0],) + tuple(input.shape[2:]):
+            raise ValueError(f'Expected target of shape (N, H, W) for (N, C, H, W) logits, got {tuple(target.shape)}')
         return _SoftmaxCE.apply(input, target, self.ignore_index)

@@ -1,1 +1,1 @@
-from . import backbones, heads, poolings  # noqa: F401
+from . import backbones, heads, necks, poolings  # noqa: F401

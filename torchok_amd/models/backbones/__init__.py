@@ -1,1 +1,1 @@
-from . import resnet  # noqa: F401
+from . import hrnet, resnet  # noqa: F401
