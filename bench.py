@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 ALG_BYTES_PER_IMG = {'resnet50': 309.7e6, 'resnet18': 70.6e6}   # SURVEY.md App. C (Model F + weights @B=256)
+ALG_BYTES_SEG = {('hrnet_w48', 512, 1024): 8.08e9}               # HRNet-W48 seg 512x1024
 HBM_PEAK = 8.0e12
 # PMC-measured HBM bytes of ONE step of the default workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
 # passes of this same command, summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md)
@@ -38,6 +39,25 @@ def measured_traffic(backbone: str, res: int, batch: int):
         return None
     with open(PMC_TRAFFIC) as f:
         return round(json.load(f)['hbm_bytes_per_step'] / 1e9, 2)
+
+
+def build_seg_task(backbone: str, num_classes: int, h: int, w: int):
+    """HRNet + HRNetSegmentationNeck + SegmentationHead + CrossEntropyLoss (secondary workload,
+    `--backbone hrnet_w48 --res 512 --width 1024 --classes 19 --batch 8`; never the default line)."""
+    import torchok_amd as T
+    from torchok_amd.constructor.config import apply_schema
+    cfg = apply_schema({
+        'task': {'name': 'SegmentationTask',
+                 'params': {'backbone_name': backbone, 'backbone_params': {'pretrained': False, 'in_channels': 3},
+                            'neck_name': 'HRNetSegmentationNeck', 'head_name': 'SegmentationHead',
+                            'head_params': {'num_classes': num_classes},
+                            'inputs': [{'shape': [3, h, w], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'params': {'ignore_index': 255},
+                                   'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.01, 'weight_decay': 5e-4, 'momentum': 0.9}}}],
+        'data': {}, 'trainer': {'precision': 'bf16', 'strategy': 'ddp'},
+    })
+    return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
 
 
 def build_task(backbone: str, num_classes: int):
@@ -104,8 +124,11 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--res', type=int, default=224)
+    ap.add_argument('--width', type=int, default=0, help='image width when it differs from --res (segmentation)')
     ap.add_argument('--classes', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as one hipGraph, 0: eager launches '
+                    '(default: graph for the launch-bound HRNet workload, eager otherwise)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -126,7 +149,10 @@ def main():
         ge.build()
 
     torch.manual_seed(1234)
-    task = build_task(args.backbone, args.classes).cuda().train()
+    seg = args.backbone.startswith('hrnet')
+    width = args.width or args.res
+    task = (build_seg_task(args.backbone, args.classes, args.res, width) if seg
+            else build_task(args.backbone, args.classes)).cuda().train()
     opt = task.configure_optimizers()[0]['optimizer']
     reducer = None
     if world > 1:
@@ -134,11 +160,20 @@ def main():
         reducer = GradientAllReducer(opt)
 
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
-    image = torch.randn(args.batch, 3, args.res, args.res, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
-    target = torch.randint(0, args.classes, (args.batch,), generator=g, device='cuda')
+    image = torch.randn(args.batch, 3, args.res, width, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
+    target = torch.randint(0, args.classes, (args.batch, args.res, width) if seg else (args.batch,), generator=g,
+                           device='cuda')
     batch = {'image': image, 'target': target}
 
+    use_graph = (args.graph == 1 or (args.graph < 0 and seg)) and world == 1
+    graphed = None
+    if use_graph:
+        from torchok_amd.engine.graph import GraphedTrainingStep
+        graphed = GraphedTrainingStep(task, opt, batch)
+
     def step(i):
+        if graphed is not None:
+            return graphed(batch)['loss']
         out = task.training_step(batch, i)
         opt.zero_grad(set_to_none=True)
         if reducer is not None:
@@ -175,10 +210,11 @@ def main():
 
     if rank == 0:
         value = args.batch * world * args.steps / dt
-        alg = ALG_BYTES_PER_IMG.get(args.backbone)
+        alg = ALG_BYTES_SEG.get((args.backbone, args.res, width)) if seg else \
+            (ALG_BYTES_PER_IMG.get(args.backbone) if args.res == 224 else None)
         ev_ms = sum(step_ms) / len(step_ms)
         roofline = None
-        if alg is not None and args.res == 224:
+        if alg is not None:
             achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                         'frac': round(achieved * 1e9 / HBM_PEAK, 4),
@@ -195,13 +231,16 @@ def main():
             'step_p50_ms': round(statistics.median(step_ms), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
             'data': 'synthetic', 'final_loss': round(final_loss, 4),
-            'config': {'workload': f'{args.backbone} + ClassificationTask(Pooling, ClassificationHead {args.classes}) '
+            'config': {'workload': (f'{args.backbone} + SegmentationTask(HRNetSegmentationNeck, SegmentationHead '
+                                    f'{args.classes}) + CrossEntropyLoss + SGD(momentum 0.9, wd 5e-4), synthetic '
+                                    f'3x{args.res}x{width} bf16, batch {args.batch}/GPU') if seg else
+                                   f'{args.backbone} + ClassificationTask(Pooling, ClassificationHead {args.classes}) '
                                    f'+ CrossEntropyLoss + SGD(momentum 0.9, wd 1e-4), synthetic 3x{args.res}x{args.res} '
                                    f'bf16, batch {args.batch}/GPU', 'global_batch': args.batch * world,
-                       'parallelism': f'dp{world}'},
+                       'parallelism': f'dp{world}', 'launch_mode': 'hipGraph replay' if use_graph else 'eager'},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not seg:
             line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
         print(json.dumps(line))
     if world > 1:

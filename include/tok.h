@@ -78,6 +78,20 @@ int tok_pack_weight_dgrad(const float* src, int k, int r, int s, int c,
 int tok_pack_weight_both(const float* src, int k, int r, int s, int c, void* dst_fwd, int k_pad,
                          int s_pad, int c_pad, void* dst_dgrad, void* stream);
 
+/* every weight of an optimizer in ONE launch (called right after the optimizer step: the bf16
+ * operands of the next forward are refreshed while the masters are still in cache).  `items_dev`
+ * is a DEVICE array sorted by block_start, block_start[i+1] = block_start[i] +
+ * tok_pack_item_blocks(&item[i]); dst_dgrad (or dst_fwd) may be NULL.                          */
+typedef struct tok_pack_item {
+  const float* src;
+  void* dst_fwd;
+  void* dst_dgrad;
+  int32_t k, r, s, c, k_pad, s_pad, c_pad;
+  int32_t block_start;
+} tok_pack_item;
+int tok_pack_item_blocks(const tok_pack_item* item /* host */);
+int tok_pack_weights_batched(const tok_pack_item* items_dev, int n_items, int total_blocks, void* stream);
+
 /* ---- convolution (implicit GEMM on MFMA) --------------------------------------------
  * Replace aten::conv2d fwd/bwd reached from resnet.py:488 (stem), [timm] BasicBlock /
  * Bottleneck conv1-3, downsample_conv (resnet.py:383-387), hrnet.py:64-69,122,133,156,
@@ -118,15 +132,18 @@ int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void* dy, float*
 /* Reduce tok_conv_fwd partials -> mean, rstd (biased var), scale = gamma*rstd,
  * shift = beta - mean*scale; running_mean/var momentum update (unbiased var), and
  * num_batches_tracked += 1 (int64) — the semantics of torch.nn.BatchNorm2d in training.
- * running_* / nbt may be NULL (track_running_stats=False).                                 */
-int tok_bn_finalize(const float* stats, int rows, int64_t count, int c,
+ * running_* / nbt may be NULL (track_running_stats=False).
+ * c = padded channel count of the activation (multiple of 8), c_real <= c the module's
+ * num_features (HRNet-W18: 18 -> 24): parameter / running-stat arrays hold c_real entries,
+ * padding channels get scale = shift = mean = rstd = 0 (their activations stay zero).        */
+int tok_bn_finalize(const float* stats, int rows, int64_t count, int c, int c_real,
                     const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* nbt,
                     float momentum, float eps,
                     float* mean, float* rstd, float* scale, float* shift, void* stream);
 /* eval mode: scale/shift from running statistics                                          */
 int tok_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                       const float* running_var, float eps, int c,
+                       const float* running_var, float eps, int c, int c_real,
                        float* scale, float* shift, void* stream);
 /* per-channel sum / sumsq partials of an NHWC bf16 tensor (BN after a non-conv producer)  */
 int tok_bn_stats_rows(int64_t m, int c);
@@ -148,7 +165,7 @@ int tok_bn_bwd_reduce(const void* dout, const void* y, const uint8_t* mask,
 /* dgamma, dbeta (+= if accumulate) and the 3 per-channel coefficients of
  * dy = a1*dz + a2*y + a3  ->  coef[3][c].  dzy_form != 0: the second partial is sum(dz * y)
  * (what tok_conv_dgrad_bnstats accumulates) instead of sum(dz * xhat).                     */
-int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c,
+int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c, int c_real,
                         const float* gamma, const float* mean, const float* rstd,
                         float* dgamma, float* dbeta, float* coef, int accumulate, int dzy_form,
                         void* stream);
@@ -175,9 +192,10 @@ int tok_colsum(const void* dy, int64_t m, int n_pad, int n_real, float* out, int
 /* ---- loss -------------------------------------------------------------------------------
  * torch.nn.CrossEntropyLoss(mean, ignore_index) registered at losses/__init__.py:26, called
  * from JointLoss.forward (losses/base.py:78-79).  logits bf16 [rows][ld] (classes <= ld).  */
+#define TOK_CE_LOSS_FLOATS 2050 /* loss buffer: [0]=mean loss, [1]=n_valid, rest = reduction scratch */
 int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
                        int64_t ignore_index, float* lse, float* row_loss,
-                       float* loss /* [0]=mean loss, [1]=n_valid */, void* stream);
+                       float* loss /* TOK_CE_LOSS_FLOATS floats, 8-byte aligned */, void* stream);
 /* dlogits = (softmax - onehot) * gscale[0] / n_valid  (0 for ignored rows / pad columns)   */
 int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* lse,
                        const float* loss, const float* gscale, int rows, int classes, int ld,

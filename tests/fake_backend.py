@@ -78,6 +78,28 @@ class FakeTok:
         self.tok_pack_weight_fwd(src, k, r, s, c, dst_f, k_pad, s_pad, c_pad, st)
         return self.tok_pack_weight_dgrad(src, k, r, s, c, dst_d, k_pad, c_pad, st)
 
+    def tok_pack_item_blocks(self, item):
+        it = _desc(item)
+        tf = it.k_pad * it.r * it.s_pad * it.c_pad if it.dst_fwd else 0
+        td = it.c_pad * it.r * it.s * it.k_pad if it.dst_dgrad else 0
+        return (max(tf, td) + 1023) // 1024
+
+    def tok_pack_weights_batched(self, items, n_items, total_blocks, st):
+        from torchok_amd._C import PackItem
+        self.calls.append('pack_weights_batched')
+        arr = ctypes.cast(ctypes.c_void_p(int(items)), ctypes.POINTER(PackItem))
+        blocks = 0
+        for i in range(n_items):
+            it = arr[i]
+            assert it.block_start == blocks
+            blocks += self.tok_pack_item_blocks(it)
+            if it.dst_fwd:
+                self.tok_pack_weight_fwd(it.src, it.k, it.r, it.s, it.c, it.dst_fwd, it.k_pad, it.s_pad, it.c_pad, st)
+            if it.dst_dgrad:
+                self.tok_pack_weight_dgrad(it.src, it.k, it.r, it.s, it.c, it.dst_dgrad, it.k_pad, it.c_pad, st)
+        assert blocks == total_blocks
+        return 0
+
     # ---- conv -----------------------------------------------------------------------------------
     def tok_conv_fwd_stat_rows(self, d):
         d = _desc(d)
@@ -159,19 +181,19 @@ class FakeTok:
         return 0
 
     # ---- batch norm -------------------------------------------------------------------------------
-    def tok_bn_finalize(self, stats, rows, count, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd,
+    def tok_bn_finalize(self, stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd,
                         scale, shift, st):
-        s = _t(stats, (2, rows, c), torch.float32).double().sum(1)
+        s = _t(stats, (2, rows, cp), torch.float32).double().sum(1)[:, :c]
         mu = s[0] / count
         var = (s[1] / count - mu * mu).clamp_min(0)
         g, b = _t(gamma, (c,), torch.float32), _t(beta, (c,), torch.float32)
         muf = mu.float()
         rs = (1.0 / torch.sqrt(var + eps)).float()
-        _t(mean, (c,), torch.float32).copy_(muf)
-        _t(rstd, (c,), torch.float32).copy_(rs)
         sc = g * rs
-        _t(scale, (c,), torch.float32).copy_(sc)
-        _t(shift, (c,), torch.float32).copy_(b - muf * sc)
+        for dst, val in ((mean, muf), (rstd, rs), (scale, sc), (shift, b - muf * sc)):
+            d = _t(dst, (cp,), torch.float32)
+            d.zero_()
+            d[:c] = val
         if rm is not None:
             unb = count / (count - 1) if count > 1 else 1.0
             m_, v_ = _t(rm, (c,), torch.float32), _t(rv, (c,), torch.float32)
@@ -181,12 +203,14 @@ class FakeTok:
             _t(nbt, (1,), torch.int64).add_(1)
         return 0
 
-    def tok_bn_eval_coeffs(self, gamma, beta, rm, rv, eps, c, scale, shift, st):
+    def tok_bn_eval_coeffs(self, gamma, beta, rm, rv, eps, cp, c, scale, shift, st):
         g, b = _t(gamma, (c,), torch.float32), _t(beta, (c,), torch.float32)
         m_, v_ = _t(rm, (c,), torch.float32), _t(rv, (c,), torch.float32)
         sc = g / torch.sqrt(v_ + eps)
-        _t(scale, (c,), torch.float32).copy_(sc)
-        _t(shift, (c,), torch.float32).copy_(b - m_ * sc)
+        for dst, val in ((scale, sc), (shift, b - m_ * sc)):
+            d = _t(dst, (cp,), torch.float32)
+            d.zero_()
+            d[:c] = val
         return 0
 
     def tok_bn_stats_rows(self, m, c):
@@ -234,10 +258,11 @@ class FakeTok:
         p[1, 0] = (dz * xhat).sum(0)
         return 0
 
-    def tok_bn_bwd_finalize(self, partial, rows, m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, st):
-        p = _t(partial, (2, rows, c), torch.float32).double().sum(1)
+    def tok_bn_bwd_finalize(self, partial, rows, m, cp, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy,
+                            st):
+        p = _t(partial, (2, rows, cp), torch.float32).double().sum(1)[:, :c].clone()
         if dzy:
-            p[1] = _t(rstd, (c,), torch.float32).double() * (p[1] - _t(mean, (c,), torch.float32).double() * p[0])
+            p[1] = _t(rstd, (cp,), torch.float32)[:c].double() * (p[1] - _t(mean, (cp,), torch.float32)[:c].double() * p[0])
         sdz, sdzx = p[0].float(), p[1].float()
         for ptr_, val in ((dgamma, sdzx), (dbeta, sdz)):
             if ptr_ is not None:
@@ -246,12 +271,14 @@ class FakeTok:
                     t.add_(val)
                 else:
                     t.copy_(val)
-        g, mu, rs = (_t(q, (c,), torch.float32) for q in (gamma, mean, rstd))
+        g = _t(gamma, (c,), torch.float32)
+        mu, rs = _t(mean, (cp,), torch.float32)[:c], _t(rstd, (cp,), torch.float32)[:c]
         m1, m2 = (p[0] / m).float(), (p[1] / m).float()
         c1 = g * rs
         c2 = -c1 * rs * m2
-        co = _t(coef, (3, c), torch.float32)
-        co[0], co[1], co[2] = c1, c2, -c1 * m1 - c2 * mu
+        co = _t(coef, (3, cp), torch.float32)
+        co.zero_()
+        co[0, :c], co[1, :c], co[2, :c] = c1, c2, -c1 * m1 - c2 * mu
         return 0
 
     def tok_bn_bwd_apply(self, dout, y, out, scale, shift, coef, relu, dy, dshortcut, ds_acc, m, c, st):

@@ -165,3 +165,42 @@ def test_state_dict_roundtrip_after_arena(fake_backend, tmp_path):
     for (n, a), (_, b) in zip(task.state_dict().items(), task2.state_dict().items()):
         assert torch.equal(a, b), n
     assert sd['backbone.conv1.weight'].shape == (64, 3, 7, 7)
+
+
+def test_packs_follow_the_masters(fake_backend):
+    """bf16 MFMA operand packs vs fp32 masters: the fused optimizer refreshes all of them in ONE launch after
+    its step; a forward re-packs a weight individually only if torch saw it change (`_version`) or after
+    invalidate_packs()."""
+    from torchok_amd.engine import functional as EF
+    torch.manual_seed(3)
+    task, _ = _pair()
+    opt = task.configure_optimizers()[0]['optimizer']
+    x, y = torch.randn(4, 3, 32, 32), torch.randint(0, 10, (4,))
+    conv = task.backbone.layer2[0].conv1
+
+    def fwd_pack_in_sync():
+        pk = EF._packs[id(conv.weight)][1]
+        want = conv.weight.detach().permute(0, 2, 3, 1).to(torch.bfloat16)
+        return torch.equal(pk.fwd[:, :, :want.shape[2], :], want) and pk.synced == conv.weight._version
+
+    for it in range(3):
+        out = task.training_step({'image': x, 'target': y}, it)
+        opt.zero_grad()
+        out['loss'].backward()
+        n_single = fake_backend.calls.count('pack_weights_batched')
+        opt.step()
+        assert fake_backend.calls.count('pack_weights_batched') == n_single + (1 if it > 0 else 0) or it == 0
+        if it > 0:     # step 0 re-homes the masters into the arena: packs are re-derived by the next forward
+            assert fwd_pack_in_sync()
+    assert fake_backend.calls.count('pack_weights_batched') >= 2
+    # a torch-visible write is caught by the next forward ...
+    with torch.no_grad():
+        conv.weight.mul_(1.5)
+    assert not fwd_pack_in_sync()
+    task.training_step({'image': x, 'target': y}, 9)
+    assert fwd_pack_in_sync()
+    # ... a write behind torch's back needs invalidate_packs()
+    conv.weight.data.mul_(2.0)
+    EF.invalidate_packs()
+    task.training_step({'image': x, 'target': y}, 10)
+    assert fwd_pack_in_sync()

@@ -129,3 +129,49 @@ def test_eval_forward_and_single_class(dev):
         y = task(torch.rand(2, 3, 64, 64).to(dev))
     assert y.shape == (2, 64, 64)                    # heads/segmentation/base.py:38-39 squeeze
     assert len(task.as_module()) == 3
+
+
+def test_padded_channel_variant_step(dev):
+    """hrnet_w18_small_v2: branch widths 18/36/72/144 (not multiples of 8) -> zero-padded activations, BatchNorm over
+    num_features < padded width, concat at logical offsets (270 -> pitch 272).  Step vs the fp32 oracle."""
+    cfg = seg_config('hrnet_w18_small_v2', classes=5, size=64)
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 7)
+    task.load_state_dict(sd, strict=False)
+    task.to(dev).train()
+    ora = H.SegmentationModel('hrnet_w18_small_v2', 5).train()
+    ora.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    y = torch.randint(0, 5, (4, 64, 64), generator=g)
+    feats = task.backbone.forward_features(x.to(dev))
+    assert [tuple(f.shape) for f in feats[1:]] == [(4, 18, 16, 16), (4, 36, 8, 8), (4, 72, 4, 4), (4, 144, 2, 2)]
+    neck_out = task.neck(feats)
+    assert neck_out[1].shape == (4, 270, 16, 16)
+    out = task.training_step({'image': x.to(dev), 'target': y.to(dev)}, 0)
+    o32 = ora.forward_with_gt({'image': x, 'target': y})
+    l32 = torch.nn.functional.cross_entropy(o32['prediction'], y, ignore_index=255)
+    assert abs(float(out['loss'].detach()) - float(l32.detach())) < 3e-2 * float(l32.detach())
+    out['loss'].backward()
+    l32.backward()
+    ac = copy.deepcopy(ora)
+    ac.zero_grad()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        oa = ac.forward_with_gt({'image': x, 'target': y})
+    torch.nn.functional.cross_entropy(oa['prediction'].float(), y, ignore_index=255).backward()
+    g32 = {n: p.grad for n, p in ora.named_parameters()}
+    yard = np.array([rel_err(p.grad, g32[n]) for n, p in ac.named_parameters()])
+    errs = np.array([rel_err(p.grad, g32[n]) for n, p in task.named_parameters()])
+    assert all(p.grad.shape == p.shape for p in task.parameters())
+    assert np.median(errs) < 1.5 * np.median(yard) + 1e-2, (np.median(errs), np.median(yard))
+
+
+def test_reference_neck_test_w18(dev):
+    """tests/additional_tests/models/necks/test_hrnet.py:20-26 of the reference (hrnet_w18, 2x3x224x224)."""
+    backbone = T.BACKBONES.get('hrnet_w18')(pretrained=False).to(dev)
+    neck = T.NECKS.get('HRNetSegmentationNeck')(backbone.out_encoder_channels).to(dev)
+    x = torch.rand(2, 3, 224, 224).to(dev)
+    with torch.no_grad():
+        input_image, features = neck(backbone.forward_features(x))
+    assert tuple(features.shape) == (2, 270, 56, 56)
+    assert tuple(input_image.shape) == (2, 3, 224, 224)

@@ -201,7 +201,7 @@ def test_bn_chain(libs, m, c, relu, with_sc):
     gamma, beta = rnd(c, seed=1) * 0.5 + 1, rnd(c, seed=2) * 0.2
     rm, rv, nbt = rnd(c, seed=3), rnd(c, seed=4).abs() + 0.5, torch.tensor([7])
     mean, rstd, scale, shift = (torch.zeros(c) for _ in range(4))
-    dv = both(libs, 'tok_bn_finalize', lambda fn: [fn(stats), rows, m, c, fn(gamma), fn(beta), fn(rm), fn(rv),
+    dv = both(libs, 'tok_bn_finalize', lambda fn: [fn(stats), rows, m, c, c, fn(gamma), fn(beta), fn(rm), fn(rv),
                                                    fn(nbt), 0.1, 1e-5, fn(mean), fn(rstd), fn(scale), fn(shift), None])
     for t in (mean, rstd, scale, shift, rm, rv):
         assert maxrel(dv[id(t)], t, 1e-3) < 1e-4
@@ -242,9 +242,9 @@ def test_bn_chain(libs, m, c, relu, with_sc):
 
     dg_d, db_d, coef_d = (torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(3, c, device=DEV))
     dg_h, db_h, coef_h = torch.zeros(c), torch.zeros(c), torch.zeros(3, c)
-    assert lib.tok_bn_bwd_finalize(P(part_d), rows_b, m, c, P(cd['gamma']), P(cd['mean']), P(cd['rstd']), P(dg_d),
+    assert lib.tok_bn_bwd_finalize(P(part_d), rows_b, m, c, c, P(cd['gamma']), P(cd['mean']), P(cd['rstd']), P(dg_d),
                                    P(db_d), P(coef_d), 0, 0, st) == 0
-    assert fake.tok_bn_bwd_finalize(P(part_h), 1, m, c, P(gamma), P(mean), P(rstd), P(dg_h), P(db_h), P(coef_h), 0,
+    assert fake.tok_bn_bwd_finalize(P(part_h), 1, m, c, c, P(gamma), P(mean), P(rstd), P(dg_h), P(db_h), P(coef_h), 0,
                                     0, None) == 0
     torch.cuda.synchronize()
     assert relerr(dg_d, dg_h) < 1e-3 and relerr(db_d, db_h) < 1e-3 and relerr(coef_d, coef_h) < 1e-3
@@ -310,16 +310,16 @@ def test_gap_colsum(libs):
     assert relerr(dv[id(out)], out) < 1e-4
 
 
-@pytest.mark.parametrize('rows,classes', [(256, 1000), (7, 10), (64, 11318)])
+@pytest.mark.parametrize('rows,classes', [(256, 1000), (7, 10), (64, 11318), (70001, 19)])
 def test_softmax_ce(libs, rows, classes):
     ld = (classes + 7) // 8 * 8
     z = (rnd(rows, ld) * 3).to(BF16)
     t = torch.randint(0, classes, (rows,), generator=torch.Generator().manual_seed(1))
     t[::5] = -100
-    lse, rl, loss = torch.zeros(rows), torch.zeros(rows), torch.zeros(2)
+    lse, rl, loss = torch.zeros(rows), torch.zeros(rows), torch.zeros(_C.TOK_CE_LOSS_FLOATS)
     dv = both(libs, 'tok_softmax_ce_fwd', lambda f: [f(z), f(t), rows, classes, ld, -100, f(lse), f(rl), f(loss), None])
     assert maxrel(dv[id(lse)], lse, 1e-3) < 1e-4
-    assert maxrel(dv[id(loss)], loss, 1e-6) < 1e-5
+    assert maxrel(dv[id(loss)][:2], loss[:2], 1e-6) < 1e-5
     ref = torch.nn.functional.cross_entropy(z.float()[:, :classes], t, ignore_index=-100)
     assert abs(float(dv[id(loss)][0]) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
     assert float(dv[id(loss)][1]) == float((t != -100).sum())
@@ -402,7 +402,7 @@ def test_conv_dgrad_bnstats(libs, case, with_mask):
     outs = []
     for partial, nrows, form in ((got.reshape(2, 1, c).contiguous(), 1, 1), (ph, 1, 0)):
         dg, db, coef = torch.zeros(c), torch.zeros(c), torch.zeros(3, c)
-        assert fake.tok_bn_bwd_finalize(partial.data_ptr(), nrows, m, c, gamma.data_ptr(), mean.data_ptr(),
+        assert fake.tok_bn_bwd_finalize(partial.data_ptr(), nrows, m, c, c, gamma.data_ptr(), mean.data_ptr(),
                                         rstd.data_ptr(), dg.data_ptr(), db.data_ptr(), coef.data_ptr(), 0, form,
                                         None) == 0
         outs.append((dg, db, coef))
@@ -412,7 +412,7 @@ def test_conv_dgrad_bnstats(libs, case, with_mask):
     dev = lambda t: t.to(DEV)  # noqa: E731
     dgd, dbd, cod = dev(torch.zeros(c)), dev(torch.zeros(c)), dev(torch.zeros(3, c))
     pd, gd, md, rd = dev(got.reshape(2, 1, c).contiguous()), dev(gamma), dev(mean), dev(rstd)
-    assert lib.tok_bn_bwd_finalize(pd.data_ptr(), 1, m, c, gd.data_ptr(), md.data_ptr(), rd.data_ptr(), dgd.data_ptr(),
+    assert lib.tok_bn_bwd_finalize(pd.data_ptr(), 1, m, c, c, gd.data_ptr(), md.data_ptr(), rd.data_ptr(), dgd.data_ptr(),
                                    dbd.data_ptr(), cod.data_ptr(), 0, 1, st) == 0
     torch.cuda.synchronize()
     assert relerr(dgd, outs[0][0]) < 1e-3 and relerr(cod, outs[0][2]) < 1e-3
@@ -547,7 +547,8 @@ def test_fuse_sum_relu(libs, n, h, w, c, shifts, relu):
 
 @pytest.mark.parametrize('n,hs,ws,c,hd,wd,ld,off', [(2, 8, 8, 16, 16, 16, 16, 0), (2, 4, 8, 32, 32, 64, 96, 32),
                                                     (1, 16, 16, 24, 64, 64, 24, 0), (2, 16, 16, 16, 16, 16, 48, 16),
-                                                    (1, 5, 7, 8, 13, 20, 8, 0), (1, 9, 9, 8, 4, 5, 8, 0)])
+                                                    (1, 5, 7, 8, 13, 20, 8, 0), (1, 9, 9, 8, 4, 5, 8, 0),
+                                                    (2, 4, 4, 36, 16, 16, 272, 18), (1, 8, 8, 18, 8, 8, 56, 0)])
 def test_bilinear(libs, n, hs, ws, c, hd, wd, ld, off):
     src = rnd(n, hs, ws, c).to(BF16)
     dst = rnd(n, hd, wd, ld, seed=2).to(BF16)       # other slices must stay untouched
@@ -578,3 +579,56 @@ def test_bilinear_adjoint_property(libs):
     a = float((up.double() * g.double()).sum())
     b = float((x.double() * gx.double()).sum())
     assert abs(a - b) < 2e-2 * (up.double().norm() * g.double().norm()).item() ** 0.5 + 1e-2 * abs(a)
+
+
+def test_pack_weights_batched_equals_single_packs(libs):
+    """tok_pack_weights_batched over a table of ragged weights == tok_pack_weight_both per weight (bit-exact)."""
+    lib, _ = libs
+    shapes = [(64, 7, 7, 3, 64, 8, 4), (64, 1, 1, 64, 64, 1, 64), (128, 3, 3, 64, 128, 3, 64), (19, 1, 1, 720, 24, 1, 720),
+              (1000, 1, 1, 2048, 1000, 1, 2048), (48, 3, 3, 48, 48, 3, 48)]
+    st = torch.cuda.current_stream().cuda_stream
+    items, keep, block = [], [], 0
+    for i, (k, r, s, c, kp, sp, cp) in enumerate(shapes):
+        w = rnd(k, r, s, c, seed=i).cuda()
+        f1 = torch.empty(kp * r * sp * cp, dtype=BF16, device='cuda')
+        d1 = torch.empty(cp * r * s * kp, dtype=BF16, device='cuda')
+        want_d = i != 0
+        f2, d2 = torch.full_like(f1, 7.0), torch.full_like(d1, 7.0)
+        assert lib.tok_pack_weight_both(w.data_ptr(), k, r, s, c, f1.data_ptr(), kp, sp, cp, d1.data_ptr(), st) == 0
+        it = _C.PackItem(w.data_ptr(), f2.data_ptr(), d2.data_ptr() if want_d else None, k, r, s, c, kp, sp, cp, block)
+        block += lib.tok_pack_item_blocks(ctypes.byref(it))
+        items.append(it)
+        keep.append((w, f1, d1, f2, d2, want_d))
+    arr = (_C.PackItem * len(items))(*items)
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    assert lib.tok_pack_weights_batched(table.data_ptr(), len(items), block, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    for w, f1, d1, f2, d2, want_d in keep:
+        assert torch.equal(f1, f2)
+        assert torch.equal(d1, d2) if want_d else bool((d2 == 7.0).all())
+
+
+def test_bn_padded_channels(libs):
+    """num_features (18) < padded activation width (24): parameter arrays are c_real long, padding channels get
+    zero coefficients (finalize fwd / eval / bwd)."""
+    m, c, cr, rows = 4096, 24, 18, 3
+    stats = rnd(2, rows, c).abs() * m
+    stats[1] += stats[0] ** 2 / m * 1.5
+    gamma, beta, rm, rv = rnd(cr, seed=1) + 1.5, rnd(cr, seed=2), rnd(cr, seed=3), rnd(cr, seed=4).abs() + 0.5
+    nbt = torch.zeros(1, dtype=torch.int64)
+    mean, rstd, scale, shift = (torch.full((c,), 9.0) for _ in range(4))
+    dv = both(libs, 'tok_bn_finalize', lambda f: [f(stats), rows, m, c, cr, f(gamma), f(beta), f(rm), f(rv), f(nbt), 0.1,
+                                                  1e-5, f(mean), f(rstd), f(scale), f(shift), None])
+    for t in (mean, rstd, scale, shift, rm, rv):
+        assert relerr(dv[id(t)], t) < 1e-5
+    assert float(dv[id(scale)][cr:].abs().max()) == 0.0 and float(dv[id(shift)][cr:].abs().max()) == 0.0
+    sc2, sh2 = torch.full((c,), 9.0), torch.full((c,), 9.0)
+    dv = both(libs, 'tok_bn_eval_coeffs', lambda f: [f(gamma), f(beta), f(rm), f(rv), 1e-5, c, cr, f(sc2), f(sh2), None])
+    assert relerr(dv[id(sc2)], sc2) < 1e-6 and relerr(dv[id(sh2)], sh2) < 1e-6
+    partial = rnd(2, rows, c, seed=8)
+    dg, db, coef = torch.zeros(cr), torch.zeros(cr), torch.full((3, c), 9.0)
+    dv = both(libs, 'tok_bn_bwd_finalize', lambda f: [f(partial), rows, m, c, cr, f(gamma), f(mean), f(rstd), f(dg), f(db),
+                                                      f(coef), 0, 1, None])
+    for t in (dg, db, coef):
+        assert relerr(dv[id(t)], t) < 1e-5
+    assert float(dv[id(coef)][:, cr:].abs().max()) == 0.0

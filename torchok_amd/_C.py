@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libtok_gfx950.so')
 
 TOK_F32, TOK_F16, TOK_BF16 = 0, 1, 2
+TOK_CE_LOSS_FLOATS = 2050
 
 
 class ConvDesc(Structure):
@@ -22,6 +23,13 @@ class ConvDesc(Structure):
                 ('k', c_int32), ('r', c_int32), ('s', c_int32),
                 ('p', c_int32), ('q', c_int32),
                 ('stride', c_int32), ('pad', c_int32), ('s_pad', c_int32)]
+
+
+class PackItem(Structure):
+    """Mirror of ``tok_pack_item`` (include/tok.h)."""
+    _fields_ = [('src', c_void_p), ('dst_fwd', c_void_p), ('dst_dgrad', c_void_p),
+                ('k', c_int32), ('r', c_int32), ('s', c_int32), ('c', c_int32),
+                ('k_pad', c_int32), ('s_pad', c_int32), ('c_pad', c_int32), ('block_start', c_int32)]
 
 
 _P = c_void_p
@@ -36,6 +44,8 @@ PROTOTYPES = {
     'tok_pack_weight_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     'tok_pack_weight_dgrad': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     'tok_pack_weight_both': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    'tok_pack_item_blocks': (c_int, [POINTER(PackItem)]),
+    'tok_pack_weights_batched': (c_int, [_P, c_int, c_int, _P]),
     'tok_conv_fwd_stat_rows': (c_int, [_PD]),
     'tok_conv_fwd': (c_int, [_PD, _P, _P, _P, _P, _P, _P]),
     'tok_conv_dgrad': (c_int, [_PD, _P, _P, _P, c_int, _P]),
@@ -43,15 +53,15 @@ PROTOTYPES = {
     'tok_conv_dgrad_bnstats': (c_int, [_PD, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'tok_conv_wgrad_ws_bytes': (c_size_t, [_PD]),
     'tok_conv_wgrad': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
-    'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, c_float, c_float,
+    'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float,
                                 _P, _P, _P, _P, _P]),
-    'tok_bn_eval_coeffs': (c_int, [_P, _P, _P, _P, c_float, c_int, _P, _P, _P]),
+    'tok_bn_eval_coeffs': (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'tok_bn_stats_rows': (c_int, [c_int64, c_int]),
     'tok_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P]),
     'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P]),
     'tok_bn_bwd_rows': (c_int, [c_int64, c_int]),
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
-    'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
     'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
 
 // 4 channels per block, 64 row-lanes each; fp64 accumulation across partial rows.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows,
-                                                          double inv_count, double unbias, int C,
+                                                          double inv_count, double unbias, int C, int Creal,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* running_mean, float* running_var,
@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
     __syncthreads();
   }
-  if (rl == 0 && c < C) {
+  if (rl == 0 && c >= Creal && c < C) {   // padding channel (num_features not a multiple of 8)
+    mean[c] = 0.f; rstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f;
+  }
+  if (rl == 0 && c < Creal) {
     const double mu = red[0][tid] * inv_count;
     double var = red[1][tid] * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -166,9 +169,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm,
-                                      const float* rv, float eps, int C, float* scale, float* shift) {
+                                      const float* rv, float eps, int C, int Creal, float* scale, float* shift) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
+  if (c >= Creal && c < C) { scale[c] = 0.f; shift[c] = 0.f; }
+  if (c < Creal) {
     const float rs = 1.0f / sqrtf(rv[c] + eps);
     const float sc = gamma[c] * rs;
     scale[c] = sc;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
-    const float* __restrict__ partial, int rows, double inv_m, int C, const float* __restrict__ gamma,
+    const float* __restrict__ partial, int rows, double inv_m, int C, int Creal, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* dgamma, float* dbeta,
     float* coef, int accumulate, int dzy_form) {
   __shared__ double red[2][256];
@@ -263,7 +267,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     }
     __syncthreads();
   }
-  if (rl == 0 && c < C) {
+  if (rl == 0 && c >= Creal && c < C) {
+    coef[c] = 0.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f;
+  }
+  if (rl == 0 && c < Creal) {
     if (dzy_form) {   // second sum is sum(dz * y): sum(dz * xhat) = rstd * (sum(dz*y) - mean * sum(dz))
       red[1][tid] = (double)rstd[c] * (red[1][tid] - (double)mean[c] * red[0][tid]);
     }
@@ -339,27 +346,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 static const int kStreamCap = 2048;   // blocks of elementwise kernels (8 per CU)
 static const int kReduceCap = 1024;   // partial rows of the reducing kernels
 
-extern "C" int tok_bn_finalize(const float* stats, int rows, int64_t count, int c, const float* gamma,
+extern "C" int tok_bn_finalize(const float* stats, int rows, int64_t count, int c, int c_real, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                int64_t* nbt, float momentum, float eps, float* mean, float* rstd,
                                float* scale, float* shift, void* stream) {
   TOK_CHECK_ARG(stats && gamma && beta && mean && rstd && scale && shift, "tok_bn_finalize: null pointer");
-  TOK_CHECK_ARG(rows > 0 && count > 0 && c > 0, "tok_bn_finalize: bad sizes");
+  TOK_CHECK_ARG(rows > 0 && count > 0 && c > 0 && c_real > 0 && c_real <= c, "tok_bn_finalize: bad sizes");
   TOK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "tok_bn_finalize: running stats");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), stats, rows,
-                     1.0 / (double)count, unbias, c, gamma, beta, running_mean, running_var, nbt,
+                     1.0 / (double)count, unbias, c, c_real, gamma, beta, running_mean, running_var, nbt,
                      momentum, eps, mean, rstd, scale, shift);
   TOK_CHECK_LAUNCH("tok_bn_finalize");
   return TOK_OK;
 }
 
 extern "C" int tok_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
-                                  const float* running_var, float eps, int c, float* scale,
+                                  const float* running_var, float eps, int c, int c_real, float* scale,
                                   float* shift, void* stream) {
   TOK_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift, "tok_bn_eval_coeffs: null");
+  TOK_CHECK_ARG(c > 0 && c_real > 0 && c_real <= c, "tok_bn_eval_coeffs: bad sizes");
   hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((c + 255) / 256), dim3(256), 0, tok_stream(stream), gamma,
-                     beta, running_mean, running_var, eps, c, scale, shift);
+                     beta, running_mean, running_var, eps, c, c_real, scale, shift);
   TOK_CHECK_LAUNCH("tok_bn_eval_coeffs");
   return TOK_OK;
 }
@@ -405,12 +413,13 @@ extern "C" int tok_bn_bwd_reduce(const void* dout, const void* y, const uint8_t*
   return TOK_OK;
 }
 
-extern "C" int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c, const float* gamma,
+extern "C" int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, int c, int c_real, const float* gamma,
                                    const float* mean, const float* rstd, float* dgamma, float* dbeta,
                                    float* coef, int accumulate, int dzy_form, void* stream) {
   TOK_CHECK_ARG(partial && gamma && mean && rstd && coef, "tok_bn_bwd_finalize: null pointer");
+  TOK_CHECK_ARG(c > 0 && c_real > 0 && c_real <= c, "tok_bn_bwd_finalize: bad sizes");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), partial,
-                     rows, 1.0 / (double)m, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
+                     rows, 1.0 / (double)m, c, c_real, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
   TOK_CHECK_LAUNCH("tok_bn_bwd_finalize");
   return TOK_OK;
 }

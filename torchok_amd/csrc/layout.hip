@@ -116,6 +116,51 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
   }
 }
 
+// every weight of a model in ONE launch: block b serves item i (largest block_start <= b) and covers 1024
+// consecutive indices of that item's max(forward, dgrad) pack index space
+__global__ __launch_bounds__(256) void pack_batched_kernel(const tok_pack_item* __restrict__ items, int n_items) {
+  int lo = 0, hi = n_items - 1;
+  const int b = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block_start <= b) lo = mid; else hi = mid - 1;
+  }
+  const tok_pack_item it = items[lo];
+  const float* __restrict__ src = it.src;
+  bf16* __restrict__ fwd = (bf16*)it.dst_fwd;
+  bf16* __restrict__ dgr = (bf16*)it.dst_dgrad;
+  const int k = it.k, r = it.r, s = it.s, c = it.c, k_pad = it.k_pad, s_pad = it.s_pad, c_pad = it.c_pad;
+  const size_t total_f = fwd ? (size_t)k_pad * r * s_pad * c_pad : 0;
+  const size_t total_d = dgr ? (size_t)c_pad * r * s * k_pad : 0;
+  const size_t base = (size_t)(b - it.block_start) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t i = base + u * 256 + threadIdx.x;
+    if (i < total_f) {
+      const int cc = (int)(i % c_pad);
+      size_t rest = i / c_pad;
+      const int ss = (int)(rest % s_pad);
+      rest /= s_pad;
+      const int rr = (int)(rest % r);
+      const int kk = (int)(rest / r);
+      float v = 0.f;
+      if (kk < k && ss < s && cc < c) v = src[(((size_t)kk * r + rr) * s + ss) * c + cc];
+      fwd[i] = f2bf(v);
+    }
+    if (i < total_d) {
+      const int kk = (int)(i % k_pad);
+      size_t rest = i / k_pad;
+      const int ss = (int)(rest % s);
+      rest /= s;
+      const int rr = (int)(rest % r);
+      const int cc = (int)(rest / r);
+      float v = 0.f;
+      if (kk < k && cc < c) v = src[(((size_t)kk * r + (r - 1 - rr)) * s + (s - 1 - ss)) * c + cc];
+      dgr[i] = f2bf(v);
+    }
+  }
+}
+
 inline int grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -184,5 +229,19 @@ extern "C" int tok_pack_weight_both(const float* src, int k, int r, int s, int c
   hipLaunchKernelGGL(pack_both_kernel, dim3(grid_for(tf > td ? tf : td)), dim3(256), 0, tok_stream(stream), src, k,
                      r, s, c, (bf16*)dst_fwd, k_pad, s_pad, c_pad, (bf16*)dst_dgrad);
   TOK_CHECK_LAUNCH("tok_pack_weight_both");
+  return TOK_OK;
+}
+
+extern "C" int tok_pack_item_blocks(const tok_pack_item* item) {
+  if (!item) return 0;
+  const size_t tf = item->dst_fwd ? (size_t)item->k_pad * item->r * item->s_pad * item->c_pad : 0;
+  const size_t td = item->dst_dgrad ? (size_t)item->c_pad * item->r * item->s * item->k_pad : 0;
+  return (int)(((tf > td ? tf : td) + 1023) / 1024);
+}
+
+extern "C" int tok_pack_weights_batched(const tok_pack_item* items_dev, int n_items, int total_blocks, void* stream) {
+  TOK_CHECK_ARG(items_dev && n_items > 0 && total_blocks > 0, "tok_pack_weights_batched: bad args");
+  hipLaunchKernelGGL(pack_batched_kernel, dim3(total_blocks), dim3(256), 0, tok_stream(stream), items_dev, n_items);
+  TOK_CHECK_LAUNCH("tok_pack_weights_batched");
   return TOK_OK;
 }

@@ -33,26 +33,44 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
   }
 }
 
-// single block: deterministic mean over valid rows
-__global__ __launch_bounds__(256) void ce_mean_kernel(const float* __restrict__ row_loss,
-                                                      const int64_t* __restrict__ target, int rows,
-                                                      int64_t ignore_index, float* loss) {
+// deterministic mean over valid rows in two fixed-order stages: up to 512 blocks each reduce one contiguous
+// chunk into a (sum, count) double pair kept in the caller's loss buffer, then one block folds the pairs
+constexpr int CE_PARTS = (TOK_CE_LOSS_FLOATS - 2) / 4;   // (sum, count) doubles
+
+__device__ __forceinline__ void block_reduce2(double& s, double& c) {
   __shared__ double rs[256];
   __shared__ double rc[256];
-  double s = 0.0, cnt = 0.0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    if (target[r] != ignore_index) { s += (double)row_loss[r]; cnt += 1.0; }
-  }
   rs[threadIdx.x] = s;
-  rc[threadIdx.x] = cnt;
+  rc[threadIdx.x] = c;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
     if (threadIdx.x < k) { rs[threadIdx.x] += rs[threadIdx.x + k]; rc[threadIdx.x] += rc[threadIdx.x + k]; }
     __syncthreads();
   }
+  s = rs[0];
+  c = rc[0];
+}
+
+__global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict__ row_loss,
+                                                         const int64_t* __restrict__ target, int rows,
+                                                         int64_t ignore_index, int chunk, double* __restrict__ part) {
+  const int r0 = blockIdx.x * chunk;
+  const int r1 = min(rows, r0 + chunk);
+  double s = 0.0, cnt = 0.0;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    if (target[r] != ignore_index) { s += (double)row_loss[r]; cnt += 1.0; }
+  }
+  block_reduce2(s, cnt);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void ce_mean_kernel(const double* __restrict__ part, int nparts, float* loss) {
+  double s = 0.0, cnt = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { s += part[2 * i]; cnt += part[2 * i + 1]; }
+  block_reduce2(s, cnt);
   if (threadIdx.x == 0) {
-    loss[0] = (float)(rs[0] / rc[0]);  // 0/0 = nan, as torch
-    loss[1] = (float)rc[0];
+    loss[0] = (float)(s / cnt);  // 0/0 = nan, as torch
+    loss[1] = (float)cnt;
   }
 }
 
@@ -89,7 +107,14 @@ extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int
   hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16*)logits, target, rows,
                      classes, ld, ignore_index, lse, row_loss);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd");
-  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, row_loss, target, rows, ignore_index, loss);
+  double* part = reinterpret_cast<double*>(loss + 2);   // loss holds TOK_CE_LOSS_FLOATS floats, 8-byte aligned
+  TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_softmax_ce_fwd: loss must be 8-byte aligned");
+  const int nparts = rows < 4096 ? 1 : (tok_cdiv(rows, 4096) < CE_PARTS ? tok_cdiv(rows, 4096) : CE_PARTS);
+  const int chunk = tok_cdiv(rows, nparts);
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(nparts), dim3(256), 0, st, row_loss, target, rows, ignore_index, chunk,
+                     part);
+  TOK_CHECK_LAUNCH("tok_softmax_ce_fwd(partial)");
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, part, nparts, loss);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd(mean)");
   return TOK_OK;
 }

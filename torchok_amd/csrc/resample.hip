@@ -187,19 +187,81 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const bf16* __restric
   }
 }
 
+// channel counts / slice offsets that are not multiples of 8 (HRNet-W18/W30/W44: 18+36+72+144 = 270 concat
+// channels): one element per thread, same index math
+__global__ __launch_bounds__(256) void bilinear_fwd_generic_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst,
+                                                                   BilArgs a) {
+  const size_t total = (size_t)a.n * a.hd * a.wd * a.c;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int ch = (int)(idx % a.c);
+    const size_t pix = idx / a.c;
+    const int x = (int)(pix % a.wd);
+    const size_t t2 = pix / a.wd;
+    const int y = (int)(t2 % a.hd);
+    const int b = (int)(t2 / a.hd);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    src_index(a.sh, y, a.hs, y0, y1, ly);
+    src_index(a.sw, x, a.ws, x0, x1, lx);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const bf16* base = src + (size_t)b * a.hs * a.ws * a.ld_src + ch;
+    const float v00 = bf2f(base[((size_t)y0 * a.ws + x0) * a.ld_src]), v01 = bf2f(base[((size_t)y0 * a.ws + x1) * a.ld_src]);
+    const float v10 = bf2f(base[((size_t)y1 * a.ws + x0) * a.ld_src]), v11 = bf2f(base[((size_t)y1 * a.ws + x1) * a.ld_src]);
+    dst[pix * a.ld_dst + a.ch_off + ch] = f2bf(hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_generic_kernel(const bf16* __restrict__ ddst, bf16* dsrc, BilArgs a,
+                                                                   int accumulate) {
+  const size_t total = (size_t)a.n * a.hs * a.ws * a.c;
+  const float rh = 1.f / a.sh, rw = 1.f / a.sw;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int ch = (int)(idx % a.c);
+    const size_t pix = idx / a.c;
+    const int xs = (int)(pix % a.ws);
+    const size_t t2 = pix / a.ws;
+    const int ys = (int)(t2 % a.hs);
+    const int b = (int)(t2 / a.hs);
+    int yd0 = ys == 0 ? 0 : (int)floorf(((float)ys - 0.5f) * rh - 0.5f) - 1;
+    int yd1 = (int)ceilf(((float)ys + 1.5f) * rh - 0.5f) + 1;
+    int xd0 = xs == 0 ? 0 : (int)floorf(((float)xs - 0.5f) * rw - 0.5f) - 1;
+    int xd1 = (int)ceilf(((float)xs + 1.5f) * rw - 0.5f) + 1;
+    yd0 = yd0 < 0 ? 0 : yd0;  xd0 = xd0 < 0 ? 0 : xd0;
+    yd1 = yd1 > a.hd - 1 ? a.hd - 1 : yd1;  xd1 = xd1 > a.wd - 1 ? a.wd - 1 : xd1;
+    float acc = 0.f;
+    for (int yd = yd0; yd <= yd1; ++yd) {
+      int y0, y1; float ly;
+      src_index(a.sh, yd, a.hs, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int xd = xd0; xd <= xd1; ++xd) {
+        int x0, x1; float lx;
+        src_index(a.sw, xd, a.ws, x0, x1, lx);
+        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        if (wx == 0.f) continue;
+        acc = fmaf(wy * wx, bf2f(ddst[(((size_t)b * a.hd + yd) * a.wd + xd) * a.ld_dst + a.ch_off + ch]), acc);
+      }
+    }
+    bf16* d = dsrc + pix * a.ld_src + ch;
+    *d = f2bf(accumulate ? acc + bf2f(*d) : acc);
+  }
+}
+
 inline int blocks_for(size_t total) {
   const size_t b = (total + 255) / 256;
   return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
 }
 
 bool fill_bil(BilArgs& a, int n, int hs, int ws, int c, int ld_src, int hd, int wd, int ld_dst, int ch_off) {
-  if (n <= 0 || hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || c <= 0 || (c & 7) || (ld_src & 7) || (ld_dst & 7) ||
-      (ch_off & 7) || ld_src < c || ld_dst < ch_off + c) return false;
+  if (n <= 0 || hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || c <= 0 || ch_off < 0 || ld_src < c || ld_dst < ch_off + c)
+    return false;
   a.n = n; a.hs = hs; a.ws = ws; a.c = c; a.ld_src = ld_src; a.hd = hd; a.wd = wd; a.ld_dst = ld_dst; a.ch_off = ch_off;
   a.sh = (float)hs / (float)hd;
   a.sw = (float)ws / (float)wd;
   return true;
 }
+
+inline bool vec_ok(const BilArgs& a) { return !((a.c | a.ld_src | a.ld_dst | a.ch_off) & 7); }
 
 }  // namespace
 
@@ -242,8 +304,12 @@ extern "C" int tok_bilinear_fwd(const void* src, int n, int hs, int ws, int c, i
                                 int ld_dst, int ch_off, void* stream) {
   BilArgs a;
   TOK_CHECK_ARG(src && dst && fill_bil(a, n, hs, ws, c, ld_src, hd, wd, ld_dst, ch_off), "tok_bilinear_fwd: bad args");
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks_for((size_t)n * hd * wd * (c >> 3))), dim3(256), 0,
-                     tok_stream(stream), (const bf16*)src, (bf16*)dst, a);
+  if (vec_ok(a))
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(blocks_for((size_t)n * hd * wd * (c >> 3))), dim3(256), 0,
+                       tok_stream(stream), (const bf16*)src, (bf16*)dst, a);
+  else
+    hipLaunchKernelGGL(bilinear_fwd_generic_kernel, dim3(blocks_for((size_t)n * hd * wd * c)), dim3(256), 0,
+                       tok_stream(stream), (const bf16*)src, (bf16*)dst, a);
   TOK_CHECK_LAUNCH("tok_bilinear_fwd");
   return TOK_OK;
 }
@@ -252,8 +318,12 @@ extern "C" int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_
                                 int ws, int c, int ld_src, int accumulate, void* stream) {
   BilArgs a;
   TOK_CHECK_ARG(ddst && dsrc && fill_bil(a, n, hs, ws, c, ld_src, hd, wd, ld_dst, ch_off), "tok_bilinear_bwd: bad args");
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks_for((size_t)n * hs * ws * (c >> 3))), dim3(256), 0,
-                     tok_stream(stream), (const bf16*)ddst, (bf16*)dsrc, a, accumulate);
+  if (vec_ok(a))
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(blocks_for((size_t)n * hs * ws * (c >> 3))), dim3(256), 0,
+                       tok_stream(stream), (const bf16*)ddst, (bf16*)dsrc, a, accumulate);
+  else
+    hipLaunchKernelGGL(bilinear_bwd_generic_kernel, dim3(blocks_for((size_t)n * hs * ws * c)), dim3(256), 0,
+                       tok_stream(stream), (const bf16*)ddst, (bf16*)dsrc, a, accumulate);
   TOK_CHECK_LAUNCH("tok_bilinear_bwd");
   return TOK_OK;
 }

@@ -212,8 +212,13 @@ class Region:
         if x.dim() == 4:
             n, c, h, w = x.shape
             cp = (c + c_pad_to - 1) // c_pad_to * c_pad_to
+            cp8 = pad8(c)
             if x.dtype == BF16 and cp == c and x.permute(0, 2, 3, 1).is_contiguous():
                 data = x.detach().permute(0, 2, 3, 1)
+            elif x.dtype == BF16 and cp8 != c and x.stride() == (h * w * cp8, 1, w * cp8, cp8) \
+                    and _padded_rows.get(x.data_ptr()) == cp8:
+                # the logical view of one of our own zero-padded NHWC buffers (e.g. an 18-channel HRNet branch)
+                data = torch.as_strided(x.detach(), (n, h, w, cp8), (h * w * cp8, w * cp8, cp8, 1))
             else:
                 if need:
                     raise RuntimeError('torchok_amd: a 4-D region input that requires grad must already be '
@@ -253,6 +258,9 @@ class Region:
                 n.release()
             self.nodes = []
             res = tuple(o.torch_view() for o in outs)
+            for o in outs:
+                if o.data.dim() == 4 and o.c != o.cp:
+                    mark_padded(o.data)
         else:
             tins = [x for _, x in self.inputs]
             res = _RegionFn.apply(self, list(outs), _anchor(self.device), *tins)
@@ -302,6 +310,9 @@ class _RegionFn(torch.autograd.Function):
         ctx.region = region
         ctx.outs = outs
         ctx.set_materialize_grads(False)
+        for o in outs:
+            if o.data.dim() == 4 and o.c != o.cp:
+                mark_padded(o.data)      # lets the next region take the padded buffer without a copy
         return tuple(o.torch_view() for o in outs)
 
     @staticmethod
@@ -325,7 +336,7 @@ class _RegionFn(torch.autograd.Function):
             else:
                 gt = TTensor(t.grad, t.c)
                 gins.append(gt.torch_view())
-                if x.dim() == 2 and t.c != t.cp:
+                if t.c != t.cp:
                     mark_padded(t.grad)
         ctx.region = None
         ctx.outs = None

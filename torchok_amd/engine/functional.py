@@ -33,13 +33,15 @@ class _Packs:
     """bf16 MFMA operands derived from one fp32 master weight: the forward pack [Kp][R][Sp][Cp]
     and the dgrad pack [Cp][R][S][Kp] (flipped taps).  Re-derived whenever `refresh` is asked
     (every training forward: the optimizer has moved the master since)."""
-    __slots__ = ('fwd', 'dgrad', 'bias', 'key')
+    __slots__ = ('fwd', 'dgrad', 'bias', 'key', 'synced', 'dims')
 
     def __init__(self):
         self.fwd = None
         self.dgrad = None
         self.bias = None
         self.key = None
+        self.synced = None   # weight._version the packs were derived at (None: unknown / stale)
+        self.dims = None     # (k, r, s, c, kp, sp, cp)
 
 
 _packs = {}  # id(weight) -> (weakref(weight), _Packs); Tensor.__eq__ rules out a WeakKeyDictionary
@@ -79,19 +81,33 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
     key = (weight.data_ptr(), kp, sp, cp, weight.device)
     lib = _C.lib()
     st = stream_ptr()
-    stale = refresh or pk.key != key
+    global _pack_generation
+    # packs stay valid while the master is untouched: torch-visible writes bump `_version`; the fused
+    # optimizers (whose kernels do not) refresh every pack themselves right after the step (repack_after_step)
+    stale = pk.key != key or (refresh and pk.synced != weight._version)
     if want_dgrad and (pk.fwd is None or pk.dgrad is None or stale):
         if pk.fwd is None or pk.key != key:
             pk.fwd = torch.empty((kp, r, sp, cp), dtype=BF16, device=weight.device)
+            _pack_generation += 1
         if pk.dgrad is None or pk.key != key:
             pk.dgrad = torch.empty((cp, r, s, kp), dtype=BF16, device=weight.device)
+            _pack_generation += 1
         _C.check(lib.tok_pack_weight_both(ptr(weight), k, r, s, c, ptr(pk.fwd), kp, sp, cp, ptr(pk.dgrad), st),
                  'tok_pack_weight_both')
+        pk.synced = weight._version
     elif pk.fwd is None or stale:
         if pk.fwd is None or pk.key != key:
             pk.fwd = torch.empty((kp, r, sp, cp), dtype=BF16, device=weight.device)
+            _pack_generation += 1
+        if pk.key != key:
+            pk.dgrad = None
         _C.check(lib.tok_pack_weight_fwd(ptr(weight), k, r, s, c, ptr(pk.fwd), kp, sp, cp, st),
                  'tok_pack_weight_fwd')
+        if pk.dgrad is not None:       # an older dgrad pack is no longer in step with the master
+            pk.dgrad = None
+            _pack_generation += 1
+        pk.synced = weight._version
+    pk.dims = (k, r, s, c, kp, sp, cp)
     if bias is not None:
         if kp == k:
             pk.bias = bias.detach()
@@ -103,6 +119,55 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
         pk.bias = None
     pk.key = key
     return pk
+
+
+_pack_generation = 0   # bumped whenever a pack buffer is (re)allocated: invalidates cached batch tables
+
+
+def invalidate_packs():
+    """Force every bf16 operand pack to be re-derived at its next use.  Needed only after writing a weight
+    behind torch's back (`p.data.mul_(...)`, a custom kernel): such writes do not bump `p._version`."""
+    for _, pk in list(_packs.values()):
+        pk.synced = None
+
+
+def repack_after_step(params, cache: dict, arena_sig) -> None:
+    """Refresh the packs of every weight in `params` with ONE launch (tok_pack_weights_batched).  Called by
+    the fused optimizers at the end of step(): their kernels update the masters without touching
+    `_version`, so this is what keeps packs and masters in step."""
+    import ctypes
+    sig = (_pack_generation, arena_sig)
+    if cache.get('sig') != sig:
+        items, entries, skipped = [], [], []
+        block = 0
+        for p in params:
+            ent = _packs.get(id(p))
+            if ent is None or ent[0]() is not p:
+                continue
+            pk = ent[1]
+            if pk.fwd is None or pk.key is None or pk.dims is None or pk.key[0] != p.data_ptr():
+                skipped.append(pk)
+                continue
+            k, r, s, c, kp, sp, cp = pk.dims
+            it = _C.PackItem(p.data_ptr(), pk.fwd.data_ptr(), pk.dgrad.data_ptr() if pk.dgrad is not None else None,
+                             k, r, s, c, kp, sp, cp, block)
+            block += _C.lib().tok_pack_item_blocks(ctypes.byref(it))
+            items.append(it)
+            entries.append((p, pk))
+        dev = None
+        if items:
+            arr = (_C.PackItem * len(items))(*items)
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            dev = host.to(entries[0][0].device)
+        cache.clear()
+        cache.update(sig=sig, dev=dev, n=len(items), blocks=block, entries=entries, skipped=skipped)
+    for pk in cache['skipped']:
+        pk.synced = None
+    if cache['n']:
+        _C.check(_C.lib().tok_pack_weights_batched(ptr(cache['dev']), cache['n'], cache['blocks'], stream_ptr()),
+                 'tok_pack_weights_batched')
+        for p, pk in cache['entries']:
+            pk.synced = p._version
 
 
 def _conv_desc(x: TTensor, k_pad: int, r: int, s: int, stride: int, pad: int) -> _C.ConvDesc:
@@ -182,7 +247,7 @@ class _ConvBnActNode(Node):
                     # rare mixed state: run the accumulate-free form and fix up on the host side
                     gacc = torch.empty_like(gs) if g_need else None
                     bacc = torch.empty_like(bs) if b_need else None
-                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
+                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
                                                      ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, dzy, st),
                              'tok_bn_bwd_finalize')
                     for p_, acc_ in ((bn.weight, gacc), (bn.bias, bacc)):
@@ -194,7 +259,7 @@ class _ConvBnActNode(Node):
                             for h_ in core_hooks():
                                 h_(p_)
                 else:
-                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, ptr(bn.weight), ptr(self.mean),
+                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
                                                      ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
                                                      1 if (gm == 1 or bm == 1) else 0, dzy, st), 'tok_bn_bwd_finalize')
                     if g_need:
@@ -276,8 +341,8 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
         k_real = conv.out_channels
     x4 = x
     kp = pad8(k_real)
-    if bn is not None and kp != k_real:
-        raise NotImplementedError('BatchNorm over a channel count that is not a multiple of 8')
+    if bn is not None and bn.num_features != k_real:
+        raise ValueError(f'BatchNorm num_features {bn.num_features} != conv output channels {k_real}')
     d = _conv_desc(x4, kp, r, s, stride, pad)
     training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or
                                      (bn is not None and bn.weight.requires_grad))
@@ -304,7 +369,7 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             mean = torch.empty(kp, dtype=F32, device=dev)
             rstd = torch.empty(kp, dtype=F32, device=dev)
             track = bn.training and bn.track_running_stats and bn.running_mean is not None
-            _C.check(lib.tok_bn_finalize(ptr(stats), rows, m, kp, ptr(bn.weight), ptr(bn.bias),
+            _C.check(lib.tok_bn_finalize(ptr(stats), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean) if track else None,
                                          ptr(bn.running_var) if track else None,
                                          ptr(bn.num_batches_tracked) if track else None,
@@ -312,7 +377,7 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
                                          ptr(scale), ptr(shift), st), 'tok_bn_finalize')
         else:
             _C.check(lib.tok_bn_eval_coeffs(ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-                                            ptr(bn.running_var), float(bn.eps), kp, ptr(scale), ptr(shift), st),
+                                            ptr(bn.running_var), float(bn.eps), kp, bn.num_features, ptr(scale), ptr(shift), st),
                      'tok_bn_eval_coeffs')
         out_data = torch.empty_like(y)
         mask = None

@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 import torch
 
 from .. import _C
-from .core import BF16, Node, Region, TTensor, grad_target, ptr, stream_ptr
+from .core import BF16, Node, Region, TTensor, grad_target, pad8, ptr, stream_ptr
 
 
 class _FuseSumNode(Node):
@@ -86,40 +86,44 @@ class _BilinearNode(Node):
         n, hd, wd, ld = self.out.shape
         lib, st = _C.lib(), stream_ptr()
         off = 0
-        for t in self.srcs:
+        for t, cw in zip(self.srcs, self.widths):
             _, hs, ws, cp = t.shape
             if t.requires_grad:
                 tgt, acc = grad_target(t)
-                _C.check(lib.tok_bilinear_bwd(ptr(g), n, hd, wd, ld, off, ptr(tgt), hs, ws, cp, cp, acc, st),
+                if cw != cp and not acc:
+                    tgt.zero_()           # padding channels of a fresh gradient buffer
+                _C.check(lib.tok_bilinear_bwd(ptr(g), n, hd, wd, ld, off, ptr(tgt), hs, ws, cw, cp, acc, st),
                          'tok_bilinear_bwd')
-            off += cp
+            off += cw
         self.out.grad = None
 
     def release(self):
-        self.srcs = self.out = None
+        self.srcs = self.out = self.widths = None
 
 
 def bilinear_concat(region: Region, srcs: List[TTensor], size: Tuple[int, int]) -> TTensor:
     """cat([interpolate(s, size, 'bilinear', align_corners=False) for s in srcs], dim=channel)."""
     n = srcs[0].shape[0]
     hd, wd = int(size[0]), int(size[1])
-    if len(srcs) > 1 and any(t.c != t.cp for t in srcs):
-        raise NotImplementedError('bilinear_concat: every concatenated map needs channels % 8 == 0')
-    ld = sum(t.cp for t in srcs)
+    # a single map keeps its padded width; concatenated maps are packed at their LOGICAL channel offsets
+    # (18 + 36 + 72 + 144 = 270 -> row pitch 272), which costs the 16-byte fast path only for odd widths
+    widths = [srcs[0].cp] if len(srcs) == 1 else [t.c for t in srcs]
+    ld = pad8(sum(widths))
     dev = srcs[0].data.device
-    out_data = torch.empty((n, hd, wd, ld), dtype=BF16, device=dev)
+    alloc = torch.zeros if ld != sum(widths) else torch.empty
+    out_data = alloc((n, hd, wd, ld), dtype=BF16, device=dev)
     lib, st = _C.lib(), stream_ptr()
     off = 0
-    for t in srcs:
+    for t, cw in zip(srcs, widths):
         _, hs, ws, cp = t.shape
-        _C.check(lib.tok_bilinear_fwd(ptr(t.data), n, hs, ws, cp, cp, ptr(out_data), hd, wd, ld, off, st),
+        _C.check(lib.tok_bilinear_fwd(ptr(t.data), n, hs, ws, cw, cp, ptr(out_data), hd, wd, ld, off, st),
                  'tok_bilinear_fwd')
-        off += cp
+        off += cw
     req = region.grad_mode and any(t.requires_grad for t in srcs)
     out = TTensor(out_data, sum(t.c for t in srcs), requires_grad=req)
     if req:
         node = _BilinearNode()
-        node.srcs, node.out = list(srcs), out
+        node.srcs, node.out, node.widths = list(srcs), out, widths
         out.node = node
         for t in srcs:
             if t.requires_grad:

@@ -37,7 +37,7 @@ class _SoftmaxCE(torch.autograd.Function):
         dev = z.device
         lse = torch.empty(rows, dtype=torch.float32, device=dev)
         row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
-        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        loss = torch.empty(_C.TOK_CE_LOSS_FLOATS, dtype=torch.float32, device=dev)
         _C.check(_C.lib().tok_softmax_ce_fwd(ptr(z), ptr(target), rows, classes, z.stride(0), ignore_index,
                                              ptr(lse), ptr(row_loss), ptr(loss), stream_ptr()),
                  'tok_softmax_ce_fwd')

@@ -52,6 +52,14 @@ class _ArenaOptimizer(Optimizer):
     def _restore_state(self, old_state):
         pass
 
+    def _repack(self):
+        """The step kernels moved the fp32 masters: refresh every bf16 MFMA operand pack in one launch."""
+        from ..engine.functional import repack_after_step
+        if not hasattr(self, '_pack_cache'):
+            self._pack_cache = {}
+        params = [p for a in self._arenas if a is not None for p in a.params if p.dim() >= 2]
+        repack_after_step(params, self._pack_cache, tuple(a.master.data_ptr() for a in self._arenas if a is not None))
+
     def _runs(self, arena: ParamArena, key_fn):
         """Maximal runs of consecutive parameters that have a gradient and share key_fn(i)."""
         runs = []
@@ -130,6 +138,7 @@ class SGD(_ArenaOptimizer):
                 if mom != 0 and not inited:
                     for i in range(a, b + 1):
                         self.state[arena.params[i]]['momentum_buffer'] = arena.state_view(0, i)
+        self._repack()
         return loss
 
 
@@ -195,6 +204,7 @@ class _AdamBase(_ArenaOptimizer):
                         s['exp_avg'] = arena.state_view(0, i)
                         s['exp_avg_sq'] = arena.state_view(1, i)
                     s['step'] = t + 1
+        self._repack()
         return loss
 
 
