@@ -247,6 +247,51 @@ int tok_bilinear_fwd(const void* src, int n, int hs, int ws, int c, int ld_src, 
 int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_dst, int ch_off, void* dsrc,
                      int hs, int ws, int c, int ld_src, int accumulate, void* stream);
 
+/* ---- token-major transformer units (SwinV2) -------------------------------------------------------
+ * swin.py:71-256 over [timm 0.6.13] swin_transformer_v2.  Tokens are rows of a bf16 [rows][ld] matrix
+ * (rows = B*H*W, first c columns valid).                                                            */
+
+/* out = shortcut + row_scale[row / rows_per_sample] * LayerNorm(x)   (shortcut / row_scale may be NULL):
+ * nn.LayerNorm, and the res-post-norm residual `x + drop_path(norm(f(x)))` of SwinTransformerBlock with the
+ * per-sample stochastic-depth factor.  mean / rstd [rows] fp32 are saved for the backward.            */
+int tok_layernorm_fwd(const void* x, const void* shortcut, const float* row_scale, int rows_per_sample,
+                      const float* gamma, const float* beta, void* out, float* mean, float* rstd,
+                      int64_t rows, int c, int ld, float eps, void* stream);
+int tok_layernorm_bwd_rows(int64_t rows, int c);
+/* dx (+)= LN backward of (dout * row_scale); partial [2][tok_layernorm_bwd_rows][c]: dgamma rows then dbeta
+ * rows, to be folded by tok_colsum_f32.                                                                          */
+int tok_layernorm_bwd(const void* dout, const void* x, const float* mean, const float* rstd,
+                      const float* gamma, const float* row_scale, int rows_per_sample, void* dx,
+                      int accumulate, float* partial, int64_t rows, int c, int ld, void* stream);
+/* dst[col] (+)= sum_r src[r][col]: fixed-order fp64 fold of fp32 partial rows                           */
+int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream);
+/* kind 0: ReLU (cpb_mlp), 1: GELU erf (Mlp); count % 8 == 0.  tok_act_bwd also takes kind 2 = identity
+ * (dx (+)= dout: the pass-through branch of a residual)                                                  */
+int tok_act_fwd(int kind, const void* x, void* out, size_t count, void* stream);
+int tok_act_bwd(int kind, const void* dout, const void* x, void* dx, int accumulate, size_t count, void* stream);
+/* WindowAttention.forward + the roll / window_partition / window_reverse of SwinTransformerBlock._attn:
+ * qkv [B*H*W][ld] (q | k | v, each c = heads*32 wide) -> out [B*H*W][c] in token order.
+ * attn = normalize(q) normalize(k)^T * exp(min(logit_scale[h], ln 100)) + bias[h] (+ mask[window]), softmax, @ v.
+ * bias fp32 [heads][N][N], mask fp32 [nW][N][N] or NULL, lse fp32 [B*nW*heads][N] (saved).              */
+int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int c, int heads, int ws, int shift, int ld,
+                        const float* logit_scale, const float* bias, const float* mask, void* out,
+                        float* lse, void* stream);
+/* dqkv [B*H*W][ld]; ds_scratch fp32 [B*nW][heads][N][N] receives d(attn logits) TRANSPOSED per window
+ * ([j][i]) — tok_colsum_f32 over its B*nW rows is d(bias)^T; dscale_part fp32 [B*nW*heads] -> colsum per head
+ * = d(logit_scale).                                                                                      */
+int tok_window_attn_bwd(const void* qkv, const void* dout, int batch, int h, int w, int c, int heads, int ws,
+                        int shift, int ld, const float* logit_scale, const float* bias, const float* mask,
+                        const float* lse, void* dqkv, float* ds_scratch, float* dscale_part, void* stream);
+/* bias[h][i][j] = 16 * sigmoid(table[index[i][j]][h]); table bf16 [T][ld] = cpb_mlp(relative_coords_table),
+ * index int64 [N][N] = relative_position_index (exact gather); backward = its transpose, ordered.        */
+int tok_cpb_bias_fwd(const void* table, int ld, const int64_t* index, int heads, int n_tokens, float* bias,
+                     void* stream);
+int tok_cpb_bias_bwd(const float* dbias, int transposed, const void* table, int ld, const int64_t* index,
+                     int heads, int n_tokens, int table_rows, void* dtable, void* stream);
+/* PatchMerging gather [B][H][W][c] -> [B][H/2][W/2][4c] (x0, x1, x2, x3 order); inverse != 0: the inverse
+ * permutation (its backward)                                                                             */
+int tok_patch_merge(const void* src, void* dst, int batch, int h, int w, int c, int inverse, void* stream);
+
 /* ---- optimizers (flat arenas) -------------------------------------------------------------
  * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
  * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch

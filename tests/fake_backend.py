@@ -516,6 +516,166 @@ class FakeTok:
             d[..., :c] = _bf(gx)
         return 0
 
+    # ---- token-major transformer units (SwinV2) ----------------------------------------------------------
+    def tok_layernorm_fwd(self, x, shortcut, row_scale, rps, gamma, beta, out, mean, rstd, rows, c, ld, eps, st):
+        self.calls.append('layernorm_fwd')
+        xv = _t(x, (rows, ld), BF16)[:, :c].float()
+        mu = xv.mean(1)
+        var = ((xv - mu[:, None]) ** 2).mean(1)
+        rs = torch.rsqrt(var + eps)
+        _t(mean, (rows,), torch.float32).copy_(mu)
+        _t(rstd, (rows,), torch.float32).copy_(rs)
+        y = (xv - mu[:, None]) * rs[:, None] * _t(gamma, (c,), torch.float32) + _t(beta, (c,), torch.float32)
+        if row_scale is not None:
+            y = y * _t(row_scale, (rows // rps,), torch.float32).repeat_interleave(rps)[:, None]
+        if shortcut is not None:
+            y = y + _t(shortcut, (rows, ld), BF16)[:, :c].float()
+        o = _t(out, (rows, ld), BF16)
+        o.zero_()
+        o[:, :c] = _bf(y)
+        return 0
+
+    def tok_layernorm_bwd_rows(self, rows, c):
+        return 1
+
+    def tok_layernorm_bwd(self, dout, x, mean, rstd, gamma, row_scale, rps, dx, accumulate, partial, rows, c, ld, st):
+        self.calls.append('layernorm_bwd')
+        xv = _t(x, (rows, ld), BF16)[:, :c].float()
+        go = _t(dout, (rows, ld), BF16)[:, :c].float()
+        if row_scale is not None:
+            go = go * _t(row_scale, (rows // rps,), torch.float32).repeat_interleave(rps)[:, None]
+        mu, rs = _t(mean, (rows,), torch.float32), _t(rstd, (rows,), torch.float32)
+        xh = (xv - mu[:, None]) * rs[:, None]
+        g = go * _t(gamma, (c,), torch.float32)
+        d = rs[:, None] * (g - g.mean(1, keepdim=True) - xh * (g * xh).mean(1, keepdim=True))
+        o = _t(dx, (rows, ld), BF16)
+        if accumulate:
+            o[:, :c] = _bf(o[:, :c].float() + d)
+        else:
+            o.zero_()
+            o[:, :c] = _bf(d)
+        p = _t(partial, (2, 1, c), torch.float32)
+        p[0, 0] = (go * xh).sum(0)
+        p[1, 0] = go.sum(0)
+        return 0
+
+    def tok_colsum_f32(self, src, rows, cols, dst, accumulate, st):
+        v = _t(src, (rows, cols), torch.float32).double().sum(0).float()
+        d = _t(dst, (cols,), torch.float32)
+        d.copy_(d + v if accumulate else v)
+        return 0
+
+    def tok_act_fwd(self, kind, x, out, count, st):
+        v = _t(x, (count,), BF16).float()
+        _t(out, (count,), BF16).copy_(_bf(v.clamp_min(0) if kind == 0 else F.gelu(v)))
+        return 0
+
+    def tok_act_bwd(self, kind, dout, x, dx, accumulate, count, st):
+        v = _t(x, (count,), BF16).float()
+        g = _t(dout, (count,), BF16).float()
+        if kind == 0:
+            d = (v > 0).float()
+        elif kind == 2:
+            d = torch.ones_like(v)
+        else:
+            d = 0.5 * (1 + torch.erf(v * 0.7071067811865476)) + v * 0.3989422804014327 * torch.exp(-0.5 * v * v)
+        o = _t(dx, (count,), BF16)
+        o.copy_(_bf(g * d + (o.float() if accumulate else 0)))
+        return 0
+
+    @staticmethod
+    def _win(t, b, h, w, ws, shift):
+        """(B, H, W, X) -> (B*nW, N, X) after roll(-shift) + window_partition."""
+        if shift:
+            t = torch.roll(t, (-shift, -shift), (1, 2))
+        x = t.shape[-1]
+        return t.view(b, h // ws, ws, w // ws, ws, x).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, x)
+
+    @staticmethod
+    def _unwin(t, b, h, w, ws, shift):
+        x = t.shape[-1]
+        t = t.view(b, h // ws, w // ws, ws, ws, x).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, x)
+        return torch.roll(t, (shift, shift), (1, 2)) if shift else t
+
+    def _attn(self, qkv, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask):
+        n = ws * ws
+        nw = (h // ws) * (w // ws)
+        x = _t(qkv, (b, h, w, ld), BF16)[..., :3 * c].float().clone().requires_grad_(True)
+        xw = self._win(x, b, h, w, ws, shift).view(-1, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+        q, k, v = xw[0], xw[1], xw[2]
+        ls = _t(logit_scale, (heads,), torch.float32).clone().requires_grad_(True)
+        bi = _t(bias, (heads, n, n), torch.float32).clone().requires_grad_(True)
+        attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
+        attn = attn * torch.clamp(ls, max=math.log(100.0)).exp()[None, :, None, None] + bi[None]
+        if mask is not None:
+            m = _t(mask, (nw, n, n), torch.float32)
+            attn = (attn.view(b, nw, heads, n, n) + m[None, :, None]).view(-1, heads, n, n)
+        lse = torch.logsumexp(attn, -1)
+        o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(-1, n, c)
+        return x, ls, bi, self._unwin(o, b, h, w, ws, shift), lse
+
+    def tok_window_attn_fwd(self, qkv, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask, out, lse, st):
+        self.calls.append('window_attn_fwd')
+        with torch.no_grad():
+            _, _, _, o, l = self._attn(qkv, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask)
+        _t(out, (b, h, w, c), BF16).copy_(_bf(o))
+        n = ws * ws
+        _t(lse, (l.numel(),), torch.float32).copy_(l.reshape(-1))
+        return 0
+
+    def tok_window_attn_bwd(self, qkv, dout, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask, lse, dqkv,
+                            ds_scratch, dscale_part, st):
+        self.calls.append('window_attn_bwd')
+        n = ws * ws
+        nw = (h // ws) * (w // ws)
+        with torch.enable_grad():
+            x, ls, bi, o, _ = self._attn(qkv, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask)
+            g = _t(dout, (b, h, w, c), BF16).float()
+            gx, gls, gbi = torch.autograd.grad(o, (x, ls, bi), g)
+        d = _t(dqkv, (b, h, w, ld), BF16)
+        d.zero_()
+        d[..., :3 * c] = _bf(gx)
+        # the stand-in reports the reduced gradients in row 0 of the scratch buffers (their colsums are what is used)
+        sc = _t(ds_scratch, (b * nw, heads, n, n), torch.float32)
+        sc.zero_()
+        sc[0] = gbi.transpose(1, 2)
+        dp = _t(dscale_part, (b * nw, heads), torch.float32)
+        dp.zero_()
+        dp[0] = gls
+        return 0
+
+    def tok_cpb_bias_fwd(self, table, ld, index, heads, n, bias, st):
+        t = _t(table, (int(_t(index, (n * n,), torch.int64).max()) + 1, ld), BF16)
+        idx = _t(index, (n * n,), torch.int64)
+        b = 16 * torch.sigmoid(t.float()[idx][:, :heads])
+        _t(bias, (heads, n, n), torch.float32).copy_(b.t().reshape(heads, n, n))
+        return 0
+
+    def tok_cpb_bias_bwd(self, dbias, transposed, table, ld, index, heads, n, rows, dtable, st):
+        g = _t(dbias, (heads, n, n), torch.float32)
+        if transposed:
+            g = g.transpose(1, 2)
+        idx = _t(index, (n * n,), torch.int64)
+        t = _t(table, (rows, ld), BF16).float()
+        acc = torch.zeros(rows, heads).index_add_(0, idx, g.reshape(heads, n * n).t().contiguous())
+        s = torch.sigmoid(t[:, :heads])
+        d = _t(dtable, (rows, ld), BF16)
+        d.zero_()
+        d[:, :heads] = _bf(acc * 16 * s * (1 - s))
+        return 0
+
+    def tok_patch_merge(self, src, dst, b, h, w, c, inverse, st):
+        if not inverse:
+            x = _t(src, (b, h, w, c), BF16)
+            o = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+            _t(dst, (b, h // 2, w // 2, 4 * c), BF16).copy_(o)
+        else:
+            x = _t(src, (b, h // 2, w // 2, 4, c), BF16)
+            o = _t(dst, (b, h, w, c), BF16)
+            o[:, 0::2, 0::2], o[:, 1::2, 0::2], o[:, 0::2, 1::2], o[:, 1::2, 1::2] = x[..., 0, :], x[..., 1, :], \
+                x[..., 2, :], x[..., 3, :]
+        return 0
+
     # ---- optimizers ---------------------------------------------------------------------------------
     def tok_sgd_step(self, param, grad, mbuf, shadow, count, lr, momentum, dampening, wd, nesterov, first,
                      maximize, st):

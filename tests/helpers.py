@@ -61,6 +61,13 @@ def deterministic_state(state_dict, seed: int):
         g = torch.Generator().manual_seed((zlib.crc32(k.encode()) + seed) & 0x7fffffff)
         if k.endswith('num_batches_tracked'):
             out[k] = torch.zeros_like(v)
+        elif k.endswith('attn_mask') or k.endswith('relative_position_index') or k.endswith('relative_coords_table'):
+            out[k] = v.clone()                     # structural buffers of SwinV2 blocks
+        elif k.endswith('logit_scale'):
+            out[k] = torch.full(v.shape, 2.302585) + torch.randn(v.shape, generator=g) * 0.2
+        elif k.endswith('norm1.weight') or k.endswith('norm2.weight'):
+            # res-post-norm gains (the reference initialises them to 0, swin.py:188-189): small but alive
+            out[k] = 0.5 + torch.randn(v.shape, generator=g) * 0.1
         elif k.endswith('running_mean'):
             out[k] = torch.randn(v.shape, generator=g) * 0.1
         elif k.endswith('running_var'):

@@ -632,3 +632,128 @@ def test_bn_padded_channels(libs):
     for t in (dg, db, coef):
         assert relerr(dv[id(t)], t) < 1e-5
     assert float(dv[id(coef)][:, cr:].abs().max()) == 0.0
+
+
+# ---- token-major transformer kernels (transformer.hip) ---------------------------------------------------------
+@pytest.mark.parametrize('rows,c,ld,sc,rs', [(37, 96, 96, 0, 0), (64, 768, 768, 1, 1), (50, 18, 24, 1, 0),
+                                             (4096, 192, 192, 1, 1)])
+def test_layernorm(libs, rows, c, ld, sc, rs):
+    rps = rows // 2 if rows % 2 == 0 else rows
+    x = torch.zeros(rows, ld)
+    x[:, :c] = rnd(rows, c, scale=2.0) + 0.5
+    x = x.to(BF16)
+    short = torch.zeros(rows, ld)
+    short[:, :c] = rnd(rows, c, seed=3)
+    short = short.to(BF16)
+    scale = torch.tensor([0.0, 2.0][:rows // rps]) if rs else None
+    gamma, beta = rnd(c, seed=1) + 1.0, rnd(c, seed=2)
+    out, mean, rstd = torch.empty(rows, ld, dtype=BF16), torch.empty(rows), torch.empty(rows)
+    dv = both(libs, 'tok_layernorm_fwd', lambda d: [d(x), d(short) if sc else None, d(scale) if rs else None, rps,
+                                                    d(gamma), d(beta), d(out), d(mean), d(rstd), rows, c, ld, 1e-5, None])
+    assert relerr(dv[id(out)].float(), out.float()) < 4e-3
+    assert relerr(dv[id(mean)], mean) < 1e-4 and relerr(dv[id(rstd)], rstd) < 1e-4
+    g = torch.zeros(rows, ld)
+    g[:, :c] = rnd(rows, c, seed=5)
+    g = g.to(BF16)
+    lib, fake = libs
+    nrows = lib.tok_layernorm_bwd_rows(rows, c)
+    for acc in (0, 1):
+        dx_h = (rnd(rows, ld, seed=6) if acc else torch.zeros(rows, ld)).to(BF16)
+        dx_h[:, c:] = 0
+        dx_d = dx_h.cuda()
+        part_h, part_d = torch.zeros(2, 1, c), torch.zeros(2, nrows, c, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        assert lib.tok_layernorm_bwd(P(g.cuda()), P(x.cuda()), P(mean.cuda()), P(rstd.cuda()), P(gamma.cuda()),
+                                     P(scale.cuda()) if rs else None, rps, P(dx_d), acc, P(part_d), rows, c, ld, st) == 0
+        assert fake.tok_layernorm_bwd(P(g), P(x), P(mean), P(rstd), P(gamma), P(scale) if rs else None, rps, P(dx_h), acc,
+                                      P(part_h), rows, c, ld, None) == 0
+        torch.cuda.synchronize()
+        assert relerr(dx_d.float(), dx_h.float()) < 8e-3
+        assert relerr(part_d.sum(1), part_h.sum(1)) < 2e-3
+        red = torch.zeros(c, device='cuda') + 1.0
+        assert lib.tok_colsum_f32(part_d[0].data_ptr(), nrows, c, red.data_ptr(), 1, st) == 0
+        torch.cuda.synchronize()
+        assert relerr(red - 1.0, part_d[0].double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('kind', [0, 1])
+def test_activation(libs, kind):
+    x = (rnd(4096 * 8) * 2).to(BF16)
+    y = torch.empty_like(x)
+    dv = both(libs, 'tok_act_fwd', lambda d: [kind, d(x), d(y), x.numel(), None])
+    assert relerr(dv[id(y)].float(), y.float()) < 4e-3
+    g = rnd(4096 * 8, seed=2).to(BF16)
+    for acc in (0, 1):
+        dx = (rnd(4096 * 8, seed=3) if acc else torch.zeros(4096 * 8)).to(BF16)
+        dv = both(libs, 'tok_act_bwd', lambda d: [kind, d(g), d(x), d(dx), acc, x.numel(), None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < 6e-3
+    dx = rnd(4096 * 8, seed=4).to(BF16)
+    dv = both(libs, 'tok_act_bwd', lambda d: [2, d(g), d(g), d(dx), 1, x.numel(), None])     # identity accumulate
+    assert relerr(dv[id(dx)].float(), dx.float()) < 4e-3
+
+
+@pytest.mark.parametrize('b,h,w,heads,ws,shift', [(2, 8, 8, 3, 4, 0), (2, 8, 8, 3, 4, 2), (1, 16, 16, 2, 8, 4),
+                                                  (3, 7, 7, 6, 7, 0), (1, 32, 32, 1, 16, 8), (2, 14, 14, 3, 7, 3)])
+def test_window_attention(libs, b, h, w, heads, ws, shift):
+    lib, fake = libs
+    c = heads * 32
+    n, nw = ws * ws, (h // ws) * (w // ws)
+    qkv = rnd(b * h * w, 3 * c).to(BF16)
+    ls = torch.full((heads,), 2.3) + rnd(heads, seed=1) * 0.3
+    ls[0] = 5.0                                            # above ln(100): the clamp is active for head 0
+    bias = rnd(heads, n, n, seed=2)
+    mask = None
+    if shift:
+        img = torch.zeros(1, h, w, 1)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, h // ws, ws, w // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        mask = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).contiguous()
+    out, lse = torch.empty(b * h * w, c, dtype=BF16), torch.empty(b * nw * heads * n)
+    dv = both(libs, 'tok_window_attn_fwd', lambda d: [d(qkv), b, h, w, c, heads, ws, shift, 3 * c, d(ls), d(bias),
+                                                      d(mask) if mask is not None else None, d(out), d(lse), None])
+    assert relerr(dv[id(out)].float(), out.float()) < 5e-3
+    # lse layout: fake (B*nW, heads, N) == kernel ((b*nW + win)*heads + h, N)
+    assert relerr(dv[id(lse)], lse) < 1e-4
+    g = rnd(b * h * w, c, seed=7).to(BF16)
+    dq = torch.empty(b * h * w, 3 * c, dtype=BF16)
+    scr, dsp = torch.empty(b * nw, heads * n * n), torch.empty(b * nw, heads)
+    dv = both(libs, 'tok_window_attn_bwd', lambda d: [d(qkv), d(g), b, h, w, c, heads, ws, shift, 3 * c, d(ls), d(bias),
+                                                      d(mask) if mask is not None else None, d(lse), d(dq), d(scr), d(dsp),
+                                                      None])
+    assert relerr(dv[id(dq)].float(), dq.float()) < 1e-2
+    assert relerr(dv[id(scr)].sum(0), scr.sum(0)) < 5e-3          # d(bias)^T
+    assert relerr(dv[id(dsp)].sum(0), dsp.sum(0)) < 5e-3 + 1e-3   # d(logit_scale)
+    assert float(dv[id(dsp)][:, 0].abs().max()) == 0.0            # clamped head: zero gradient
+
+
+def test_cpb_bias_and_patch_merge(libs):
+    heads, ws = 3, 4
+    n, T_ = ws * ws, (2 * ws - 1) ** 2
+    coords = torch.flatten(torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing='ij')), 1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    index = rel.sum(-1).contiguous()
+    table = rnd(T_, 8).to(BF16)
+    bias = torch.empty(heads, n, n)
+    dv = both(libs, 'tok_cpb_bias_fwd', lambda d: [d(table), 8, d(index), heads, n, d(bias), None])
+    assert relerr(dv[id(bias)], bias) < 1e-5
+    for tr in (0, 1):
+        db = rnd(heads, n, n, seed=4)
+        dt = torch.full((T_, 8), float('nan'), dtype=BF16)
+        dv = both(libs, 'tok_cpb_bias_bwd', lambda d: [d(db), tr, d(table), 8, d(index), heads, n, T_, d(dt), None])
+        assert relerr(dv[id(dt)].float(), dt.float()) < 6e-3          # incl. zeroed padding columns
+    x = rnd(2, 8, 12, 16).to(BF16)
+    y = torch.empty(2, 4, 6, 64, dtype=BF16)
+    dv = both(libs, 'tok_patch_merge', lambda d: [d(x), d(y), 2, 8, 12, 16, 0, None])
+    assert torch.equal(dv[id(y)].cpu(), y)                       # permutation: bit-exact
+    back = torch.empty_like(x)
+    dv2 = both(libs, 'tok_patch_merge', lambda d: [d(y), d(back), 2, 8, 12, 16, 1, None])
+    assert torch.equal(dv2[id(back)].cpu(), x)                   # inverse round trip

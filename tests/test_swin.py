@@ -1,0 +1,102 @@
+"""SwinV2 row: SwinTransformerV2 backbone (+ ClassificationTask) against oracle/swin_ref.py and
+tests/golden/swinv2_cls_step.npz (one training step of the reference's own swin.py, tools/gen_golden.py).
+Each test runs on the host stand-in and, marked gpu, through libtok_gfx950.so."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle.swin_ref as S
+import torchok_amd as T
+from helpers import deterministic_state, rel_err
+
+KW = dict(img_size=64, window_size=4, depths=(2, 2, 2, 2), drop_path_rate=0.0)
+
+
+@pytest.fixture(params=['host', pytest.param('hip', marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == 'host':
+        request.getfixturevalue('fake_backend')
+        return 'cpu'
+    assert torch.cuda.is_available()
+    return 'cuda'
+
+
+def _pair(seed=17, **kw):
+    kw = dict(KW, **kw)
+    m = T.BACKBONES.get('swinv2_custom')(**kw)
+    ref = S.SwinV2(**kw)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
+        {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    sd = deterministic_state(ref.state_dict(), seed)
+    ref.load_state_dict(sd)
+    m.load_state_dict(sd)
+    return m, ref
+
+
+def test_structure_and_index_buffers():
+    m, ref = _pair()
+    for (n1, b1), (n2, b2) in zip(m.named_buffers(), ref.named_buffers()):
+        assert n1 == n2 and torch.equal(b1, b2), n1          # attn_mask, relative_position_index, coords table: exact
+    assert sorted(m.no_weight_decay()) == sorted(
+        ['absolute_pos_embed'] + [n for n, _ in ref.named_modules() if 'cpb_mlp' in n or 'logit_scale' in n])
+    assert m.out_encoder_channels == (96, 192, 384, 768) and m.out_channels == 768
+    assert len(m.get_stages(2)) == 4
+    big = S.SwinV2(img_size=224, window_size=7)
+    assert sum(p.numel() for p in big.parameters()) == 27579498            # 28.35 M with the 1000-way head
+
+
+def test_forward_features_and_backward_vs_oracle(dev):
+    m, ref = _pair()
+    m.to(dev).train()
+    ref.train()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    feats = m.forward_features(x.to(dev))
+    rfeats = ref.forward_features(x)
+    assert [tuple(f.shape) for f in feats] == [tuple(f.shape) for f in rfeats]
+    for i, (a, b) in enumerate(zip(feats[1:], rfeats[1:])):
+        assert rel_err(a.float(), b) < 2e-2, i
+    w = [torch.randn(f.shape, generator=g) for f in rfeats[1:]]
+    sum((f.float() * wi.to(dev)).sum() for f, wi in zip(feats[1:], w)).backward()
+    sum((f * wi).sum() for f, wi in zip(rfeats[1:], w)).backward()
+    ac = copy.deepcopy(ref)
+    ac.zero_grad()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        af = ac.forward_features(x)
+    sum((f.float() * wi).sum() for f, wi in zip(af[1:], w)).backward()
+    g32 = {n: p.grad for n, p in ref.named_parameters()}
+    yard = {n: rel_err(p.grad, g32[n]) for n, p in ac.named_parameters()}
+    errs = {n: rel_err(p.grad, g32[n]) for n, p in m.named_parameters()}
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in m.parameters())
+    assert np.median(list(errs.values())) < 1.5 * np.median(list(yard.values())) + 1e-2
+    bad = [n for n in errs if errs[n] > 1.5 * yard[n] + 0.08]
+    assert len(bad) <= 0.05 * len(errs), [(n, errs[n], yard[n]) for n in bad][:8]
+
+
+def test_reference_shape_tests(dev):
+    """tests/additional_tests/models/backbones/test_backbone.py:161-178 (swinv2_tiny_window16_256 on 2x3x256x256)."""
+    m = T.BACKBONES.get('swinv2_tiny_window16_256')(pretrained=False).to(dev).eval()
+    x = torch.rand(2, 3, 256, 256).to(dev)
+    with torch.no_grad():
+        assert tuple(m(x).shape) == (2, 768, 8, 8)
+        feats = m.forward_features(x)
+    assert [tuple(f.shape) for f in feats] == [(2, 3, 256, 256), (2, 96, 64, 64), (2, 192, 32, 32), (2, 384, 16, 16),
+                                               (2, 768, 8, 8)]
+
+
+def test_stochastic_depth_scales_whole_samples(dev):
+    m, ref = _pair(drop_path_rate=0.5)
+    m.to(dev).train()
+    x = torch.randn(8, 3, 64, 64)
+    torch.manual_seed(0)
+    a = m(x.to(dev)).float().cpu()
+    torch.manual_seed(1)
+    b = m(x.to(dev)).float().cpu()
+    assert not torch.allclose(a, b)                 # different drop masks
+    m.eval()
+    with torch.no_grad():
+        c, d = m(x.to(dev)).float().cpu(), ref.eval()(x)
+    assert rel_err(c, d) < 2e-2                     # eval: no drop

@@ -81,6 +81,18 @@ PROTOTYPES = {
     'tok_fuse_sum_relu_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_bilinear_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_bilinear_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_layernorm_fwd': (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P]),
+    'tok_layernorm_bwd_rows': (c_int, [c_int64, c_int]),
+    'tok_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int64, c_int, c_int, _P]),
+    'tok_colsum_f32': (c_int, [_P, c_int64, c_int, _P, c_int, _P]),
+    'tok_act_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
+    'tok_act_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_size_t, _P]),
+    'tok_window_attn_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'tok_window_attn_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                    _P, _P, _P]),
+    'tok_cpb_bias_fwd': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
+    'tok_cpb_bias_bwd': (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    'tok_patch_merge': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,

@@ -1,0 +1,548 @@
+// Token-major kernels of the SwinV2 row: swin.py:71-256 over [timm 0.6.13]
+// swin_transformer_v2 (SwinTransformerBlock / WindowAttention / PatchMerging).
+//   layernorm fwd/bwd       res-post-norm  x = shortcut + drop_path(LN(y))  (per-sample scale = stochastic depth)
+//   act fwd/bwd             GELU (erf) of the MLP, ReLU of the cpb_mlp
+//   window attention        cosine attention with learned logit scale, continuous relative position bias and the
+//                           shifted-window mask; roll / window_partition / window_reverse are index arithmetic on
+//                           the token grid (exact), nothing is permuted in HBM
+//   cpb bias                16 * sigmoid(table)[relative_position_index]  (exact gather) and its transpose
+//   patch merge             the 2x2 strided gather of PatchMerging (exact permutation) and its inverse
+//   colsum_f32              fixed-order reduction of fp32 partial rows (dgamma/dbeta, dbias, dlogit_scale)
+// Tokens are rows of a [B*H*W][C] bf16 matrix; statistics and softmax in fp32.  Deterministic: no atomics.
+#include "tok_common.h"
+#include <math.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row.
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shortcut,
+                                                     const float* __restrict__ row_scale, int rows_per_sample,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16* __restrict__ out, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int64_t rows, int c, int ld, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16* xr = x + row * ld;
+  float s = 0.f;
+  for (int i = lane; i < c; i += 64) s += bf2f(xr[i]);
+  const float mu = wave_sum(s) / (float)c;
+  float v = 0.f;
+  for (int i = lane; i < c; i += 64) { const float d = bf2f(xr[i]) - mu; v = fmaf(d, d, v); }
+  const float rs = rsqrtf(wave_sum(v) / (float)c + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+  bf16* orow = out + row * ld;
+  const bf16* srow = shortcut ? shortcut + row * ld : nullptr;
+  for (int i = lane; i < ld; i += 64) {
+    float o = 0.f;
+    if (i < c) {
+      o = ((bf2f(xr[i]) - mu) * rs * gamma[i] + beta[i]) * sc;
+      if (srow) o += bf2f(srow[i]);
+    }
+    orow[i] = f2bf(o);
+  }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dout * scale * gamma;  partial dgamma/dbeta per block
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ row_scale,
+                                                     int rows_per_sample, bf16* dx, int accumulate,
+                                                     float* __restrict__ partial, int64_t rows, int c, int ld) {
+  extern __shared__ float sm[];   // [4 waves][2][c]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* pg = sm + (size_t)wv * 2 * c;
+  float* pb = pg + c;
+  for (int i = lane; i < c; i += 64) { pg[i] = 0.f; pb[i] = 0.f; }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bf16* xr = x + row * ld;
+    const bf16* gr = dout + row * ld;
+    const float mu = mean[row], rs = rstd[row];
+    const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < c; i += 64) {
+      const float xh = (bf2f(xr[i]) - mu) * rs;
+      const float go = bf2f(gr[i]) * sc;
+      const float g = go * gamma[i];
+      s1 += g;
+      s2 = fmaf(g, xh, s2);
+      pg[i] = fmaf(go, xh, pg[i]);   // each lane owns its columns: no conflicts inside a wave
+      pb[i] += go;
+    }
+    const float m1 = wave_sum(s1) / (float)c, m2 = wave_sum(s2) / (float)c;
+    bf16* dr = dx + row * ld;
+    for (int i = lane; i < ld; i += 64) {
+      float o = 0.f;
+      if (i < c) {
+        const float xh = (bf2f(xr[i]) - mu) * rs;
+        o = rs * (bf2f(gr[i]) * sc * gamma[i] - m1 - xh * m2);
+        if (accumulate) o += bf2f(dr[i]);
+      }
+      dr[i] = f2bf(o);
+    }
+  }
+  __syncthreads();
+  // partial [2][gridDim.x][c]: dgamma rows, then dbeta rows
+  for (int i = threadIdx.x; i < 2 * c; i += 256) {
+    const float v = sm[i] + sm[2 * c + i] + sm[4 * c + i] + sm[6 * c + i];
+    if (i < c) partial[(size_t)blockIdx.x * c + i] = v;
+    else partial[((size_t)gridDim.x + blockIdx.x) * c + (i - c)] = v;
+  }
+}
+
+// dst[col] (+)= sum_r src[r][col], fixed order, fp64 accumulation
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, int64_t rows, int cols,
+                                                         float* dst, int accumulate) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cl;
+  double a = 0.0;
+  if (col < cols)
+    for (int64_t r = rl; r < rows; r += 16) a += (double)src[r * cols + col];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 8; s > 0; s >>= 1) {
+    if (rl < s) red[threadIdx.x] += red[threadIdx.x + s * 16];
+    __syncthreads();
+  }
+  if (rl == 0 && col < cols) dst[col] = (float)red[threadIdx.x] + (accumulate ? dst[col] : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// activations (kind 0 = ReLU, 1 = GELU erf)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(int kind, const bf16* __restrict__ x, bf16* __restrict__ out,
+                                                      size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = ldg16(x + i * 8);
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f(v[e]);
+      o[e] = f2bf(kind == 0 ? fmaxf(f, 0.f) : gelu_f(f));
+    }
+    stg16(out + i * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(int kind, const bf16* __restrict__ dout,
+                                                      const bf16* __restrict__ x, bf16* dx, int accumulate, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = ldg16(x + i * 8), g = ldg16(dout + i * 8);
+    bf16x8 o;
+    bf16x8 prev = accumulate ? ldg16(dx + i * 8) : zero8();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f(v[e]);
+      const float d = kind == 0 ? (f > 0.f ? 1.f : 0.f) : (kind == 1 ? gelu_d(f) : 1.f);
+      o[e] = f2bf(bf2f(g[e]) * d + bf2f(prev[e]));
+    }
+    stg16(dx + i * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// window attention.  One wave per (image, window, head); lane = query row (rows loop for N > 64).
+struct AttnArgs {
+  int B, H, W, C, heads, ws, shift, nWx, nW, N, ld;   // ld: row pitch of qkv (>= 3C); head_dim = 32
+};
+
+constexpr int HD = 32;
+
+__device__ __forceinline__ int64_t token_row(const AttnArgs& a, int b, int win, int t) {
+  const int wy = win / a.nWx, wx = win - wy * a.nWx;
+  const int iy = t / a.ws, ix = t - iy * a.ws;
+  int oy = wy * a.ws + iy + a.shift, ox = wx * a.ws + ix + a.shift;   // roll(-shift): rolled[i] = x[(i + shift) % H]
+  oy = oy >= a.H ? oy - a.H : oy;
+  ox = ox >= a.W ? ox - a.W : ox;
+  return ((int64_t)b * a.H + oy) * a.W + ox;
+}
+
+// loads q, k, v of one (b, window, head) into LDS as fp32, q and k L2-normalised (F.normalize eps 1e-12)
+__device__ __forceinline__ void load_qkv(const AttnArgs& a, const bf16* __restrict__ qkv, int b, int win, int h,
+                                         float* qn, float* kn, float* v, float* qinv, float* kinv) {
+  const int lane = threadIdx.x;
+  for (int t = lane; t < a.N; t += 64) {
+    const bf16* r = qkv + token_row(a, b, win, t) * a.ld + h * HD;
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      const bf16x8 q8 = ldg16(r + d), k8 = ldg16(r + a.C + d), v8 = ldg16(r + 2 * a.C + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float qf = bf2f(q8[e]), kf = bf2f(k8[e]);
+        qn[t * HD + d + e] = qf;
+        kn[t * HD + d + e] = kf;
+        v[t * HD + d + e] = bf2f(v8[e]);
+        sq = fmaf(qf, qf, sq);
+        sk = fmaf(kf, kf, sk);
+      }
+    }
+    const float qi = 1.f / fmaxf(sqrtf(sq), 1e-12f), ki = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+    if (qinv) { qinv[t] = qi; kinv[t] = ki; }
+    for (int d = 0; d < HD; ++d) { qn[t * HD + d] *= qi; kn[t * HD + d] *= ki; }
+  }
+}
+
+__global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a, const bf16* __restrict__ qkv,
+                                                      const float* __restrict__ logit_scale,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      bf16* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ float sm[];
+  float* qn = sm;
+  float* kn = qn + a.N * HD;
+  float* v = kn + a.N * HD;
+  const int h = blockIdx.x % a.heads;
+  const int win = (blockIdx.x / a.heads) % a.nW;
+  const int b = blockIdx.x / (a.heads * a.nW);
+  load_qkv(a, qkv, b, win, h, qn, kn, v, nullptr, nullptr);
+  __syncthreads();
+  const float scale = expf(fminf(logit_scale[h], 4.605170185988092f));   // clamp(max = ln 100).exp()
+  const float* bh = bias + (size_t)h * a.N * a.N;
+  const float* mw = mask ? mask + (size_t)win * a.N * a.N : nullptr;
+  for (int i = threadIdx.x; i < a.N; i += 64) {
+    float q[HD], o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qn[i * HD + d]; o[d] = 0.f; }
+    float mx = -INFINITY, den = 0.f;
+    for (int j = 0; j < a.N; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(q[d], kn[j * HD + d], s);
+      s = s * scale + bh[i * a.N + j] + (mw ? mw[i * a.N + j] : 0.f);
+      const float nm = fmaxf(mx, s);
+      const float corr = expf(mx - nm), p = expf(s - nm);
+      den = den * corr + p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = fmaf(o[d], corr, p * v[j * HD + d]);
+      mx = nm;
+    }
+    const float inv = 1.f / den;
+    bf16* orow = out + token_row(a, b, win, i) * a.C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = f2bf(o[d + e] * inv);
+      stg16(orow + d, o8);
+    }
+    lse[((size_t)blockIdx.x) * a.N + i] = mx + logf(den);
+  }
+}
+
+// backward, phase A (lane = query i): dS row -> scratch dST[(b,w)][h][j][i] (fp32), dq; partial dscale
+// phase B (lane = key j): dv_j, dk_j from the columns of P and dS
+__global__ __launch_bounds__(64) void attn_bwd_kernel(AttnArgs a, const bf16* __restrict__ qkv,
+                                                      const bf16* __restrict__ dout, const float* __restrict__ logit_scale,
+                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                      const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                      float* __restrict__ dST, float* __restrict__ dscale_part) {
+  extern __shared__ float sm[];
+  const int N = a.N;
+  float* qn = sm;
+  float* kn = qn + N * HD;
+  float* v = kn + N * HD;
+  float* dO = v + N * HD;
+  float* qinv = dO + N * HD;
+  float* kinv = qinv + N;
+  float* delta = kinv + N;
+  float* lrow = delta + N;
+  const int h = blockIdx.x % a.heads;
+  const int win = (blockIdx.x / a.heads) % a.nW;
+  const int b = blockIdx.x / (a.heads * a.nW);
+  load_qkv(a, qkv, b, win, h, qn, kn, v, qinv, kinv);
+  const float raw = logit_scale[h];
+  const float scale = expf(fminf(raw, 4.605170185988092f));
+  const float* bh = bias + (size_t)h * N * N;
+  const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
+  float* dS = dST + (size_t)blockIdx.x * N * N;
+  for (int t = threadIdx.x; t < N; t += 64) {
+    const bf16* g = dout + token_row(a, b, win, t) * a.C + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      const bf16x8 g8 = ldg16(g + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dO[t * HD + d + e] = bf2f(g8[e]);
+    }
+    lrow[t] = lse[(size_t)blockIdx.x * N + t];
+  }
+  __syncthreads();
+  float dsc = 0.f;
+  // ---- phase A ----
+  for (int i = threadIdx.x; i < N; i += 64) {
+    float q[HD], go[HD], dq[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { q[d] = qn[i * HD + d]; go[d] = dO[i * HD + d]; dq[d] = 0.f; }
+    const float li = lrow[i];
+    // delta_i = sum_j p_ij dP_ij  (= dO_i . O_i)
+    float dl = 0.f;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { s = fmaf(q[d], kn[j * HD + d], s); dp = fmaf(go[d], v[j * HD + d], dp); }
+      const float p = expf(s * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - li);
+      dl = fmaf(p, dp, dl);
+    }
+    delta[i] = dl;
+    for (int j = 0; j < N; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) { s = fmaf(q[d], kn[j * HD + d], s); dp = fmaf(go[d], v[j * HD + d], dp); }
+      const float p = expf(s * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - li);
+      const float ds = p * (dp - dl);
+      dS[(size_t)j * N + i] = ds;
+      dsc = fmaf(ds, s, dsc);
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds * scale, kn[j * HD + d], dq[d]);
+    }
+    // through F.normalize: dq_raw = (dqn - qn (qn . dqn)) / |q|
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dot = fmaf(q[d], dq[d], dot);
+    bf16* dr = dqkv + token_row(a, b, win, i) * a.ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      bf16x8 o8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = f2bf((dq[d + e] - q[d + e] * dot) * qinv[i]);
+      stg16(dr + d, o8);
+    }
+  }
+  dsc = wave_sum(dsc);
+  // d logit_scale = d scale * scale (zero where the clamp is active)
+  if (threadIdx.x == 0) dscale_part[blockIdx.x] = raw < 4.605170185988092f ? dsc * scale : 0.f;
+  __syncthreads();
+  // ---- phase B ----
+  for (int j = threadIdx.x; j < N; j += 64) {
+    float k[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { k[d] = kn[j * HD + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int i = 0; i < N; ++i) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(qn[i * HD + d], k[d], s);
+      const float p = expf(s * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - lrow[i]);
+      const float ds = dS[(size_t)j * N + i] * scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        dv[d] = fmaf(p, dO[i * HD + d], dv[d]);
+        dk[d] = fmaf(ds, qn[i * HD + d], dk[d]);
+      }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dot = fmaf(k[d], dk[d], dot);
+    bf16* dr = dqkv + token_row(a, b, win, j) * a.ld + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      bf16x8 k8, v8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        k8[e] = f2bf((dk[d + e] - k[d + e] * dot) * kinv[j]);
+        v8[e] = f2bf(dv[d + e]);
+      }
+      stg16(dr + a.C + d, k8);
+      stg16(dr + 2 * a.C + d, v8);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// continuous position bias: bias[h][i][j] = 16 * sigmoid(table[index[i][j]][h])
+__global__ __launch_bounds__(256) void cpb_bias_fwd_kernel(const bf16* __restrict__ table, int ld,
+                                                           const int64_t* __restrict__ index, int heads, int nn,
+                                                           float* __restrict__ bias) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= heads * nn) return;
+  const int h = i / nn, ij = i - h * nn;
+  const float t = bf2f(table[index[ij] * ld + h]);
+  bias[i] = 16.f / (1.f + expf(-t));
+}
+
+// dtable[t][h] = sum_{(i,j): index == t} dbias[h][i][j] * 16 s (1 - s)     (gather over the index: exact, ordered)
+__global__ __launch_bounds__(64) void cpb_bias_bwd_kernel(const float* __restrict__ dbias, const bf16* __restrict__ table,
+                                                          int ld, const int64_t* __restrict__ index, int heads, int n,
+                                                          int transposed, bf16* __restrict__ dtable) {
+  const int t = blockIdx.x;
+  const int h = blockIdx.y;
+  const int nn = n * n;
+  if (h >= heads) {   // padding columns of the cpb_mlp output row: defined zeros for the GEMMs downstream
+    if (threadIdx.x == 0) dtable[(size_t)t * ld + h] = f2bf(0.f);
+    return;
+  }
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < nn; p += 64) {
+    // transposed: dbias is stored [h][j][i] (what tok_window_attn_bwd's scratch reduces to)
+    const int ij = transposed ? (p % n) * n + p / n : p;
+    if (index[ij] == t) acc += dbias[(size_t)h * nn + p];
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) {
+    const float s = 1.f / (1.f + expf(-bf2f(table[(size_t)t * ld + h])));
+    dtable[(size_t)t * ld + h] = f2bf(acc * 16.f * s * (1.f - s));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PatchMerging gather: out[b][y][x][q*C + c] = in[b][2y + (q & 1)][2x + (q >> 1)][c]   (x0, x1, x2, x3 order)
+__global__ __launch_bounds__(256) void patch_merge_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int B,
+                                                          int H, int W, int C, int inverse) {
+  const int cg = C >> 3, H2 = H >> 1, W2 = W >> 1;
+  const size_t total = (size_t)B * H2 * W2 * 4 * cg;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int g = (int)(i % cg);
+    size_t r = i / cg;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int x = (int)(r % W2);
+    r /= W2;
+    const int y = (int)(r % H2);
+    const int b = (int)(r / H2);
+    const size_t merged = ((((size_t)b * H2 + y) * W2 + x) * 4 + q) * C + g * 8;
+    const size_t plain = (((size_t)b * H + 2 * y + (q & 1)) * W + 2 * x + (q >> 1)) * C + g * 8;
+    if (inverse) stg16(dst + plain, ldg16(src + merged));
+    else stg16(dst + merged, ldg16(src + plain));
+  }
+}
+
+inline int blocks_for(size_t total) {
+  const size_t b = (total + 255) / 256;
+  return (int)(b > 65536 ? 65536 : (b < 1 ? 1 : b));
+}
+
+bool fill_attn(AttnArgs& a, int B, int H, int W, int C, int heads, int ws, int shift, int ld) {
+  if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || ws <= 0 || C != heads * HD || H % ws || W % ws || shift < 0 ||
+      shift >= ws || ld < 3 * C || (ld & 7)) return false;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.ws = ws; a.shift = shift;
+  a.nWx = W / ws; a.nW = (H / ws) * a.nWx; a.N = ws * ws; a.ld = ld;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int tok_layernorm_fwd(const void* x, const void* shortcut, const float* row_scale, int rows_per_sample,
+                                 const float* gamma, const float* beta, void* out, float* mean, float* rstd,
+                                 int64_t rows, int c, int ld, float eps, void* stream) {
+  TOK_CHECK_ARG(x && gamma && beta && out && mean && rstd && rows > 0 && c > 0 && ld >= c, "tok_layernorm_fwd: bad args");
+  TOK_CHECK_ARG(!row_scale || rows_per_sample > 0, "tok_layernorm_fwd: rows_per_sample");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, tok_stream(stream), (const bf16*)x,
+                     (const bf16*)shortcut, row_scale, rows_per_sample, gamma, beta, (bf16*)out, mean, rstd, rows, c, ld,
+                     eps);
+  TOK_CHECK_LAUNCH("tok_layernorm_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_layernorm_bwd_rows(int64_t rows, int c) {
+  const int64_t b = (rows + 3) / 4;
+  (void)c;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* mean, const float* rstd,
+                                 const float* gamma, const float* row_scale, int rows_per_sample, void* dx,
+                                 int accumulate, float* partial, int64_t rows, int c, int ld, void* stream) {
+  TOK_CHECK_ARG(dout && x && mean && rstd && gamma && dx && partial && rows > 0 && c > 0 && ld >= c,
+                "tok_layernorm_bwd: bad args");
+  TOK_CHECK_ARG((size_t)c * 8 * sizeof(float) <= 64 * 1024, "tok_layernorm_bwd: c too large (%d)", c);
+  const int g = tok_layernorm_bwd_rows(rows, c);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), (size_t)c * 8 * sizeof(float), tok_stream(stream),
+                     (const bf16*)dout, (const bf16*)x, mean, rstd, gamma, row_scale, rows_per_sample, (bf16*)dx,
+                     accumulate, partial, rows, c, ld);
+  TOK_CHECK_LAUNCH("tok_layernorm_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream) {
+  TOK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "tok_colsum_f32: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(256), 0, tok_stream(stream), src, rows, cols, dst,
+                     accumulate);
+  TOK_CHECK_LAUNCH("tok_colsum_f32");
+  return TOK_OK;
+}
+
+extern "C" int tok_act_fwd(int kind, const void* x, void* out, size_t count, void* stream) {
+  TOK_CHECK_ARG(x && out && count > 0 && count % 8 == 0 && (kind == 0 || kind == 1), "tok_act_fwd: bad args");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(count / 8)), dim3(256), 0, tok_stream(stream), kind, (const bf16*)x,
+                     (bf16*)out, count / 8);
+  TOK_CHECK_LAUNCH("tok_act_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_act_bwd(int kind, const void* dout, const void* x, void* dx, int accumulate, size_t count,
+                           void* stream) {
+  TOK_CHECK_ARG(dout && x && dx && count > 0 && count % 8 == 0 && kind >= 0 && kind <= 2, "tok_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(count / 8)), dim3(256), 0, tok_stream(stream), kind,
+                     (const bf16*)dout, (const bf16*)x, (bf16*)dx, accumulate, count / 8);
+  TOK_CHECK_LAUNCH("tok_act_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int c, int heads, int ws, int shift, int ld,
+                                   const float* logit_scale, const float* bias, const float* mask, void* out,
+                                   float* lse, void* stream) {
+  AttnArgs a;
+  TOK_CHECK_ARG(qkv && logit_scale && bias && out && lse && fill_attn(a, batch, h, w, c, heads, ws, shift, ld),
+                "tok_window_attn_fwd: bad args (head_dim must be 32, h/w multiples of the window)");
+  const size_t smem = (size_t)a.N * HD * 3 * sizeof(float);
+  TOK_CHECK_ARG(smem <= 160 * 1024, "tok_window_attn_fwd: window %d too large", ws);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * a.nW * heads), dim3(64), smem, tok_stream(stream), a,
+                     (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse);
+  TOK_CHECK_LAUNCH("tok_window_attn_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch, int h, int w, int c, int heads, int ws,
+                                   int shift, int ld, const float* logit_scale, const float* bias, const float* mask,
+                                   const float* lse, void* dqkv, float* ds_scratch, float* dscale_part, void* stream) {
+  AttnArgs a;
+  TOK_CHECK_ARG(qkv && dout && logit_scale && bias && lse && dqkv && ds_scratch && dscale_part &&
+                fill_attn(a, batch, h, w, c, heads, ws, shift, ld), "tok_window_attn_bwd: bad args");
+  const size_t smem = ((size_t)a.N * HD * 4 + (size_t)a.N * 4) * sizeof(float);
+  TOK_CHECK_ARG(smem <= 160 * 1024, "tok_window_attn_bwd: window %d too large", ws);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * a.nW * heads), dim3(64), smem, tok_stream(stream), a,
+                     (const bf16*)qkv, (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch,
+                     dscale_part);
+  TOK_CHECK_LAUNCH("tok_window_attn_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_cpb_bias_fwd(const void* table, int ld, const int64_t* index, int heads, int n_tokens, float* bias,
+                                void* stream) {
+  TOK_CHECK_ARG(table && index && bias && heads > 0 && n_tokens > 0 && ld >= heads, "tok_cpb_bias_fwd: bad args");
+  const int nn = n_tokens * n_tokens;
+  hipLaunchKernelGGL(cpb_bias_fwd_kernel, dim3((heads * nn + 255) / 256), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)table, ld, index, heads, nn, bias);
+  TOK_CHECK_LAUNCH("tok_cpb_bias_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_cpb_bias_bwd(const float* dbias, int transposed, const void* table, int ld, const int64_t* index,
+                                int heads, int n_tokens, int table_rows, void* dtable, void* stream) {
+  TOK_CHECK_ARG(dbias && table && index && dtable && heads > 0 && n_tokens > 0 && table_rows > 0 && ld >= heads,
+                "tok_cpb_bias_bwd: bad args");
+  hipLaunchKernelGGL(cpb_bias_bwd_kernel, dim3(table_rows, ld), dim3(64), 0, tok_stream(stream), dbias,
+                     (const bf16*)table, ld, index, heads, n_tokens, transposed, (bf16*)dtable);
+  TOK_CHECK_LAUNCH("tok_cpb_bias_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_patch_merge(const void* src, void* dst, int batch, int h, int w, int c, int inverse, void* stream) {
+  TOK_CHECK_ARG(src && dst && batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % 8 == 0,
+                "tok_patch_merge: bad args");
+  hipLaunchKernelGGL(patch_merge_kernel, dim3(blocks_for((size_t)batch * h * w * (c >> 3))), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)src, (bf16*)dst, batch, h, w, c, inverse);
+  TOK_CHECK_LAUNCH("tok_patch_merge");
+  return TOK_OK;
+}

@@ -1,0 +1,393 @@
+"""Engine units of the token-major (SwinV2) rows.  Tokens are rows of a bf16 [B*H*W][C] matrix.
+
+Unit                 replaces ([timm 0.6.13] swin_transformer_v2 through torchok/models/backbones/swin.py)
+-------------------  -------------------------------------------------------------------------------------
+linear_op            F.linear (qkv with cat(q_bias, k_bias, v_bias); proj; Mlp.fc1/fc2; PatchMerging.reduction;
+                     cpb_mlp) on the MFMA conv kernels (1x1, h = w = 1)
+layer_norm           nn.LayerNorm, optionally fused with the res-post-norm residual  x + drop_path(norm(.))
+activation           GELU (Mlp) / ReLU (cpb_mlp)
+cpb_bias             16 * sigmoid(cpb_mlp(relative_coords_table))[relative_position_index]
+window_attention     WindowAttention.forward between qkv and proj, with roll / window_partition / window_reverse
+                     folded into the kernel's token addressing
+patch_merge          PatchMerging's strided 2x2 gather + cat
+reshape              .view between (B, H, W, C) maps and (B*H*W, C) token rows (zero copy)
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from .. import _C
+from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target, pad8, param_grad_target,
+                   ptr, stream_ptr)
+from .functional import _krsc, get_packs
+
+F32 = torch.float32
+
+
+def _rows(t: TTensor) -> int:
+    return t.data.numel() // t.data.shape[-1]
+
+
+# ---- reshape (zero copy) --------------------------------------------------------------------------------
+class _ReshapeNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        gv = g.view(self.x.data.shape)
+        if not donate_grad(self.x, gv):
+            tgt, _ = grad_target(self.x)
+            _C.check(_C.lib().tok_act_bwd(2, ptr(gv), ptr(gv), ptr(tgt), 1, gv.numel(), stream_ptr()), 'tok_act_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def reshape(region: Region, x: TTensor, shape: Sequence[int]) -> TTensor:
+    out = TTensor(x.data.view(*shape), x.c, requires_grad=x.requires_grad and region.grad_mode)
+    if out.requires_grad:
+        node = _ReshapeNode()
+        node.x, node.out = x, out
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out
+
+
+# ---- linear --------------------------------------------------------------------------------------------------
+class _LinearNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None:
+            return
+        x, w, d = self.x, self.weight, self.desc
+        m, kp = g.shape
+        if self.bias_sinks:
+            tmp = torch.empty(kp, dtype=F32, device=g.device)
+            _C.check(lib.tok_colsum(ptr(g), m, kp, kp, ptr(tmp), 0, st), 'tok_colsum')
+            for p, start in self.bias_sinks:
+                if not p.requires_grad:
+                    continue
+                slot, mode = param_grad_target(p)
+                seg = tmp[start:start + p.numel()]
+                if mode == 1:
+                    slot.add_(seg)
+                else:
+                    slot.copy_(seg)
+                commit_param_grad(p, slot, mode)
+        if w.requires_grad:
+            k, r, s, c = _krsc(w)
+            ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
+            slot, mode = param_grad_target(w)
+            _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                        1 if mode == 1 else 0, st), 'tok_conv_wgrad')
+            commit_param_grad(w, slot, mode)
+        if x.requires_grad:
+            tgt, acc = grad_target(x)
+            _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = self.pk = None
+
+
+def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Optional[torch.Tensor] = None,
+              bias_sinks: Sequence[Tuple[nn.Parameter, int]] = ()) -> TTensor:
+    """y = x W^T + bias_vec.  `bias_vec` is an fp32 vector of the (padded) output width; `bias_sinks` lists the
+    parameters it was assembled from as (param, start column) — their gradients are column sums of dy."""
+    lib, st = _C.lib(), stream_ptr()
+    k, c = weight.shape
+    n, cp = x.shape
+    if pad8(c) != cp:
+        raise ValueError(f'linear_op: input width {cp} does not match in_features {c}')
+    kp = pad8(k)
+    need_dx = region.grad_mode and x.requires_grad
+    pk = get_packs(weight, None, kp, 1, cp, want_dgrad=need_dx, refresh=True)
+    if bias_vec is not None and bias_vec.shape[0] != kp:
+        b = torch.zeros(kp, dtype=F32, device=bias_vec.device)
+        b[:bias_vec.shape[0]] = bias_vec
+        bias_vec = b
+    d = _C.ConvDesc(n, 1, 1, cp, kp, 1, 1, 1, 1, 1, 0, 1)
+    y = torch.empty((n, kp), dtype=BF16, device=x.data.device)
+    _C.check(lib.tok_conv_fwd(d, ptr(x.data), ptr(pk.fwd), ptr(bias_vec), ptr(y), None, st), 'tok_conv_fwd')
+    req = region.grad_mode and (x.requires_grad or weight.requires_grad or any(p.requires_grad for p, _ in bias_sinks))
+    out = TTensor(y, k, requires_grad=req)
+    if req:
+        node = _LinearNode()
+        node.x, node.out, node.weight, node.desc, node.pk = x, out, weight, d, pk
+        node.bias_sinks = list(bias_sinks)
+        out.node = node
+        if x.requires_grad:
+            x.uses += 1
+        region.add(node)
+    return out
+
+
+def linear_module(region: Region, x: TTensor, fc: nn.Linear) -> TTensor:
+    if fc.bias is None:
+        return linear_op(region, x, fc.weight)
+    return linear_op(region, x, fc.weight, fc.bias.detach(), [(fc.bias, 0)])
+
+
+# ---- layer norm (+ residual, + stochastic depth) ---------------------------------------------------------------------
+class _LayerNormNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None:
+            return
+        x, ln, sc = self.x, self.ln, self.shortcut
+        rows, cp = _rows(x), x.cp
+        c = x.c
+        need_param = ln.weight.requires_grad or ln.bias.requires_grad
+        if x.requires_grad or need_param:
+            nrows = lib.tok_layernorm_bwd_rows(rows, c)
+            partial = torch.empty((2, nrows, c), dtype=F32, device=g.device)
+            if x.requires_grad:
+                tgt, acc = grad_target(x)
+            else:
+                tgt, acc = torch.empty_like(x.data), 0
+            _C.check(lib.tok_layernorm_bwd(ptr(g), ptr(x.data), ptr(self.mean), ptr(self.rstd), ptr(ln.weight),
+                                           ptr(self.row_scale), self.rps, ptr(tgt), acc, ptr(partial), rows, c, cp, st),
+                     'tok_layernorm_bwd')
+            for p, part in ((ln.weight, partial[0]), (ln.bias, partial[1])):
+                if p.requires_grad:
+                    slot, mode = param_grad_target(p)
+                    if mode == 2:
+                        tmp = torch.empty_like(slot)
+                        _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(tmp), 0, st), 'tok_colsum_f32')
+                        p.grad.add_(tmp)
+                        commit_param_grad(p, slot, 1)
+                    else:
+                        _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(slot), 1 if mode == 1 else 0, st),
+                                 'tok_colsum_f32')
+                        commit_param_grad(p, slot, mode)
+        if sc is not None and sc.requires_grad:
+            # the residual branch passes the gradient through: hand the buffer over when we own it
+            if not (self.out.grad_owned and donate_grad(sc, g.view(sc.data.shape))):
+                tgt, acc = grad_target(sc)
+                _C.check(lib.tok_act_bwd(2, ptr(g), ptr(g), ptr(tgt), acc, g.numel(), st), 'tok_act_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = self.shortcut = self.mean = self.rstd = self.row_scale = None
+
+
+def layer_norm(region: Region, x: TTensor, ln: nn.LayerNorm, shortcut: Optional[TTensor] = None,
+               row_scale: Optional[torch.Tensor] = None, rows_per_sample: int = 0) -> TTensor:
+    """out = shortcut + row_scale[sample] * LayerNorm(x)."""
+    if ln.weight is None or ln.bias is None or len(ln.normalized_shape) != 1 or ln.normalized_shape[0] != x.c:
+        raise NotImplementedError('layer_norm: affine LayerNorm over the channel dimension only')
+    lib, st = _C.lib(), stream_ptr()
+    rows, cp = _rows(x), x.cp
+    dev = x.data.device
+    out_data = torch.empty_like(x.data)
+    mean = torch.empty(rows, dtype=F32, device=dev)
+    rstd = torch.empty(rows, dtype=F32, device=dev)
+    _C.check(lib.tok_layernorm_fwd(ptr(x.data), ptr(shortcut.data) if shortcut is not None else None, ptr(row_scale),
+                                   rows_per_sample, ptr(ln.weight), ptr(ln.bias), ptr(out_data), ptr(mean), ptr(rstd),
+                                   rows, x.c, cp, float(ln.eps), st), 'tok_layernorm_fwd')
+    req = region.grad_mode and (x.requires_grad or ln.weight.requires_grad or ln.bias.requires_grad or
+                                (shortcut is not None and shortcut.requires_grad))
+    out = TTensor(out_data, x.c, requires_grad=req)
+    if req:
+        node = _LayerNormNode()
+        node.x, node.out, node.ln, node.shortcut = x, out, ln, shortcut
+        node.mean, node.rstd, node.row_scale, node.rps = mean, rstd, row_scale, rows_per_sample
+        out.node = node
+        if x.requires_grad:
+            x.uses += 1
+        if shortcut is not None and shortcut.requires_grad:
+            shortcut.uses += 1
+        region.add(node)
+    return out
+
+
+# ---- activations ----------------------------------------------------------------------------------------------------------
+RELU, GELU = 0, 1
+
+
+class _ActNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        tgt, acc = grad_target(self.x)
+        _C.check(_C.lib().tok_act_bwd(self.kind, ptr(g), ptr(self.x.data), ptr(tgt), acc, g.numel(), stream_ptr()),
+                 'tok_act_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def activation(region: Region, x: TTensor, kind: int) -> TTensor:
+    y = torch.empty_like(x.data)
+    _C.check(_C.lib().tok_act_fwd(kind, ptr(x.data), ptr(y), y.numel(), stream_ptr()), 'tok_act_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, x.c, requires_grad=req)
+    if req:
+        node = _ActNode()
+        node.x, node.out, node.kind = x, out, kind
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out
+
+
+# ---- continuous relative position bias ------------------------------------------------------------------------------------
+class _CpbBiasNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        if self.dbias_t is None or not self.table.requires_grad:
+            return
+        rows, ld = self.table.shape
+        tgt, acc = grad_target(self.table)
+        if acc:
+            raise RuntimeError('cpb_bias: the cpb_mlp output has a single consumer')
+        _C.check(_C.lib().tok_cpb_bias_bwd(ptr(self.dbias_t), 1, ptr(self.table.data), ld, ptr(self.index), self.heads,
+                                           self.n, rows, ptr(tgt), stream_ptr()), 'tok_cpb_bias_bwd')
+
+    def release(self):
+        self.table = self.index = self.bias = self.dbias_t = None
+
+
+def cpb_bias(region: Region, table: TTensor, index: torch.Tensor, heads: int, n_tokens: int):
+    """(bias fp32 [heads][N][N], node).  The attention unit hands d(bias)^T back through `node.dbias_t`."""
+    rows, ld = table.shape
+    bias = torch.empty((heads, n_tokens, n_tokens), dtype=F32, device=table.data.device)
+    _C.check(_C.lib().tok_cpb_bias_fwd(ptr(table.data), ld, ptr(index), heads, n_tokens, ptr(bias), stream_ptr()),
+             'tok_cpb_bias_fwd')
+    node = None
+    if region.grad_mode and table.requires_grad:
+        node = _CpbBiasNode()
+        node.table, node.index, node.heads, node.n, node.bias, node.dbias_t = table, index, heads, n_tokens, bias, None
+        table.uses += 1
+        region.add(node)
+    return bias, node
+
+
+# ---- window attention ---------------------------------------------------------------------------------------------------------
+class _WindowAttnNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None:
+            return
+        b, h, w, c, heads, ws, shift = self.geo
+        n = ws * ws
+        nw = (h // ws) * (w // ws)
+        qkv = self.qkv
+        dev = g.device
+        scratch = torch.empty((b * nw, heads * n * n), dtype=F32, device=dev)
+        dscale = torch.empty((b * nw, heads), dtype=F32, device=dev)
+        tgt, acc = grad_target(qkv)
+        if acc:
+            raise RuntimeError('window_attention: qkv has a single consumer')
+        _C.check(lib.tok_window_attn_bwd(ptr(qkv.data), ptr(g), b, h, w, c, heads, ws, shift, qkv.cp,
+                                         ptr(self.logit_scale), ptr(self.bias), ptr(self.mask), ptr(self.lse), ptr(tgt),
+                                         ptr(scratch), ptr(dscale), st), 'tok_window_attn_bwd')
+        if qkv.cp != 3 * c:
+            tgt[:, 3 * c:] = 0
+        if self.bias_node is not None:
+            dbias_t = torch.empty(heads * n * n, dtype=F32, device=dev)
+            _C.check(lib.tok_colsum_f32(ptr(scratch), b * nw, heads * n * n, ptr(dbias_t), 0, st), 'tok_colsum_f32')
+            self.bias_node.dbias_t = dbias_t
+        ls = self.logit_scale
+        if ls.requires_grad:
+            slot, mode = param_grad_target(ls)
+            if mode == 2:
+                tmp = torch.empty_like(slot)
+                _C.check(lib.tok_colsum_f32(ptr(dscale), b * nw, heads, ptr(tmp), 0, st), 'tok_colsum_f32')
+                ls.grad.add_(tmp)
+                commit_param_grad(ls, slot, 1)
+            else:
+                _C.check(lib.tok_colsum_f32(ptr(dscale), b * nw, heads, ptr(slot), 1 if mode == 1 else 0, st),
+                         'tok_colsum_f32')
+                commit_param_grad(ls, slot, mode)
+        self.out.grad = None
+
+    def release(self):
+        self.qkv = self.out = self.bias = self.mask = self.lse = self.bias_node = None
+
+
+def window_attention(region: Region, qkv: TTensor, geo: Tuple[int, int, int, int, int, int, int],
+                     logit_scale: nn.Parameter, bias: torch.Tensor, bias_node, mask: Optional[torch.Tensor]) -> TTensor:
+    """qkv rows [B*H*W][3C] -> attention output rows [B*H*W][C]; geo = (B, H, W, C, heads, window, shift)."""
+    b, h, w, c, heads, ws, shift = geo
+    if c != heads * 32:
+        raise NotImplementedError('window_attention: head_dim 32 (every SwinV2 variant of the reference)')
+    lib, st = _C.lib(), stream_ptr()
+    n = ws * ws
+    nw = (h // ws) * (w // ws)
+    dev = qkv.data.device
+    out_data = torch.empty((b * h * w, c), dtype=BF16, device=dev)
+    lse = torch.empty(b * nw * heads * n, dtype=F32, device=dev)
+    _C.check(lib.tok_window_attn_fwd(ptr(qkv.data), b, h, w, c, heads, ws, shift, qkv.cp, ptr(logit_scale), ptr(bias),
+                                     ptr(mask), ptr(out_data), ptr(lse), st), 'tok_window_attn_fwd')
+    req = region.grad_mode and (qkv.requires_grad or logit_scale.requires_grad or bias_node is not None)
+    out = TTensor(out_data, c, requires_grad=req)
+    if req:
+        node = _WindowAttnNode()
+        node.qkv, node.out, node.geo, node.logit_scale = qkv, out, geo, logit_scale
+        node.bias, node.bias_node, node.mask, node.lse = bias, bias_node, mask, lse
+        out.node = node
+        qkv.uses += 1
+        region.add(node)
+    return out
+
+
+# ---- patch merging gather ----------------------------------------------------------------------------------------------------------
+class _PatchMergeNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        b, h, w, c = self.geo
+        tgt, acc = grad_target(self.x)
+        lib, st = _C.lib(), stream_ptr()
+        if acc:      # the stage output also feeds its feature norm (forward_features): un-permute, then add
+            tmp = torch.empty_like(tgt)
+            _C.check(lib.tok_patch_merge(ptr(g), ptr(tmp), b, h, w, c, 1, st), 'tok_patch_merge')
+            _C.check(lib.tok_act_bwd(2, ptr(tmp), ptr(tmp), ptr(tgt), 1, tmp.numel(), st), 'tok_act_bwd')
+        else:
+            _C.check(lib.tok_patch_merge(ptr(g), ptr(tgt), b, h, w, c, 1, st), 'tok_patch_merge')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def patch_merge(region: Region, x: TTensor, b: int, h: int, w: int) -> TTensor:
+    """token rows [B*H*W][C] -> [B*(H/2)*(W/2)][4C] (x0, x1, x2, x3 concatenation of PatchMerging)."""
+    c = x.c
+    if c != x.cp:
+        raise NotImplementedError('patch_merge: channels % 8 == 0')
+    y = torch.empty((b * (h // 2) * (w // 2), 4 * c), dtype=BF16, device=x.data.device)
+    _C.check(_C.lib().tok_patch_merge(ptr(x.data), ptr(y), b, h, w, c, 0, stream_ptr()), 'tok_patch_merge')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, 4 * c, requires_grad=req)
+    if req:
+        node = _PatchMergeNode()
+        node.x, node.out, node.geo = x, out, (b, h, w, c)
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out

@@ -1,1 +1,1 @@
-from . import hrnet, resnet  # noqa: F401
+from . import hrnet, resnet, swin  # noqa: F401
