@@ -60,6 +60,30 @@ def build_seg_task(backbone: str, num_classes: int, h: int, w: int):
     return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
 
 
+ALG_FLOPS_PER_IMG = {('swinv2_custom', 224): 26.94e9}             # SwinV2-T 224 (window 7)
+MFMA_PEAK_BF16 = 2.5e15
+
+
+def build_swin_task(num_classes: int, res: int):
+    """SwinV2-T (embed 96, depths 2-2-6-2, heads 3-6-12-24, window 7) + ClassificationTask + AdamW
+    (secondary workload: `--backbone swinv2_custom --res 224 --batch 128`; never the default line)."""
+    import torchok_amd as T
+    from torchok_amd.constructor.config import apply_schema
+    cfg = apply_schema({
+        'task': {'name': 'ClassificationTask',
+                 'params': {'backbone_name': 'swinv2_custom',
+                            'backbone_params': {'pretrained': False, 'in_channels': 3, 'img_size': res, 'window_size': 7,
+                                                'drop_path_rate': 0.1},
+                            'pooling_name': 'Pooling', 'head_name': 'ClassificationHead',
+                            'head_params': {'num_classes': num_classes},
+                            'inputs': [{'shape': [3, res, res], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': 'AdamW', 'params': {'lr': 1e-3, 'weight_decay': 0.05}}}],
+        'data': {}, 'trainer': {'precision': 'bf16', 'strategy': 'ddp'},
+    })
+    return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+
+
 def build_task(backbone: str, num_classes: int):
     import torchok_amd as T
     from torchok_amd.constructor.config import apply_schema
@@ -151,7 +175,11 @@ def main():
     torch.manual_seed(1234)
     seg = args.backbone.startswith('hrnet')
     width = args.width or args.res
+    swin = args.backbone.startswith('swinv2')
+    if swin and args.backbone != 'swinv2_custom':
+        raise SystemExit('bench.py: the SwinV2 workload is swinv2_custom (SwinV2-T geometry, window 7) at --res')
     task = (build_seg_task(args.backbone, args.classes, args.res, width) if seg
+            else build_swin_task(args.classes, args.res) if swin
             else build_task(args.backbone, args.classes)).cuda().train()
     opt = task.configure_optimizers()[0]['optimizer']
     reducer = None
@@ -214,7 +242,13 @@ def main():
             (ALG_BYTES_PER_IMG.get(args.backbone) if args.res == 224 else None)
         ev_ms = sum(step_ms) / len(step_ms)
         roofline = None
-        if alg is not None:
+        flops = ALG_FLOPS_PER_IMG.get((args.backbone, args.res)) if swin else None
+        if flops is not None:
+            ach = flops * args.batch / (ev_ms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
+                        'frac': round(ach * 1e12 / MFMA_PEAK_BF16, 4), 'traffic': None,
+                        'launch': f'one training step, HIP-event avg {ev_ms:.3f} ms'}
+        elif alg is not None:
             achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                         'frac': round(achieved * 1e9 / HBM_PEAK, 4),
@@ -234,13 +268,16 @@ def main():
             'config': {'workload': (f'{args.backbone} + SegmentationTask(HRNetSegmentationNeck, SegmentationHead '
                                     f'{args.classes}) + CrossEntropyLoss + SGD(momentum 0.9, wd 5e-4), synthetic '
                                     f'3x{args.res}x{width} bf16, batch {args.batch}/GPU') if seg else
+                                   (f'SwinV2-T(window 7, drop_path 0.1) + ClassificationTask(Pooling, ClassificationHead '
+                                    f'{args.classes}) + CrossEntropyLoss + AdamW, synthetic 3x{args.res}x{args.res} bf16, '
+                                    f'batch {args.batch}/GPU') if swin else
                                    f'{args.backbone} + ClassificationTask(Pooling, ClassificationHead {args.classes}) '
                                    f'+ CrossEntropyLoss + SGD(momentum 0.9, wd 1e-4), synthetic 3x{args.res}x{args.res} '
                                    f'bf16, batch {args.batch}/GPU', 'global_batch': args.batch * world,
                        'parallelism': f'dp{world}', 'launch_mode': 'hipGraph replay' if use_graph else 'eager'},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and not seg:
+        if world == 1 and not args.no_cpu_baseline and not seg and not swin:
             line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
         print(json.dumps(line))
     if world > 1:

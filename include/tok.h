@@ -263,6 +263,10 @@ int tok_layernorm_bwd_rows(int64_t rows, int c);
 int tok_layernorm_bwd(const void* dout, const void* x, const float* mean, const float* rstd,
                       const float* gamma, const float* row_scale, int rows_per_sample, void* dx,
                       int accumulate, float* partial, int64_t rows, int c, int ld, void* stream);
+/* column sums of a TALL bf16 matrix (bias gradients over B*H*W token rows): partial fp32
+ * [tok_colsum_partial_rows(m, n_pad)][n_pad], one row per contiguous row chunk, folded by tok_colsum_f32  */
+int tok_colsum_partial_rows(int64_t m, int n_pad);
+int tok_colsum_partial(const void* dy, int64_t m, int n_pad, float* partial, void* stream);
 /* dst[col] (+)= sum_r src[r][col]: fixed-order fp64 fold of fp32 partial rows                           */
 int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream);
 /* kind 0: ReLU (cpb_mlp), 1: GELU erf (Mlp); count % 8 == 0.  tok_act_bwd also takes kind 2 = identity

@@ -559,6 +559,13 @@ class FakeTok:
         p[1, 0] = go.sum(0)
         return 0
 
+    def tok_colsum_partial_rows(self, m, n_pad):
+        return 1
+
+    def tok_colsum_partial(self, dy, m, n_pad, partial, st):
+        _t(partial, (1, n_pad), torch.float32).copy_(_t(dy, (m, n_pad), BF16).float().sum(0, keepdim=True))
+        return 0
+
     def tok_colsum_f32(self, src, rows, cols, dst, accumulate, st):
         v = _t(src, (rows, cols), torch.float32).double().sum(0).float()
         d = _t(dst, (cols,), torch.float32)

@@ -757,3 +757,18 @@ def test_cpb_bias_and_patch_merge(libs):
     back = torch.empty_like(x)
     dv2 = both(libs, 'tok_patch_merge', lambda d: [d(y), d(back), 2, 8, 12, 16, 1, None])
     assert torch.equal(dv2[id(back)].cpu(), x)                   # inverse round trip
+
+
+@pytest.mark.parametrize('m,n', [(200704, 288), (1000, 8), (50176, 3072), (77, 768)])
+def test_colsum_partial(libs, m, n):
+    lib, _ = libs
+    x = rnd(m, n).to(BF16).cuda()
+    rows = lib.tok_colsum_partial_rows(m, n)
+    part = torch.empty(rows, n, device='cuda')
+    out = torch.empty(n, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tok_colsum_partial(x.data_ptr(), m, n, part.data_ptr(), st) == 0, lib.tok_last_error()
+    assert lib.tok_colsum_f32(part.data_ptr(), rows, n, out.data_ptr(), 0, st) == 0
+    torch.cuda.synchronize()
+    ref = x.double().sum(0)
+    assert float((out.double() - ref).abs().max()) < 1e-4 * float(x.double().abs().sum(0).max())

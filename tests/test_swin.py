@@ -100,3 +100,43 @@ def test_stochastic_depth_scales_whole_samples(dev):
     with torch.no_grad():
         c, d = m(x.to(dev)).float().cpu(), ref.eval()(x)
     assert rel_err(c, d) < 2e-2                     # eval: no drop
+
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'swinv2_cls_step.npz'))
+
+
+def test_classification_step_vs_reference_golden(dev):
+    """ClassificationTask(swinv2_custom + Pooling + ClassificationHead) + CE + AdamW: one step of the reference's own
+    swin.py (golden) — logits, loss, every gradient norm, parameters after the optimizer step."""
+    from helpers import cls_config
+    cfg = cls_config('swinv2_custom', int(GOLD['num_classes']), optimizer='AdamW',
+                     opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                     backbone_params=dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0),
+                     inputs_shape=(3, 64, 64))
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')},
+                             int(GOLD['seed']))
+    task.load_state_dict(sd, strict=False)
+    task.to(dev).train()
+    x = torch.from_numpy(GOLD['x'].astype(np.float32)).to(dev)
+    y = torch.from_numpy(GOLD['y']).to(dev)
+    last = task.backbone(x)
+    assert rel_err(last.float(), torch.from_numpy(GOLD['last_feature'])) < 2e-2
+    out = task.training_step({'image': x, 'target': y}, 0)
+    pred = task.forward_with_gt({'image': x, 'target': y})['prediction']
+    assert rel_err(pred.float(), torch.from_numpy(GOLD['prediction'])) < 3e-2
+    assert abs(float(out['loss'].detach()) - float(GOLD['loss'])) < 2e-2 * float(GOLD['loss'])
+    opt = task.configure_optimizers()[0]['optimizer']
+    opt.zero_grad()
+    out['loss'].backward()
+    names = [str(n) for n in GOLD['param_names']]
+    params = dict(task.named_parameters())
+    assert sorted(n for n, p in params.items() if p.grad is None) == sorted(str(n) for n in GOLD['no_grad_names'])
+    gn = np.array([float(params[n].grad.detach().double().norm()) for n in names])
+    assert np.median(np.abs(gn / GOLD['grad_norm'] - 1)) < 0.05
+    for n in (str(s) for s in GOLD['small_names']):
+        ref = torch.from_numpy(GOLD['grad__' + n])
+        assert rel_err(params[n].grad.float(), ref) < 0.15 + 0.02 / (float(ref.norm()) + 1e-9) * 1e-3, n
+    opt.step()
+    pn = np.array([float(params[n].detach().double().norm()) for n in names])
+    assert np.abs(pn / GOLD['post_step_norm'] - 1).max() < 2e-3

@@ -158,6 +158,73 @@ def golden_hrnet(out_path, variant='hrnet_w18_small', classes=19, batch=4, size=
     print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params, restatement == reference files: OK')
 
 
+def golden_swin(out_path, seed=51):
+    """ClassificationTask wiring (tasks/classification.py:90-119) over the reference's OWN swin.py
+    (SwinTransformerV2 / BasicLayer override), Pooling and ClassificationHead; timm.models.swin_transformer_v2 and
+    timm.models.layers are stubbed by oracle/swin_ref.py.  Asserts the restated wiring (oracle SwinV2) is
+    bit-identical to the reference's class."""
+    import oracle.swin_ref as S
+    lay = sys.modules['timm.models.layers']
+    lay.trunc_normal_, lay.to_2tuple = S.trunc_normal_, S.to_2tuple
+    sw = _fake_pkg('timm.models.swin_transformer_v2')
+    for n in ('BasicLayer', 'checkpoint_filter_fn', 'PatchEmbed', 'PatchMerging'):
+        setattr(sw, n, getattr(S, n))
+    # timm's build_model_with_cfg forwards unknown kwargs (pretrained_filter_fn) to its loader, not the model
+    h = sys.modules['timm.models.helpers']
+    base_build = h.build_model_with_cfg
+    h.build_model_with_cfg = lambda cls, variant, pretrained, pretrained_filter_fn=None, **kw: \
+        base_build(cls, variant, pretrained, **kw)
+    swin = _load('torchok.models.backbones.swin', f'{REF}/models/backbones/swin.py')
+    pooling = sys.modules['torchok.models.poolings.classification.pooling']
+    head = sys.modules['torchok.models.heads.classification.classification_head']
+    kw = dict(img_size=64, window_size=4, depths=(2, 2, 2, 2), drop_path_rate=0.0)
+    classes, batch = 10, 4
+
+    class RefCls(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = swin.swinv2_custom(pretrained=False, in_channels=3, **kw)
+            self.pooling = pooling.Pooling(in_channels=self.backbone.out_channels)
+            self.head = head.ClassificationHead(in_channels=self.pooling.out_channels, num_classes=classes)
+
+    torch.manual_seed(seed)
+    task = RefCls().train()
+    sd = deterministic_state(task.state_dict(), seed)
+    task.load_state_dict(sd)
+    ora = S.SwinV2(**kw).train()
+    bsd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
+    assert set(ora.state_dict()) == set(bsd), 'state_dict keys differ: restated wiring != reference'
+    ora.load_state_dict(bsd)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, 64, 64, generator=g).half().float()
+    y = torch.randint(0, classes, (batch,), generator=g)
+    feats = task.backbone.forward_features(x)
+    ofeats = ora.forward_features(x)
+    assert all(torch.equal(a, b) for a, b in zip(feats, ofeats))
+    assert torch.equal(task.backbone(x), ora(x))
+    emb = task.pooling(task.backbone(x))
+    pred = task.head(emb, y)
+    loss = nn.functional.cross_entropy(pred, y)
+    loss.backward()
+    opt = torch.optim.AdamW(task.parameters(), lr=1e-3, weight_decay=0.05)
+    # feature_norms.0-2 take no part in `backbone(x)` (swin.py:251-256): no gradient, exactly as in the reference
+    grads = {n: p.grad.clone() for n, p in task.named_parameters() if p.grad is not None}
+    opt.step()
+    names = [n for n, _ in task.named_parameters() if n in grads]
+    no_grad = [n for n, _ in task.named_parameters() if n not in grads]
+    small = [n for n in names if grads[n].numel() <= 768][:80]
+    np.savez_compressed(
+        out_path, seed=seed, num_classes=classes, x=x.half().numpy(), y=y.numpy(),
+        feat_shapes=np.array([list(f.shape) for f in feats[1:]]),
+        feat_sumsq=np.array([float((f.double() ** 2).sum()) for f in feats[1:]]),
+        last_feature=feats[-1].detach().numpy(), prediction=pred.detach().numpy(), loss=float(loss.detach()),
+        param_names=np.array(names), no_grad_names=np.array(no_grad),
+        grad_norm=np.array([float(grads[n].double().norm()) for n in names]),
+        post_step_norm=np.array([float(task.get_parameter(n).double().norm()) for n in names]),
+        small_names=np.array(small), **{f'grad__{n}': grads[n].numpy() for n in small})
+    print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params, restatement == reference files: OK')
+
+
 def golden_metric(out_path):
     """ArcFaceHead / LinearHead(normalize) / ContrastiveLoss / calc_relevance_matrix from the reference's
     own files; asserts oracle/metric_ref.py == reference bit-for-bit on the same inputs."""
@@ -324,6 +391,8 @@ def main():
     # of the HIP path is checked against these same vectors)
     if '--metric-only' in sys.argv:
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
+    if '--swin-only' in sys.argv:
+        return golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     if '--hrnet-only' in sys.argv:
         return golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_step(mods, 'resnet18', 10, 8, 96, 11, os.path.join(gd, 'resnet18_cls_step.npz'))
@@ -331,6 +400,7 @@ def main():
     golden_heads(mods, os.path.join(gd, 'classification_head.npz'))
     golden_metric(os.path.join(gd, 'metric_heads.npz'))
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
+    golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
 
 
 if __name__ == '__main__':

@@ -179,12 +179,64 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16* __restrict__ dy
   }
 }
 
+// tall matrices (token rows of a transformer: M ~ 10^5..10^6): every block sweeps a contiguous row chunk with
+// fully coalesced 16-byte row segments and leaves one fp32 partial row; tok_colsum_f32 folds the rows
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ dy, int64_t M, int ld,
+                                                             int chunk, float* __restrict__ partial) {
+  extern __shared__ float red[];   // [rpb][ld]
+  const int cgs = ld >> 3;
+  const int cgt = cgs < 256 ? cgs : 256;      // column groups handled per pass
+  const int rpb = 256 / cgt;                  // rows in flight per pass
+  const int cgl = threadIdx.x % cgt, rl = threadIdx.x / cgt;
+  const int64_t r0 = (int64_t)blockIdx.x * chunk;
+  const int64_t r1 = r0 + chunk < M ? r0 + chunk : M;
+  for (int cg = cgl; cg < cgs; cg += cgt) {
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (rl < rpb)
+      for (int64_t m = r0 + rl; m < r1; m += rpb) {
+        const bf16x8 v = ldg16(dy + (size_t)m * ld + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+      }
+    if (rl < rpb)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(size_t)rl * ld + cg * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < ld; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < rpb; ++r) s += red[(size_t)r * ld + c];
+    partial[(size_t)blockIdx.x * ld + c] = s;
+  }
+}
+
 inline int grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
 }
 
 }  // namespace
+
+extern "C" int tok_colsum_partial_rows(int64_t m, int n_pad) {
+  (void)n_pad;
+  const int64_t b = (m + 255) / 256;
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+
+extern "C" int tok_colsum_partial(const void* dy, int64_t m, int n_pad, float* partial, void* stream) {
+  TOK_CHECK_ARG(dy && partial && m > 0 && n_pad > 0 && n_pad % 8 == 0, "tok_colsum_partial: bad args");
+  const int g = tok_colsum_partial_rows(m, n_pad);
+  const int chunk = (int)((m + g - 1) / g);
+  const int cgs = n_pad >> 3, cgt = cgs < 256 ? cgs : 256, rpb = 256 / cgt;
+  const size_t smem = (size_t)rpb * n_pad * sizeof(float);
+  TOK_CHECK_ARG(smem <= 64 * 1024, "tok_colsum_partial: n_pad too large (%d)", n_pad);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(g), dim3(256), smem, tok_stream(stream), (const bf16*)dy, m, n_pad,
+                     chunk, partial);
+  TOK_CHECK_LAUNCH("tok_colsum_partial");
+  return TOK_OK;
+}
 
 extern "C" int tok_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int n, int h, int w, int c,
                                     void* stream) {

@@ -296,8 +296,15 @@ class _ConvBnActNode(Node):
             return
         if bias_need:
             bs, bm = param_grad_target(conv.bias)
-            _C.check(lib.tok_colsum(ptr(dy), m, kp, conv.bias.shape[0], ptr(bs), 1 if bm == 1 else 0, st),
-                     'tok_colsum')
+            if m > 4096 and kp == conv.bias.shape[0]:
+                # tall dy (a conv / token GEMM bias): coalesced row-chunk partials, then a fixed-order fold
+                nrows = lib.tok_colsum_partial_rows(m, kp)
+                part = torch.empty((nrows, kp), dtype=F32, device=g.device)
+                _C.check(lib.tok_colsum_partial(ptr(dy), m, kp, ptr(part), st), 'tok_colsum_partial')
+                _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(bs), 1 if bm == 1 else 0, st), 'tok_colsum_f32')
+            else:
+                _C.check(lib.tok_colsum(ptr(dy), m, kp, conv.bias.shape[0], ptr(bs), 1 if bm == 1 else 0, st),
+                         'tok_colsum')
             commit_param_grad(conv.bias, bs, bm)
         if w_need:
             k, r, s, c = _krsc(conv.weight)

@@ -71,7 +71,10 @@ class _LinearNode(Node):
         m, kp = g.shape
         if self.bias_sinks:
             tmp = torch.empty(kp, dtype=F32, device=g.device)
-            _C.check(lib.tok_colsum(ptr(g), m, kp, kp, ptr(tmp), 0, st), 'tok_colsum')
+            nrows = lib.tok_colsum_partial_rows(m, kp)
+            part = torch.empty((nrows, kp), dtype=F32, device=g.device)
+            _C.check(lib.tok_colsum_partial(ptr(g), m, kp, ptr(part), st), 'tok_colsum_partial')
+            _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(tmp), 0, st), 'tok_colsum_f32')
             for p, start in self.bias_sinks:
                 if not p.requires_grad:
                     continue
