@@ -118,6 +118,35 @@ int tok_conv_dgrad_stat_rows(const tok_conv_desc* d);
 int tok_conv_dgrad_bnstats(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                            int accumulate, const void* bn_y, const uint8_t* bn_mask, float* partial,
                            void* stream);
+/* Fused BatchNorm finalize.  The conv launches that produce BatchNorm partial rows can also fold them: the
+ * LAST workgroup of a channel tile to deliver its row (device-side ticket) does the work of tok_bn_finalize
+ * (tok_conv_fwd_bn) or of tok_bn_bwd_finalize in dzy form (tok_conv_dgrad_bn) for that tile's channels — one
+ * kernel less on the dependency chain conv -> finalize -> apply.  `counters`: >= 64 device ints, zero on entry,
+ * left zero (give concurrent launches distinct counters).  Same arithmetic as the stand-alone finalizes.     */
+typedef struct tok_bn_fused {
+  int32_t* counters;
+  int64_t count;             /* elements per channel (n*p*q of the normalised tensor) */
+  int32_t c_real;            /* num_features (<= padded channel count) */
+  int32_t param_accumulate;  /* backward: dgamma / dbeta += */
+  float momentum, eps;       /* forward */
+  const float* gamma;
+  const float* beta;         /* forward */
+  float* running_mean;       /* forward, may be NULL (with running_var, nbt) */
+  float* running_var;
+  int64_t* nbt;
+  float* mean;               /* forward: out; backward: in */
+  float* rstd;
+  float* scale;              /* forward: out */
+  float* shift;
+  float* dgamma;             /* backward: out (may be NULL) */
+  float* dbeta;
+  float* coef;               /* backward: out [3][c] */
+} tok_bn_fused;
+int tok_conv_fwd_bn(const tok_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stats,
+                    const tok_bn_fused* bn, void* stream);
+int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                      const void* bn_y, const uint8_t* bn_mask, float* partial, const tok_bn_fused* bn,
+                      void* stream);
 size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 /* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
  * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */

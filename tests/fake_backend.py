@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 BF16 = torch.bfloat16
-_SZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int64: 8, torch.uint8: 1}
+_SZ = {torch.float32: 4, torch.bfloat16: 2, torch.float16: 2, torch.int64: 8, torch.uint8: 1, torch.int32: 4}
 
 
 def _t(ptr, shape, dtype):
@@ -157,6 +157,21 @@ class FakeTok:
         p[0, 1] = dz.sum(0)
         p[1, 1] = (dz * yv).sum(0)
         return rc
+
+    def tok_conv_fwd_bn(self, d, x, w, y, stats, bn, st):
+        b = _desc(bn)
+        rc = self.tok_conv_fwd(d, x, w, None, y, stats, st)
+        dd = _desc(d)
+        assert _t(b.counters, (64,), torch.int32).abs().sum() == 0
+        return rc or self.tok_bn_finalize(stats, self.tok_conv_fwd_stat_rows(d), b.count, dd.k, b.c_real, b.gamma, b.beta, b.running_mean,
+                                          b.running_var, b.nbt, b.momentum, b.eps, b.mean, b.rstd, b.scale, b.shift, st)
+
+    def tok_conv_dgrad_bn(self, d, dy, wd, dx, accumulate, bn_y, bn_mask, partial, bn, st):
+        b = _desc(bn)
+        rc = self.tok_conv_dgrad_bnstats(d, dy, wd, dx, accumulate, bn_y, bn_mask, partial, st)
+        dd = _desc(d)
+        return rc or self.tok_bn_bwd_finalize(partial, self.tok_conv_dgrad_stat_rows(d), b.count, dd.c, b.c_real, b.gamma, b.mean, b.rstd, b.dgamma,
+                                              b.dbeta, b.coef, b.param_accumulate, 1, st)
 
     @staticmethod
     def _bits(mask, m, c):

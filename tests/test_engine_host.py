@@ -204,3 +204,21 @@ def test_packs_follow_the_masters(fake_backend):
     EF.invalidate_packs()
     task.training_step({'image': x, 'target': y}, 10)
     assert fwd_pack_in_sync()
+
+
+def test_fused_bn_finalize_path(fake_backend, monkeypatch):
+    """Opt-in engine path over tok_conv_fwd_bn / tok_conv_dgrad_bn (off by default: measured slower)."""
+    from torchok_amd.engine import functional as EF
+    monkeypatch.setattr(EF, 'FUSE_BN_FINALIZE', True)
+    torch.manual_seed(0)
+    task, ref = _pair()
+    x, y = torch.randn(8, 3, 64, 64), torch.randint(0, 10, (8,))
+    out = task.training_step({'image': x, 'target': y}, 0)
+    out['loss'].backward()
+    ref_loss, _ = R.training_step(ref, {'image': x, 'target': y}, None)
+    assert abs(float(out['loss']) - float(ref_loss)) < 2e-2 * max(1, abs(float(ref_loss)))
+    ac = _autocast_grads(ref, x, y)
+    rp = dict(ref.named_parameters())
+    for n, p in task.named_parameters():
+        assert rel_err(p.grad, rp[n].grad) < 1.5 * rel_err(ac[n], rp[n].grad) + 1e-2, n
+    assert task.backbone.bn1.num_batches_tracked.item() == 1

@@ -772,3 +772,78 @@ def test_colsum_partial(libs, m, n):
     torch.cuda.synchronize()
     ref = x.double().sum(0)
     assert float((out.double() - ref).abs().max()) < 1e-4 * float(x.double().abs().sum(0).max())
+
+
+@pytest.mark.parametrize('case', [(4, 16, 16, 64, 64, 3, 1, 1), (2, 14, 14, 256, 512, 1, 1, 0), (3, 9, 11, 32, 24, 3, 2, 1),
+                                  (8, 28, 28, 128, 128, 3, 1, 1)])
+def test_fused_bn_finalize_equals_standalone(libs, case):
+    """tok_conv_fwd_bn / tok_conv_dgrad_bn ("last workgroup of a channel tile finalizes") == tok_conv_fwd + tok_bn_finalize
+    / tok_conv_dgrad_bnstats + tok_bn_bwd_finalize, and the ticket counters come back zero."""
+    lib, _ = libs
+    n, h, w, c, k, r, stride, pad = case
+    p, q = (h + 2 * pad - r) // stride + 1, (w + 2 * pad - r) // stride + 1
+    d = _C.ConvDesc(n, h, w, c, k, r, r, p, q, stride, pad, r)
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+    dev = 'cuda'
+    x = rnd(n, h, w, c).to(BF16).to(dev)
+    wt = rnd(k, r, r, c, seed=1, scale=0.1).to(dev)
+    wf = torch.empty(k, r, r, c, dtype=BF16, device=dev)
+    wd = torch.empty(c, r, r, k, dtype=BF16, device=dev)
+    assert lib.tok_pack_weight_both(P(wt), k, r, r, c, P(wf), k, r, c, P(wd), st) == 0
+    k_real = k - 3 if k % 8 == 0 and k > 8 else k
+    gamma, beta = (rnd(k_real, seed=2) + 1.0).to(dev), rnd(k_real, seed=3).to(dev)
+    m = n * p * q
+    rows = lib.tok_conv_fwd_stat_rows(ctypes.byref(d))
+    counters = torch.zeros(64, dtype=torch.int32, device=dev)
+    res = []
+    for fused in (0, 1):
+        y = torch.empty(n, p, q, k, dtype=BF16, device=dev)
+        stats = torch.empty(2, rows, k, device=dev)
+        rm, rv = torch.zeros(k_real, device=dev), torch.ones(k_real, device=dev)
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+        mean, rstd, scale, shift = (torch.full((k,), 7.0, device=dev) for _ in range(4))
+        if fused:
+            fb = _C.BnFused(P(counters), m, k_real, 0, 0.1, 1e-5, P(gamma), P(beta), P(rm), P(rv), P(nbt), P(mean), P(rstd),
+                            P(scale), P(shift), None, None, None)
+            assert lib.tok_conv_fwd_bn(ctypes.byref(d), P(x), P(wf), P(y), P(stats), ctypes.byref(fb), st) == 0, \
+                lib.tok_last_error()
+        else:
+            assert lib.tok_conv_fwd(ctypes.byref(d), P(x), P(wf), None, P(y), P(stats), st) == 0
+            assert lib.tok_bn_finalize(P(stats), rows, m, k, k_real, P(gamma), P(beta), P(rm), P(rv), P(nbt), 0.1, 1e-5,
+                                       P(mean), P(rstd), P(scale), P(shift), st) == 0
+        torch.cuda.synchronize()
+        res.append((y, mean, rstd, scale, shift, rm, rv, nbt))
+    assert int(counters.abs().sum()) == 0
+    assert torch.equal(res[0][0], res[1][0]) and int(res[1][7]) == 1
+    for a, b in zip(res[0][1:7], res[1][1:7]):
+        assert relerr(b, a) < 1e-6
+    # backward: dgrad of this conv completing d(x) for a producer BatchNorm over x's channels
+    if c % 8 == 0:
+        y, mean_k = res[0][0], None
+        dy = rnd(n, p, q, k, seed=5).to(BF16).to(dev)
+        bn_y = rnd(n, h, w, c, seed=6).to(BF16).to(dev)
+        mask = torch.randint(0, 256, (n * h * w, c // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
+        pmean, prstd = rnd(c, seed=7).to(dev), (rnd(c, seed=8).abs() + 0.5).to(dev)
+        pgamma = (rnd(c, seed=9) + 1.0).to(dev)
+        prow = lib.tok_conv_dgrad_stat_rows(ctypes.byref(d))
+        out = []
+        for fused in (0, 1):
+            dx = torch.empty(n, h, w, c, dtype=BF16, device=dev)
+            part = torch.empty(2, prow, c, device=dev)
+            dg, db, coef = torch.ones(c, device=dev), torch.ones(c, device=dev), torch.empty(3, c, device=dev)
+            if fused:
+                fb = _C.BnFused(P(counters), n * h * w, c, 1, 0.0, 0.0, P(pgamma), None, None, None, None, P(pmean),
+                                P(prstd), None, None, P(dg), P(db), P(coef))
+                assert lib.tok_conv_dgrad_bn(ctypes.byref(d), P(dy), P(wd), P(dx), 0, P(bn_y), P(mask), P(part),
+                                             ctypes.byref(fb), st) == 0, lib.tok_last_error()
+            else:
+                assert lib.tok_conv_dgrad_bnstats(ctypes.byref(d), P(dy), P(wd), P(dx), 0, P(bn_y), P(mask), P(part), st) == 0
+                assert lib.tok_bn_bwd_finalize(P(part), prow, n * h * w, c, c, P(pgamma), P(pmean), P(prstd), P(dg), P(db),
+                                               P(coef), 1, 1, st) == 0
+            torch.cuda.synchronize()
+            out.append((dx, dg, db, coef))
+        assert int(counters.abs().sum()) == 0
+        assert torch.equal(out[0][0], out[1][0])
+        for a, b in zip(out[0][1:], out[1][1:]):
+            assert relerr(b, a) < 1e-5

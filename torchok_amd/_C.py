@@ -32,6 +32,15 @@ class PackItem(Structure):
                 ('k_pad', c_int32), ('s_pad', c_int32), ('c_pad', c_int32), ('block_start', c_int32)]
 
 
+class BnFused(Structure):
+    """Mirror of ``tok_bn_fused`` (include/tok.h)."""
+    _fields_ = [('counters', c_void_p), ('count', c_int64), ('c_real', c_int32), ('param_accumulate', c_int32),
+                ('momentum', c_float), ('eps', c_float), ('gamma', c_void_p), ('beta', c_void_p),
+                ('running_mean', c_void_p), ('running_var', c_void_p), ('nbt', c_void_p), ('mean', c_void_p),
+                ('rstd', c_void_p), ('scale', c_void_p), ('shift', c_void_p), ('dgamma', c_void_p),
+                ('dbeta', c_void_p), ('coef', c_void_p)]
+
+
 _P = c_void_p
 _PD = POINTER(ConvDesc)
 
@@ -51,6 +60,8 @@ PROTOTYPES = {
     'tok_conv_dgrad': (c_int, [_PD, _P, _P, _P, c_int, _P]),
     'tok_conv_dgrad_stat_rows': (c_int, [_PD]),
     'tok_conv_dgrad_bnstats': (c_int, [_PD, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'tok_conv_fwd_bn': (c_int, [_PD, _P, _P, _P, _P, POINTER(BnFused), _P]),
+    'tok_conv_dgrad_bn': (c_int, [_PD, _P, _P, _P, c_int, _P, _P, _P, POINTER(BnFused), _P]),
     'tok_conv_wgrad_ws_bytes': (c_size_t, [_PD]),
     'tok_conv_wgrad': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
     'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float,

@@ -66,6 +66,11 @@ struct ConvArgs {
   FastDiv fd_pq, fd_q;
   unsigned long long* timing;   // TOK_TIMING builds only: per-phase cycle totals of wave 0
   int stat_rows;   // workgroups per channel tile = rows of the partial-statistics buffer
+  // fused BatchNorm finalize: the LAST workgroup of a channel tile to deliver its statistics row (device
+  // ticket counter) folds the rows of that tile — saves the separate finalize launch between two dependent
+  // kernels.  fin_mode 0: off, 1: forward (mean/rstd/scale/shift/running stats), 2: backward (dgamma/dbeta/coef)
+  int fin_mode;
+  tok_bn_fused fin;
   // IN_DIV == 2: per parity class (ph*2 + pw); m-tile index = 4 * (tile inside class) + class
   int cls_M[4], cls_nw[4], cls_hw[4];
   FastDiv cls_fd_hw[4], cls_fd_w[4];
@@ -561,7 +566,89 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
       for (int w_ = 0; w_ < WGM; ++w_) t += red[(which * WGM + w_) * BN + c];
       const int row = xcd * S8 + jm;
       const int n = bn_fixed * BN + c;
-      if (n < a.K) a.stats[((size_t)which * a.stat_rows + row) * a.K + n] = t;
+      if (n < a.K) {
+        float* dst = &a.stats[((size_t)which * a.stat_rows + row) * a.K + n];
+        // fused finalize: device-coherent (sc1, write-through) store so that the folding workgroup can read the row
+        // without anybody flushing or invalidating an L2 — an agent-scope release fence here costs a full L2
+        // write-back per workgroup (measured: +40 % step time)
+        if (a.fin_mode != 0) __hip_atomic_store(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = t;
+      }
+    }
+    if (a.fin_mode != 0) {
+      __shared__ int s_ticket;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's row elements have reached the coherence point
+      __syncthreads();
+      if (tid == 0) s_ticket = __hip_atomic_fetch_add(&a.fin.counters[bn_fixed], 1, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (s_ticket == a.stat_rows - 1) {
+        constexpr int PARTS = NT / BN;
+        double* scr = reinterpret_cast<double*>(smem);   // [2][PARTS][BN]; the tile buffers are dead by now
+        const int c = tid % BN, part = tid / BN;
+        const int n = bn_fixed * BN + c;
+        double a1 = 0.0, a2 = 0.0;
+        if (n < a.K)
+          for (int r = part; r < a.stat_rows; r += PARTS) {
+            a1 += (double)__hip_atomic_load(&a.stats[(size_t)r * a.K + n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a2 += (double)__hip_atomic_load(&a.stats[((size_t)a.stat_rows + r) * a.K + n], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+          }
+        scr[(0 * PARTS + part) * BN + c] = a1;
+        scr[(1 * PARTS + part) * BN + c] = a2;
+        __syncthreads();
+        if (part == 0 && n < a.K) {
+#pragma unroll
+          for (int q = 1; q < PARTS; ++q) { a1 += scr[(0 * PARTS + q) * BN + c]; a2 += scr[(1 * PARTS + q) * BN + c]; }
+          const tok_bn_fused& f = a.fin;
+          const bool real = n < f.c_real;
+          if (a.fin_mode == 1) {
+            const double inv = 1.0 / (double)f.count;
+            const double mu = a1 * inv;
+            double var = a2 * inv - mu * mu;
+            if (var < 0.0) var = 0.0;
+            const float muf = (float)mu;
+            const float rs = (float)(1.0 / sqrt(var + (double)f.eps));
+            if (real) {
+              f.mean[n] = muf;
+              f.rstd[n] = rs;
+              const float sc = f.gamma[n] * rs;
+              f.scale[n] = sc;
+              f.shift[n] = fmaf(-muf, sc, f.beta[n]);
+              if (f.running_mean != nullptr) {
+                const double unbias = f.count > 1 ? (double)f.count / (double)(f.count - 1) : 1.0;
+                f.running_mean[n] = (1.f - f.momentum) * f.running_mean[n] + f.momentum * muf;
+                f.running_var[n] = (1.f - f.momentum) * f.running_var[n] + f.momentum * (float)(var * unbias);
+              }
+            } else {
+              f.mean[n] = 0.f; f.rstd[n] = 0.f; f.scale[n] = 0.f; f.shift[n] = 0.f;
+            }
+          } else {
+            float* coef = f.coef;
+            if (real) {
+              // second sum is sum(dz * y): sum(dz * xhat) = rstd * (sum(dz*y) - mean * sum(dz))
+              const double sx = (double)f.rstd[n] * (a2 - (double)f.mean[n] * a1);
+              const float sdz = (float)a1, sdzx = (float)sx;
+              if (f.dgamma != nullptr) f.dgamma[n] = f.param_accumulate ? f.dgamma[n] + sdzx : sdzx;
+              if (f.dbeta != nullptr) f.dbeta[n] = f.param_accumulate ? f.dbeta[n] + sdz : sdz;
+              const double inv_m = 1.0 / (double)f.count;
+              const float m1 = (float)(a1 * inv_m), m2 = (float)(sx * inv_m);
+              const float g = f.gamma[n], rs = f.rstd[n], mu = f.mean[n];
+              const float c1 = g * rs;
+              const float c2 = -c1 * rs * m2;
+              coef[n] = c1;
+              coef[a.K + n] = c2;
+              coef[2 * a.K + n] = -c1 * m1 - c2 * mu;
+            } else {
+              coef[n] = 0.f; coef[a.K + n] = 0.f; coef[2 * a.K + n] = 0.f;
+            }
+          }
+        }
+        if (tid == 0) {
+          a.fin.counters[bn_fixed] = 0;     // leave the ticket counters zero for the next launch
+          if (a.fin_mode == 1 && bn_fixed == 0 && a.fin.nbt != nullptr) *a.fin.nbt += 1;
+        }
+      }
     }
   }
 }
@@ -666,11 +753,42 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   return plan_grid(bn_tile, gridM, gridN) / gridN;
 }
 
+namespace {
+int check_fused(const tok_bn_fused* bn, int k, bool fwd, const char* who) {
+  TOK_CHECK_ARG(bn->counters && bn->count > 0 && bn->c_real > 0 && bn->c_real <= k && bn->gamma && bn->mean && bn->rstd,
+                "%s: bad tok_bn_fused", who);
+  if (fwd) TOK_CHECK_ARG(bn->beta && bn->scale && bn->shift && ((bn->running_mean == nullptr) == (bn->running_var == nullptr)),
+                         "%s: bad tok_bn_fused (forward fields)", who);
+  else TOK_CHECK_ARG(bn->coef, "%s: bad tok_bn_fused (coef)", who);
+  return 0;
+}
+int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
+                  const tok_bn_fused* bn, void* stream);
+}  // namespace
+
 extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w,
                             const float* bias, void* y, float* stats, void* stream) {
+  return conv_fwd_impl(d, x, w, bias, y, stats, nullptr, stream);
+}
+
+extern "C" int tok_conv_fwd_bn(const tok_conv_desc* d, const void* x, const void* w, void* y, float* stats,
+                               const tok_bn_fused* bn, void* stream) {
+  TOK_CHECK_ARG(stats && bn, "tok_conv_fwd_bn: stats / bn must not be null");
+  return conv_fwd_impl(d, x, w, nullptr, y, stats, bn, stream);
+}
+
+namespace {
+int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
+                  const tok_bn_fused* bn, void* stream) {
   if (int e = check_desc(d, "tok_conv_fwd")) return e;
   TOK_CHECK_ARG(x && w && y, "tok_conv_fwd: null pointer");
   ConvArgs a = {};
+  if (bn != nullptr) {
+    if (int e = check_fused(bn, d->k, true, "tok_conv_fwd_bn")) return e;
+    TOK_CHECK_ARG(tok_cdiv(d->k, 64) <= 64, "tok_conv_fwd_bn: more than 64 channel tiles");
+    a.fin_mode = 1;
+    a.fin = *bn;
+  }
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.bias = bias; a.stats = stats;
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad;
   a.P = d->p; a.Q = d->q; a.stride = d->stride; a.pad = d->pad;
@@ -693,6 +811,7 @@ extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w
   TOK_CHECK_LAUNCH("tok_conv_fwd");
   return TOK_OK;
 }
+}  // namespace
 
 namespace {
 
@@ -737,7 +856,8 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
 }
 
 int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-               const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who) {
+               const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who,
+               const tok_bn_fused* bn = nullptr) {
   if (int e = check_desc(d, who)) return e;
   TOK_CHECK_ARG(dy && w_dgrad && dx, "%s: null pointer", who);
   ConvArgs a = {};
@@ -746,6 +866,12 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
   a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr;
   a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask;
   a.accumulate = accumulate;
+  if (bn != nullptr) {
+    if (int e = check_fused(bn, d->c, false, who)) return e;
+    TOK_CHECK_ARG(tok_cdiv(d->c, 64) <= 64, "%s: more than 64 channel tiles", who);
+    a.fin_mode = 2;
+    a.fin = *bn;
+  }
   hipStream_t st = tok_stream(stream);
   if (pl.bn_tile == 64) {
     if (d->stride == 1) launch<128, 64, 1, false>(a, st); else launch<128, 64, 2, false>(a, st);
@@ -776,4 +902,11 @@ extern "C" int tok_conv_dgrad_bnstats(const tok_conv_desc* d, const void* dy, co
                                       float* partial, void* stream) {
   TOK_CHECK_ARG(bn_y && partial, "tok_conv_dgrad_bnstats: bn_y / partial must not be null");
   return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bnstats");
+}
+
+extern "C" int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                                 const void* bn_y, const uint8_t* bn_mask, float* partial, const tok_bn_fused* bn,
+                                 void* stream) {
+  TOK_CHECK_ARG(bn_y && partial && bn, "tok_conv_dgrad_bn: bn_y / partial / bn must not be null");
+  return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bn", bn);
 }

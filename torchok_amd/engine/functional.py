@@ -121,6 +121,20 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
     return pk
 
 
+FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
+_ticket_rings = {}
+
+
+def _ticket_counters(device):
+    """Pointer to 64 zeroed device ints for one fused-finalize launch.  A ring of 256 slots per device: kernels
+    leave their counters zero, and no 256 such launches are ever in flight at once."""
+    ring = _ticket_rings.get(device)
+    if ring is None:
+        ring = _ticket_rings[device] = [torch.zeros(256 * 64, dtype=torch.int32, device=device), 0]
+    ring[1] = (ring[1] + 1) & 255
+    return ring[0].data_ptr() + ring[1] * 256
+
+
 _pack_generation = 0   # bumped whenever a pack buffer is (re)allocated: invalidates cached batch tables
 
 
@@ -200,15 +214,58 @@ class _ConvBnActNode(Node):
         self.x = self.out = self.shortcut = None
         self.y = self.mask = None
         self.fused_partial = None   # (partial, rows) when a consumer's dgrad epilogue did our BN-bwd reduce
+        self.fused_coef = None      # apply coefficients when that dgrad also finalized (tok_conv_dgrad_bn)
+        self.coef = None
 
     def release(self):
         self.x = self.out = self.shortcut = None
-        self.y = self.pk = self.mask = self.fused_partial = None
+        self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = None
         self.mean = self.rstd = self.scale = self.shift = None
 
     def wants_fused_bwd_stats(self) -> bool:
         """Can the kernel that completes d(out) also reduce sum(dz), sum(dz*y) for this unit?"""
         return self.bn is not None and self.batch_stats and (not self.relu or self.mask is not None)
+
+    def _finalize_bwd(self, lib, st, g, mask, m, kp, g_need, b_need):
+        """sum(dz), sum(dz*xhat) -> dgamma, dbeta, apply coefficients (stand-alone reduce / finalize launches)."""
+        bn = self.bn
+        dzy = 0
+        if self.fused_partial is not None:
+            partial, rows = self.fused_partial   # reduced by the dgrad that completed d(out)
+            dzy = 1
+        else:
+            rows = lib.tok_bn_bwd_rows(m, kp)
+            partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
+            _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale), ptr(self.shift),
+                                           ptr(self.mean), ptr(self.rstd), int(self.relu), m, kp, ptr(partial), st),
+                     'tok_bn_bwd_reduce')
+        coef = torch.empty((3, kp), dtype=F32, device=g.device)
+        gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
+        bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
+        if gm == 2 or bm == 2 or (gm != bm and g_need and b_need):
+            # rare mixed state: run the accumulate-free form and fix up on the host side
+            gacc = torch.empty_like(gs) if g_need else None
+            bacc = torch.empty_like(bs) if b_need else None
+            _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
+                                             ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, dzy, st),
+                     'tok_bn_bwd_finalize')
+            for p_, acc_ in ((bn.weight, gacc), (bn.bias, bacc)):
+                if acc_ is not None:
+                    if p_.grad is None:
+                        p_.grad = acc_
+                    else:
+                        p_.grad.add_(acc_)
+                    for h_ in core_hooks():
+                        h_(p_)
+        else:
+            _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
+                                             ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
+                                             1 if (gm == 1 or bm == 1) else 0, dzy, st), 'tok_bn_bwd_finalize')
+            if g_need:
+                commit_param_grad(bn.weight, gs, gm)
+            if b_need:
+                commit_param_grad(bn.bias, bs, bm)
+        self.coef = coef
 
     def backward(self):
         lib, st = _C.lib(), stream_ptr()
@@ -230,42 +287,13 @@ class _ConvBnActNode(Node):
             sc_need = sc is not None and sc.requires_grad
             mask = self.mask if self.relu else None
             if self.batch_stats:
-                dzy = 0
-                if self.fused_partial is not None:
-                    partial, rows = self.fused_partial   # reduced by the dgrad that completed d(out)
-                    dzy = 1
+                if self.fused_coef is not None:
+                    # the dgrad that completed d(out) reduced AND finalized (tok_conv_dgrad_bn): dgamma / dbeta are
+                    # already in their slots, only the apply coefficients are needed here
+                    coef = self.fused_coef
                 else:
-                    rows = lib.tok_bn_bwd_rows(m, kp)
-                    partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
-                    _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
-                                                   ptr(self.shift), ptr(self.mean), ptr(self.rstd),
-                                                   int(self.relu), m, kp, ptr(partial), st), 'tok_bn_bwd_reduce')
-                coef = torch.empty((3, kp), dtype=F32, device=g.device)
-                gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
-                bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
-                if gm == 2 or bm == 2 or (gm != bm and g_need and b_need):
-                    # rare mixed state: run the accumulate-free form and fix up on the host side
-                    gacc = torch.empty_like(gs) if g_need else None
-                    bacc = torch.empty_like(bs) if b_need else None
-                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
-                                                     ptr(self.rstd), ptr(gacc), ptr(bacc), ptr(coef), 0, dzy, st),
-                             'tok_bn_bwd_finalize')
-                    for p_, acc_ in ((bn.weight, gacc), (bn.bias, bacc)):
-                        if acc_ is not None:
-                            if p_.grad is None:
-                                p_.grad = acc_
-                            else:
-                                p_.grad.add_(acc_)
-                            for h_ in core_hooks():
-                                h_(p_)
-                else:
-                    _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
-                                                     ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
-                                                     1 if (gm == 1 or bm == 1) else 0, dzy, st), 'tok_bn_bwd_finalize')
-                    if g_need:
-                        commit_param_grad(bn.weight, gs, gm)
-                    if b_need:
-                        commit_param_grad(bn.bias, bs, bm)
+                    self._finalize_bwd(lib, st, g, mask, m, kp, g_need, b_need)
+                    coef = self.coef
             else:
                 # eval-mode BN: y -> out is a fixed affine map: dy = scale * dz, dgamma/dbeta unsupported
                 if g_need or b_need:
@@ -317,17 +345,39 @@ class _ConvBnActNode(Node):
         if x_need:
             prod = x.node
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
-                    and prod.fused_partial is None)
+                    and prod.fused_partial is None and prod.fused_coef is None)
             tgt, acc = grad_target(x)
             if fuse:
                 # this dgrad completes d(x): its epilogue also reduces the BatchNorm-backward sums of the
                 # unit that produced x (saves that unit a full pass over d(x) and y)
                 rows = lib.tok_conv_dgrad_stat_rows(d)
                 partial = torch.empty((2, rows, x.cp), dtype=F32, device=g.device)
-                _C.check(lib.tok_conv_dgrad_bnstats(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, ptr(prod.y),
-                                                    ptr(prod.mask) if prod.relu else None, ptr(partial), st),
-                         'tok_conv_dgrad_bnstats')
-                prod.fused_partial = (partial, rows)
+                pbn = prod.bn
+                pg, pb = pbn.weight.requires_grad, pbn.bias.requires_grad
+                gs, gm = param_grad_target(pbn.weight) if pg else (None, 0)
+                bs, bm = param_grad_target(pbn.bias) if pb else (None, 0)
+                simple = FUSE_BN_FINALIZE and gm != 2 and bm != 2 and not (pg and pb and gm != bm)
+                if simple:
+                    # ... and folds them: dgamma, dbeta, apply coefficients of the producer (last workgroup per
+                    # channel tile) — the producer's backward starts directly with its apply pass
+                    pm = prod.y.numel() // prod.y.shape[-1]
+                    coef = torch.empty((3, x.cp), dtype=F32, device=g.device)
+                    fb = _C.BnFused(_ticket_counters(g.device), pm, pbn.num_features, 1 if (gm == 1 or bm == 1) else 0,
+                                    0.0, 0.0, ptr(pbn.weight), None, None, None, None, ptr(prod.mean), ptr(prod.rstd),
+                                    None, None, ptr(gs), ptr(bs), ptr(coef))
+                    _C.check(lib.tok_conv_dgrad_bn(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, ptr(prod.y),
+                                                   ptr(prod.mask) if prod.relu else None, ptr(partial), fb, st),
+                             'tok_conv_dgrad_bn')
+                    prod.fused_coef = coef
+                    if pg:
+                        commit_param_grad(pbn.weight, gs, gm)
+                    if pb:
+                        commit_param_grad(pbn.bias, bs, bm)
+                else:
+                    _C.check(lib.tok_conv_dgrad_bnstats(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, ptr(prod.y),
+                                                        ptr(prod.mask) if prod.relu else None, ptr(partial), st),
+                             'tok_conv_dgrad_bnstats')
+                    prod.fused_partial = (partial, rows)
             else:
                 _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
 
@@ -363,14 +413,28 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
     if batch_stats:
         rows = lib.tok_conv_fwd_stat_rows(d)
         stats = torch.empty((2, rows, kp), dtype=F32, device=dev)
-    _C.check(lib.tok_conv_fwd(d, ptr(x4.data), ptr(pk.fwd), ptr(pk.bias), ptr(y), ptr(stats), st), 'tok_conv_fwd')
-
+    fused_fin = batch_stats and pk.bias is None and FUSE_BN_FINALIZE
     node = _ConvBnActNode()
+    if fused_fin:
+        # the conv launch also folds its statistics rows (last workgroup per channel tile): no finalize launch
+        if bn.momentum is None:
+            raise NotImplementedError('BatchNorm momentum=None (cumulative average)')
+        scale, shift, mean, rstd = (torch.empty(kp, dtype=F32, device=dev) for _ in range(4))
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        fb = _C.BnFused(_ticket_counters(dev), m, bn.num_features, 0, float(bn.momentum), float(bn.eps), ptr(bn.weight),
+                        ptr(bn.bias), ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                        ptr(bn.num_batches_tracked) if track else None, ptr(mean), ptr(rstd), ptr(scale), ptr(shift),
+                        None, None, None)
+        _C.check(lib.tok_conv_fwd_bn(d, ptr(x4.data), ptr(pk.fwd), ptr(y), ptr(stats), fb, st), 'tok_conv_fwd_bn')
+    else:
+        _C.check(lib.tok_conv_fwd(d, ptr(x4.data), ptr(pk.fwd), ptr(pk.bias), ptr(y), ptr(stats), st), 'tok_conv_fwd')
+
     if bn is not None:
-        scale = torch.empty(kp, dtype=F32, device=dev)
-        shift = torch.empty(kp, dtype=F32, device=dev)
-        mean = rstd = None
-        if batch_stats:
+        if not fused_fin:
+            scale = torch.empty(kp, dtype=F32, device=dev)
+            shift = torch.empty(kp, dtype=F32, device=dev)
+            mean = rstd = None
+        if batch_stats and not fused_fin:
             if bn.momentum is None:
                 raise NotImplementedError('BatchNorm momentum=None (cumulative average)')
             mean = torch.empty(kp, dtype=F32, device=dev)
@@ -382,7 +446,7 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
                                          ptr(bn.num_batches_tracked) if track else None,
                                          float(bn.momentum), float(bn.eps), ptr(mean), ptr(rstd),
                                          ptr(scale), ptr(shift), st), 'tok_bn_finalize')
-        else:
+        elif not batch_stats:
             _C.check(lib.tok_bn_eval_coeffs(ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                             ptr(bn.running_var), float(bn.eps), kp, bn.num_features, ptr(scale), ptr(shift), st),
                      'tok_bn_eval_coeffs')
