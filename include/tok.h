@@ -309,9 +309,10 @@ int tok_act_bwd(int kind, const void* dout, const void* x, void* dx, int accumul
 int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int c, int heads, int ws, int shift, int ld,
                         const float* logit_scale, const float* bias, const float* mask, void* out,
                         float* lse, void* stream);
-/* dqkv [B*H*W][ld]; ds_scratch fp32 [B*nW][heads][N][N] receives d(attn logits) TRANSPOSED per window
- * ([j][i]) — tok_colsum_f32 over its B*nW rows is d(bias)^T; dscale_part fp32 [B*nW*heads] -> colsum per head
- * = d(logit_scale).                                                                                      */
+/* dqkv [B*H*W][ld]; with R = tok_window_attn_bwd_rows(...): ds_scratch fp32 [R][heads][N][N] receives partial
+ * sums of d(attn logits) — tok_colsum_f32 over its R rows is d(bias); dscale_part fp32 [R][heads] -> colsum per
+ * head = d(logit_scale).  (Windows of <= 64 tokens run on MFMA tiles and fold several images per wave: R < B*nW.) */
+int tok_window_attn_bwd_rows(int batch, int h, int w, int heads, int ws);
 int tok_window_attn_bwd(const void* qkv, const void* dout, int batch, int h, int w, int c, int heads, int ws,
                         int shift, int ld, const float* logit_scale, const float* bias, const float* mask,
                         const float* lse, void* dqkv, float* ds_scratch, float* dscale_part, void* stream);

@@ -645,6 +645,9 @@ class FakeTok:
         _t(lse, (l.numel(),), torch.float32).copy_(l.reshape(-1))
         return 0
 
+    def tok_window_attn_bwd_rows(self, b, h, w, heads, ws):
+        return b * (h // ws) * (w // ws)
+
     def tok_window_attn_bwd(self, qkv, dout, b, h, w, c, heads, ws, shift, ld, logit_scale, bias, mask, lse, dqkv,
                             ds_scratch, dscale_part, st):
         self.calls.append('window_attn_bwd')
@@ -660,7 +663,7 @@ class FakeTok:
         # the stand-in reports the reduced gradients in row 0 of the scratch buffers (their colsums are what is used)
         sc = _t(ds_scratch, (b * nw, heads, n, n), torch.float32)
         sc.zero_()
-        sc[0] = gbi.transpose(1, 2)
+        sc[0] = gbi
         dp = _t(dscale_part, (b * nw, heads), torch.float32)
         dp.zero_()
         dp[0] = gls

@@ -717,19 +717,31 @@ def test_window_attention(libs, b, h, w, heads, ws, shift):
     out, lse = torch.empty(b * h * w, c, dtype=BF16), torch.empty(b * nw * heads * n)
     dv = both(libs, 'tok_window_attn_fwd', lambda d: [d(qkv), b, h, w, c, heads, ws, shift, 3 * c, d(ls), d(bias),
                                                       d(mask) if mask is not None else None, d(out), d(lse), None])
-    assert relerr(dv[id(out)].float(), out.float()) < 5e-3
+    assert relerr(dv[id(out)].float(), out.float()) < 1e-2     # MFMA path: qn, kn, P are bf16 operands
     # lse layout: fake (B*nW, heads, N) == kernel ((b*nW + win)*heads + h, N)
-    assert relerr(dv[id(lse)], lse) < 1e-4
+    assert relerr(dv[id(lse)], lse) < 3e-3      # logits from bf16-rounded qn, kn on the MFMA path
     g = rnd(b * h * w, c, seed=7).to(BF16)
-    dq = torch.empty(b * h * w, 3 * c, dtype=BF16)
-    scr, dsp = torch.empty(b * nw, heads * n * n), torch.empty(b * nw, heads)
-    dv = both(libs, 'tok_window_attn_bwd', lambda d: [d(qkv), d(g), b, h, w, c, heads, ws, shift, 3 * c, d(ls), d(bias),
-                                                      d(mask) if mask is not None else None, d(lse), d(dq), d(scr), d(dsp),
-                                                      None])
-    assert relerr(dv[id(dq)].float(), dq.float()) < 1e-2
-    assert relerr(dv[id(scr)].sum(0), scr.sum(0)) < 5e-3          # d(bias)^T
-    assert relerr(dv[id(dsp)].sum(0), dsp.sum(0)) < 5e-3 + 1e-3   # d(logit_scale)
-    assert float(dv[id(dsp)][:, 0].abs().max()) == 0.0            # clamped head: zero gradient
+    rows = lib.tok_window_attn_bwd_rows(b, h, w, heads, ws)
+    assert rows <= b * nw
+    # host reference with its own lse; the device backward gets the lse of the DEVICE forward (as in training: the
+    # recomputed probabilities must be normalised by the same bf16-operand logits that produced them)
+    P = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    dq_h = torch.empty(b * h * w, 3 * c, dtype=BF16)
+    scr_h, dsp_h = torch.zeros(b * nw, heads * n * n), torch.zeros(b * nw, heads)
+    assert fake.tok_window_attn_bwd(P(qkv), P(g), b, h, w, c, heads, ws, shift, 3 * c, P(ls), P(bias), P(mask), P(lse),
+                                    P(dq_h), P(scr_h), P(dsp_h), None) == 0
+    dq_d = torch.empty(b * h * w, 3 * c, dtype=BF16, device='cuda')
+    scr_d, dsp_d = torch.zeros(rows, heads * n * n, device='cuda'), torch.zeros(rows, heads, device='cuda')
+    dev_in = [t_.cuda() if t_ is not None else None for t_ in (qkv, g, ls, bias, mask)]
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tok_window_attn_bwd(P(dev_in[0]), P(dev_in[1]), b, h, w, c, heads, ws, shift, 3 * c, P(dev_in[2]),
+                                   P(dev_in[3]), P(dev_in[4]), P(dv[id(lse)]), P(dq_d), P(scr_d), P(dsp_d), st) == 0, \
+        lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert relerr(dq_d.float(), dq_h.float()) < 3e-2
+    assert relerr(scr_d.sum(0), scr_h.sum(0)) < 3e-2                     # d(bias)
+    assert relerr(dsp_d.sum(0)[1:], dsp_h.sum(0)[1:]) < 3e-2 or heads == 1   # d(logit_scale)
+    assert float(dsp_d[:, 0].abs().max()) == 0.0                         # clamped head: zero gradient
 
 
 def test_cpb_bias_and_patch_merge(libs):

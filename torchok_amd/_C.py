@@ -101,6 +101,7 @@ PROTOTYPES = {
     'tok_act_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
     'tok_act_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_size_t, _P]),
     'tok_window_attn_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    'tok_window_attn_bwd_rows': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'tok_window_attn_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
                                     _P, _P, _P]),
     'tok_cpb_bias_fwd': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),

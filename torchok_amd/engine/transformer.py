@@ -255,21 +255,21 @@ class _CpbBiasNode(Node):
     needs_backward = True
 
     def backward(self):
-        if self.dbias_t is None or not self.table.requires_grad:
+        if self.dbias is None or not self.table.requires_grad:
             return
         rows, ld = self.table.shape
         tgt, acc = grad_target(self.table)
         if acc:
             raise RuntimeError('cpb_bias: the cpb_mlp output has a single consumer')
-        _C.check(_C.lib().tok_cpb_bias_bwd(ptr(self.dbias_t), 1, ptr(self.table.data), ld, ptr(self.index), self.heads,
+        _C.check(_C.lib().tok_cpb_bias_bwd(ptr(self.dbias), 0, ptr(self.table.data), ld, ptr(self.index), self.heads,
                                            self.n, rows, ptr(tgt), stream_ptr()), 'tok_cpb_bias_bwd')
 
     def release(self):
-        self.table = self.index = self.bias = self.dbias_t = None
+        self.table = self.index = self.bias = self.dbias = None
 
 
 def cpb_bias(region: Region, table: TTensor, index: torch.Tensor, heads: int, n_tokens: int):
-    """(bias fp32 [heads][N][N], node).  The attention unit hands d(bias)^T back through `node.dbias_t`."""
+    """(bias fp32 [heads][N][N], node).  The attention unit hands d(bias) back through `node.dbias`."""
     rows, ld = table.shape
     bias = torch.empty((heads, n_tokens, n_tokens), dtype=F32, device=table.data.device)
     _C.check(_C.lib().tok_cpb_bias_fwd(ptr(table.data), ld, ptr(index), heads, n_tokens, ptr(bias), stream_ptr()),
@@ -277,7 +277,7 @@ def cpb_bias(region: Region, table: TTensor, index: torch.Tensor, heads: int, n_
     node = None
     if region.grad_mode and table.requires_grad:
         node = _CpbBiasNode()
-        node.table, node.index, node.heads, node.n, node.bias, node.dbias_t = table, index, heads, n_tokens, bias, None
+        node.table, node.index, node.heads, node.n, node.bias, node.dbias = table, index, heads, n_tokens, bias, None
         table.uses += 1
         region.add(node)
     return bias, node
@@ -297,8 +297,9 @@ class _WindowAttnNode(Node):
         nw = (h // ws) * (w // ws)
         qkv = self.qkv
         dev = g.device
-        scratch = torch.empty((b * nw, heads * n * n), dtype=F32, device=dev)
-        dscale = torch.empty((b * nw, heads), dtype=F32, device=dev)
+        rows = lib.tok_window_attn_bwd_rows(b, h, w, heads, ws)
+        scratch = torch.empty((rows, heads * n * n), dtype=F32, device=dev)
+        dscale = torch.empty((rows, heads), dtype=F32, device=dev)
         tgt, acc = grad_target(qkv)
         if acc:
             raise RuntimeError('window_attention: qkv has a single consumer')
@@ -308,19 +309,19 @@ class _WindowAttnNode(Node):
         if qkv.cp != 3 * c:
             tgt[:, 3 * c:] = 0
         if self.bias_node is not None:
-            dbias_t = torch.empty(heads * n * n, dtype=F32, device=dev)
-            _C.check(lib.tok_colsum_f32(ptr(scratch), b * nw, heads * n * n, ptr(dbias_t), 0, st), 'tok_colsum_f32')
-            self.bias_node.dbias_t = dbias_t
+            dbias = torch.empty(heads * n * n, dtype=F32, device=dev)
+            _C.check(lib.tok_colsum_f32(ptr(scratch), rows, heads * n * n, ptr(dbias), 0, st), 'tok_colsum_f32')
+            self.bias_node.dbias = dbias
         ls = self.logit_scale
         if ls.requires_grad:
             slot, mode = param_grad_target(ls)
             if mode == 2:
                 tmp = torch.empty_like(slot)
-                _C.check(lib.tok_colsum_f32(ptr(dscale), b * nw, heads, ptr(tmp), 0, st), 'tok_colsum_f32')
+                _C.check(lib.tok_colsum_f32(ptr(dscale), rows, heads, ptr(tmp), 0, st), 'tok_colsum_f32')
                 ls.grad.add_(tmp)
                 commit_param_grad(ls, slot, 1)
             else:
-                _C.check(lib.tok_colsum_f32(ptr(dscale), b * nw, heads, ptr(slot), 1 if mode == 1 else 0, st),
+                _C.check(lib.tok_colsum_f32(ptr(dscale), rows, heads, ptr(slot), 1 if mode == 1 else 0, st),
                          'tok_colsum_f32')
                 commit_param_grad(ls, slot, mode)
         self.out.grad = None
