@@ -8,45 +8,47 @@ import torch.nn as nn
 from torch import Tensor
 
 
+def _required(attr: str, message: str, as_tuple: bool = False):
+    """Read-only property over a private attribute that must have been set by the subclass constructor."""
+    def getter(self):
+        value = getattr(self, attr, None)
+        if value is None:
+            raise ValueError(message)
+        return tuple(value) if as_tuple else value
+    return property(getter)
+
+
 class BaseModel(nn.Module, ABC):
+    """in_channels / out_channels contract used by the Tasks to chain backbone -> neck -> pooling -> head."""
+    in_channels = _required('_in_channels', 'TorchOk Models must have self._in_channels attribute.')
+    out_channels = _required('_out_channels', 'TorchOk Models must have self._out_channels attribute.')
+
     def __init__(self, in_channels=None, out_channels=None):
         super().__init__()
-        self._in_channels = in_channels
-        self._out_channels = out_channels
+        self._in_channels, self._out_channels = in_channels, out_channels
 
     @abstractmethod
     def forward(self, *args, **kwargs) -> Tensor:
-        pass
+        ...
 
     def no_weight_decay(self) -> List[str]:
-        return list()
-
-    @property
-    def in_channels(self):
-        if self._in_channels is None:
-            raise ValueError('TorchOk Models must have self._in_channels attribute.')
-        return self._in_channels
-
-    @property
-    def out_channels(self):
-        if self._out_channels is None:
-            raise ValueError('TorchOk Models must have self._out_channels attribute.')
-        return self._out_channels
+        return []
 
     def init_weights(self):
-        # reference models/base.py:50-63
-        for name, m in self.named_modules():
+        """Default initialisation of heads / necks (reference models/base.py:50-63): Kaiming-uniform convs,
+        unit BatchNorm, Xavier-uniform linears, zero biases."""
+        for m in self.modules():
+            bias = getattr(m, 'bias', None)
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, mode='fan_in', nonlinearity='relu')
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
             elif isinstance(m, nn.BatchNorm2d):
                 nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
             elif isinstance(m, nn.Linear):
                 nn.init.xavier_uniform_(m.weight)
-                if m.bias is not None:
-                    nn.init.constant_(m.bias, 0)
+            else:
+                continue
+            if bias is not None:
+                nn.init.constant_(bias, 0)
 
 
 class BaseBackbone(BaseModel, ABC):
@@ -64,11 +66,8 @@ class BaseBackbone(BaseModel, ABC):
     def forward_features(self, x: Tensor) -> List[Tensor]:
         pass
 
-    @property
-    def out_encoder_channels(self) -> Tuple[int]:
-        if self._out_encoder_channels is None:
-            raise ValueError('TorchOk Backbones must have self._out_feature_channels attribute.')
-        return tuple(self._out_encoder_channels)
+    out_encoder_channels = _required('_out_encoder_channels',
+                                     'TorchOk Backbones must have self._out_feature_channels attribute.', as_tuple=True)
 
     @abstractmethod
     def get_stages(self, stage: int) -> nn.Module:

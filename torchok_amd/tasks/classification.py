@@ -17,42 +17,39 @@ class ClassificationTask(BaseTask):
                  head_name: str = None, backbone_params: dict = None, neck_params: dict = None,
                  pooling_params: dict = None, head_params: dict = None, inputs: dict = None):
         super().__init__(hparams, inputs)
-        self.backbone = BACKBONES.get(backbone_name)(**(backbone_params or dict()))
-        if neck_name is None:
-            self.neck = nn.Identity()
-            pooling_in_channels = self.backbone.out_channels
-        else:
-            self.neck = NECKS.get(neck_name)(in_channels=self.backbone.out_encoder_channels, **(neck_params or dict()))
-            pooling_in_channels = self.neck.out_channels
-        if pooling_name is None:
-            self.pooling = nn.Identity()
-            head_in_channels = self.backbone.out_channels
-        else:
-            self.pooling = POOLINGS.get(pooling_name)(in_channels=pooling_in_channels, **(pooling_params or dict()))
-            head_in_channels = self.pooling.out_channels
-        if head_name is None:
-            self.head = nn.Identity()
-        else:
-            self.head = HEADS.get(head_name)(in_channels=head_in_channels, **(head_params or dict()))
+        self.backbone = BACKBONES.get(backbone_name)(**(backbone_params or {}))
+        width = self.backbone.out_channels            # channel count handed down the chain
+        # a missing stage is an Identity and (reference quirk, classification.py:52-71) the head then takes the
+        # BACKBONE width, whatever the neck produced
+        self.neck = nn.Identity()
+        if neck_name is not None:
+            self.neck = NECKS.get(neck_name)(in_channels=self.backbone.out_encoder_channels, **(neck_params or {}))
+            width = self.neck.out_channels
+        self.pooling = nn.Identity()
+        head_width = self.backbone.out_channels
+        if pooling_name is not None:
+            self.pooling = POOLINGS.get(pooling_name)(in_channels=width, **(pooling_params or {}))
+            head_width = self.pooling.out_channels
+        self.head = nn.Identity() if head_name is None else \
+            HEADS.get(head_name)(in_channels=head_width, **(head_params or {}))
+
+    def _stages(self):
+        return self.backbone, self.neck, self.pooling
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.backbone(x)
-        x = self.neck(x)
-        x = self.pooling(x)
-        x = self.head(x)
-        return x
+        for stage in self._stages():
+            x = stage(x)
+        return self.head(x)
 
     def forward_with_gt(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Tensor]:
-        input_data = batch.get('image')
         target = batch.get('target')
-        features = self.backbone(input_data)
-        features = self.neck(features)
-        embeddings = self.pooling(features)
-        prediction = self.head(embeddings, target)
-        output = {'embeddings': embeddings, 'prediction': prediction}
+        x = batch.get('image')
+        for stage in self._stages():
+            x = stage(x)
+        output = {'embeddings': x, 'prediction': self.head(x, target)}
         if target is not None:
             output['target'] = target
         return output
 
     def as_module(self) -> nn.Sequential:
-        return nn.Sequential(self.backbone, self.neck, self.pooling, self.head)
+        return nn.Sequential(*self._stages(), self.head)
