@@ -206,3 +206,35 @@ class SegmentationModel(nn.Module):
     def forward_with_gt(self, batch):                    # tasks/segmentation.py:60-93
         feats = self.backbone.forward_features(batch['image'])
         return {'prediction': self.head_forward(self.neck_forward(feats)), 'target': batch['target']}
+
+
+class ClassificationNeck(nn.Module):
+    """`HRNetClassificationNeck` (necks/classification/hrnet.py:12-92), including its forward as written: the loop
+    OVERWRITES y with incre_modules[i + 1](x[i + 1]) (:88-90), so only the last branch reaches final_layer."""
+
+    class _CBA(nn.Module):          # models/modules/bricks/convbnact.py
+        def __init__(self, cin, cout, k, pad, stride, act=True):
+            super().__init__()
+            self.conv = nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=False)
+            self.bn = nn.BatchNorm2d(cout)
+            self.act = nn.ReLU(inplace=True) if act else nn.Identity()
+
+        def forward(self, x):
+            return self.act(self.bn(self.conv(x)))
+
+    def __init__(self, in_channels):
+        super().__init__()
+        hc, e = [32, 64, 128, 256], Bottleneck.expansion
+        self.incre_modules = nn.ModuleList(
+            nn.Sequential(Bottleneck(c, hc[i], 1, self._CBA(c, hc[i] * e, 1, 0, 1, act=False) if c != hc[i] * e else None))
+            for i, c in enumerate(in_channels))
+        self.downsamp_modules = nn.ModuleList(self._CBA(hc[i] * e, hc[i + 1] * e, 3, 1, 2) for i in range(len(in_channels) - 1))
+        self.final_layer = self._CBA(hc[3] * e, 2048, 1, 0, 1)
+
+    def forward(self, x):
+        y = self.incre_modules[0](x[0])
+        for i in range(len(self.downsamp_modules)):
+            y = self.downsamp_modules[i](y)
+            if i + 1 < len(x):
+                y = self.incre_modules[i + 1](x[i + 1])
+        return self.final_layer(y)

@@ -175,3 +175,38 @@ def test_reference_neck_test_w18(dev):
         input_image, features = neck(backbone.forward_features(x))
     assert tuple(features.shape) == (2, 270, 56, 56)
     assert tuple(input_image.shape) == (2, 3, 224, 224)
+
+
+def test_classification_neck(dev):
+    """HRNetClassificationNeck: reference shape test (necks/test_hrnet.py:15-19, hrnet_w18 -> (2, 2048, 7, 7)) and values /
+    gradients / BatchNorm side effects vs the oracle restatement (the loop overwrites y, as in the reference)."""
+    chans = (16, 32, 64, 128)
+    neck = T.NECKS.get('HRNetClassificationNeck')(chans)
+    ref = H.ClassificationNeck(chans)
+    assert {k: tuple(v.shape) for k, v in neck.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    sd = deterministic_state(ref.state_dict(), 9)
+    ref.load_state_dict(sd)
+    neck.load_state_dict(sd)
+    neck.to(dev).train()
+    ref.train()
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(4, c, 32 >> i, 32 >> i, generator=g) for i, c in enumerate(chans)]
+    xd = [t.to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last).requires_grad_(True) for t in xs]
+    xr = [t.to(torch.bfloat16).float().requires_grad_(True) for t in xs]
+    y, yr = neck(xd), ref(xr)
+    assert tuple(y.shape) == (4, 2048, 4, 4)
+    assert rel_err(y.float(), yr) < 2e-2
+    w = torch.randn(yr.shape, generator=g)
+    (y.float() * w.to(dev)).sum().backward()
+    (yr * w).sum().backward()
+    assert rel_err(xd[3].grad.float(), xr[3].grad) < 0.12     # bf16 through 4 BatchNorms over 64 samples + ReLU masks
+    assert all(t.grad is None for t in xd[:3]) or all(float(t.grad.abs().max()) == 0 for t in xd[:3] if t.grad is not None)
+    used = {n for n, p in ref.named_parameters() if p.grad is not None}
+    for n, p in neck.named_parameters():
+        assert (p.grad is not None) == (n in used), n
+    # the dead down-sampling branch still moved its running statistics (training-mode BatchNorm), as in the reference
+    assert rel_err(neck.downsamp_modules[0].bn.running_mean, ref.downsamp_modules[0].bn.running_mean) < 2e-2
+    bb = T.BACKBONES.get('hrnet_w18')(pretrained=False).to(dev)
+    nk = T.NECKS.get('HRNetClassificationNeck')(bb.out_channels).to(dev)
+    with torch.no_grad():
+        assert tuple(nk(bb(torch.rand(2, 3, 224, 224).to(dev))).shape) == (2, 2048, 7, 7)

@@ -59,7 +59,7 @@ class BasicBlock(nn.Module):
         shortcut = x
         y = EF.conv_bn_act(r, x, self.conv1, self.bn1, relu=True)
         if self.downsample is not None:
-            shortcut = EF.conv_bn_act(r, x, self.downsample[0], self.downsample[1], relu=False)
+            shortcut = _run_downsample(r, x, self.downsample)
         return EF.conv_bn_act(r, y, self.conv2, self.bn2, relu=True, shortcut=shortcut)
 
 
@@ -96,8 +96,16 @@ class Bottleneck(nn.Module):
         y = EF.conv_bn_act(r, x, self.conv1, self.bn1, relu=True)
         y = EF.conv_bn_act(r, y, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
-            shortcut = EF.conv_bn_act(r, x, self.downsample[0], self.downsample[1], relu=False)
+            shortcut = _run_downsample(r, x, self.downsample)
         return EF.conv_bn_act(r, y, self.conv3, self.bn3, relu=True, shortcut=shortcut)
+
+
+def _run_downsample(r, x, downsample):
+    """Shortcut projection: an ``nn.Sequential(conv, bn)`` ([timm] downsample_conv, hrnet.py) or a ConvBnAct brick
+    without activation (necks/classification/hrnet.py:62-69)."""
+    if hasattr(downsample, 'run'):
+        return downsample.run(r, x)
+    return EF.conv_bn_act(r, x, downsample[0], downsample[1], relu=False)
 
 
 def _unsupported(**flags):

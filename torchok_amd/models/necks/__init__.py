@@ -1,1 +1,2 @@
+from .hrnet_classification import HRNetClassificationNeck  # noqa: F401
 from .hrnet_segmentation import HRNetSegmentationNeck  # noqa: F401
