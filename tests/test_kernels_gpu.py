@@ -636,7 +636,7 @@ def test_bn_padded_channels(libs):
 
 # ---- token-major transformer kernels (transformer.hip) ---------------------------------------------------------
 @pytest.mark.parametrize('rows,c,ld,sc,rs', [(37, 96, 96, 0, 0), (64, 768, 768, 1, 1), (50, 18, 24, 1, 0),
-                                             (4096, 192, 192, 1, 1)])
+                                             (4096, 192, 192, 1, 1), (333, 384, 384, 1, 0), (130, 1024, 1024, 0, 1)])
 def test_layernorm(libs, rows, c, ld, sc, rs):
     rps = rows // 2 if rows % 2 == 0 else rows
     x = torch.zeros(rows, ld)

@@ -16,7 +16,155 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row.
+// LayerNorm.  16-byte vector lanes: a row of c channels is covered by LPR lanes (16 / 32 / 64) holding VPL vectors
+// of 8 channels each, so a wave normalises 64 / LPR rows at once and every global access is a full 16-byte lane
+// (c % 8 == 0, c <= 1024).  Other widths (HRNet never, SwinV2 never) use the scalar one-wave-per-row kernels.
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shortcut,
+                                                         const float* __restrict__ row_scale, int rows_per_sample,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         bf16* __restrict__ out, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int64_t rows, int c, float eps) {
+  constexpr int RPW = 64 / LPR;                 // rows per wave
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < rows;
+  const int cg = c >> 3;
+  float v[VPL][8];
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int g = sub + u * LPR;
+    if (live && g < cg) {
+      const bf16x8 t = ldg16(x + row * c + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[u][e] = bf2f(t[e]); s += v[u][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+  const float mu = s / (float)c;
+  float q = 0.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u)
+    if (sub + u * LPR < cg)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[u][e] - mu; q = fmaf(d, d, q); }
+#pragma unroll
+  for (int off = 1; off < LPR; off <<= 1) q += __shfl_xor(q, off, 64);
+  const float rs = rsqrtf(q / (float)c + eps);
+  if (!live) return;
+  if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float sc = row_scale ? row_scale[row / rows_per_sample] : 1.f;
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int g = sub + u * LPR;
+    if (g >= cg) continue;
+    float ga[8], be[8];
+    *reinterpret_cast<f32x4*>(ga) = *reinterpret_cast<const f32x4*>(gamma + g * 8);
+    *reinterpret_cast<f32x4*>(ga + 4) = *reinterpret_cast<const f32x4*>(gamma + g * 8 + 4);
+    *reinterpret_cast<f32x4*>(be) = *reinterpret_cast<const f32x4*>(beta + g * 8);
+    *reinterpret_cast<f32x4*>(be + 4) = *reinterpret_cast<const f32x4*>(beta + g * 8 + 4);
+    bf16x8 o;
+    if (shortcut != nullptr) {
+      const bf16x8 sh = ldg16(shortcut + row * c + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(((v[u][e] - mu) * rs * ga[e] + be[e]) * sc + bf2f(sh[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(((v[u][e] - mu) * rs * ga[e] + be[e]) * sc);
+    }
+    stg16(out + row * c + g * 8, o);
+  }
+}
+
+// backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dout * scale * gamma; each lane keeps the dgamma /
+// dbeta contributions of ITS 8*VPL columns in registers across all the rows it visits, then the lanes that own the
+// same columns are folded through LDS -> one partial row per block (fixed order: deterministic)
+template <int LPR, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ x,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ row_scale,
+                                                         int rows_per_sample, bf16* dx, int accumulate,
+                                                         float* __restrict__ partial, int64_t rows, int c) {
+  constexpr int RPW = 64 / LPR, RPB = 4 * RPW;  // rows per wave / per block pass
+  extern __shared__ float sm[];                 // [RPB][2][c]
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int rl = (threadIdx.x >> 6) * RPW + lane / LPR;     // row slot inside the block pass
+  const int cg = c >> 3;
+  float ga[VPL][8], pg[VPL][8], pb[VPL][8];
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int g = sub + u * LPR;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ga[u][e] = g < cg ? gamma[g * 8 + e] : 0.f; pg[u][e] = 0.f; pb[u][e] = 0.f; }
+  }
+  for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < rows; row0 += (int64_t)gridDim.x * RPB) {
+    const int64_t row = row0 + rl;
+    const bool live = row < rows;
+    const float mu = live ? mean[row] : 0.f, rs = live ? rstd[row] : 0.f;
+    const float sc = (live && row_scale) ? row_scale[row / rows_per_sample] : 1.f;
+    float xh[VPL][8], gg[VPL][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < VPL; ++u) {
+      const int g = sub + u * LPR;
+      if (live && g < cg) {
+        const bf16x8 xv = ldg16(x + row * c + g * 8), gv = ldg16(dout + row * c + g * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[u][e] = (bf2f(xv[e]) - mu) * rs;
+          const float go = bf2f(gv[e]) * sc;
+          gg[u][e] = go * ga[u][e];
+          s1 += gg[u][e];
+          s2 = fmaf(gg[u][e], xh[u][e], s2);
+          pg[u][e] = fmaf(go, xh[u][e], pg[u][e]);
+          pb[u][e] += go;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xh[u][e] = 0.f; gg[u][e] = 0.f; }
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < LPR; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    const float m1 = s1 / (float)c, m2 = s2 / (float)c;
+    if (live)
+#pragma unroll
+      for (int u = 0; u < VPL; ++u) {
+        const int g = sub + u * LPR;
+        if (g >= cg) continue;
+        bf16* d = dx + row * c + g * 8;
+        bf16x8 o;
+        const bf16x8 prev = accumulate ? ldg16(d) : zero8();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(rs * (gg[u][e] - m1 - xh[u][e] * m2) + bf2f(prev[e]));
+        stg16(d, o);
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < VPL; ++u) {
+    const int g = sub + u * LPR;
+    if (g < cg)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sm[((size_t)rl * 2 + 0) * c + g * 8 + e] = pg[u][e];
+        sm[((size_t)rl * 2 + 1) * c + g * 8 + e] = pb[u][e];
+      }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * c; i += 256) {
+    const int which = i / c, col = i - which * c;
+    float t = 0.f;
+    for (int r = 0; r < RPB; ++r) t += sm[((size_t)r * 2 + which) * c + col];
+    partial[((size_t)which * gridDim.x + blockIdx.x) * c + col] = t;
+  }
+}
+
+// scalar fallback: one wave per row.
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ shortcut,
                                                      const float* __restrict__ row_scale, int rows_per_sample,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -794,9 +942,23 @@ extern "C" int tok_layernorm_fwd(const void* x, const void* shortcut, const floa
                                  int64_t rows, int c, int ld, float eps, void* stream) {
   TOK_CHECK_ARG(x && gamma && beta && out && mean && rstd && rows > 0 && c > 0 && ld >= c, "tok_layernorm_fwd: bad args");
   TOK_CHECK_ARG(!row_scale || rows_per_sample > 0, "tok_layernorm_fwd: rows_per_sample");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, tok_stream(stream), (const bf16*)x,
-                     (const bf16*)shortcut, row_scale, rows_per_sample, gamma, beta, (bf16*)out, mean, rstd, rows, c, ld,
-                     eps);
+  hipStream_t st = tok_stream(stream);
+  if (c == ld && c % 8 == 0 && c <= 1024) {
+#define TOK_LN_FWD(LPR, VPL)                                                                                          \
+  hipLaunchKernelGGL((ln_fwd_vec_kernel<LPR, VPL>), dim3((unsigned)tok_cdiv(rows, 4 * (64 / LPR))), dim3(256), 0, st, \
+                     (const bf16*)x, (const bf16*)shortcut, row_scale, rows_per_sample, gamma, beta, (bf16*)out, mean,  \
+                     rstd, rows, c, eps)
+    const int cg = c >> 3;
+    if (cg <= 16) TOK_LN_FWD(16, 1);
+    else if (cg <= 32) TOK_LN_FWD(32, 1);
+    else if (cg <= 64) TOK_LN_FWD(64, 1);
+    else TOK_LN_FWD(64, 2);
+#undef TOK_LN_FWD
+  } else {
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)x,
+                       (const bf16*)shortcut, row_scale, rows_per_sample, gamma, beta, (bf16*)out, mean, rstd, rows, c, ld,
+                       eps);
+  }
   TOK_CHECK_LAUNCH("tok_layernorm_fwd");
   return TOK_OK;
 }
@@ -812,11 +974,27 @@ extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* m
                                  int accumulate, float* partial, int64_t rows, int c, int ld, void* stream) {
   TOK_CHECK_ARG(dout && x && mean && rstd && gamma && dx && partial && rows > 0 && c > 0 && ld >= c,
                 "tok_layernorm_bwd: bad args");
-  TOK_CHECK_ARG((size_t)c * 8 * sizeof(float) <= 64 * 1024, "tok_layernorm_bwd: c too large (%d)", c);
   const int g = tok_layernorm_bwd_rows(rows, c);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), (size_t)c * 8 * sizeof(float), tok_stream(stream),
-                     (const bf16*)dout, (const bf16*)x, mean, rstd, gamma, row_scale, rows_per_sample, (bf16*)dx,
-                     accumulate, partial, rows, c, ld);
+  hipStream_t st = tok_stream(stream);
+  if (c == ld && c % 8 == 0 && c <= 1024) {
+#define TOK_LN_BWD(LPR, VPL)                                                                                              \
+  do {                                                                                                                    \
+    const size_t smem = (size_t)(4 * (64 / LPR)) * 2 * c * sizeof(float);                                                 \
+    hipLaunchKernelGGL((ln_bwd_vec_kernel<LPR, VPL>), dim3(g), dim3(256), smem, st, (const bf16*)dout, (const bf16*)x,    \
+                       mean, rstd, gamma, row_scale, rows_per_sample, (bf16*)dx, accumulate, partial, rows, c);           \
+  } while (0)
+    const int cg = c >> 3;
+    if (cg <= 16) TOK_LN_BWD(16, 1);
+    else if (cg <= 32) TOK_LN_BWD(32, 1);
+    else if (cg <= 64) TOK_LN_BWD(64, 1);
+    else TOK_LN_BWD(64, 2);
+#undef TOK_LN_BWD
+  } else {
+    TOK_CHECK_ARG((size_t)c * 8 * sizeof(float) <= 64 * 1024, "tok_layernorm_bwd: c too large (%d)", c);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(256), (size_t)c * 8 * sizeof(float), st, (const bf16*)dout,
+                       (const bf16*)x, mean, rstd, gamma, row_scale, rows_per_sample, (bf16*)dx, accumulate, partial,
+                       rows, c, ld);
+  }
   TOK_CHECK_LAUNCH("tok_layernorm_bwd");
   return TOK_OK;
 }
