@@ -40,6 +40,18 @@ def resnet50_convs(B):
     return out
 
 
+def swinv2t_linears(B):
+    """The token GEMMs of SwinV2-T at 224 (window 7): 1x1 'convs' over (B, H, W, C) token maps."""
+    out = []
+    for res, c, blocks in ((56, 96, 2), (28, 192, 2), (14, 384, 6), (7, 768, 2)):
+        for _ in range(blocks):
+            for name, cin, cout in (('qkv', c, 3 * c), ('proj', c, c), ('fc1', c, 4 * c), ('fc2', 4 * c, c)):
+                out.append(dict(name=name, n=B, h=res, w=res, c=cin, k=cout, r=1, stride=1, pad=0))
+        if res > 7:
+            out.append(dict(name='merge', n=B, h=res // 2, w=res // 2, c=4 * c, k=2 * c, r=1, stride=1, pad=0))
+    return out
+
+
 def timeit(fn, iters=8, warm=2):
     for _ in range(warm):
         fn()
@@ -58,12 +70,13 @@ def main():
     ap.add_argument('--lib', default=None)
     ap.add_argument('--what', default='fwd,dgrad,wgrad')
     ap.add_argument('--batch', type=int, default=256)
+    ap.add_argument('--net', default='resnet50', choices=['resnet50', 'swinv2t'])
     args = ap.parse_args()
     lib = _C.load_library(args.lib)
     what = args.what.split(',')
     st = torch.cuda.current_stream().cuda_stream
     shapes = OrderedDict()
-    for c in resnet50_convs(args.batch):
+    for c in (resnet50_convs if args.net == 'resnet50' else swinv2t_linears)(args.batch):
         key = (c['h'], c['c'], c['k'], c['r'], c['stride'])
         shapes.setdefault(key, [c, 0])
         shapes[key][1] += 1

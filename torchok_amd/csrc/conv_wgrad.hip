@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   if (C4) { kr = k0 >> 5; ks = (k0 & 31) >> 2; kc0 = 0; }
   else { const int tap = k0 / a.C; kc0 = k0 - tap * a.C; kr = tap / a.S; ks = tap - kr * a.S; }
   const bool k_ok = kr < a.R;
+  const bool pointwise = !C4 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
 
   int xm[XP], xq[XP], xp[XP], xpix[XP];
 #pragma unroll
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
           for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
         }
       } else {
-        const uint32_t off = (ok && (unsigned)ww < (unsigned)a.W)
+        // pointwise (1x1, stride 1, no padding: every Linear and most ResNet convs): input pixel == output pixel
+        const uint32_t off = pointwise ? ((k_ok && xm[i] < mend) ? (uint32_t)(xm[i] * a.C + kc0) * 2u : 0xFFFFFFF0u)
+                             : (ok && (unsigned)ww < (unsigned)a.W)
                                  ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
         if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
         else v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
@@ -143,10 +146,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
       rx[i] = v;
       // advance this row cursor by MS output pixels
       xm[i] += MS;
-      xq[i] += MS;
-      while (xq[i] >= a.Q) {
-        xq[i] -= a.Q;
-        if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
+      if (!pointwise) {
+        xq[i] += MS;
+        if (a.Q >= MS) {            // at most one row wrap per step
+          while (xq[i] >= a.Q) {
+            xq[i] -= a.Q;
+            if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
+          }
+        } else if (xq[i] >= a.Q) {  // narrow maps (7x7 and below): the wrap count comes from a division, not a loop
+          const int adv = xq[i] / a.Q;
+          xq[i] -= adv * a.Q;
+          xp[i] += adv;
+          if (xp[i] >= a.P) {
+            const int imgs = xp[i] / a.P;
+            xp[i] -= imgs * a.P;
+            xpix[i] += imgs * a.HW;
+          }
+        }
       }
     }
   };
