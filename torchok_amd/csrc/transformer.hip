@@ -385,167 +385,158 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a, const bf16* __
   }
 }
 
-// ---- MFMA forward for windows of up to 64 tokens (7x7, 8x8): one wave per (image, window, head) -----------------
-// S = Qn Kn^T as 4x4 tiles of mfma_f32_16x16x32_bf16 (K = head_dim = 32: one instruction per tile), fp32 softmax on
+// ---- MFMA kernels for windows of up to 64 tokens (7x7, 8x8): one 4-wave workgroup per (image, window, head) ------
+// S = Qn Kn^T as 16x16 tiles of mfma_f32_16x16x32_bf16 (K = head_dim = 32: one instruction per tile), fp32 softmax on
 // the accumulator layout (row = 4*(lane>>4)+reg, col = lane&15), P through LDS (bf16) into the A operand of
-// O = P V (V kept transposed in LDS so a lane's 8 k-slots are 8 consecutive keys).
+// O = P V (V kept transposed in LDS so a lane's 8 k-slots are 8 consecutive keys).  Wave w owns query tile w; the
+// four waves stage q / k / v (/ dO) in parallel.  (One wave per unit left < 1 wave per SIMD resident: LDS-bound
+// occupancy, every latency exposed.)
 constexpr int QPITCH = 40;    // bf16 elements per Q/K row in LDS (32 + 8: spreads 16 rows over the banks)
-constexpr int PPITCH = 72;    // P rows / V^T rows: 64 keys + 8
-constexpr int MFMA_WAVE_LDS = (2 * 64 * QPITCH + 32 * PPITCH + 64 * PPITCH) * 2;   // bytes per wave
+constexpr int PPITCH = 72;    // P rows / transposed rows: 64 + 8
+constexpr int MFMA_FWD_LDS = (2 * 64 * QPITCH + 32 * PPITCH + 64 * PPITCH) * 2;   // bytes per workgroup
+
+// token t of the unit: loads one 32-wide head slice, optionally L2-normalises it (F.normalize, eps 1e-12)
+__device__ __forceinline__ float load_head_row(const bf16* __restrict__ src, bool valid, bool normalise, bf16x8 (&o)[4]) {
+  float f[HD], ss = 0.f;
+  if (valid) {
+#pragma unroll
+    for (int d = 0; d < HD; d += 8) {
+      const bf16x8 t8 = ldg16(src + d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { f[d + e] = bf2f(t8[e]); ss = fmaf(f[d + e], f[d + e], ss); }
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) f[d] = 0.f;
+  }
+  const float inv = normalise ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+#pragma unroll
+  for (int d = 0; d < HD; d += 8)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[d >> 3][e] = f2bf(f[d + e] * inv);
+  return inv;
+}
+
+__device__ __forceinline__ void put_row(bf16* rowmaj, bf16* trans, int t, const bf16x8 (&v)[4]) {
+#pragma unroll
+  for (int d = 0; d < HD; d += 8) {
+    if (rowmaj) *reinterpret_cast<bf16x8*>(rowmaj + t * QPITCH + d) = v[d >> 3];
+    if (trans)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) trans[(d + e) * PPITCH + t] = v[d >> 3][e];
+  }
+}
 
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
                                                             const float* __restrict__ logit_scale,
                                                             const float* __restrict__ bias, const float* __restrict__ mask,
-                                                            bf16* __restrict__ out, float* __restrict__ lse, int units) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ char smraw[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wv;
-  if (unit >= units) return;            // whole wave exits: no block-level barriers below
-  bf16* qs = reinterpret_cast<bf16*>(smraw + (size_t)wv * MFMA_WAVE_LDS);
+  bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
   bf16* vt = ks + 64 * QPITCH;          // [32 dims][PPITCH keys]
   bf16* ps = vt + 32 * PPITCH;          // [64 queries][PPITCH keys]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int unit = blockIdx.x;
   const int h = unit % a.heads;
   const int win = (unit / a.heads) % a.nW;
   const int b = unit / (a.heads * a.nW);
   const int N = a.N;
-  // ---- stage q (normalised), k (normalised), v^T as bf16; rows >= N are zero ----
-  {
+  if (wv < 3) {   // wave 0: q (normalised), wave 1: k (normalised), wave 2: v^T
     const int t = lane;
-    float q[HD], k[HD];
-    bf16x8 vv[4];
-    float sq = 0.f, sk = 0.f;
-    if (t < N) {
-      const bf16* r = qkv + token_row(a, b, win, t) * a.ld + h * HD;
-#pragma unroll
-      for (int d = 0; d < HD; d += 8) {
-        const bf16x8 q8 = ldg16(r + d), k8 = ldg16(r + a.C + d);
-        vv[d >> 3] = ldg16(r + 2 * a.C + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          q[d + e] = bf2f(q8[e]); k[d + e] = bf2f(k8[e]);
-          sq = fmaf(q[d + e], q[d + e], sq); sk = fmaf(k[d + e], k[d + e], sk);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int d = 0; d < HD; ++d) { q[d] = 0.f; k[d] = 0.f; }
-#pragma unroll
-      for (int d = 0; d < 4; ++d) vv[d] = zero8();
-    }
-    const float qi = 1.f / fmaxf(sqrtf(sq), 1e-12f), ki = 1.f / fmaxf(sqrtf(sk), 1e-12f);
-#pragma unroll
-    for (int d = 0; d < HD; d += 8) {
-      bf16x8 q8, k8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { q8[e] = f2bf(q[d + e] * qi); k8[e] = f2bf(k[d + e] * ki); }
-      *reinterpret_cast<bf16x8*>(qs + t * QPITCH + d) = q8;
-      *reinterpret_cast<bf16x8*>(ks + t * QPITCH + d) = k8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vt[(d + e) * PPITCH + t] = vv[d >> 3][e];
-    }
+    bf16x8 r8[4];
+    const bf16* src = qkv + token_row(a, b, win, t < N ? t : 0) * a.ld + h * HD + wv * a.C;
+    load_head_row(src, t < N, wv < 2, r8);
+    put_row(wv == 0 ? qs : (wv == 1 ? ks : nullptr), wv == 2 ? vt : nullptr, t, r8);
   }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const int l15 = lane & 15, g = lane >> 4;
+  __syncthreads();
+  const int l15 = lane & 15, g = lane >> 4, qi = wv;
   const float scale = expf(fminf(logit_scale[h], 4.605170185988092f));
   const float* bh = bias + (size_t)h * N * N;
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
-  bf16x8 kf[4];
+  const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
+  f32x4 sc[4];
 #pragma unroll
-  for (int kj = 0; kj < 4; ++kj) kf[kj] = *reinterpret_cast<const bf16x8*>(ks + (kj * 16 + l15) * QPITCH + g * 8);
-  float rsum[4][4], rmax[4][4];
+  for (int kj = 0; kj < 4; ++kj) {
+    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (kj * 16 + l15) * QPITCH + g * 8);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
+  }
+  float rsum[4], rmax[4];
+  // element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
 #pragma unroll
-  for (int qi = 0; qi < 4; ++qi) {
-    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
-    f32x4 sc[4];
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = qi * 16 + 4 * g + reg;
+    float mx = -INFINITY;
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[kj], z, 0, 0, 0);
+      const int j = kj * 16 + l15;
+      float v = -INFINITY;
+      if (i < N && j < N) v = sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f);
+      sc[kj][reg] = v;
+      mx = fmaxf(mx, v);
     }
-    // element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+      const float p = (i < N) ? expf(sc[kj][reg] - mx) : 0.f;
+      sc[kj][reg] = p;
+      sum += p;
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+    rsum[reg] = sum;
+    rmax[reg] = mx;
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) ps[i * PPITCH + kj * 16 + l15] = f2bf(sc[kj][reg]);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();      // P rows of this query tile are produced and consumed by the same wave
+  // ---- O = P V : A = P[query][key slots], B = V^T[dim][key slots] ----
+  bf16x8 pf[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+    pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
+#pragma unroll
+  for (int dj = 0; dj < 2; ++dj) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (dj * 16 + l15) * PPITCH + kt * 32 + g * 8);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kt], vf, o, 0, 0, 0);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kj = 0; kj < 4; ++kj) {
-        const int j = kj * 16 + l15;
-        float v = -INFINITY;
-        if (i < N && j < N) v = sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f);
-        sc[kj][reg] = v;
-        mx = fmaxf(mx, v);
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      float sum = 0.f;
-#pragma unroll
-      for (int kj = 0; kj < 4; ++kj) {
-        const float p = (i < N) ? expf(sc[kj][reg] - mx) : 0.f;
-        sc[kj][reg] = p;
-        sum += p;
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
-      rsum[qi][reg] = sum;
-      rmax[qi][reg] = mx;
-#pragma unroll
-      for (int kj = 0; kj < 4; ++kj) ps[i * PPITCH + kj * 16 + l15] = f2bf(sc[kj][reg]);
+      if (i < N) out[token_row(a, b, win, i) * a.C + h * HD + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // ---- O = P V : A = P[query][key slots], B = V^T[dim][key slots] ----
-  bf16x8 vf[2][2];
 #pragma unroll
-  for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-      vf[dj][kt] = *reinterpret_cast<const bf16x8*>(vt + (dj * 16 + l15) * PPITCH + kt * 32 + g * 8);
-#pragma unroll
-  for (int qi = 0; qi < 4; ++qi) {
-    bf16x8 pf[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-      pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[0], vf[dj][0], o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[1], vf[dj][1], o, 0, 0, 0);
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = qi * 16 + 4 * g + reg;
-        if (i < N) out[token_row(a, b, win, i) * a.C + h * HD + dj * 16 + l15] = f2bf(o[reg] / rsum[qi][reg]);
-      }
-    }
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int i = qi * 16 + 4 * g + reg;
-      if (i < N && l15 == 0) lse[(size_t)unit * N + i] = rmax[qi][reg] + logf(rsum[qi][reg]);
-    }
+  for (int reg = 0; reg < 4; ++reg) {
+    const int i = qi * 16 + 4 * g + reg;
+    if (i < N && l15 == 0) lse[(size_t)unit * N + i] = rmax[reg] + logf(rsum[reg]);
   }
 }
 
-// ---- MFMA backward for windows of up to 64 tokens: one wave per (image group, window, head) -------------------------
-// Recomputes P from (Qn, Kn, lse); dP = dO V^T on the same accumulator layout, dS = P (dP - delta) in registers;
-// dV = P^T dO, dKn = dS^T Qn, dQn = dS Kn through bf16 LDS staging; F.normalize backward on the accumulators.
-// A wave walks `bpw` images of its (window, head) and keeps d(logits) summed in registers, so the d(bias) scratch
-// holds one [N][N] tile per wave instead of one per (image, window, head).
+// Backward: recomputes P from (Qn, Kn, lse); dP = dO V^T on the same accumulator layout, dS = P (dP - delta) in
+// registers; dV = P^T dO, dKn = dS^T Qn, dQn = dS Kn through bf16 LDS staging; F.normalize backward on the
+// accumulators.  A workgroup walks `bpw` images of its (window, head) and sums d(logits) into ONE [N][N] scratch tile
+// (L2-resident read-modify-write by the owning lane), so the d(bias) scratch is bpw times smaller.
 constexpr int BW_ROWMAJ = 4 * 64 * QPITCH;            // qn, kn, v, dO (bf16 elements); later reused: dS, dS^T staging
 constexpr int BW_TRANS = 3 * 32 * PPITCH;             // Qn^T, Kn^T, dO^T
 constexpr int BW_PT = 64 * PPITCH;                    // P^T staging
-constexpr int MFMA_BWD_LDS = (BW_ROWMAJ + BW_TRANS + BW_PT) * 2 + 2 * 64 * 4;   // + qinv, kinv (fp32)
+constexpr int MFMA_BWD_LDS = (BW_ROWMAJ + BW_TRANS + BW_PT) * 2 + (2 * 64 + 4) * 4;   // + qinv, kinv, 4 partial sums
 static_assert(2 * 64 * PPITCH <= BW_ROWMAJ, "staging must fit the row-major region");
 
-__global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
-                                                           const bf16* __restrict__ dout,
-                                                           const float* __restrict__ logit_scale,
-                                                           const float* __restrict__ bias, const float* __restrict__ mask,
-                                                           const float* __restrict__ lse, bf16* __restrict__ dqkv,
-                                                           float* __restrict__ ds_scratch, float* __restrict__ dscale_part,
-                                                           int bpw) {
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
+                                                            const bf16* __restrict__ dout,
+                                                            const float* __restrict__ logit_scale,
+                                                            const float* __restrict__ bias, const float* __restrict__ mask,
+                                                            const float* __restrict__ lse, bf16* __restrict__ dqkv,
+                                                            float* __restrict__ ds_scratch, float* __restrict__ dscale_part,
+                                                            int bpw) {
   extern __shared__ char smraw[];
   bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
@@ -557,9 +548,10 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnArgs a, const bf1
   bf16* pt = gt + 32 * PPITCH;           // P^T [key][query]
   float* qinv = reinterpret_cast<float*>(pt + 64 * PPITCH);
   float* kinv = qinv + 64;
+  float* wsum = kinv + 64;
   bf16* dsr = qs;                        // dS  [query][key]  (aliases the row-major region after the fragment loads)
   bf16* dst = qs + 64 * PPITCH;          // dS^T [key][query]
-  const int lane = threadIdx.x, l15 = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int N = a.N;
   const int h = blockIdx.x % a.heads;
   const int win = (blockIdx.x / a.heads) % a.nW;
@@ -568,126 +560,70 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnArgs a, const bf1
   const float scale = expf(fminf(raw_ls, 4.605170185988092f));
   const float* bh = bias + (size_t)h * N * N;
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
-  float* dS = ds_scratch + (size_t)blockIdx.x * N * N;   // this wave's d(logits) tile, summed over its images (L2-resident)
+  float* dS = ds_scratch + (size_t)blockIdx.x * N * N;
   float dsc = 0.f;
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
-    if (b >= a.B) break;
+    if (b >= a.B) break;                 // uniform for the workgroup
     const size_t unit = ((size_t)b * a.nW + win) * a.heads + h;
-    // ---- stage: qn, kn, v, dO row-major; qn^T, kn^T, dO^T; 1/|q|, 1/|k| ----
-    {
+    {   // wave 0: q, wave 1: k (normalised, + transposes, + 1/norm); wave 2: v; wave 3: dO (+ transpose)
       const int t = lane;
-      float q[HD], k[HD];
-      bf16x8 vv[4], gg[4];
-      float sq = 0.f, sk = 0.f;
-      if (t < N) {
-        const int64_t row = token_row(a, b, win, t);
-        const bf16* r = qkv + row * a.ld + h * HD;
-        const bf16* gr = dout + row * a.C + h * HD;
-#pragma unroll
-        for (int d = 0; d < HD; d += 8) {
-          const bf16x8 q8 = ldg16(r + d), k8 = ldg16(r + a.C + d);
-          vv[d >> 3] = ldg16(r + 2 * a.C + d);
-          gg[d >> 3] = ldg16(gr + d);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            q[d + e] = bf2f(q8[e]); k[d + e] = bf2f(k8[e]);
-            sq = fmaf(q[d + e], q[d + e], sq); sk = fmaf(k[d + e], k[d + e], sk);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int d = 0; d < HD; ++d) { q[d] = 0.f; k[d] = 0.f; }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) { vv[d] = zero8(); gg[d] = zero8(); }
-      }
-      const float qi_ = 1.f / fmaxf(sqrtf(sq), 1e-12f), ki_ = 1.f / fmaxf(sqrtf(sk), 1e-12f);
-      qinv[t] = qi_;
-      kinv[t] = ki_;
-#pragma unroll
-      for (int d = 0; d < HD; d += 8) {
-        bf16x8 q8, k8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { q8[e] = f2bf(q[d + e] * qi_); k8[e] = f2bf(k[d + e] * ki_); }
-        *reinterpret_cast<bf16x8*>(qs + t * QPITCH + d) = q8;
-        *reinterpret_cast<bf16x8*>(ks + t * QPITCH + d) = k8;
-        *reinterpret_cast<bf16x8*>(vs + t * QPITCH + d) = vv[d >> 3];
-        *reinterpret_cast<bf16x8*>(gs + t * QPITCH + d) = gg[d >> 3];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          qt[(d + e) * PPITCH + t] = q8[e];
-          kt[(d + e) * PPITCH + t] = k8[e];
-          gt[(d + e) * PPITCH + t] = gg[d >> 3][e];
-        }
-      }
+      bf16x8 r8[4];
+      const int64_t row = token_row(a, b, win, t < N ? t : 0);
+      const bf16* src = wv < 3 ? qkv + row * a.ld + h * HD + wv * a.C : dout + row * a.C + h * HD;
+      const float inv = load_head_row(src, t < N, wv < 2, r8);
+      if (wv == 0) { put_row(qs, qt, t, r8); qinv[t] = inv; }
+      else if (wv == 1) { put_row(ks, kt, t, r8); kinv[t] = inv; }
+      else if (wv == 2) put_row(vs, nullptr, t, r8);
+      else put_row(gs, gt, t, r8);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    bf16x8 qf[4], kf[4], vf[4], gf[4];
+    __syncthreads();
+    const int qi = wv;
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
+    const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gs + (qi * 16 + l15) * QPITCH + g * 8);
+    f32x4 sc[4], dp[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      qf[i] = *reinterpret_cast<const bf16x8*>(qs + (i * 16 + l15) * QPITCH + g * 8);
-      kf[i] = *reinterpret_cast<const bf16x8*>(ks + (i * 16 + l15) * QPITCH + g * 8);
-      vf[i] = *reinterpret_cast<const bf16x8*>(vs + (i * 16 + l15) * QPITCH + g * 8);
-      gf[i] = *reinterpret_cast<const bf16x8*>(gs + (i * 16 + l15) * QPITCH + g * 8);
+    for (int kj = 0; kj < 4; ++kj) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (kj * 16 + l15) * QPITCH + g * 8);
+      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vs + (kj * 16 + l15) * QPITCH + g * 8);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
+      dp[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, z, 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();      // row-major region is free from here on (dS / dS^T staging)
+    __syncthreads();                     // every wave has its fragments: the row-major region becomes staging
     // ---- P, dP, dS on the accumulator layout: query i = qi*16 + 4g + reg, key j = kj*16 + l15 ----
-#pragma unroll 1
-    for (int qi = 0; qi < 4; ++qi) {
-      f32x4 sc[4], dp[4];
-      const bf16x8 qfi = qi == 0 ? qf[0] : qi == 1 ? qf[1] : qi == 2 ? qf[2] : qf[3];
-      const bf16x8 gfi = qi == 0 ? gf[0] : qi == 1 ? gf[1] : qi == 2 ? gf[2] : gf[3];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = qi * 16 + 4 * g + reg;
+      const float li = i < N ? lse[unit * N + i] : 0.f;
+      float p[4], dl = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfi, kf[kj], z, 0, 0, 0);
-        dp[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfi, vf[kj], z, 0, 0, 0);
+        const int j = kj * 16 + l15;
+        p[kj] = (i < N && j < N) ? expf(sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - li) : 0.f;
+        dl = fmaf(p[kj], dp[kj][reg], dl);
       }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = qi * 16 + 4 * g + reg;
-        const float li = i < N ? lse[unit * N + i] : 0.f;
-        float p[4], dl = 0.f;
+      for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off, 64);
 #pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-          const int j = kj * 16 + l15;
-          p[kj] = (i < N && j < N) ? expf(sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - li) : 0.f;
-          dl = fmaf(p[kj], dp[kj][reg], dl);
+      for (int kj = 0; kj < 4; ++kj) {
+        const int j = kj * 16 + l15;
+        const float ds = p[kj] * (dp[kj][reg] - dl);
+        if (i < N && j < N) {
+          float* dd = dS + (size_t)i * N + j;
+          *dd = bb == 0 ? ds : *dd + ds;
         }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off, 64);
-#pragma unroll
-        for (int kj = 0; kj < 4; ++kj) {
-          const int j = kj * 16 + l15;
-          const float ds = p[kj] * (dp[kj][reg] - dl);
-          if (i < N && j < N) {
-            float* dd = dS + (size_t)i * N + j;
-            *dd = bb == 0 ? ds : *dd + ds;
-          }
-          dsc = fmaf(ds, sc[kj][reg], dsc);
-          const bf16 dsb = f2bf(ds * scale);     // d(qn kn^T) = d(logits) * scale
-          dsr[i * PPITCH + j] = dsb;
-          dst[j * PPITCH + i] = dsb;
-          pt[j * PPITCH + i] = f2bf(p[kj]);
-        }
+        dsc = fmaf(ds, sc[kj][reg], dsc);
+        const bf16 dsb = f2bf(ds * scale);     // d(qn kn^T) = d(logits) * scale
+        dsr[i * PPITCH + j] = dsb;
+        dst[j * PPITCH + i] = dsb;
+        pt[j * PPITCH + i] = f2bf(p[kj]);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    // ---- dV = P^T dO, dKn = dS^T Qn (rows = keys), dQn = dS Kn (rows = queries); K-slots: 64 = 2 x 32 ----
-    bf16x8 gtf[2][2], qtf[2][2], ktf[2][2];
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        gtf[dj][kk] = *reinterpret_cast<const bf16x8*>(gt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-        qtf[dj][kk] = *reinterpret_cast<const bf16x8*>(qt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-        ktf[dj][kk] = *reinterpret_cast<const bf16x8*>(kt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-      }
-#pragma unroll 1
-    for (int mt = 0; mt < 4; ++mt) {
+    __syncthreads();
+    // ---- wave mt: dV, dKn of key tile mt (= P^T dO, dS^T Qn) and dQn of query tile mt (= dS Kn); K-slots 64 = 2 x 32 ----
+    {
+      const int mt = wv;
       bf16x8 pa[2], dsta[2], dsra[2];
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -698,13 +634,16 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnArgs a, const bf1
       f32x4 dv[2], dk[2], dq[2];
 #pragma unroll
       for (int dj = 0; dj < 2; ++dj) {
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        dv[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[0], gtf[dj][0], z, 0, 0, 0);
-        dv[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1], gtf[dj][1], dv[dj], 0, 0, 0);
-        dk[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsta[0], qtf[dj][0], z, 0, 0, 0);
-        dk[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsta[1], qtf[dj][1], dk[dj], 0, 0, 0);
-        dq[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsra[0], ktf[dj][0], z, 0, 0, 0);
-        dq[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsra[1], ktf[dj][1], dq[dj], 0, 0, 0);
+        dv[dj] = dk[dj] = dq[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const bf16x8 gtf = *reinterpret_cast<const bf16x8*>(gt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
+          const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(qt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
+          const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(kt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
+          dv[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kk], gtf, dv[dj], 0, 0, 0);
+          dk[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsta[kk], qtf, dk[dj], 0, 0, 0);
+          dq[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsra[kk], ktf, dq[dj], 0, 0, 0);
+        }
       }
       // accumulator element (reg, dj): token t = mt*16 + 4g + reg, dim = dj*16 + l15
 #pragma unroll
@@ -733,11 +672,13 @@ __global__ __launch_bounds__(64) void attn_bwd_mfma_kernel(AttnArgs a, const bf1
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();      // before the next image overwrites the staging
+    __syncthreads();                     // before the next image overwrites the staging
   }
   dsc = wave_sum(dsc);
-  if (lane == 0) dscale_part[blockIdx.x] = raw_ls < 4.605170185988092f ? dsc * scale : 0.f;
+  if (lane == 0) wsum[wv] = dsc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    dscale_part[blockIdx.x] = raw_ls < 4.605170185988092f ? (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale : 0.f;
 }
 
 // backward, phase A (lane = query i): dS row -> scratch dS[(b,w)][h][i][j] (fp32), dq; partial dscale
@@ -1032,11 +973,8 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
                 "tok_window_attn_fwd: bad args (head_dim must be 32, h/w multiples of the window)");
   if (a.N <= 64 && !tok_attn_scalar()) {
     const int units = batch * a.nW * heads;
-    static bool attr_m = false;
-    if (!attr_m) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_mfma_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((units + 3) / 4), dim3(256), 4 * MFMA_WAVE_LDS, tok_stream(stream), a,
-                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse, units);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(units), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
+                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse);
     TOK_CHECK_LAUNCH("tok_window_attn_fwd(mfma)");
     return TOK_OK;
   }
@@ -1079,7 +1017,7 @@ extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch,
     static bool attr_m = false;
     if (!attr_m) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(waves), dim3(64), MFMA_BWD_LDS, tok_stream(stream), a, (const bf16*)qkv,
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(waves), dim3(256), MFMA_BWD_LDS, tok_stream(stream), a, (const bf16*)qkv,
                        (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch, dscale_part, bpw);
     TOK_CHECK_LAUNCH("tok_window_attn_bwd(mfma)");
     return TOK_OK;
