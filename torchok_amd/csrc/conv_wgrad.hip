@@ -34,7 +34,7 @@ __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
 }
 
-template <int TN, int TK, bool C4, int MS, bool DMA_T>
+template <int TN, int TK, bool C4, int MS, bool DMA_T, bool PWK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {              // reduction rows staged per barrier (2 MFMA k-steps of 32)
   constexpr int CN = TN / 8, CK = TK / 8;      // 16-byte chunks per tile row
   constexpr int RPY = 256 / CN, RPX = 256 / CK;  // rows covered per pass
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   if (C4) { kr = k0 >> 5; ks = (k0 & 31) >> 2; kc0 = 0; }
   else { const int tap = k0 / a.C; kc0 = k0 - tap * a.C; kr = tap / a.S; ks = tap - kr * a.S; }
   const bool k_ok = kr < a.R;
-  const bool pointwise = !C4 && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
+  // PWK: 1x1, stride 1, no padding (every Linear and most ResNet convs): input pixel == output pixel, no row cursor
+  constexpr bool pointwise = PWK;
 
   int xm[XP], xq[XP], xp[XP], xpix[XP];
 #pragma unroll
@@ -148,20 +149,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
       xm[i] += MS;
       if (!pointwise) {
         xq[i] += MS;
-        if (a.Q >= MS) {            // at most one row wrap per step
-          while (xq[i] >= a.Q) {
-            xq[i] -= a.Q;
-            if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
-          }
-        } else if (xq[i] >= a.Q) {  // narrow maps (7x7 and below): the wrap count comes from a division, not a loop
-          const int adv = xq[i] / a.Q;
-          xq[i] -= adv * a.Q;
-          xp[i] += adv;
-          if (xp[i] >= a.P) {
-            const int imgs = xp[i] / a.P;
-            xp[i] -= imgs * a.P;
-            xpix[i] += imgs * a.HW;
-          }
+        while (xq[i] >= a.Q) {
+          xq[i] -= a.Q;
+          if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
         }
       }
     }
@@ -340,17 +330,25 @@ Plan make_plan(const tok_conv_desc* d) {
   return p;
 }
 
-template <int TN, int TK, bool C4, int MS, bool DMA_T>
-void launch_wgrad_dma(const WgradArgs& a, hipStream_t st) {
+template <int TN, int TK, bool C4, int MS, bool DMA_T, bool PWK>
+void launch_wgrad_pw(const WgradArgs& a, hipStream_t st) {
   constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);   // (the unpadded DMA layout needs less)
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS, DMA_T>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS, DMA_T, PWK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS, DMA_T>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
+  hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS, DMA_T, PWK>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
                      smem, st, a);
+}
+
+template <int TN, int TK, bool C4, int MS, bool DMA_T>
+void launch_wgrad_dma(const WgradArgs& a, hipStream_t st) {
+  if constexpr (!C4) {
+    if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) { launch_wgrad_pw<TN, TK, C4, MS, DMA_T, true>(a, st); return; }
+  }
+  launch_wgrad_pw<TN, TK, C4, MS, DMA_T, false>(a, st);
 }
 
 template <int TN, int TK, bool C4, int MS>
