@@ -722,9 +722,18 @@ static int force_bn64() {
 // Channel-tile width.  Short-K layers are HBM-streaming problems: the 128x64 tile (4 waves, 3
 // workgroups per CU) keeps more loads/stores in flight; deep-K layers are MFMA-bound and want the
 // 128x128 tile's operand reuse.  (Measured on the ResNet-50 shapes, tools/bench_conv.py.)
-int pick_bn(int n_out, int ktot) {
+static int small_m_tiles() {   // TOK_SMALLM_TILES=<n>: layers with fewer 128x128 tiles than n take the 128x64 tile
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_SMALLM_TILES"); v = e ? atoi(e) : 0; }
+  return v;
+}
+
+int pick_bn(int n_out, int ktot, int grid_m) {
   if (n_out <= 64 || force_bn64()) return 64;
-  return ktot <= 768 ? 64 : 128;
+  if (ktot <= 768) return 64;
+  // few pixels x deep K (HRNet's low-resolution branches, the 7x7 ResNet stage): 128x128 tiles cannot fill 256 CUs
+  if ((long long)grid_m * tok_cdiv(n_out, 128) < small_m_tiles()) return 64;
+  return 128;
 }
 
 int check_desc(const tok_conv_desc* d, const char* who) {
@@ -748,7 +757,7 @@ int check_desc(const tok_conv_desc* d, const char* who) {
 extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   if (check_desc(d, "tok_conv_fwd_stat_rows")) return TOK_ERR_INVALID;
   const int gridM = tok_cdiv((long long)d->n * d->p * d->q, 128);
-  const int bn_tile = pick_bn(d->k, d->r * d->s_pad * d->c);
+  const int bn_tile = pick_bn(d->k, d->r * d->s_pad * d->c, gridM);
   const int gridN = tok_cdiv(d->k, bn_tile);
   return plan_grid(bn_tile, gridM, gridN) / gridN;
 }
@@ -801,7 +810,7 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (pick_bn(d->k, a.Ktot) == 64) {
+  if (pick_bn(d->k, a.Ktot, a.gridM) == 64) {
     a.gridN = tok_cdiv(d->k, 64);
     if (c4) launch<128, 64, 1, true>(a, st); else launch<128, 64, 1, false>(a, st);
   } else {
@@ -849,7 +858,7 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
     }
     a.gridM = 4 * tmax;   // classes interleaved (m-tile & 3) so heavy and light tiles mix on every XCD
   }
-  pl.bn_tile = pick_bn(d->c, a.Ktot);
+  pl.bn_tile = pick_bn(d->c, a.Ktot, a.gridM);
   a.gridN = tok_cdiv(d->c, pl.bn_tile);
   pl.gridM = a.gridM; pl.gridN = a.gridN;
   return 0;
