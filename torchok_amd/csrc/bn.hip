@@ -6,6 +6,7 @@
 // Backward:  tok_bn_bwd_reduce (partials) -> tok_bn_bwd_finalize -> tok_bn_bwd_apply
 //            dz = dout * mask ;  dy = a1*dz + a2*y + a3   (a* per channel)
 #include "tok_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -343,7 +344,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 }  // namespace
 
-static const int kStreamCap = 2048;   // blocks of elementwise kernels (8 per CU)
+static int stream_cap() {   // blocks of the elementwise kernels (TOK_BN_BLOCKS overrides).  1024 = 4 per CU = half the wave slots: the
+                            // weight-gradient kernels of the side stream run beside them (2048 measured 1.7 % slower end to end)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_BN_BLOCKS"); v = e ? atoi(e) : 1024; }
+  return v;
+}
+#define kStreamCap stream_cap()
 static const int kReduceCap = 1024;   // partial rows of the reducing kernels
 
 extern "C" int tok_bn_finalize(const float* stats, int rows, int64_t count, int c, int c_real, const float* gamma,

@@ -166,6 +166,14 @@ def commit_param_grad(p: torch.nn.Parameter, slot: torch.Tensor, mode: int):
 
 _anchors = {}
 _tls = threading.local()
+_side_streams = {}
+
+
+def _side_stream(device) -> 'torch.cuda.Stream':
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
 
 
 def _anchor(device) -> torch.Tensor:
@@ -187,6 +195,7 @@ def mark_padded(buf: torch.Tensor):
 class Node:
     """One fused unit on the tape."""
     needs_backward = False
+    region = None      # set by Region.add
 
     def backward(self):
         raise NotImplementedError
@@ -203,6 +212,8 @@ class Region:
         self.inputs = []  # (TTensor, torch.Tensor) pairs whose torch side requires grad
         self.grad_mode = torch.is_grad_enabled()
         self.device = None
+        self._side = None
+        self._deferred = []
 
     # -- entry ---------------------------------------------------------------------------------
     def input(self, x: torch.Tensor, c_pad_to: int = 8) -> TTensor:
@@ -248,6 +259,7 @@ class Region:
         return t
 
     def add(self, node: Node):
+        node.region = self
         self.nodes.append(node)
 
     # -- exit ----------------------------------------------------------------------------------
@@ -272,6 +284,31 @@ class Region:
                 node.backward()
             node.release()
         self.nodes = []
+        self.join_side()
+
+    # -- side stream (weight gradients run beside the main chain) --------------------------------
+    def fork_side(self, keep_alive):
+        """Context manager: kernels enqueued inside run on this device's side stream, ordered after everything the
+        main stream has been given so far.  `keep_alive` (tensors the side kernels read or use as scratch) stay
+        referenced until the join, so the allocator cannot hand their memory to later main-stream work."""
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        self._side = (main, side)
+        self._deferred.extend(keep_alive)
+        return torch.cuda.stream(side)
+
+    def keep_until_join(self, *tensors):
+        self._deferred.extend(tensors)
+
+    def join_side(self):
+        if self._side is not None:
+            main, side = self._side
+            main.wait_stream(side)
+            self._side = None
+        self._deferred.clear()
 
 
 _DT = {torch.float32: _C.TOK_F32, torch.float16: _C.TOK_F16, torch.bfloat16: _C.TOK_BF16}

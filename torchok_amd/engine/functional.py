@@ -12,6 +12,8 @@ linear                    nn.Linear                                      (linear
 import weakref
 from typing import Optional
 
+import os
+
 import torch
 from torch import nn
 
@@ -121,6 +123,7 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
     return pk
 
 
+WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
 FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
 
@@ -213,6 +216,7 @@ class _ConvBnActNode(Node):
     def __init__(self):
         self.x = self.out = self.shortcut = None
         self.y = self.mask = None
+        self.region = None
         self.fused_partial = None   # (partial, rows) when a consumer's dgrad epilogue did our BN-bwd reduce
         self.fused_coef = None      # apply coefficients when that dgrad also finalized (tok_conv_dgrad_bn)
         self.coef = None
@@ -337,11 +341,21 @@ class _ConvBnActNode(Node):
         if w_need:
             k, r, s, c = _krsc(conv.weight)
             ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
-            ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
-            slot, mode = param_grad_target(conv.weight)
-            _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
-                                        1 if mode == 1 else 0, st), 'tok_conv_wgrad')
-            commit_param_grad(conv.weight, slot, mode)
+
+            def run_wgrad():
+                ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
+                slot, mode = param_grad_target(conv.weight)
+                _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                            1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
+                commit_param_grad(conv.weight, slot, mode)
+                return ws
+            if WGRAD_SIDE_STREAM and g.is_cuda and self.region is not None and not torch.cuda.is_current_stream_capturing():
+                # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
+                # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
+                with self.region.fork_side((x.data, dy)):
+                    self.region.keep_until_join(run_wgrad())
+            else:
+                run_wgrad()
         if x_need:
             prod = x.node
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()

@@ -88,11 +88,21 @@ class _LinearNode(Node):
         if w.requires_grad:
             k, r, s, c = _krsc(w)
             ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
-            ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
-            slot, mode = param_grad_target(w)
-            _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
-                                        1 if mode == 1 else 0, st), 'tok_conv_wgrad')
-            commit_param_grad(w, slot, mode)
+
+            def run_wgrad():
+                ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
+                slot, mode = param_grad_target(w)
+                _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                            1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
+                commit_param_grad(w, slot, mode)
+                return ws
+            from . import functional as EF
+            if EF.WGRAD_SIDE_STREAM and g.is_cuda and self.region is not None \
+                    and not torch.cuda.is_current_stream_capturing():
+                with self.region.fork_side((x.data, g)):       # dW beside the main chain (see functional.py)
+                    self.region.keep_until_join(run_wgrad())
+            else:
+                run_wgrad()
         if x.requires_grad:
             tgt, acc = grad_target(x)
             _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
