@@ -30,12 +30,13 @@ from ..engine.core import ptr, stream_ptr
 
 
 class _Bucket:
-    __slots__ = ('lo', 'hi', 'first', 'last', 'pending', 'work')
+    __slots__ = ('lo', 'hi', 'first', 'last', 'pending', 'work', 'streams')
 
     def __init__(self, lo, hi, first, last):
         self.lo, self.hi, self.first, self.last = lo, hi, first, last
         self.pending = 0
         self.work = None
+        self.streams = {}     # streams that produced gradients of this bucket in the current step
 
 
 class GradientAllReducer:
@@ -79,6 +80,7 @@ class GradientAllReducer:
             for b in blist:
                 b.pending = sum(1 for pi in range(b.first, b.last + 1) if arena.params[pi].requires_grad)
                 b.work = None
+                b.streams = {}
         self._active = True
 
     def _on_grad(self, p):
@@ -88,6 +90,11 @@ class GradientAllReducer:
         if ent is None:
             return
         ai, b = ent
+        if self.cuda:
+            # weight gradients are produced on the engine's side stream, BatchNorm / bias gradients on the main one:
+            # the exchange has to wait for every stream that wrote into the bucket
+            cur = torch.cuda.current_stream()
+            b.streams[cur.cuda_stream] = cur
         b.pending -= 1
         if b.pending == 0:
             self._launch(ai, b)
@@ -95,10 +102,13 @@ class GradientAllReducer:
     def _launch(self, ai: int, b: _Bucket):
         view = self.arenas[ai].grad[b.lo:b.hi]
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            with torch.cuda.stream(self.comm_stream):
+            cur = torch.cuda.current_stream()
+            b.streams[cur.cuda_stream] = cur
+            for s_ in b.streams.values():
+                ev = torch.cuda.Event()
+                ev.record(s_)
                 self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
                 if self._avg is not None:
                     b.work = dist.all_reduce(view, op=self._avg, group=self.group, async_op=True)
                 else:
