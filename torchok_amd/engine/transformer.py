@@ -25,6 +25,12 @@ from .functional import _krsc, get_packs
 F32 = torch.float32
 
 
+def _use_side(node, g: torch.Tensor) -> bool:
+    from . import functional as EF
+    return bool(EF.WGRAD_SIDE_STREAM and g.is_cuda and node.region is not None
+                and not torch.cuda.is_current_stream_capturing())
+
+
 def _rows(t: TTensor) -> int:
     return t.data.numel() // t.data.shape[-1]
 
@@ -69,22 +75,31 @@ class _LinearNode(Node):
             return
         x, w, d = self.x, self.weight, self.desc
         m, kp = g.shape
+        side = _use_side(self, g)
         if self.bias_sinks:
-            tmp = torch.empty(kp, dtype=F32, device=g.device)
-            nrows = lib.tok_colsum_partial_rows(m, kp)
-            part = torch.empty((nrows, kp), dtype=F32, device=g.device)
-            _C.check(lib.tok_colsum_partial(ptr(g), m, kp, ptr(part), st), 'tok_colsum_partial')
-            _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(tmp), 0, st), 'tok_colsum_f32')
-            for p, start in self.bias_sinks:
-                if not p.requires_grad:
-                    continue
-                slot, mode = param_grad_target(p)
-                seg = tmp[start:start + p.numel()]
-                if mode == 1:
-                    slot.add_(seg)
-                else:
-                    slot.copy_(seg)
-                commit_param_grad(p, slot, mode)
+            def run_bias():
+                tmp = torch.empty(kp, dtype=F32, device=g.device)
+                nrows = lib.tok_colsum_partial_rows(m, kp)
+                part = torch.empty((nrows, kp), dtype=F32, device=g.device)
+                st_ = stream_ptr()
+                _C.check(lib.tok_colsum_partial(ptr(g), m, kp, ptr(part), st_), 'tok_colsum_partial')
+                _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(tmp), 0, st_), 'tok_colsum_f32')
+                for p, start in self.bias_sinks:
+                    if not p.requires_grad:
+                        continue
+                    slot, mode = param_grad_target(p)
+                    seg = tmp[start:start + p.numel()]
+                    if mode == 1:
+                        slot.add_(seg)
+                    else:
+                        slot.copy_(seg)
+                    commit_param_grad(p, slot, mode)
+                return tmp, part
+            if side:       # parameter gradients only: off the main chain, beside it (see functional.py)
+                with self.region.fork_side((g,)):
+                    self.region.keep_until_join(*run_bias())
+            else:
+                run_bias()
         if w.requires_grad:
             k, r, s, c = _krsc(w)
             ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
@@ -96,9 +111,7 @@ class _LinearNode(Node):
                                             1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(w, slot, mode)
                 return ws
-            from . import functional as EF
-            if EF.WGRAD_SIDE_STREAM and g.is_cuda and self.region is not None \
-                    and not torch.cuda.is_current_stream_capturing():
+            if side:
                 with self.region.fork_side((x.data, g)):       # dW beside the main chain (see functional.py)
                     self.region.keep_until_join(run_wgrad())
             else:
@@ -173,18 +186,28 @@ class _LayerNormNode(Node):
             _C.check(lib.tok_layernorm_bwd(ptr(g), ptr(x.data), ptr(self.mean), ptr(self.rstd), ptr(ln.weight),
                                            ptr(self.row_scale), self.rps, ptr(tgt), acc, ptr(partial), rows, c, cp, st),
                      'tok_layernorm_bwd')
-            for p, part in ((ln.weight, partial[0]), (ln.bias, partial[1])):
-                if p.requires_grad:
-                    slot, mode = param_grad_target(p)
-                    if mode == 2:
-                        tmp = torch.empty_like(slot)
-                        _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(tmp), 0, st), 'tok_colsum_f32')
-                        p.grad.add_(tmp)
-                        commit_param_grad(p, slot, 1)
-                    else:
-                        _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(slot), 1 if mode == 1 else 0, st),
-                                 'tok_colsum_f32')
-                        commit_param_grad(p, slot, mode)
+            def run_param_grads():
+                st_ = stream_ptr()
+                keep = []
+                for p, part in ((ln.weight, partial[0]), (ln.bias, partial[1])):
+                    if p.requires_grad:
+                        slot, mode = param_grad_target(p)
+                        if mode == 2:
+                            tmp = torch.empty_like(slot)
+                            _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(tmp), 0, st_), 'tok_colsum_f32')
+                            p.grad.add_(tmp)
+                            keep.append(tmp)
+                            commit_param_grad(p, slot, 1)
+                        else:
+                            _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(slot), 1 if mode == 1 else 0, st_),
+                                     'tok_colsum_f32')
+                            commit_param_grad(p, slot, mode)
+                return keep
+            if _use_side(self, g):
+                with self.region.fork_side((partial,)):
+                    self.region.keep_until_join(*run_param_grads())
+            else:
+                run_param_grads()
         if sc is not None and sc.requires_grad:
             # the residual branch passes the gradient through: hand the buffer over when we own it
             if not (self.out.grad_owned and donate_grad(sc, g.view(sc.data.shape))):
