@@ -155,6 +155,12 @@ def main():
                     '(default: graph only where the step is host-launch-bound: HRNet below batch 8)')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON result): native libraries that chat on file descriptor 1 (RCCL's
+    # version banner at communicator creation) are sent to stderr until that line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -279,7 +285,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and not seg and not swin:
             line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + '\n').encode())
     if world > 1:
         dist.destroy_process_group()
 
