@@ -230,6 +230,18 @@ int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* l
                        const float* loss, const float* gscale, int rows, int classes, int ld,
                        int64_t ignore_index, void* dlogits, void* stream);
 
+/* DiceLoss (losses/segmentation/dice.py:86-188) on bf16 logits rows [rows][ld] (pixels of the channel-last logits).
+ * mode 0 'multiclass': softmax + one_hot(target int64 [rows]); mode 1 'binary': sigmoid of column 0, target float32
+ * [rows], classes = 1.  dims=(0, 2) statistics per class, `1 - dice` or `-log(dice)`, classes without true pixels
+ * masked, mean over the (selected) classes.  partial fp32 [tok_dice_rows(rows)][3][classes] (scratch), loss fp32 [1],
+ * coef fp32 [2][classes] (saved: d loss / d p = coef[0][c] * y + coef[1][c]).                                      */
+int tok_dice_rows(int64_t rows);
+int tok_dice_fwd(const void* logits, const void* target, int64_t rows, int classes, int ld, int mode, float smooth,
+                 float eps, int log_loss, const int64_t* class_sel, int n_sel, float* partial, float* loss,
+                 float* coef, void* stream);
+int tok_dice_bwd(const void* logits, const void* target, const float* coef, const float* gscale, int64_t rows,
+                 int classes, int ld, int mode, void* dlogits, void* stream);
+
 /* ---- metric-learning head and loss -----------------------------------------------------------
  * F.normalize (arcface_head.py:125-126, linear_head.py:33-34): y = x / max(||x||_2, eps) per row;
  * is_f32 selects fp32 rows (class-weight matrix) instead of bf16 activations.               */

@@ -388,6 +388,58 @@ class FakeTok:
         d[:, :classes] = p.to(BF16)
         return 0
 
+    # ---- Dice loss ----------------------------------------------------------------------------------------------
+    def tok_dice_rows(self, rows):
+        return 1
+
+    @staticmethod
+    def _dice_probs(logits, target, rows, classes, ld, mode):
+        z = _t(logits, (rows, ld), BF16)[:, :classes].float()
+        if mode == 0:
+            return z.softmax(1), F.one_hot(_t(target, (rows,), torch.int64), classes).float()
+        return torch.sigmoid(z), _t(target, (rows,), torch.float32)[:, None]
+
+    def tok_dice_fwd(self, logits, target, rows, classes, ld, mode, smooth, eps, log_loss, sel, n_sel, partial, loss,
+                     coef, st):
+        p, y = self._dice_probs(logits, target, rows, classes, ld, mode)
+        I, P, Y = (p * y).sum(0), p.sum(0), y.sum(0)
+        pr = _t(partial, (1, 3, classes), torch.float32)
+        pr[0, 0], pr[0, 1], pr[0, 2] = I, P, Y
+        card = P + Y
+        den = card.clamp_min(eps) + smooth
+        num = 2 * I + smooth
+        score = num / den
+        counted = torch.ones(classes, dtype=torch.bool)
+        ncount = classes
+        if sel is not None:
+            idx = _t(sel, (n_sel,), torch.int64)
+            counted = torch.zeros(classes, dtype=torch.bool)
+            counted[idx] = True
+            ncount = n_sel
+        act = counted & (Y > 0)
+        if log_loss:
+            l = -torch.log(score.clamp_min(eps))
+            dl_ds = torch.where(score > eps, -1 / score, torch.zeros_like(score))
+        else:
+            l = 1 - score
+            dl_ds = -torch.ones_like(score)
+        _t(loss, (1,), torch.float32)[0] = (l * act).sum() / ncount
+        co = _t(coef, (2, classes), torch.float32)
+        co[0] = torch.where(act, dl_ds * 2 / den / ncount, torch.zeros_like(score))
+        co[1] = torch.where(act & (card > eps), dl_ds * (-num / den ** 2) / ncount, torch.zeros_like(score))
+        return 0
+
+    def tok_dice_bwd(self, logits, target, coef, gscale, rows, classes, ld, mode, dlogits, st):
+        p, y = self._dice_probs(logits, target, rows, classes, ld, mode)
+        co = _t(coef, (2, classes), torch.float32)
+        g = _t(gscale, (1,), torch.float32)[0] if gscale else 1.0
+        dp = co[0] * y + co[1]
+        dz = p * (dp - (p * dp).sum(1, keepdim=True)) if mode == 0 else p * (1 - p) * dp
+        d = _t(dlogits, (rows, ld), BF16)
+        d.zero_()
+        d[:, :classes] = _bf(dz * g)
+        return 0
+
     # ---- metric-learning head / loss ---------------------------------------------------------------
     def tok_l2norm_fwd(self, x, y, inv_norm, rows, c, ld, is_f32, eps, st):
         dt = torch.float32 if is_f32 else BF16

@@ -859,3 +859,36 @@ def test_fused_bn_finalize_equals_standalone(libs, case):
         assert torch.equal(out[0][0], out[1][0])
         for a, b in zip(out[0][1:], out[1][1:]):
             assert relerr(b, a) < 1e-5
+
+
+@pytest.mark.parametrize('rows,classes,ld,mode,log_loss,sel', [(5000, 19, 24, 0, 0, None), (777, 5, 8, 0, 1, [0, 3]),
+                                                              (4099, 1, 8, 1, 0, None), (100000, 3, 8, 0, 0, None)])
+def test_dice(libs, rows, classes, ld, mode, log_loss, sel):
+    lib, fake = libs
+    z = (rnd(rows, ld) * 2).to(BF16)
+    if mode == 0:
+        t = torch.randint(0, max(classes - 1, 1), (rows,), generator=torch.Generator().manual_seed(2))   # last class empty
+    else:
+        t = (torch.rand(rows, generator=torch.Generator().manual_seed(2)) < 0.3).float()
+    selt = torch.tensor(sel) if sel else None
+    nparts = lib.tok_dice_rows(rows)
+    P = lambda x: None if x is None else x.data_ptr()   # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    part_h, loss_h, coef_h = torch.zeros(1, 3, classes), torch.zeros(1), torch.zeros(2, classes)
+    assert fake.tok_dice_fwd(P(z), P(t), rows, classes, ld, mode, 0.5, 1e-7, log_loss, P(selt), len(sel) if sel else 0,
+                             P(part_h), P(loss_h), P(coef_h), None) == 0
+    zd, td = z.cuda(), t.cuda()
+    seld = selt.cuda() if sel else None
+    part_d, loss_d, coef_d = torch.zeros(nparts, 3, classes, device='cuda'), torch.zeros(1, device='cuda'), \
+        torch.zeros(2, classes, device='cuda')
+    assert lib.tok_dice_fwd(P(zd), P(td), rows, classes, ld, mode, 0.5, 1e-7, log_loss, P(seld), len(sel) if sel else 0,
+                            P(part_d), P(loss_d), P(coef_d), st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert relerr(loss_d, loss_h) < 1e-4 and relerr(coef_d, coef_h) < 1e-3
+    gs = torch.tensor([1.7])
+    d_h = torch.empty(rows, ld, dtype=BF16)
+    d_d = torch.full((rows, ld), float('nan'), dtype=BF16, device='cuda')
+    assert fake.tok_dice_bwd(P(z), P(t), P(coef_h), P(gs), rows, classes, ld, mode, P(d_h), None) == 0
+    assert lib.tok_dice_bwd(P(zd), P(td), P(coef_d), P(gs.cuda()), rows, classes, ld, mode, P(d_d), st) == 0
+    torch.cuda.synchronize()
+    assert relerr(d_d.float(), d_h.float()) < 6e-3

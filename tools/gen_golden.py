@@ -225,6 +225,30 @@ def golden_swin(out_path, seed=51):
     print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params, restatement == reference files: OK')
 
 
+def golden_dice(out_path):
+    """DiceLoss outputs and input gradients from the reference's own losses/segmentation/dice.py (imports as is)."""
+    _fake_pkg('torchok.losses.segmentation', f'{REF}/losses/segmentation')
+    dice = _load('torchok.losses.segmentation.dice', f'{REF}/losses/segmentation/dice.py')
+    g = torch.Generator().manual_seed(61)
+    out = {}
+    z = torch.randn(3, 5, 12, 10, generator=g) * 2
+    t = torch.randint(0, 4, (3, 12, 10), generator=g)          # class 4 never occurs: masked (dice.py:180-181)
+    for tag, kw in (('mc', {}), ('mc_log', dict(log_loss=True, smooth=1.0)), ('mc_sel', dict(classes=torch.tensor([0, 2, 4])))):   # a LIST goes through np.ndarray(x) in the reference
+                                                                      # (dice.py:74: uninitialised array of that SHAPE) -> NaN
+        zi = z.clone().bfloat16().float().requires_grad_(True)
+        L = dice.DiceLoss('multiclass', **kw)(zi, t)
+        L.backward()
+        out[tag + '_loss'], out[tag + '_dz'] = float(L.detach()), zi.grad.numpy()
+    zb = torch.randn(3, 12, 10, generator=g) * 2
+    tb = (torch.rand(3, 12, 10, generator=g) < 0.3).float()
+    zi = zb.clone().bfloat16().float().requires_grad_(True)
+    L = dice.DiceLoss('binary', smooth=0.5)(zi, tb)
+    L.backward()
+    out.update(bin_loss=float(L.detach()), bin_dz=zi.grad.numpy(), z=z.numpy(), t=t.numpy(), zb=zb.numpy(), tb=tb.numpy())
+    np.savez_compressed(out_path, **out)
+    print('wrote', out_path)
+
+
 def golden_metric(out_path):
     """ArcFaceHead / LinearHead(normalize) / ContrastiveLoss / calc_relevance_matrix from the reference's
     own files; asserts oracle/metric_ref.py == reference bit-for-bit on the same inputs."""
@@ -391,6 +415,8 @@ def main():
     # of the HIP path is checked against these same vectors)
     if '--metric-only' in sys.argv:
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
+    if '--dice-only' in sys.argv:
+        return golden_dice(os.path.join(gd, 'dice_loss.npz'))
     if '--swin-only' in sys.argv:
         return golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     if '--hrnet-only' in sys.argv:
@@ -401,6 +427,7 @@ def main():
     golden_metric(os.path.join(gd, 'metric_heads.npz'))
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
+    golden_dice(os.path.join(gd, 'dice_loss.npz'))
 
 
 if __name__ == '__main__':

@@ -98,6 +98,149 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16* __restrict__ lo
 
 }  // namespace
 
+namespace {
+
+// ---- Dice loss (losses/segmentation/dice.py:86-188) ------------------------------------------------------------------
+// mode 0 (multiclass): p = softmax(logits) per pixel row, y = one_hot(target);  mode 1 (binary): p = sigmoid(logit 0),
+// y = target (float).  Per class: I = sum p*y, P = sum p, Y = sum y.  One wave per pixel row, lane = class; every lane
+// keeps its class's three sums in registers over all the rows of its wave; waves -> block partial row (fixed order).
+__global__ __launch_bounds__(256) void dice_fwd_kernel(const bf16* __restrict__ logits, const void* __restrict__ target,
+                                                       int64_t rows, int classes, int ld, int mode,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[4][3][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float si = 0.f, sp = 0.f, sy = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+    const bf16* z = logits + row * ld;
+    float p = 0.f, y = 0.f;
+    if (mode == 0) {
+      const float v = lane < classes ? bf2f(z[lane]) : -INFINITY;
+      const float mx = wave_max(v);
+      const float e = lane < classes ? expf(v - mx) : 0.f;
+      const float den = wave_sum(e);
+      p = e / den;
+      y = (lane < classes && ((const int64_t*)target)[row] == lane) ? 1.f : 0.f;
+    } else if (lane == 0) {
+      p = 1.f / (1.f + expf(-bf2f(z[0])));
+      y = ((const float*)target)[row];
+    }
+    si = fmaf(p, y, si);
+    sp += p;
+    sy += y;
+  }
+  red[wv][0][lane] = si; red[wv][1][lane] = sp; red[wv][2][lane] = sy;
+  __syncthreads();
+  if (threadIdx.x < 3 * 64) {
+    const int which = threadIdx.x / 64, c = threadIdx.x & 63;
+    if (c < classes)
+      partial[((size_t)blockIdx.x * 3 + which) * classes + c] =
+          red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// folds the partial rows, evaluates the loss and the two per-class coefficients of its gradient:
+//   d loss / d p[row][c] = coef[0][c] * y[row][c] + coef[1][c]
+__global__ __launch_bounds__(64) void dice_finalize_kernel(const float* __restrict__ partial, int nparts, int classes,
+                                                           float smooth, float eps, int log_loss,
+                                                           const int64_t* __restrict__ sel, int nsel,
+                                                           float* __restrict__ loss, float* __restrict__ coef) {
+  const int c = threadIdx.x;
+  double I = 0.0, P = 0.0, Y = 0.0;
+  if (c < classes)
+    for (int r = 0; r < nparts; ++r) {
+      I += (double)partial[((size_t)r * 3 + 0) * classes + c];
+      P += (double)partial[((size_t)r * 3 + 1) * classes + c];
+      Y += (double)partial[((size_t)r * 3 + 2) * classes + c];
+    }
+  float l = 0.f, a = 0.f, b = 0.f;
+  bool counted = c < classes;
+  if (counted && sel != nullptr) {
+    counted = false;
+    for (int i = 0; i < nsel; ++i) counted = counted || sel[i] == c;
+  }
+  const int ncount = sel != nullptr ? nsel : classes;
+  if (counted && Y > 0.0) {        // classes without true pixels contribute zero (dice.py:180-181)
+    const float card = (float)(P + Y);
+    const float cc = fmaxf(card, eps);
+    const float num = 2.f * (float)I + smooth, den = cc + smooth;
+    const float score = num / den;
+    // d score / dI = 2 / den ;  d score / d card = -num / den^2 (zero where the clamp is active)
+    const float ds_dI = 2.f / den, ds_dc = card > eps ? -num / (den * den) : 0.f;
+    float dl_ds;
+    if (log_loss) { l = -logf(fmaxf(score, eps)); dl_ds = score > eps ? -1.f / score : 0.f; }
+    else { l = 1.f - score; dl_ds = -1.f; }
+    a = dl_ds * ds_dI / (float)ncount;
+    b = dl_ds * ds_dc / (float)ncount;
+  }
+  if (c < classes) { coef[c] = a; coef[classes + c] = b; }
+  const float tot = wave_sum(counted ? l : 0.f);
+  if (c == 0) loss[0] = tot / (float)ncount;
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const bf16* __restrict__ logits, const void* __restrict__ target,
+                                                       const float* __restrict__ coef, const float* __restrict__ gscale,
+                                                       int64_t rows, int classes, int ld, int mode,
+                                                       bf16* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float g = gscale ? gscale[0] : 1.f;
+  const bf16* z = logits + row * ld;
+  bf16* d = dlogits + row * ld;
+  if (mode == 0) {
+    const float v = lane < classes ? bf2f(z[lane]) : -INFINITY;
+    const float mx = wave_max(v);
+    const float e = lane < classes ? expf(v - mx) : 0.f;
+    const float p = e / wave_sum(e);
+    float dp = 0.f;
+    if (lane < classes) dp = (((const int64_t*)target)[row] == lane ? coef[lane] : 0.f) + coef[classes + lane];
+    const float dot = wave_sum(p * dp);
+    if (lane < ld) d[lane] = f2bf(lane < classes ? p * (dp - dot) * g : 0.f);
+  } else {
+    if (lane == 0) {
+      const float p = 1.f / (1.f + expf(-bf2f(z[0])));
+      const float dp = coef[0] * ((const float*)target)[row] + coef[1];
+      d[0] = f2bf(p * (1.f - p) * dp * g);
+    } else if (lane < ld) {
+      d[lane] = f2bf(0.f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tok_dice_rows(int64_t rows) {
+  const int64_t b = (rows + 3) / 4;
+  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+extern "C" int tok_dice_fwd(const void* logits, const void* target, int64_t rows, int classes, int ld, int mode,
+                            float smooth, float eps, int log_loss, const int64_t* class_sel, int n_sel, float* partial,
+                            float* loss, float* coef, void* stream) {
+  TOK_CHECK_ARG(logits && target && partial && loss && coef && rows > 0 && classes > 0 && classes <= 64 && ld >= classes &&
+                ld <= 64 && (mode == 0 || (mode == 1 && classes == 1)), "tok_dice_fwd: bad args (<= 64 classes)");
+  TOK_CHECK_ARG(!class_sel || n_sel > 0, "tok_dice_fwd: empty class selection");
+  hipStream_t st = tok_stream(stream);
+  const int g = tok_dice_rows(rows);
+  hipLaunchKernelGGL(dice_fwd_kernel, dim3(g), dim3(256), 0, st, (const bf16*)logits, target, rows, classes, ld, mode,
+                     partial);
+  TOK_CHECK_LAUNCH("tok_dice_fwd");
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, st, partial, g, classes, smooth, eps, log_loss, class_sel,
+                     n_sel, loss, coef);
+  TOK_CHECK_LAUNCH("tok_dice_fwd(finalize)");
+  return TOK_OK;
+}
+
+extern "C" int tok_dice_bwd(const void* logits, const void* target, const float* coef, const float* gscale, int64_t rows,
+                            int classes, int ld, int mode, void* dlogits, void* stream) {
+  TOK_CHECK_ARG(logits && target && coef && dlogits && rows > 0 && classes > 0 && classes <= 64 && ld >= classes && ld <= 64,
+                "tok_dice_bwd: bad args");
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)logits, target, coef, gscale, rows, classes, ld, mode, (bf16*)dlogits);
+  TOK_CHECK_LAUNCH("tok_dice_bwd");
+  return TOK_OK;
+}
+
 extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
                                   int64_t ignore_index, float* lse, float* row_loss, float* loss,
                                   void* stream) {
