@@ -140,3 +140,39 @@ def test_classification_step_vs_reference_golden(dev):
     opt.step()
     pn = np.array([float(params[n].detach().double().norm()) for n in names])
     assert np.abs(pn / GOLD['post_step_norm'] - 1).max() < 2e-3
+
+
+@pytest.mark.gpu
+def test_training_loop_learns_and_side_stream_is_transparent(monkeypatch):
+    """30 AdamW steps on a fixed mini-batch: the loss falls, and the parameters are bit-identical with the parameter-gradient
+    work on the side stream or on the main one (deterministic kernels: a cross-stream race would show)."""
+    from helpers import cls_config
+    from torchok_amd.engine import functional as EF
+    finals, losses = [], []
+    for side in (True, False):
+        monkeypatch.setattr(EF, 'WGRAD_SIDE_STREAM', side)
+        cfg = cls_config('swinv2_custom', 4, optimizer='AdamW', opt_params={'lr': 2e-3, 'weight_decay': 0.01},
+                         backbone_params=dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0),
+                         inputs_shape=(3, 64, 64))
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 23)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(16, 3, 64, 64, generator=g).cuda()
+        y = torch.randint(0, 4, (16,), generator=g).cuda()
+        hist = []
+        for it in range(30):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad(set_to_none=True)
+            out['loss'].backward()
+            opt.step()
+            hist.append(out['loss'].detach())
+        torch.cuda.synchronize()
+        losses.append([float(v) for v in hist])
+        finals.append({n: p.detach().clone() for n, p in task.named_parameters()})
+    assert losses[0][-1] < 0.8 * losses[0][0], (losses[0][0], losses[0][-1])
+    assert losses[0] == losses[1]
+    for n in finals[0]:
+        assert torch.equal(finals[0][n], finals[1][n]), n
