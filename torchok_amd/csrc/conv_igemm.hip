@@ -722,6 +722,12 @@ static int force_bn64() {
 // Channel-tile width.  Short-K layers are HBM-streaming problems: the 128x64 tile (4 waves, 3
 // workgroups per CU) keeps more loads/stores in flight; deep-K layers are MFMA-bound and want the
 // 128x128 tile's operand reuse.  (Measured on the ResNet-50 shapes, tools/bench_conv.py.)
+static int short_k() {   // TOK_SHORT_K=<k>: reduction depths up to k take the 128x64 tile (default 768, tuned on ResNet-50)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_SHORT_K"); v = e ? atoi(e) : 768; }
+  return v;
+}
+
 static int small_m_tiles() {   // TOK_SMALLM_TILES=<n>: layers with fewer 128x128 tiles than n take the 128x64 tile
   static int v = -1;
   if (v < 0) { const char* e = getenv("TOK_SMALLM_TILES"); v = e ? atoi(e) : 0; }
@@ -730,7 +736,7 @@ static int small_m_tiles() {   // TOK_SMALLM_TILES=<n>: layers with fewer 128x12
 
 int pick_bn(int n_out, int ktot, int grid_m) {
   if (n_out <= 64 || force_bn64()) return 64;
-  if (ktot <= 768) return 64;
+  if (ktot <= short_k()) return 64;
   // few pixels x deep K (HRNet's low-resolution branches, the 7x7 ResNet stage): 128x128 tiles cannot fill 256 CUs
   if ((long long)grid_m * tok_cdiv(n_out, 128) < small_m_tiles()) return 64;
   return 128;
