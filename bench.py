@@ -152,7 +152,7 @@ def main():
     ap.add_argument('--classes', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as one hipGraph, 0: eager launches '
-                    '(default: graph only where the step is host-launch-bound: HRNet below batch 8)')
+                    '(default: graph only where the step is host-launch-bound: HRNet below batch 16)')
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON result): native libraries that chat on file descriptor 1 (RCCL's
@@ -199,7 +199,7 @@ def main():
                            device='cuda')
     batch = {'image': image, 'target': target}
 
-    use_graph = (args.graph == 1 or (args.graph < 0 and seg and args.batch < 8)) and world == 1
+    use_graph = (args.graph == 1 or (args.graph < 0 and seg and args.batch < 16)) and world == 1
     graphed = None
     if use_graph:
         from torchok_amd.engine.graph import GraphedTrainingStep

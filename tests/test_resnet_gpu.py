@@ -128,10 +128,14 @@ def test_two_stream_schedule_is_bit_identical_and_learns(monkeypatch):
     """Race detector + end-to-end sanity: 40 SGD steps on a fixed mini-batch (a) drive the loss down, (b) give bit-identical
     parameters with the weight gradients on the side stream and on the main stream (every kernel is deterministic, so any
     cross-stream race would show up as a difference)."""
+    from torchok_amd.engine import core as EC
     from torchok_amd.engine import functional as EF
     finals, losses = [], []
     for side in (True, False):
         monkeypatch.setattr(EF, 'WGRAD_SIDE_STREAM', side)
+        monkeypatch.setattr(EC, 'BRANCH_STREAMS', side)      # projection shortcuts on their own stream, too
+        from torchok_amd.models.backbones import resnet as RN
+        monkeypatch.setattr(RN, 'SHORTCUT_BRANCH', side)
         cfg = cls_config('resnet18', 4, opt_params={'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4})
         task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
         sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 5)

@@ -12,6 +12,7 @@ gradient of a residual unit is handed to the shortcut branch without a copy.
 PyTorch is used for: device memory (torch.empty), the current HIP stream, the autograd graph
 between regions (backbone -> pooling -> head -> loss).  All arithmetic is in libtok_gfx950.so.
 """
+import os
 import threading
 import weakref
 from typing import List, Optional, Sequence
@@ -49,7 +50,8 @@ class TTensor:
     """Engine tensor: bf16, channel-last, channels padded to a multiple of 8.
 
     data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
-    __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', '__weakref__')
+    __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', 'ready', 'gevents',
+                 '__weakref__')
 
     def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
         self.data = data
@@ -60,6 +62,8 @@ class TTensor:
         self.requires_grad = requires_grad
         self.uses = 0       # in-region consumers that will send a gradient (counted in forward)
         self.arrived = 0    # gradient contributions received so far (backward)
+        self.ready = None   # (event, stream): produced on a branch stream (forward), see Region.branch
+        self.gevents = None  # [(event, stream)]: gradient contributions written on other streams (backward)
 
     @property
     def cp(self) -> int:
@@ -84,12 +88,39 @@ class TTensor:
 
 # ---- gradient fan-in protocol ---------------------------------------------------------------
 
+_ms = threading.local()      # multi-stream backward bookkeeping (Region.run_backward)
+
+
+def _await(events):
+    cur = torch.cuda.current_stream()
+    for ev, s in events:
+        if s != cur:
+            cur.wait_event(ev)
+
+
+def await_ready(*tensors):
+    """Forward: make the current stream wait for tensors that were produced on a branch stream."""
+    for t in tensors:
+        if t is not None and t.ready is not None:
+            _await((t.ready,))
+
+
+def _touch(x: 'TTensor'):
+    if getattr(_ms, 'active', False):
+        if x.gevents:
+            _await(x.gevents)                     # an earlier contribution may still be in flight on another stream
+            if x.grad is not None:
+                x.grad.record_stream(torch.cuda.current_stream())
+        _ms.touched.append(x)
+
+
 def grad_target(x: TTensor):
     """Buffer to write a gradient contribution of `x` into, and whether to accumulate.
 
     First arrival allocates (accumulate=0); later arrivals add in the producer's epilogue.
     A gradient tensor that came from outside the region (autograd grad_output) is never
     written in place: it is cloned first."""
+    _touch(x)
     x.arrived += 1
     if x.grad is None:
         x.grad = torch.empty_like(x.data)
@@ -104,6 +135,7 @@ def grad_target(x: TTensor):
 def donate_grad(x: TTensor, buf: torch.Tensor) -> bool:
     """Hand an already-computed gradient buffer to `x` without a copy (first arrival only)."""
     if x.grad is None:
+        _touch(x)
         x.arrived += 1
         x.grad = buf
         x.grad_owned = True
@@ -167,6 +199,55 @@ def commit_param_grad(p: torch.nn.Parameter, slot: torch.Tensor, mode: int):
 _anchors = {}
 _tls = threading.local()
 _side_streams = {}
+_branch_streams = {}
+BRANCH_STREAMS = os.environ.get('TOK_BRANCH_STREAMS', '1') == '1'
+
+
+def _branch_stream(device, idx: int) -> 'torch.cuda.Stream':
+    key = (device, idx)
+    s = _branch_streams.get(key)
+    if s is None:
+        s = _branch_streams[key] = torch.cuda.Stream(device=device)
+    return s
+
+
+class _Branch:
+    def __init__(self, region: 'Region', idx: int):
+        self.region, self.idx, self.out, self.ctx, self.prev = region, idx, [], None, 0
+
+    def publish(self, *tensors):
+        self.out.extend(t for t in tensors if t is not None)
+        return tensors[0] if len(tensors) == 1 else tensors
+
+    def __enter__(self):
+        r = self.region
+        dev = r.device
+        self.live = bool(BRANCH_STREAMS and self.idx and dev is not None and dev.type == 'cuda' and not _C.is_fake()
+                         and not torch.cuda.is_current_stream_capturing())
+        if self.live:
+            main = torch.cuda.current_stream()
+            b = _branch_stream(dev, self.idx)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            b.wait_event(ev)
+            r._streams[self.idx] = b
+            self.prev, r._tag = r._tag, self.idx
+            self.ctx = torch.cuda.stream(b)
+            self.ctx.__enter__()
+            self.stream = b
+        return self
+
+    def __exit__(self, *exc):
+        if self.live:
+            self.ctx.__exit__(*exc)
+            r = self.region
+            r._tag = self.prev
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            r._branch_done.append((done, self.stream))
+            for t in self.out:
+                t.ready = (done, self.stream)
+        return False
 
 
 def _side_stream(device) -> 'torch.cuda.Stream':
@@ -196,6 +277,7 @@ class Node:
     """One fused unit on the tape."""
     needs_backward = False
     region = None      # set by Region.add
+    stream_tag = 0     # branch stream the unit was recorded on (0 = main)
 
     def backward(self):
         raise NotImplementedError
@@ -214,6 +296,9 @@ class Region:
         self.device = None
         self._side = None
         self._deferred = []
+        self._tag = 0            # branch stream index of the units being recorded (0 = main)
+        self._streams = {}       # branch index -> stream, for the branches this region used
+        self._branch_done = []   # forward: (event, stream) of every closed branch, joined in output()
 
     # -- entry ---------------------------------------------------------------------------------
     def input(self, x: torch.Tensor, c_pad_to: int = 8) -> TTensor:
@@ -260,10 +345,29 @@ class Region:
 
     def add(self, node: Node):
         node.region = self
+        node.stream_tag = self._tag
         self.nodes.append(node)
+
+    # -- branch streams ----------------------------------------------------------------------------
+    def branch(self, idx: int):
+        """Context manager: the units recorded inside run on branch stream `idx` (forward now, their backward later),
+        concurrently with what the main stream is given meanwhile.  For sub-graphs that are independent of the main
+        chain: the projection shortcut of a residual block, the parallel branches of an HRNet module.  Publish the
+        tensors that leave the branch with `.publish(...)`: their consumers wait for the branch automatically.
+        No-op on the host stand-in, inside a hipGraph capture, for idx 0 or with TOK_BRANCH_STREAMS=0."""
+        return _Branch(self, idx)
+
+    def _join_forward(self):
+        if self._branch_done:
+            cur = torch.cuda.current_stream()
+            for ev, b in self._branch_done:
+                if b != cur:
+                    cur.wait_event(ev)
+            self._branch_done = []
 
     # -- exit ----------------------------------------------------------------------------------
     def output(self, *outs: TTensor):
+        self._join_forward()
         need = self.grad_mode and any(o.requires_grad for o in outs)
         if not need:
             for n in self.nodes:
@@ -279,12 +383,57 @@ class Region:
         return res[0] if len(res) == 1 else res
 
     def run_backward(self):
+        if self._streams and not torch.cuda.is_current_stream_capturing():
+            return self._run_backward_multi()
         for node in reversed(self.nodes):
             if node.needs_backward:
                 node.backward()
             node.release()
         self.nodes = []
         self.join_side()
+
+    def _run_backward_multi(self):
+        """Backward of a region that used branch streams: every unit runs on the stream it was recorded on; a unit waits
+        for the gradient contributions other streams wrote into its output, and leaves an event on every gradient
+        buffer it wrote.  Units of branch streams are released only after the join (their tensors may be in flight)."""
+        main = torch.cuda.current_stream()
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        for b in self._streams.values():
+            b.wait_event(ev0)
+        held = []
+        _ms.active, _ms.touched = True, []
+        try:
+            for node in reversed(self.nodes):
+                s = self._streams.get(node.stream_tag, main) if node.stream_tag else main
+                with torch.cuda.stream(s):
+                    if node.needs_backward:
+                        out = getattr(node, 'out', None)
+                        if out is not None and out.gevents:
+                            _await(out.gevents)
+                            if out.grad is not None:
+                                out.grad.record_stream(s)
+                        _ms.touched = []
+                        node.backward()
+                        if _ms.touched:
+                            ev = torch.cuda.Event()
+                            ev.record(s)
+                            for t in _ms.touched:
+                                if t.gevents is None:
+                                    t.gevents = []
+                                t.gevents.append((ev, s))
+                if s is main:
+                    node.release()
+                else:
+                    held.append(node)
+        finally:
+            _ms.active, _ms.touched = False, []
+        for b in self._streams.values():
+            main.wait_stream(b)
+        self.nodes = []
+        self.join_side()
+        for node in held:
+            node.release()
 
     # -- side stream (weight gradients run beside the main chain) --------------------------------
     def fork_side(self, keep_alive):
@@ -305,8 +454,7 @@ class Region:
 
     def join_side(self):
         if self._side is not None:
-            main, side = self._side
-            main.wait_stream(side)
+            torch.cuda.current_stream().wait_stream(self._side[1])
             self._side = None
         self._deferred.clear()
 

@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from .. import _C
-from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target,
+from .core import (BF16, Node, Region, TTensor, await_ready, commit_param_grad, donate_grad, grad_target,
                    is_last_contribution, pad8, param_grad_target, ptr, stream_ptr)
 
 F32 = torch.float32
@@ -400,6 +400,7 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
                 relu: bool = False, shortcut: Optional[TTensor] = None) -> TTensor:
     """out = act(bn(conv(x)) (+ shortcut)).  `conv` is an nn.Conv2d or nn.Linear used purely as
     the parameter container (state_dict names stay those of the reference)."""
+    await_ready(x, shortcut)
     lib, st = _C.lib(), stream_ptr()
     if isinstance(conv, nn.Linear):
         r = s = 1

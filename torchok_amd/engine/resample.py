@@ -15,7 +15,7 @@ from typing import List, Sequence, Tuple
 import torch
 
 from .. import _C
-from .core import BF16, Node, Region, TTensor, grad_target, pad8, ptr, stream_ptr
+from .core import BF16, Node, Region, TTensor, await_ready, grad_target, pad8, ptr, stream_ptr
 
 
 class _FuseSumNode(Node):
@@ -43,6 +43,7 @@ def fuse_sum_relu(region: Region, terms: Sequence[Tuple[TTensor, int]], relu: bo
     """out = relu(sum_j upsample_nearest(t_j, 2**shift_j)); the first term fixes the output shape (shift 0)."""
     if not 1 <= len(terms) <= 4:
         raise NotImplementedError('fuse_sum_relu: 1..4 terms')
+    await_ready(*(t for t, _ in terms))
     ref, sh0 = terms[0]
     n, h, w, cp = ref.shape
     h, w = h << sh0, w << sh0
@@ -103,6 +104,7 @@ class _BilinearNode(Node):
 
 def bilinear_concat(region: Region, srcs: List[TTensor], size: Tuple[int, int]) -> TTensor:
     """cat([interpolate(s, size, 'bilinear', align_corners=False) for s in srcs], dim=channel)."""
+    await_ready(*srcs)
     n = srcs[0].shape[0]
     hd, wd = int(size[0]), int(size[1])
     # a single map keeps its padded width; concatenated maps are packed at their LOGICAL channel offsets

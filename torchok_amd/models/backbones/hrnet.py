@@ -125,7 +125,13 @@ class HighResolutionModule(nn.Module):
         r = engine.current_region()
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
-        x = [branch(xi) for branch, xi in zip(self.branches, x)]
+        # the branches are independent until the fuse: branch 0 on the main stream, the low-resolution ones (few
+        # tiles, long reductions: they cannot fill the GPU alone) each on its own branch stream beside it
+        outs = []
+        for i, (branch, xi) in enumerate(zip(self.branches, x)):
+            with r.branch(i) as br:
+                outs.append(br.publish(branch(xi)))
+        x = outs
         fused = []
         for i, row in enumerate(self.fuse_layers):
             terms = []
