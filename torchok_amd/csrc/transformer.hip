@@ -430,93 +430,107 @@ __device__ __forceinline__ void put_row(bf16* rowmaj, bf16* trans, int t, const 
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
                                                             const float* __restrict__ logit_scale,
                                                             const float* __restrict__ bias, const float* __restrict__ mask,
-                                                            bf16* __restrict__ out, float* __restrict__ lse) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse, int bpw) {
   extern __shared__ char smraw[];
   bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
   bf16* vt = ks + 64 * QPITCH;          // [32 dims][PPITCH keys]
   bf16* ps = vt + 32 * PPITCH;          // [64 queries][PPITCH keys]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int unit = blockIdx.x;
-  const int h = unit % a.heads;
-  const int win = (unit / a.heads) % a.nW;
-  const int b = unit / (a.heads * a.nW);
+  const int h = blockIdx.x % a.heads;
+  const int win = (blockIdx.x / a.heads) % a.nW;
+  const int bg = blockIdx.x / (a.heads * a.nW);
   const int N = a.N;
-  if (wv < 3) {   // wave 0: q (normalised), wave 1: k (normalised), wave 2: v^T
-    const int t = lane;
-    bf16x8 r8[4];
-    const bf16* src = qkv + token_row(a, b, win, t < N ? t : 0) * a.ld + h * HD + wv * a.C;
-    load_head_row(src, t < N, wv < 2, r8);
-    put_row(wv == 0 ? qs : (wv == 1 ? ks : nullptr), wv == 2 ? vt : nullptr, t, r8);
-  }
-  __syncthreads();
   const int l15 = lane & 15, g = lane >> 4, qi = wv;
   const float scale = expf(fminf(logit_scale[h], 4.605170185988092f));
-  const float* bh = bias + (size_t)h * N * N;
-  const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
-  const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
-  f32x4 sc[4];
+  // additive logit terms of this wave's query tile (position bias + shift mask; -inf on padding): loaded once per
+  // workgroup, reused for every image it walks.  element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
+  float addt[4][4];
+  {
+    const float* bh = bias + (size_t)h * N * N;
+    const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
 #pragma unroll
-  for (int kj = 0; kj < 4; ++kj) {
-    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (kj * 16 + l15) * QPITCH + g * 8);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int kj = 0; kj < 4; ++kj) {
+        const int i = qi * 16 + 4 * g + reg, j = kj * 16 + l15;
+        addt[reg][kj] = (i < N && j < N) ? bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
+      }
   }
-  float rsum[4], rmax[4];
-  // element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int i = qi * 16 + 4 * g + reg;
-    float mx = -INFINITY;
+  for (int bb = 0; bb < bpw; ++bb) {
+    const int b = bg * bpw + bb;
+    if (b >= a.B) break;                 // uniform for the workgroup
+    const size_t unit = ((size_t)b * a.nW + win) * a.heads + h;
+    if (wv < 3) {   // wave 0: q (normalised), wave 1: k (normalised), wave 2: v^T
+      const int t = lane;
+      bf16x8 r8[4];
+      const bf16* src = qkv + token_row(a, b, win, t < N ? t : 0) * a.ld + h * HD + wv * a.C;
+      load_head_row(src, t < N, wv < 2, r8);
+      put_row(wv == 0 ? qs : (wv == 1 ? ks : nullptr), wv == 2 ? vt : nullptr, t, r8);
+    }
+    __syncthreads();
+    const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
+    f32x4 sc[4];
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) {
-      const int j = kj * 16 + l15;
-      float v = -INFINITY;
-      if (i < N && j < N) v = sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f);
-      sc[kj][reg] = v;
-      mx = fmaxf(mx, v);
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ks + (kj * 16 + l15) * QPITCH + g * 8);
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
     }
+    float rsum[4], rmax[4];
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    float sum = 0.f;
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = qi * 16 + 4 * g + reg;
+      float mx = -INFINITY;
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-      const float p = (i < N) ? expf(sc[kj][reg] - mx) : 0.f;
-      sc[kj][reg] = p;
-      sum += p;
+      for (int kj = 0; kj < 4; ++kj) {
+        const float v = fmaf(sc[kj][reg], scale, addt[reg][kj]);
+        sc[kj][reg] = v;
+        mx = fmaxf(mx, v);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int kj = 0; kj < 4; ++kj) {
+        const float p = (i < N) ? expf(sc[kj][reg] - mx) : 0.f;
+        sc[kj][reg] = p;
+        sum += p;
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+      rsum[reg] = sum;
+      rmax[reg] = mx;
+#pragma unroll
+      for (int kj = 0; kj < 4; ++kj) ps[i * PPITCH + kj * 16 + l15] = f2bf(sc[kj][reg]);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();      // P rows of this query tile are produced and consumed by the same wave
+    // ---- O = P V : A = P[query][key slots], B = V^T[dim][key slots] ----
+    bf16x8 pf[2];
 #pragma unroll
-    for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
-    rsum[reg] = sum;
-    rmax[reg] = mx;
+    for (int kt = 0; kt < 2; ++kt)
+      pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) ps[i * PPITCH + kj * 16 + l15] = f2bf(sc[kj][reg]);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();      // P rows of this query tile are produced and consumed by the same wave
-  // ---- O = P V : A = P[query][key slots], B = V^T[dim][key slots] ----
-  bf16x8 pf[2];
+    for (int dj = 0; dj < 2; ++dj) {
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-    pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
+      for (int kt = 0; kt < 2; ++kt) {
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (dj * 16 + l15) * PPITCH + kt * 32 + g * 8);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kt], vf, o, 0, 0, 0);
+      }
 #pragma unroll
-  for (int dj = 0; dj < 2; ++dj) {
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (dj * 16 + l15) * PPITCH + kt * 32 + g * 8);
-      o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kt], vf, o, 0, 0, 0);
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = qi * 16 + 4 * g + reg;
+        if (i < N) out[token_row(a, b, win, i) * a.C + h * HD + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
-      if (i < N) out[token_row(a, b, win, i) * a.C + h * HD + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
+      if (i < N && l15 == 0) lse[unit * N + i] = rmax[reg] + logf(rsum[reg]);
     }
-  }
-#pragma unroll
-  for (int reg = 0; reg < 4; ++reg) {
-    const int i = qi * 16 + 4 * g + reg;
-    if (i < N && l15 == 0) lse[(size_t)unit * N + i] = rmax[reg] + logf(rsum[reg]);
+    __syncthreads();                     // before the next image overwrites q / k / v^T
   }
 }
 
@@ -562,6 +576,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
   float* dS = ds_scratch + (size_t)blockIdx.x * N * N;
   float dsc = 0.f;
+  float addt[4][4];        // position bias + shift mask of this wave's query tile (-inf on padding), loaded once
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+      const int i = wv * 16 + 4 * g + reg, j = kj * 16 + l15;
+      addt[reg][kj] = (i < N && j < N) ? bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
+    }
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
     if (b >= a.B) break;                 // uniform for the workgroup
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const int j = kj * 16 + l15;
-        p[kj] = (i < N && j < N) ? expf(sc[kj][reg] * scale + bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) - li) : 0.f;
+        p[kj] = (i < N && j < N) ? expf(fmaf(sc[kj][reg], scale, addt[reg][kj]) - li) : 0.f;
         dl = fmaf(p[kj], dp[kj][reg], dl);
       }
 #pragma unroll
@@ -965,6 +987,15 @@ extern "C" int tok_act_bwd(int kind, const void* dout, const void* x, void* dx, 
   return TOK_OK;
 }
 
+namespace {
+int attn_bpw(const AttnArgs& a) {     // images per wave on the MFMA path
+  const long long units = (long long)a.B * a.nW * a.heads;
+  long long bpw = units / 4096;
+  bpw = bpw < 1 ? 1 : (bpw > 8 ? 8 : bpw);
+  return (int)(bpw > a.B ? a.B : bpw);
+}
+}  // namespace
+
 extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int c, int heads, int ws, int shift, int ld,
                                    const float* logit_scale, const float* bias, const float* mask, void* out,
                                    float* lse, void* stream) {
@@ -972,9 +1003,10 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
   TOK_CHECK_ARG(qkv && logit_scale && bias && out && lse && fill_attn(a, batch, h, w, c, heads, ws, shift, ld),
                 "tok_window_attn_fwd: bad args (head_dim must be 32, h/w multiples of the window)");
   if (a.N <= 64 && !tok_attn_scalar()) {
-    const int units = batch * a.nW * heads;
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(units), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
-                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse);
+    const int bpw = attn_bpw(a);
+    const int groups = tok_cdiv(batch, bpw) * a.nW * heads;
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(groups), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
+                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse, bpw);
     TOK_CHECK_LAUNCH("tok_window_attn_fwd(mfma)");
     return TOK_OK;
   }
@@ -989,14 +1021,6 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
   return TOK_OK;
 }
 
-namespace {
-int attn_bpw(const AttnArgs& a) {     // images per wave on the MFMA path
-  const long long units = (long long)a.B * a.nW * a.heads;
-  long long bpw = units / 4096;
-  bpw = bpw < 1 ? 1 : (bpw > 8 ? 8 : bpw);
-  return (int)(bpw > a.B ? a.B : bpw);
-}
-}  // namespace
 
 extern "C" int tok_window_attn_bwd_rows(int batch, int h, int w, int heads, int ws) {
   AttnArgs a;
