@@ -338,6 +338,21 @@ int tok_cpb_bias_bwd(const float* dbias, int transposed, const void* table, int 
  * permutation (its backward)                                                                             */
 int tok_patch_merge(const void* src, void* dst, int batch, int h, int w, int c, int inverse, void* stream);
 
+/* ---- self-supervised / triplet losses ---------------------------------------------------
+ * NT_XentLoss (losses/representation/unsupervised.py:7-54, emb_m = None): emb = cat(emb1, emb2) bf16 [n][ld]
+ * (n = 2B); logits = emb emb^T / T, diagonal -1e9, label(i) = (i + B) mod n, mean CE.  lse [n] is saved.        */
+int tok_ntxent_fwd(const void* emb, int n, int d, int ld, float temperature, float* lse, float* row_loss,
+                   float* loss, void* stream);
+int tok_ntxent_bwd(const void* emb, const float* lse, const float* gscale, int n, int d, int ld, float temperature,
+                   void* demb, void* stream);
+/* torch.nn.TripletMarginLoss(p=2) registered at losses/__init__.py:39: d(x, y) = ||x - y + eps||, mean over
+ * rows of relu(d_ap - d_an + margin) (swap: d_an = min(d_an, d_pn)).  dist fp32 [rows][3] is saved.             */
+int tok_triplet_fwd(const void* anchor, const void* positive, const void* negative, int rows, int d, int ld,
+                    float margin, float eps, int swap, float* dist, float* row_loss, float* loss, void* stream);
+int tok_triplet_bwd(const void* anchor, const void* positive, const void* negative, const float* dist,
+                    const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
+                    void* d_anchor, void* d_positive, void* d_negative, void* stream);
+
 /* ---- optimizers (flat arenas) -------------------------------------------------------------
  * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
  * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch

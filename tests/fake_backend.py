@@ -388,6 +388,66 @@ class FakeTok:
         d[:, :classes] = p.to(BF16)
         return 0
 
+    # ---- NT-Xent / triplet ------------------------------------------------------------------------------------------
+    def _ntx(self, emb, n, d, ld, temperature):
+        e = _t(emb, (n, ld), BF16)[:, :d].float()
+        sim = (e @ e.t()) / temperature
+        sim = sim.masked_fill(torch.eye(n, dtype=torch.bool), -1e9)
+        labels = torch.cat([torch.arange(n // 2, n), torch.arange(n // 2)])
+        return e, sim, labels
+
+    def tok_ntxent_fwd(self, emb, n, d, ld, temperature, lse, row_loss, loss, st):
+        _, sim, labels = self._ntx(emb, n, d, ld, temperature)
+        l = torch.logsumexp(sim, 1)
+        rl = l - sim[torch.arange(n), labels]
+        _t(lse, (n,), torch.float32).copy_(l)
+        _t(row_loss, (n,), torch.float32).copy_(rl)
+        _t(loss, (1,), torch.float32)[0] = rl.mean()
+        return 0
+
+    def tok_ntxent_bwd(self, emb, lse, gscale, n, d, ld, temperature, demb, st):
+        e, sim, labels = self._ntx(emb, n, d, ld, temperature)
+        g = _t(gscale, (1,), torch.float32)[0] if gscale else 1.0
+        w = torch.softmax(sim, 1) - F.one_hot(labels, n).float()
+        w = w.masked_fill(torch.eye(n, dtype=torch.bool), 0.0)
+        de = ((w + w.t()) @ e) * g / (n * temperature)
+        o = _t(demb, (n, ld), BF16)
+        o.zero_()
+        o[:, :d] = _bf(de)
+        return 0
+
+    def _trip(self, a, p, ng, rows, d, ld, eps):
+        av, pv, nv = (_t(q, (rows, ld), BF16)[:, :d].float() for q in (a, p, ng))
+        return av, pv, nv, (av - pv + eps).norm(dim=1), (av - nv + eps).norm(dim=1), (pv - nv + eps).norm(dim=1)
+
+    def tok_triplet_fwd(self, a, p, ng, rows, d, ld, margin, eps, swap, dist, row_loss, loss, st):
+        _, _, _, dap, dan, dpn = self._trip(a, p, ng, rows, d, ld, eps)
+        _t(dist, (rows, 3), torch.float32).copy_(torch.stack([dap, dan, dpn], 1))
+        dneg = torch.minimum(dan, dpn) if swap else dan
+        rl = (dap - dneg + margin).clamp_min(0)
+        _t(row_loss, (rows,), torch.float32).copy_(rl)
+        _t(loss, (1,), torch.float32)[0] = rl.mean()
+        return 0
+
+    def tok_triplet_bwd(self, a, p, ng, dist, gscale, rows, d, ld, margin, eps, swap, da, dp, dn, st):
+        av, pv, nv, dap, dan, dpn = self._trip(a, p, ng, rows, d, ld, eps)
+        g = (_t(gscale, (1,), torch.float32)[0] if gscale else 1.0) / rows
+        sw = (dpn < dan) if swap else torch.zeros_like(dan, dtype=torch.bool)
+        dneg = torch.where(sw, dpn, dan)
+        act = ((dap - dneg + margin) > 0).float()[:, None] * g
+        up = (av - pv + eps) / dap[:, None]
+        un_a = (av - nv + eps) / dan[:, None]
+        un_p = (pv - nv + eps) / dpn[:, None]
+        swf = sw.float()[:, None]
+        ga = up - (1 - swf) * un_a
+        gp = -up - swf * un_p
+        gn = (1 - swf) * un_a + swf * un_p
+        for ptr_, val in ((da, ga), (dp, gp), (dn, gn)):
+            o = _t(ptr_, (rows, ld), BF16)
+            o.zero_()
+            o[:, :d] = _bf(val * act)
+        return 0
+
     # ---- Dice loss ----------------------------------------------------------------------------------------------
     def tok_dice_rows(self, rows):
         return 1

@@ -892,3 +892,36 @@ def test_dice(libs, rows, classes, ld, mode, log_loss, sel):
     assert lib.tok_dice_bwd(P(zd), P(td), P(coef_d), P(gs.cuda()), rows, classes, ld, mode, P(d_d), st) == 0
     torch.cuda.synchronize()
     assert relerr(d_d.float(), d_h.float()) < 6e-3
+
+
+@pytest.mark.parametrize('n,d,ld', [(24, 40, 40), (512, 128, 128), (64, 20, 24)])
+def test_ntxent_kernels(libs, n, d, ld):
+    e = torch.zeros(n, ld)
+    e[:, :d] = torch.nn.functional.normalize(rnd(n, d), dim=1)
+    e = e.to(BF16)
+    lse, rl, loss = torch.empty(n), torch.empty(n), torch.empty(1)
+    dv = both(libs, 'tok_ntxent_fwd', lambda f: [f(e), n, d, ld, 0.2, f(lse), f(rl), f(loss), None])
+    assert relerr(dv[id(lse)], lse) < 1e-5 and relerr(dv[id(loss)], loss) < 1e-5
+    gs = torch.tensor([1.3])
+    de = torch.full((n, ld), float('nan'), dtype=BF16)
+    dv = both(libs, 'tok_ntxent_bwd', lambda f: [f(e), f(lse), f(gs), n, d, ld, 0.2, f(de), None])
+    assert relerr(dv[id(de)].float(), de.float()) < 6e-3
+
+
+@pytest.mark.parametrize('rows,d,ld,swap', [(16, 24, 24, 0), (1000, 128, 128, 1), (33, 20, 24, 1)])
+def test_triplet_kernels(libs, rows, d, ld, swap):
+    ts = []
+    for i in range(3):
+        t = torch.zeros(rows, ld)
+        t[:, :d] = rnd(rows, d, seed=i, scale=0.7)
+        ts.append(t.to(BF16))
+    a, p, ng = ts
+    dist, rl, loss = torch.empty(rows, 3), torch.empty(rows), torch.empty(1)
+    dv = both(libs, 'tok_triplet_fwd', lambda f: [f(a), f(p), f(ng), rows, d, ld, 0.6, 1e-6, swap, f(dist), f(rl), f(loss), None])
+    assert relerr(dv[id(dist)], dist) < 1e-5 and relerr(dv[id(loss)], loss) < 1e-5
+    gs = torch.tensor([0.9])
+    outs = [torch.full((rows, ld), float('nan'), dtype=BF16) for _ in range(3)]
+    dv = both(libs, 'tok_triplet_bwd', lambda f: [f(a), f(p), f(ng), f(dist), f(gs), rows, d, ld, 0.6, 1e-6, swap, f(outs[0]),
+                                                  f(outs[1]), f(outs[2]), None])
+    for o in outs:
+        assert relerr(dv[id(o)].float(), o.float()) < 6e-3

@@ -249,6 +249,33 @@ def golden_dice(out_path):
     print('wrote', out_path)
 
 
+def golden_unsupervised(out_path):
+    """NT_XentLoss from the reference's own losses/representation/unsupervised.py; TripletMarginLoss is torch's class
+    (what the reference registers, losses/__init__.py:39)."""
+    if 'torchok.losses.representation' not in sys.modules:
+        _fake_pkg('torchok.losses.representation', f'{REF}/losses/representation')
+    un = _load('torchok.losses.representation.unsupervised', f'{REF}/losses/representation/unsupervised.py')
+    g = torch.Generator().manual_seed(71)
+    out = {}
+    e1 = torch.nn.functional.normalize(torch.randn(12, 40, generator=g)).bfloat16().float().requires_grad_(True)
+    e2 = torch.nn.functional.normalize(torch.randn(12, 40, generator=g)).bfloat16().float().requires_grad_(True)
+    L = un.NT_XentLoss(temperature=0.2)(e1, e2)
+    L.backward()
+    out.update(ntx_e1=e1.detach().numpy(), ntx_e2=e2.detach().numpy(), ntx_loss=float(L.detach()), ntx_d1=e1.grad.numpy(),
+               ntx_d2=e2.grad.numpy())
+    a, p, n = ((torch.randn(16, 24, generator=g) * 0.7).bfloat16().float().requires_grad_(True) for _ in range(3))
+    for tag, kw in (('tri', dict(margin=1.0)), ('tri_swap', dict(margin=0.5, swap=True))):
+        for t in (a, p, n):
+            t.grad = None
+        L = torch.nn.TripletMarginLoss(**kw)(a, p, n)
+        L.backward()
+        out.update({f'{tag}_loss': float(L.detach()), f'{tag}_da': a.grad.numpy().copy(), f'{tag}_dp': p.grad.numpy().copy(),
+                    f'{tag}_dn': n.grad.numpy().copy()})
+    out.update(tri_a=a.detach().numpy(), tri_p=p.detach().numpy(), tri_n=n.detach().numpy())
+    np.savez_compressed(out_path, **out)
+    print('wrote', out_path)
+
+
 def golden_metric(out_path):
     """ArcFaceHead / LinearHead(normalize) / ContrastiveLoss / calc_relevance_matrix from the reference's
     own files; asserts oracle/metric_ref.py == reference bit-for-bit on the same inputs."""
@@ -415,6 +442,8 @@ def main():
     # of the HIP path is checked against these same vectors)
     if '--metric-only' in sys.argv:
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
+    if '--unsup-only' in sys.argv:
+        return golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     if '--dice-only' in sys.argv:
         return golden_dice(os.path.join(gd, 'dice_loss.npz'))
     if '--swin-only' in sys.argv:
@@ -428,6 +457,7 @@ def main():
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     golden_dice(os.path.join(gd, 'dice_loss.npz'))
+    golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
 
 
 if __name__ == '__main__':

@@ -110,6 +110,10 @@ PROTOTYPES = {
     'tok_cpb_bias_fwd': (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     'tok_cpb_bias_bwd': (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, _P, _P]),
     'tok_patch_merge': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_ntxent_fwd': (c_int, [_P, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
+    'tok_ntxent_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P]),
+    'tok_triplet_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
+    'tok_triplet_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,

@@ -185,6 +185,113 @@ __global__ __launch_bounds__(256) void contrastive_bwd_kernel(const bf16* __rest
   }
 }
 
+// ---- NT-Xent (losses/representation/unsupervised.py:7-54): rows of E = cat(emb1, emb2) [2B][d] ----------------------------
+// logits_ij = <e_i, e_j> / T with the diagonal at -1e9, label(i) = (i + B) mod 2B, mean cross-entropy.  One wave per row.
+__global__ __launch_bounds__(256) void ntxent_fwd_kernel(const bf16* __restrict__ e, int n, int d, int ld, float inv_t,
+                                                         float* __restrict__ lse, float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const bf16* a = e + (size_t)i * ld;
+  const int lab = (i + n / 2) % n;
+  float mx = -INFINITY, den = 0.f, pos = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const bf16* b = e + (size_t)j * ld;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s = fmaf(bf2f(a[k]), bf2f(b[k]), s);
+    s = j == i ? -1e9f : wave_sum(s) * inv_t;
+    if (j == lab) pos = s;
+    const float nm = fmaxf(mx, s);
+    den = den * expf(mx - nm) + expf(s - nm);
+    mx = nm;
+  }
+  if (lane == 0) { const float l = mx + logf(den); lse[i] = l; row_loss[i] = l - pos; }
+}
+
+// d e_i = sum_{j != i} (w_ij + w_ji) e_j * g / (n T),  w_ij = softmax_ij - [j == label(i)]   (logits are symmetric)
+__global__ __launch_bounds__(256) void ntxent_bwd_kernel(const bf16* __restrict__ e, const float* __restrict__ lse,
+                                                         const float* __restrict__ gscale, int n, int d, int ld,
+                                                         float inv_t, bf16* __restrict__ de) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const bf16* a = e + (size_t)i * ld;
+  const int half = n / 2;
+  const float g = (gscale ? gscale[0] : 1.f) * inv_t / (float)n;
+  const float li = lse[i];
+  float acc[16];     // d <= 1024: 16 columns per lane
+#pragma unroll
+  for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+  for (int j = 0; j < n; ++j) {
+    if (j == i) continue;
+    const bf16* b = e + (size_t)j * ld;
+    float s = 0.f;
+    for (int k = lane; k < d; k += 64) s = fmaf(bf2f(a[k]), bf2f(b[k]), s);
+    s = wave_sum(s) * inv_t;
+    const float w = (expf(s - li) - (j == (i + half) % n ? 1.f : 0.f)) + (expf(s - lse[j]) - (i == (j + half) % n ? 1.f : 0.f));
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = lane + u * 64;
+      if (k < d) acc[u] = fmaf(w, bf2f(b[k]), acc[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k = lane + u * 64;
+    if (k < ld) de[(size_t)i * ld + k] = f2bf(k < d ? acc[u] * g : 0.f);
+  }
+}
+
+// ---- torch.nn.TripletMarginLoss (p = 2): d(x, y) = || x - y + eps ||_2, loss = mean(relu(d_ap - d_an + margin)) -------------
+__global__ __launch_bounds__(256) void triplet_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ p,
+                                                          const bf16* __restrict__ ng, int rows, int d, int ld, float margin,
+                                                          float eps, int swap, float* __restrict__ dist,
+                                                          float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const size_t o = (size_t)i * ld;
+  float sap = 0.f, san = 0.f, spn = 0.f;
+  for (int k = lane; k < d; k += 64) {
+    const float av = bf2f(a[o + k]), pv = bf2f(p[o + k]), nv = bf2f(ng[o + k]);
+    const float x = av - pv + eps, y = av - nv + eps, z = pv - nv + eps;
+    sap = fmaf(x, x, sap); san = fmaf(y, y, san); spn = fmaf(z, z, spn);
+  }
+  const float dap = sqrtf(wave_sum(sap)), dan = sqrtf(wave_sum(san)), dpn = sqrtf(wave_sum(spn));
+  if (lane == 0) {
+    dist[i * 3 + 0] = dap; dist[i * 3 + 1] = dan; dist[i * 3 + 2] = dpn;
+    const float dneg = (swap && dpn < dan) ? dpn : dan;
+    row_loss[i] = fmaxf(dap - dneg + margin, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ p,
+                                                          const bf16* __restrict__ ng, const float* __restrict__ dist,
+                                                          const float* __restrict__ gscale, int rows, int d, int ld,
+                                                          float margin, float eps, int swap, bf16* __restrict__ da,
+                                                          bf16* __restrict__ dp, bf16* __restrict__ dn) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const size_t o = (size_t)i * ld;
+  const float dap = dist[i * 3], dan = dist[i * 3 + 1], dpn = dist[i * 3 + 2];
+  const bool sw = swap && dpn < dan;
+  const float dneg = sw ? dpn : dan;
+  const bool active = dap - dneg + margin > 0.f;
+  const float g = active ? (gscale ? gscale[0] : 1.f) / (float)rows : 0.f;
+  for (int k = lane; k < ld; k += 64) {
+    float ga = 0.f, gp = 0.f, gn = 0.f;
+    if (k < d && active) {
+      const float av = bf2f(a[o + k]), pv = bf2f(p[o + k]), nv = bf2f(ng[o + k]);
+      const float up = dap > 0.f ? (av - pv + eps) / dap : 0.f;      // d d_ap / d a
+      ga += up; gp -= up;
+      if (sw) { const float un = dpn > 0.f ? (pv - nv + eps) / dpn : 0.f; gp -= un; gn += un; }
+      else { const float un = dan > 0.f ? (av - nv + eps) / dan : 0.f; ga -= un; gn += un; }
+    }
+    da[o + k] = f2bf(ga * g); dp[o + k] = f2bf(gp * g); dn[o + k] = f2bf(gn * g);
+  }
+}
+
 inline int grid_for(size_t total) {
   size_t b = (total + 255) / 256;
   return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -272,5 +379,53 @@ extern "C" int tok_contrastive_bwd(const void* e1, const void* e2, const float* 
   hipLaunchKernelGGL(contrastive_bwd_kernel, dim3((n2 + 3) / 4), dim3(256), 0, st, (const bf16*)e1, (const bf16*)e2,
                      R, S, gscale, n1, n2, d, ld, margin, 1, (bf16*)(same_tensor ? de1 : de2), same_tensor ? 1 : 0);
   TOK_CHECK_LAUNCH("tok_contrastive_bwd(2)");
+  return TOK_OK;
+}
+
+extern "C" int tok_ntxent_fwd(const void* emb, int n, int d, int ld, float temperature, float* lse, float* row_loss,
+                              float* loss, void* stream) {
+  TOK_CHECK_ARG(emb && lse && row_loss && loss && n > 1 && n % 2 == 0 && d > 0 && ld >= d && temperature > 0.f,
+                "tok_ntxent_fwd: bad args");
+  hipStream_t st = tok_stream(stream);
+  hipLaunchKernelGGL(ntxent_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const bf16*)emb, n, d, ld, 1.f / temperature,
+                     lse, row_loss);
+  TOK_CHECK_LAUNCH("tok_ntxent_fwd");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, n, loss);
+  TOK_CHECK_LAUNCH("tok_ntxent_fwd(mean)");
+  return TOK_OK;
+}
+
+extern "C" int tok_ntxent_bwd(const void* emb, const float* lse, const float* gscale, int n, int d, int ld,
+                              float temperature, void* demb, void* stream) {
+  TOK_CHECK_ARG(emb && lse && demb && n > 1 && n % 2 == 0 && d > 0 && d <= 1024 && ld >= d && ld <= 1024 && temperature > 0.f,
+                "tok_ntxent_bwd: bad args (d <= 1024)");
+  hipLaunchKernelGGL(ntxent_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, tok_stream(stream), (const bf16*)emb, lse, gscale,
+                     n, d, ld, 1.f / temperature, (bf16*)demb);
+  TOK_CHECK_LAUNCH("tok_ntxent_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_triplet_fwd(const void* anchor, const void* positive, const void* negative, int rows, int d, int ld,
+                               float margin, float eps, int swap, float* dist, float* row_loss, float* loss, void* stream) {
+  TOK_CHECK_ARG(anchor && positive && negative && dist && row_loss && loss && rows > 0 && d > 0 && ld >= d,
+                "tok_triplet_fwd: bad args");
+  hipStream_t st = tok_stream(stream);
+  hipLaunchKernelGGL(triplet_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16*)anchor, (const bf16*)positive,
+                     (const bf16*)negative, rows, d, ld, margin, eps, swap, dist, row_loss);
+  TOK_CHECK_LAUNCH("tok_triplet_fwd");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, rows, loss);
+  TOK_CHECK_LAUNCH("tok_triplet_fwd(mean)");
+  return TOK_OK;
+}
+
+extern "C" int tok_triplet_bwd(const void* anchor, const void* positive, const void* negative, const float* dist,
+                               const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
+                               void* d_anchor, void* d_positive, void* d_negative, void* stream) {
+  TOK_CHECK_ARG(anchor && positive && negative && dist && d_anchor && d_positive && d_negative && rows > 0 && d > 0 &&
+                ld >= d, "tok_triplet_bwd: bad args");
+  hipLaunchKernelGGL(triplet_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, tok_stream(stream), (const bf16*)anchor,
+                     (const bf16*)positive, (const bf16*)negative, dist, gscale, rows, d, ld, margin, eps, swap,
+                     (bf16*)d_anchor, (bf16*)d_positive, (bf16*)d_negative);
+  TOK_CHECK_LAUNCH("tok_triplet_bwd");
   return TOK_OK;
 }
