@@ -210,3 +210,38 @@ def test_classification_neck(dev):
     nk = T.NECKS.get('HRNetClassificationNeck')(bb.out_channels).to(dev)
     with torch.no_grad():
         assert tuple(nk(bb(torch.rand(2, 3, 224, 224).to(dev))).shape) == (2, 2048, 7, 7)
+
+
+@pytest.mark.gpu
+def test_branch_streams_are_transparent(monkeypatch):
+    """12 SGD steps of the segmentation task: bit-identical parameters with the module branches on their own HIP streams
+    (+ weight gradients on the side stream) and with everything on the main stream; the loss falls."""
+    from torchok_amd.engine import core as EC
+    from torchok_amd.engine import functional as EF
+    finals, losses = [], []
+    for multi in (True, False):
+        monkeypatch.setattr(EC, 'BRANCH_STREAMS', multi)
+        monkeypatch.setattr(EF, 'WGRAD_SIDE_STREAM', multi)
+        cfg = seg_config('hrnet_w18_small', classes=5, size=64)
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 13)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(4, 3, 64, 64, generator=g).cuda()
+        y = torch.randint(0, 5, (4, 64, 64), generator=g).cuda()
+        hist = []
+        for it in range(12):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad(set_to_none=True)
+            out['loss'].backward()
+            opt.step()
+            hist.append(out['loss'].detach())
+        torch.cuda.synchronize()
+        losses.append([float(v) for v in hist])
+        finals.append({n: p.detach().clone() for n, p in task.named_parameters()})
+    assert losses[0][-1] < losses[0][0]
+    assert losses[0] == losses[1]
+    for n in finals[0]:
+        assert torch.equal(finals[0][n], finals[1][n]), n
