@@ -55,6 +55,13 @@ def _worker(rank, world, port, tmp):
     others = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(others, flat)
     assert torch.equal(others[0], others[1])
+    # logged losses: mean over ranks from one collective (reference: all_gather + mean, tasks/base.py:163-173)
+    mine = out['loss'].detach().float()
+    both = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(both, mine)
+    logged = task.on_train_batch_end({'loss': out['loss']}, None, 0)
+    assert set(logged) == {'loss'} and abs(float(logged['loss']) - float(sum(both) / world)) < 1e-6
+    assert 'train/loss' in task.logged
     red.close()
     dist.destroy_process_group()
     open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')

@@ -86,3 +86,40 @@ class BaseTask(nn.Module, ABC):
 
     def predict_step(self, batch, batch_idx: int, dataloader_idx: int = 0) -> Dict[str, Tensor]:
         return self.forward_with_gt(batch)
+
+    # ---- per-batch / per-epoch hooks (reference tasks/base.py:163-200) -----------------------------------------
+    def _mean_over_ranks(self, outputs: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """The reference all_gathers every logged value and takes the mean (tasks/base.py:170,182): the same numbers
+        from ONE collective here — the values are stacked and mean-all-reduced over RCCL (gloo on CPU)."""
+        import torch.distributed as dist
+        tags = list(outputs)
+        if not tags:
+            return {}
+        vals = torch.stack([outputs[t].detach().float().mean() for t in tags])
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(vals)
+            vals = vals / dist.get_world_size()
+        return {t: vals[i] for i, t in enumerate(tags)}
+
+    def on_train_batch_end(self, outputs: Dict[str, Tensor], batch, batch_idx: int, dataloader_idx: int = 0):
+        output_dict = self._mean_over_ranks(outputs)
+        for tag, value in output_dict.items():
+            self.log(f'train/{tag}', value, on_step=False, on_epoch=True, batch_size=len(outputs))
+        return output_dict
+
+    def on_validation_batch_end(self, outputs: Dict[str, Tensor], batch, batch_idx: int, dataloader_idx: int = 0):
+        output_dict = self._mean_over_ranks(outputs)
+        for tag, value in output_dict.items():
+            self.log(f'valid/{tag}', value, on_step=False, on_epoch=True, batch_size=len(outputs))
+        return output_dict
+
+    def on_train_epoch_end(self) -> None:
+        self.log_dict(self.metrics_manager.on_epoch_end(Phase.TRAIN))
+        self.log('step', float(self.current_epoch), on_step=False, on_epoch=True)
+
+    def on_validation_epoch_end(self) -> None:
+        self.log_dict(self.metrics_manager.on_epoch_end(Phase.VALID))
+        self.log('step', float(self.current_epoch), on_step=False, on_epoch=True)
+
+    def on_test_epoch_end(self) -> None:
+        self.log_dict(self.metrics_manager.on_epoch_end(Phase.TEST))
