@@ -159,3 +159,37 @@ def test_two_stream_schedule_is_bit_identical_and_learns(monkeypatch):
     assert losses[0] == losses[1]
     for n in finals[0]:
         assert torch.equal(finals[0][n], finals[1][n]), n
+
+
+def test_hipgraph_replay_equals_eager():
+    """GraphedTrainingStep (3 eager warm-up steps, one capture, n replays) leaves bit-identical parameters, BatchNorm buffers
+    and loss to 3 + n eager steps: the captured graph holds exactly the kernels of one step."""
+    from torchok_amd.engine.graph import GraphedTrainingStep
+    n_replays = 4
+    results = []
+    for graphed in (False, True):
+        cfg = cls_config('resnet18', 6, opt_params={'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4})
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 9)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(11)
+        batch = {'image': torch.randn(16, 3, 64, 64, generator=g).cuda(), 'target': torch.randint(0, 6, (16,), generator=g).cuda()}
+        if graphed:
+            step = GraphedTrainingStep(task, opt, batch, warmup=3)
+            for _ in range(n_replays):
+                loss = step(batch)['loss']
+        else:
+            for it in range(3 + n_replays):
+                out = task.training_step(batch, it)
+                opt.zero_grad(set_to_none=True)
+                out['loss'].backward()
+                opt.step()
+                loss = out['loss']
+        torch.cuda.synchronize()
+        results.append((float(loss), {k: v.detach().clone() for k, v in task.state_dict().items()
+                                      if not k.startswith('input_tensors')}))
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
