@@ -242,6 +242,13 @@ int tok_dice_fwd(const void* logits, const void* target, int64_t rows, int class
 int tok_dice_bwd(const void* logits, const void* target, const float* coef, const float* gscale, int64_t rows,
                  int classes, int ld, int mode, void* dlogits, void* stream);
 
+/* On-device classification statistics behind the Accuracy / F1Score metrics the reference configs log every step
+ * (metrics/metrics_manager.py:147-158, classification_cifar10.yaml:134-150; torchmetrics itself is third-party):
+ * counts int64 [3][classes] += {true positives, predicted, actual} per class.  Predictions are bf16 logits
+ * [rows][ld] (first maximum, as torch.argmax) or int64 labels; rows whose target is ignore_index are skipped.   */
+int tok_cls_stats_update(const void* logits, const int64_t* labels, const int64_t* target, int64_t rows,
+                         int classes, int ld, int64_t ignore_index, int64_t* counts, void* stream);
+
 /* ---- metric-learning head and loss -----------------------------------------------------------
  * F.normalize (arcface_head.py:125-126, linear_head.py:33-34): y = x / max(||x||_2, eps) per row;
  * is_f32 selects fp32 rows (class-weight matrix) instead of bf16 activations.               */

@@ -448,6 +448,17 @@ class FakeTok:
             o[:, :d] = _bf(val * act)
         return 0
 
+    def tok_cls_stats_update(self, logits, labels, target, rows, classes, ld, ignore_index, counts, st):
+        t = _t(target, (rows,), torch.int64)
+        pred = _t(labels, (rows,), torch.int64) if labels is not None else _t(logits, (rows, ld), BF16)[:, :classes].float().argmax(1)
+        ok = (t != ignore_index) & (t >= 0) & (t < classes)
+        cnt = _t(counts, (3, classes), torch.int64)
+        for c in range(classes):
+            cnt[0, c] += int(((pred == c) & (t == c) & ok).sum())
+            cnt[1, c] += int(((pred == c) & ok).sum())
+            cnt[2, c] += int(((t == c) & ok).sum())
+        return 0
+
     # ---- Dice loss ----------------------------------------------------------------------------------------------
     def tok_dice_rows(self, rows):
         return 1

@@ -1,0 +1,101 @@
+"""MetricsManager (reference metrics/metrics_manager.py:13-206) over the on-device Accuracy / F1Score statistics: values
+against a plain numpy evaluation of the torchmetrics definitions (torchmetrics itself is third-party and absent), manager
+semantics against the reference's documented behaviour.  Host stand-in and, marked gpu, libtok_gfx950.so."""
+import numpy as np
+import pytest
+import torch
+
+import torchok_amd as T
+from helpers import cls_config
+from torchok_amd.constructor.config import Phase
+from torchok_amd.metrics import MetricsManager
+
+
+@pytest.fixture(params=['host', pytest.param('hip', marks=pytest.mark.gpu)])
+def dev(request):
+    if request.param == 'host':
+        request.getfixturevalue('fake_backend')
+        return 'cpu'
+    assert torch.cuda.is_available()
+    return 'cuda'
+
+
+def _reference(pred, tgt, c):
+    tp = np.array([((pred == k) & (tgt == k)).sum() for k in range(c)], dtype=np.float64)
+    pp = np.array([(pred == k).sum() for k in range(c)], dtype=np.float64)
+    ap = np.array([(tgt == k).sum() for k in range(c)], dtype=np.float64)
+    seen = (pp + ap) > 0
+    f1 = 2 * tp / np.maximum(pp + ap, 1)
+    acc = tp / np.maximum(ap, 1)
+    return dict(acc_micro=tp.sum() / ap.sum(), acc_macro=acc[seen].mean(), f1_micro=2 * tp.sum() / (pp.sum() + ap.sum()),
+                f1_macro=f1[seen].mean(), f1_weighted=(f1 * ap / ap.sum()).sum(), f1_none=f1)
+
+
+def test_accuracy_and_f1_values(dev):
+    g = torch.Generator().manual_seed(0)
+    c = 7
+    logits = torch.randn(500, c, generator=g)
+    tgt = torch.randint(0, c - 1, (500,), generator=g)             # class 6 never occurs as a target
+    logits[torch.arange(0, 500, 3), tgt[::3]] += 3.0                  # make a third of the rows right
+    pred = logits.to(torch.bfloat16).float().argmax(1).numpy()
+    want = _reference(pred, tgt.numpy(), c)
+    mk = lambda name, **kw: T.METRICS.get(name)(task='multiclass', num_classes=c, **kw).to(dev)   # noqa: E731
+    metrics = dict(acc_micro=mk('Accuracy'), acc_macro=mk('Accuracy', average='macro'), f1_micro=mk('F1Score'),
+                   f1_macro=mk('F1Score', average='macro'), f1_weighted=mk('F1Score', average='weighted'),
+                   f1_none=mk('F1Score', average='none'))
+    for m in metrics.values():
+        m.update(preds=logits[:300].to(dev), target=tgt[:300].to(dev))     # two updates accumulate
+        m.update(preds=logits[300:].to(dev), target=tgt[300:].to(dev))
+    for k, m in metrics.items():
+        assert np.allclose(m.compute().cpu().numpy(), want[k], rtol=1e-6), k
+    m = metrics['acc_micro']
+    m.reset()
+    m.update(preds=torch.from_numpy(pred).to(dev), target=tgt.to(dev))     # integer predictions
+    assert np.allclose(float(m.compute()), want['acc_micro'], rtol=1e-6)
+    ig = T.METRICS.get('Accuracy')(task='multiclass', num_classes=c, ignore_index=2).to(dev)
+    ig.update(preds=logits.to(dev), target=tgt.to(dev))
+    keep = tgt.numpy() != 2
+    assert np.allclose(float(ig.compute()), (pred[keep] == tgt.numpy()[keep]).mean(), rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        T.METRICS.get('Accuracy')(task='binary')
+    with pytest.raises(KeyError):
+        T.METRICS.get('AUROC')
+
+
+def test_manager_semantics(dev):
+    params = [dict(name='Accuracy', params=dict(task='multiclass', num_classes=4), mapping=dict(preds='prediction', target='target')),
+              dict(name='F1Score', params=dict(task='multiclass', num_classes=4, average='macro'), tag='f1',
+                   mapping=dict(preds='prediction', target='target'), phases=['VALID'], val_dataloader_idxs=[0, 1])]
+    mm = MetricsManager(params).to(dev)
+    assert len(mm.phase2metrics['TRAIN']) == 1 and len(mm.phase2metrics['VALID']) == 3
+    pred = torch.eye(4)[[0, 1, 2, 3, 0, 1]].to(dev) * 5
+    tgt = torch.tensor([0, 1, 2, 0, 0, 2]).to(dev)
+    mm.update(Phase.TRAIN, prediction=pred, target=tgt, embeddings=None)
+    mm.update(Phase.VALID, 1, prediction=pred, target=tgt)
+    log = mm.on_epoch_end(Phase.TRAIN)
+    assert set(log) == {'train/Accuracy'} and abs(float(log['train/Accuracy']) - 4 / 6) < 1e-6
+    assert float(mm.on_epoch_end(Phase.TRAIN)['train/Accuracy']) == 0.0          # reset after the epoch
+    vlog = mm.on_epoch_end(Phase.VALID)
+    assert set(vlog) == {'valid/Accuracy', 'valid/f1_dataloader_0', 'valid/f1_dataloader_1'}
+    assert float(vlog['valid/f1_dataloader_0']) == 0.0 and float(vlog['valid/f1_dataloader_1']) > 0.5
+    with pytest.raises(ValueError, match='Cannot find'):
+        mm.update(Phase.TRAIN, target=tgt)
+    with pytest.raises(ValueError, match='identical names'):
+        MetricsManager([params[0], params[0]])
+
+
+def test_task_logs_configured_metrics(dev):
+    cfg = cls_config('resnet18', 5)
+    cfg['metrics'] = [dict(name='Accuracy', params=dict(task='multiclass', num_classes=5),
+                           mapping=dict(preds='prediction', target='target'))]
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).to(dev).train()
+    x, y = torch.randn(8, 3, 32, 32).to(dev), torch.randint(0, 5, (8,)).to(dev)
+    task.training_step({'image': x, 'target': y}, 0)
+    pred = task.forward_with_gt({'image': x, 'target': y})['prediction'].float().argmax(1)
+    task.on_train_epoch_end()
+    assert 'train/Accuracy' in task.logged
+    task.eval()
+    with torch.no_grad():
+        task.validation_step({'image': x, 'target': y}, 0)
+    task.on_validation_epoch_end()
+    assert 0.0 <= float(task.logged['valid/Accuracy']) <= 1.0 and pred.shape == (8,)

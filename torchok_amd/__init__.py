@@ -7,8 +7,8 @@ Everything numeric runs in hand-written HIP kernels for gfx950 behind the C ABI 
 (torchok_amd/lib/libtok_gfx950.so, built by __graft_entry__.build()).  No CPU fallback exists.
 """
 from . import constructor  # noqa: F401
-from . import models, losses, optim, tasks  # noqa: F401
-from .constructor import (BACKBONES, HEADS, LOSSES, NECKS, OPTIMIZERS, POOLINGS, SCHEDULERS, TASKS)  # noqa: F401
+from . import models, losses, metrics, optim, tasks  # noqa: F401
+from .constructor import (BACKBONES, HEADS, LOSSES, METRICS, NECKS, OPTIMIZERS, POOLINGS, SCHEDULERS, TASKS)  # noqa: F401
 from .constructor.config import load_config  # noqa: F401
 
 __version__ = '0.1.0'

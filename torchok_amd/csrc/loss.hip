@@ -273,3 +273,52 @@ extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, con
   TOK_CHECK_LAUNCH("tok_softmax_ce_bwd");
   return TOK_OK;
 }
+
+namespace {
+// classification statistics for the on-device metrics: per class c: counts[0][c] += [argmax == c == target],
+// counts[1][c] += [argmax == c], counts[2][c] += [target == c]  (int64 atomics: exact, order-independent)
+__global__ __launch_bounds__(256) void cls_stats_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                        const int64_t* __restrict__ target, int64_t rows, int classes,
+                                                        int ld, int64_t ignore_index, unsigned long long* counts) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
+    const int64_t t = target[row];
+    if (t == ignore_index || t < 0 || t >= classes) continue;
+    int pred;
+    if (labels != nullptr) {
+      pred = (int)labels[row];
+    } else {                       // first maximum, as torch.argmax
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = lane; c < classes; c += 64) {
+        const float v = bf2f(logits[row * ld + c]);
+        if (v > best) { best = v; bi = c; }
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      }
+      pred = bi;
+    }
+    if (lane == 0) {
+      if (pred >= 0 && pred < classes) {
+        atomicAdd(&counts[classes + pred], 1ull);
+        if (pred == (int)t) atomicAdd(&counts[pred], 1ull);
+      }
+      atomicAdd(&counts[2 * classes + (int)t], 1ull);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int tok_cls_stats_update(const void* logits, const int64_t* labels, const int64_t* target, int64_t rows,
+                                    int classes, int ld, int64_t ignore_index, int64_t* counts, void* stream) {
+  TOK_CHECK_ARG((logits != nullptr) != (labels != nullptr), "tok_cls_stats_update: give logits OR predicted labels");
+  TOK_CHECK_ARG(target && counts && rows > 0 && classes > 0 && (labels || ld >= classes), "tok_cls_stats_update: bad args");
+  const int64_t b = (rows + 3) / 4;
+  hipLaunchKernelGGL(cls_stats_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)logits, labels, target, rows, classes, ld, ignore_index, (unsigned long long*)counts);
+  TOK_CHECK_LAUNCH("tok_cls_stats_update");
+  return TOK_OK;
+}
