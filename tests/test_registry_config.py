@@ -167,3 +167,28 @@ def test_paramwise_cfg_groups():
     by_name = dict(zip(names, groups))
     assert by_name['bn1.weight']['weight_decay'] == 0.0 and by_name['conv1.weight']['weight_decay'] == 1e-2
     assert abs(by_name['layer4.0.conv1.weight']['lr'] - 0.01) < 1e-12 and by_name['layer3.0.conv1.weight']['lr'] == 0.1
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/examples/configs/classification_cifar10.yaml'),
+                    reason='the reference checkout exists only in the build container')
+def test_reference_cifar10_recipe_runs_a_step(fake_backend):
+    """BASELINE.json configs[0]: the reference's own examples/configs/classification_cifar10.yaml (ResNet-18,
+    ClassificationTask, CrossEntropyLoss, Adam, Accuracy + F1Score) loads unchanged and runs a training step, an optimizer
+    step and the epoch-end metric summary (datasets / trainer sections are parsed and ignored: no data pipeline here)."""
+    import torch
+    import torchok_amd as T
+    os.environ.setdefault('HOME', '/root')
+    # the recipe asks for pretrained weights (a download): overridden the way the launcher overrides keys
+    cfg = T.load_config('/root/reference/examples/configs/classification_cifar10.yaml',
+                        overrides={'task.params.backbone_params.pretrained': False})
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).train()
+    assert type(task.backbone).__name__ == 'ResNet' and len(task.metrics_manager.phase2metrics['TRAIN']) >= 1
+    opt = task.configure_optimizers()[0]['optimizer']
+    assert type(opt).__name__ == 'Adam'
+    x, y = torch.randn(4, 3, 32, 32), torch.randint(0, 10, (4,))
+    out = task.training_step({'image': x, 'target': y, 'index': torch.arange(4)}, 0)
+    opt.zero_grad()
+    out['loss'].backward()
+    opt.step()
+    task.on_train_epoch_end()
+    assert any(k.startswith('train/') for k in task.logged)
