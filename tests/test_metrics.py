@@ -99,3 +99,31 @@ def test_task_logs_configured_metrics(dev):
         task.validation_step({'image': x, 'target': y}, 0)
     task.on_validation_epoch_end()
     assert 0.0 <= float(task.logged['valid/Accuracy']) <= 1.0 and pred.shape == (8,)
+
+
+def test_jaccard_index_and_legacy_forms(dev):
+    g = torch.Generator().manual_seed(1)
+    c = 4
+    logits = torch.randn(2, c, 16, 16, generator=g)
+    tgt = torch.randint(0, 3, (2, 16, 16), generator=g)                         # class 3 never a target
+    pred = logits.to(torch.bfloat16).float().argmax(1).numpy().reshape(-1)
+    t = tgt.numpy().reshape(-1)
+    tp = np.array([((pred == k) & (t == k)).sum() for k in range(c)], dtype=np.float64)
+    pp = np.array([(pred == k).sum() for k in range(c)], dtype=np.float64)
+    ap = np.array([(t == k).sum() for k in range(c)], dtype=np.float64)
+    iou = tp / (pp + ap - tp)
+    # legacy form (segmentation_sweet_pepper.yaml:161-168): ignore_index drops class 0 from the mean, pixels all count
+    m = T.METRICS.get('JaccardIndex')(num_classes=c, ignore_index=0).to(dev)
+    m.update(preds=logits.to(dev), target=tgt.to(dev))
+    assert np.allclose(float(m.compute()), iou[1:].mean(), rtol=1e-6)
+    # task form: ignore_index drops the PIXELS labelled 0, macro over observed classes
+    m2 = T.METRICS.get('JaccardIndex')(task='multiclass', num_classes=c, ignore_index=0).to(dev)
+    m2.update(preds=logits.to(dev), target=tgt.to(dev))
+    keep = t != 0
+    tp2 = np.array([((pred[keep] == k) & (t[keep] == k)).sum() for k in range(c)], dtype=np.float64)
+    un2 = np.array([(pred[keep] == k).sum() + (t[keep] == k).sum() for k in range(c)], dtype=np.float64) - tp2
+    assert np.allclose(float(m2.compute()), (tp2[un2 > 0] / un2[un2 > 0]).mean(), rtol=1e-6)
+    # legacy Accuracy(): the class count comes from the predictions
+    a = T.METRICS.get('Accuracy')().to(dev)
+    a.update(preds=logits.to(dev), target=tgt.to(dev))
+    assert a.num_classes == c and np.allclose(float(a.compute()), (pred == t).mean(), rtol=1e-6)

@@ -24,16 +24,25 @@ class _MulticlassStat(nn.Module):
                  ignore_index: Optional[int] = None, threshold: float = 0.5, multidim_average: str = 'global',
                  validate_args: bool = True, **kwargs):
         super().__init__()
-        if task != 'multiclass' or num_classes is None or top_k != 1 or multidim_average != 'global':
-            raise NotImplementedError(f"torchok_amd {type(self).__name__}: task='multiclass', num_classes=N, top_k=1")
+        # task=None is the pre-0.11 torchmetrics call style the shipped recipes still use (torchmetrics 0.11.4 keeps it):
+        # multiclass inferred from (N, C, ...) float predictions, num_classes taken from them when not given
+        if task not in (None, 'multiclass') or top_k not in (1, None) or multidim_average != 'global':
+            raise NotImplementedError(f"torchok_amd {type(self).__name__}: multiclass (task='multiclass' or the legacy "
+                                      f"task-less form), top_k=1")
         if average not in ('micro', 'macro', 'weighted', 'none', None):
             raise ValueError(f'Expected argument `average` to be one of micro / macro / weighted / none, got {average}')
-        self.num_classes, self.average = int(num_classes), average
+        self.legacy = task is None
+        self.num_classes, self.average = (None if num_classes is None else int(num_classes)), average
         self.ignore_index = -100 if ignore_index is None else int(ignore_index)
-        self.register_buffer('counts', torch.zeros(3, self.num_classes, dtype=torch.int64), persistent=False)
+        self.register_buffer('counts', torch.zeros(3, self.num_classes or 0, dtype=torch.int64), persistent=False)
 
     def update(self, preds: Tensor, target: Tensor) -> None:
         require_device(preds)
+        if self.num_classes is None:
+            if not preds.is_floating_point() or preds.dim() < 2:
+                raise ValueError(f'{type(self).__name__}: give num_classes (it cannot be inferred from label predictions)')
+            self.num_classes = int(preds.shape[1])
+            self.counts = torch.zeros(3, self.num_classes, dtype=torch.int64, device=preds.device)
         c = self.num_classes
         tgt = target.reshape(-1).to(torch.int64).contiguous()
         if self.counts.device != preds.device:
@@ -47,12 +56,15 @@ class _MulticlassStat(nn.Module):
             p = preds.detach()
             if p.dtype != BF16 or p.stride(-1) != 1:
                 p = p.to(BF16).contiguous()
-            _C.check(lib.tok_cls_stats_update(ptr(p), None, ptr(tgt), p.shape[0], c, p.stride(0), self.ignore_index,
+            _C.check(lib.tok_cls_stats_update(ptr(p), None, ptr(tgt), p.shape[0], c, p.stride(0), self._pixel_ignore(),
                                               ptr(self.counts), st), 'tok_cls_stats_update')
         else:
             lab = preds.detach().reshape(-1).to(torch.int64).contiguous()
-            _C.check(lib.tok_cls_stats_update(None, ptr(lab), ptr(tgt), lab.shape[0], c, pad8(c), self.ignore_index,
+            _C.check(lib.tok_cls_stats_update(None, ptr(lab), ptr(tgt), lab.shape[0], c, pad8(c), self._pixel_ignore(),
                                               ptr(self.counts), st), 'tok_cls_stats_update')
+
+    def _pixel_ignore(self) -> int:
+        return self.ignore_index
 
     def reset(self) -> None:
         self.counts.zero_()
@@ -85,6 +97,35 @@ class F1Score(_MulticlassStat):
         if self.average == 'micro':      # single-label multiclass: micro F1 == accuracy
             return (2 * tp.sum() / (pp.sum() + ap.sum()).clamp_min(1)).float()
         return self._reduce(2 * tp / (pp + ap).clamp_min(1), ap, (ap + pp) > 0)
+
+
+@METRICS.register_class
+class JaccardIndex(_MulticlassStat):
+    """Intersection over union per class from the same {tp, predicted, actual} counts.  Legacy (task-less) form, as in
+    segmentation_sweet_pepper.yaml:161-168: `ignore_index` drops that CLASS from the average (every pixel still counts),
+    classes absent from prediction and target score `absent_score`; task='multiclass': `ignore_index` drops the pixels."""
+
+    def __init__(self, num_classes: int = None, average: Optional[str] = 'macro', ignore_index: Optional[int] = None,
+                 absent_score: float = 0.0, threshold: float = 0.5, multilabel: bool = False,
+                 reduction: str = 'elementwise_mean', task: str = None, **kwargs):
+        if multilabel or reduction not in ('elementwise_mean', 'none', None):
+            raise NotImplementedError('torchok_amd JaccardIndex: multiclass, mean / none reduction')
+        super().__init__(task=task, num_classes=num_classes, average=average if task else 'macro',
+                         ignore_index=ignore_index, **kwargs)
+        self.absent_score, self.reduction, self.drop_class = absent_score, reduction, ignore_index
+
+    def _pixel_ignore(self) -> int:
+        return -100 if self.legacy else self.ignore_index
+
+    def compute(self) -> Tensor:
+        tp, pp, ap = self._stats()
+        union = pp + ap - tp
+        iou = torch.where(union > 0, tp / union.clamp_min(1), torch.full_like(tp, self.absent_score))
+        if self.legacy:
+            if self.drop_class is not None and 0 <= self.drop_class < iou.numel():
+                iou = torch.cat([iou[:self.drop_class], iou[self.drop_class + 1:]])
+            return iou.float() if self.reduction in ('none', None) else iou.mean().float()
+        return self._reduce(iou, ap, union > 0)
 
 
 class MetricWithUtils(nn.Module):
