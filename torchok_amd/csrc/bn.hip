@@ -117,6 +117,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
   }
 }
 
+// Per-lane fold of partial rows rl, rl+64, ... for both sums: 8 loads in flight (the serial version was bound by the
+// load latency: 12 dependent round trips on 768 rows), additions in row order so the result does not depend on it.
+__device__ __forceinline__ void fold_rows(const float* __restrict__ p, int rows, int C, int c, int rl, double& a1,
+                                          double& a2) {
+  const float* p1 = p + c;
+  const float* p2 = p + (size_t)rows * C + c;
+  for (int r = rl; r < rows; r += 256) {
+    float v1[4], v2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ru = r + 64 * u;
+      const int rc = ru < rows ? ru : rows - 1;      // unconditional loads (a branch would serialise them)
+      v1[u] = p1[(size_t)rc * C];
+      v2[u] = p2[(size_t)rc * C];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool live = r + 64 * u < rows;
+      a1 += live ? (double)v1[u] : 0.0;
+      a2 += live ? (double)v2[u] : 0.0;
+    }
+  }
+}
+
 // 4 channels per block, 64 row-lanes each; fp64 accumulation across partial rows.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows,
                                                           double inv_count, double unbias, int C, int Creal,
@@ -132,10 +156,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 4 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int r = rl; r < rows; r += 64) {
-      a1 += (double)stats[(size_t)r * C + c];
-      a2 += (double)stats[((size_t)rows + r) * C + c];
-    }
+    fold_rows(stats, rows, C, c, rl, a1, a2);
   }
   red[0][tid] = a1;
   red[1][tid] = a2;
@@ -253,10 +274,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
   const int c = blockIdx.x * 4 + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    for (int r = rl; r < rows; r += 64) {
-      a1 += (double)partial[(size_t)r * C + c];
-      a2 += (double)partial[((size_t)rows + r) * C + c];
-    }
+    fold_rows(partial, rows, C, c, rl, a1, a2);
   }
   red[0][tid] = a1;
   red[1][tid] = a2;

@@ -194,12 +194,25 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
     float acc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-    if (rl < rpb)
-      for (int64_t m = r0 + rl; m < r1; m += rpb) {
-        const bf16x8 v = ldg16(dy + (size_t)m * ld + cg * 8);
+    if (rl < rpb && r0 < r1) {
+      // 8 independent 16-byte loads in flight per lane (rows past the chunk are clamped and dropped); the
+      // additions keep the row order, so the partial sums do not depend on the unroll factor
+      const bf16* col = dy + cg * 8;
+      for (int64_t m = r0 + rl; m < r1; m += 8 * (int64_t)rpb) {
+        bf16x8 v[8];
+        bool live[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        for (int u = 0; u < 8; ++u) {
+          const int64_t mu = m + (int64_t)u * rpb;
+          live[u] = mu < r1;
+          v[u] = ldg16(col + (size_t)(mu < r1 ? mu : r1 - 1) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += live[u] ? bf2f(v[u][e]) : 0.f;
       }
+    }
     if (rl < rpb)
 #pragma unroll
       for (int e = 0; e < 8; ++e) red[(size_t)rl * ld + cg * 8 + e] = acc[e];

@@ -248,8 +248,19 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + cl;
   double a = 0.0;
-  if (col < cols)
-    for (int64_t r = rl; r < rows; r += 16) a += (double)src[r * cols + col];
+  if (col < cols) {
+    const float* s0 = src + col;
+    for (int64_t r = rl; r < rows; r += 128) {   // 8 loads in flight, additions in row order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t ru = r + 16 * u;
+        v[u] = s0[(ru < rows ? ru : rows - 1) * cols];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += r + 16 * u < rows ? (double)v[u] : 0.0;
+    }
+  }
   red[threadIdx.x] = a;
   __syncthreads();
   for (int s = 8; s > 0; s >>= 1) {
