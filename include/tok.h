@@ -360,6 +360,32 @@ int tok_triplet_bwd(const void* anchor, const void* positive, const void* negati
                     const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
                     void* d_anchor, void* d_positive, void* d_negative, void* stream);
 
+/* ---- retrieval meters (validation path) -------------------------------------------------------
+ * IndexBasedMeter.compute (metrics/index_base_metric.py:170-270) with exact_index=True: the faiss flat index
+ * (:523-545) is an exhaustive search = similarity matrix + k best per row; the ranx metric functions bound by
+ * metrics/representation_ranx.py:56-123 are evaluated per query on the device.
+ * tok_sim_matrix: out[i][j] = <q_i, g_j> (metric 0, IndexFlatIP) or -|q_i - g_j|^2 (metric 1, IndexFlatL2; negated
+ * so that larger is closer), fp32 [nq][ldo] for fp32 rows q [nq][ldq], g [ng][ldg].                        */
+int tok_sim_matrix(const float* q, const float* g, int nq, int ng, int d, int ldq, int ldg, int metric,
+                   float* out, int64_t ldo, void* stream);
+/* k best columns per row, larger value first, lower index on ties; k > cols is padded with (-inf, -1) as
+ * faiss does.  vals fp32 [rows][k], idx int64 [rows][k].                                                  */
+int tok_topk_rows(const float* s, int rows, int cols, int64_t ld, int k, float* vals, int64_t* idx, void* stream);
+/* Number of relevant vectors per query.  labels != NULL (classification data, :379-418): vectors with the label
+ * of row q_row[i], the query excluded.  Otherwise scores fp32 [n][n_cols] (representation data, :342-377): rows
+ * whose entry in column q_col[i] reaches ranx's relevance level 1.                                        */
+int tok_retrieval_nrel(const int64_t* labels, const float* scores, int n, int n_cols, const int64_t* q_row,
+                       const int64_t* q_col, int nq, int32_t* n_rel, void* stream);
+/* Per-query metric of the kk - 1 results left by clear_faiss_output (:420-444: drop the first of the kk = k + 1
+ * found when drop_first[i], else the last).  kind 0 hit_rate, 1 precision, 2 recall, 3 average_precision,
+ * 4 ndcg (Jarvelin, linear gains).  idx int64 [nq][kk] are rows of `gallery` (int64 [ng] -> global row; NULL =
+ * identity), -1 meaning gallery[ng-1] (:503).  ideal fp32 [nq][kk-1] = descending gains of the relevant set
+ * (NULL: all ones).  out fp32 [nq].                                                                        */
+int tok_retrieval_eval(int kind, const int64_t* idx, int kk, const uint8_t* drop_first, const int64_t* gallery,
+                       int ng, const int64_t* labels, const float* scores, int n_cols, const int64_t* q_row,
+                       const int64_t* q_col, const int32_t* n_rel, const float* ideal, int nq, float* out,
+                       void* stream);
+
 /* ---- optimizers (flat arenas) -------------------------------------------------------------
  * torch.optim.SGD / Adam / AdamW registered at optim/optimizers/__init__.py:11,13,18 and
  * built by Constructor.create_optimizer (constructor/constructor.py:151-158).  One launch

@@ -448,6 +448,85 @@ class FakeTok:
             o[:, :d] = _bf(val * act)
         return 0
 
+    # ---- retrieval meters ------------------------------------------------------------------------------------------------
+    def tok_sim_matrix(self, q, g, nq, ng, d, ldq, ldg, metric, out, ldo, st):
+        qv = _t(q, (nq, ldq), torch.float32)[:, :d]
+        gv = _t(g, (ng, ldg), torch.float32)[:, :d]
+        s = qv @ gv.t() if metric == 0 else -((qv[:, None, :] - gv[None, :, :]) ** 2).sum(-1)
+        _t(out, (nq, ldo), torch.float32)[:, :ng] = s
+        return 0
+
+    def tok_topk_rows(self, s, rows, cols, ld, k, vals, idx, st):
+        sv = _t(s, (rows, ld), torch.float32)[:, :cols]
+        order = torch.argsort(-sv, dim=1, stable=True)[:, :k]
+        v = torch.gather(sv, 1, order)
+        vo, io = _t(vals, (rows, k), torch.float32), _t(idx, (rows, k), torch.int64)
+        vo.fill_(float('-inf'))
+        io.fill_(-1)
+        vo[:, :order.shape[1]] = v
+        io[:, :order.shape[1]] = order
+        return 0
+
+    def tok_retrieval_nrel(self, labels, scores, n, n_cols, q_row, q_col, nq, n_rel, st):
+        out = _t(n_rel, (nq,), torch.int32)
+        if labels is not None:
+            lab, rows = _t(labels, (n,), torch.int64), _t(q_row, (nq,), torch.int64)
+            out.copy_(((lab[None, :] == lab[rows][:, None]).sum(1) - 1).int())
+        else:
+            sc, cols = _t(scores, (n, n_cols), torch.float32), _t(q_col, (nq,), torch.int64)
+            out.copy_((sc[:, cols] >= 1).sum(0).int())
+        return 0
+
+    def tok_retrieval_eval(self, kind, idx, kk, drop_first, gallery, ng, labels, scores, n_cols, q_row, q_col, n_rel,
+                           ideal, nq, out, st):
+        import math
+        iv = _t(idx, (nq, kk), torch.int64)
+        df = _t(drop_first, (nq,), torch.uint8)
+        gal = _t(gallery, (ng,), torch.int64) if gallery is not None else None
+        rows = _t(q_row, (nq,), torch.int64)
+        nr = _t(n_rel, (nq,), torch.int32)
+        k = kk - 1
+        n_all = int(max(int(rows.max()), int(gal.max()) if gal is not None else ng - 1)) + 1
+        lab = _t(labels, (n_all,), torch.int64) if labels is not None else None
+        cols = _t(q_col, (nq,), torch.int64) if labels is None else None
+        idl = _t(ideal, (nq, k), torch.float32) if ideal is not None else None
+        o = _t(out, (nq,), torch.float32)
+        for qi in range(nq):
+            if int(nr[qi]) == 0 or k <= 0:
+                o[qi] = 0.
+                continue
+            first = 1 if int(df[qi]) else 0
+            hits = ap = dcg = 0.0
+            for p_ in range(k):
+                li = int(iv[qi, first + p_])
+                li = ng - 1 if li < 0 else li
+                gi = int(gal[li]) if gal is not None else li
+                if lab is not None:
+                    gain = 1.0 if (int(lab[gi]) == int(lab[int(rows[qi])]) and gi != int(rows[qi])) else 0.0
+                else:
+                    # scores has n_all rows at least up to gi; address it flat
+                    gain = float(_t(scores, (gi + 1, n_cols), torch.float32)[gi, int(cols[qi])])
+                    gain = gain if gain >= 1 else 0.0
+                if gain > 0:
+                    hits += 1
+                    ap += hits / (p_ + 1)
+                    dcg += gain / math.log2(p_ + 2)
+            n_r = int(nr[qi])
+            if kind == 0:
+                v = 1.0 if hits > 0 else 0.0
+            elif kind == 1:
+                v = hits / k
+            elif kind == 2:
+                v = hits / n_r
+            elif kind == 3:
+                v = ap / n_r
+            else:
+                ki = min(k, n_r)
+                idcg = sum((float(idl[qi, p_]) if idl is not None else 1.0) / math.log2(p_ + 2) for p_ in range(ki))
+                v = dcg / idcg
+            o[qi] = v
+        return 0
+
     def tok_cls_stats_update(self, logits, labels, target, rows, classes, ld, ignore_index, counts, st):
         t = _t(target, (rows,), torch.int64)
         pred = _t(labels, (rows,), torch.int64) if labels is not None else _t(logits, (rows, ld), BF16)[:, :classes].float().argmax(1)

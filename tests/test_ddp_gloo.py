@@ -63,6 +63,16 @@ def _worker(rank, world, port, tmp):
     assert set(logged) == {'loss'} and abs(float(logged['loss']) - float(sum(both) / world)) < 1e-6
     assert 'train/loss' in task.logged
     red.close()
+    # retrieval meter states are concatenated over ranks (torchmetrics dist_reduce_fx="cat",
+    # metrics/index_base_metric.py:112-120; reference test: tests/base_tests/metrics/representation/
+    # test_representation_ddp.py): uneven shards of the known-answer data give every rank the single-process value
+    import numpy as np
+    known = np.load(os.path.join(HERE, 'golden', 'retrieval_known_answers.npz'))
+    sl = slice(0, 5) if rank == 0 else slice(5, 9)
+    for k in (1, 3, 6):
+        m = T.METRICS.get('RecallAtKMeter')(dataset_type='classification', normalize_vectors=True, k=k)
+        m.update(vectors=torch.from_numpy(known['vectors'][sl]), group_labels=torch.from_numpy(known['targets'][sl]))
+        assert abs(m.compute() - known['answer__classification__recall'][k - 1]) < 1e-6
     dist.destroy_process_group()
     open(os.path.join(tmp, f'ok{rank}'), 'w').write('ok')
 

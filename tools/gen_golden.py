@@ -434,12 +434,131 @@ def golden_heads(mods, out_path):
     print('wrote', out_path)
 
 
+def golden_retrieval(out_known, out_meters):
+    """Retrieval meters.  (a) The reference's own known-answer tables
+    (tests/base_tests/metrics/representation/data.py) are copied as DATA.  (b) The reference's own
+    metrics/index_base_metric.py + representation_ranx.py run unmodified on random data with the absent third-party
+    packages stubbed: faiss.IndexFlat{IP,L2} -> exhaustive search (oracle.retrieval_ref.flat_search), ranx.metrics ->
+    the restated per-query functions, torchmetrics.Metric -> a bare state holder.  One adapter: the list returned by
+    RanxBasedMeter.process_data_for_metric_func gets a `.shape`, which index_base_metric.py:262 reads (a plain list
+    has none, so compute() of the shipped file raises there).  normalize_vectors stays False in (b): the literal
+    axis-0 normalisation of :190 contradicts the known answers of (a), which pin unit-length rows."""
+    import oracle.retrieval_ref as RR
+    spec = importlib.util.spec_from_file_location(
+        '_ref_retrieval_data', '/root/reference/tests/base_tests/metrics/representation/data.py')
+    d = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(d)
+    known = dict(vectors=d.VECTORS.numpy(), targets=d.TARGETS.numpy(), group_labels=d.GROUP_LABELS.numpy(),
+                 queries_idx=d.QUERIES_IDX.numpy(), scores=d.SCORES.numpy(),
+                 scores_query_as_relevant=d.SCORES_QUERY_AS_RELEVANT.numpy())
+    for table, name in ((d.CLASSIFICATION_ANSWERS, 'classification'), (d.REPRESENTATION_ANSWERS, 'representation'),
+                        (d.REPRESENTATION_QUERY_AS_RELEVANT_ANSWERS, 'query_as_relevant')):
+        for metric, by_k in table.items():
+            known[f'answer__{name}__{metric}'] = np.array([by_k[k] for k in range(1, 7)], dtype=np.float64)
+    np.savez_compressed(out_known, **known)
+    print('wrote', out_known)
+
+    # ---- stubs of the absent third-party packages --------------------------------------------------------------
+    if not hasattr(np, 'bool'):
+        np.bool = bool                       # index_base_metric.py:417 uses the pre-1.24 alias
+
+    class _Flat:
+        metric = 'IP'
+
+        def __init__(self, dim):
+            self.dim, self.x = dim, None
+
+        def add(self, x):
+            self.x = np.array(x, dtype=np.float32)
+
+        def search(self, q, k):
+            return RR.flat_search(self.x, np.asarray(q), k, self.metric)
+
+    fa = _fake_pkg('faiss')
+    fa.IndexFlatIP = type('IndexFlatIP', (_Flat,), dict(metric='IP'))
+    fa.IndexFlatL2 = type('IndexFlatL2', (_Flat,), dict(metric='L2'))
+    fa.IndexIVFFlat = None
+    _fake_pkg('ranx')
+    rm = _fake_pkg('ranx.metrics')
+    for name, fn in RR.RANX.items():
+        setattr(rm, name, (lambda f: lambda qrels, run, k: np.array(
+            [f([(int(a), float(b)) for a, b in q], [int(r[0]) for r in rr], k) for q, rr in zip(qrels, run)]))(fn))
+
+    class Metric:
+        def __init__(self, **kw):
+            pass
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, list(default))
+    tm = _fake_pkg('torchmetrics')
+    tm.Metric = Metric
+    _fake_pkg('torchok.metrics', f'{REF}/metrics')
+    _load('torchok.metrics.index_base_metric', f'{REF}/metrics/index_base_metric.py')
+    rr = _load('torchok.metrics.representation_ranx', f'{REF}/metrics/representation_ranx.py')
+
+    class _Shaped(list):
+        @property
+        def shape(self):
+            return (len(self), 2)
+    orig = rr.RanxBasedMeter.process_data_for_metric_func
+
+    def shaped(self, **kw):
+        out = orig(self, **kw)
+        return [_Shaped(out[0]), out[1], out[2]]
+    rr.RanxBasedMeter.process_data_for_metric_func = shaped
+
+    rng = np.random.default_rng(5)
+    n, dim = 48, 8
+    vectors = rng.standard_normal((n, dim)).astype(np.float32)
+    labels = np.repeat(np.arange(6), 8)[rng.permutation(n)]
+    groups = rng.integers(0, 3, n)
+    # representation data: 5 queries, two of them also relevant to another query
+    n_q = 5
+    query_idxs = -np.ones(n, dtype=np.int64)
+    q_rows = rng.choice(n, n_q, replace=False)
+    query_idxs[q_rows] = rng.permutation(n_q)
+    scores = np.zeros((n, n_q), dtype=np.float32)
+    for c in range(n_q):
+        # ragged on purpose: equal-length relevant lists make np.array(..., dtype=object) 2-D and :45 fails on it
+        rows = rng.choice(np.setdiff1d(np.arange(n), q_rows[2:]), 4 + 2 * c, replace=False)
+        rows = rows[rows != q_rows[list(query_idxs[q_rows]).index(c)]]
+        scores[rows, c] = rng.integers(1, 5, len(rows))
+    meters = dict(hit_rate=rr.HitAtKMeter, precision=rr.PrecisionAtKMeter, recall=rr.RecallAtKMeter,
+                  average_precision=rr.MeanAveragePrecisionAtKMeter, ndcg=rr.NDCGAtKMeter)
+    cases, expected = [], []
+    for metric, cls in meters.items():
+        for ds in ('classification', 'representation'):
+            for k, dist, ga, katl in ((1, 'IP', False, False), (3, 'IP', False, False), (5, 'L2', False, False),
+                                      (4, 'IP', True, False), (2, 'L2', True, False), (1, 'IP', True, True)):
+                m = cls(dataset_type=ds, k=k, metric_distance=dist, group_averaging=ga, k_as_target_len=katl,
+                        search_batch_size=7)
+                gl = labels if ds == 'classification' else groups
+                for lo in range(0, n, 10):
+                    sl = slice(lo, lo + 10)
+                    if ds == 'classification':
+                        m.update(vectors=torch.tensor(vectors[sl]), group_labels=torch.tensor(gl[sl]))
+                    else:
+                        m.update(vectors=torch.tensor(vectors[sl]), group_labels=torch.tensor(gl[sl]),
+                                 query_idxs=torch.tensor(query_idxs[sl]), scores=torch.tensor(scores[sl]))
+                ref = m.compute()
+                mine = RR.meter_compute(metric, vectors, ds, k=k, group_labels=gl, query_idxs=query_idxs, scores=scores,
+                                        metric_distance=dist, group_averaging=ga, k_as_target_len=katl)
+                assert abs(ref - mine) < 1e-12, (metric, ds, k, dist, ga, katl, ref, mine)
+                cases.append(f'{metric}|{ds}|{k}|{dist}|{int(ga)}|{int(katl)}')
+                expected.append(ref)
+    np.savez_compressed(out_meters, vectors=vectors, labels=labels, groups=groups, query_idxs=query_idxs, scores=scores,
+                        cases=np.array(cases), expected=np.array(expected, dtype=np.float64))
+    print(f'wrote {out_meters}: {len(cases)} cases, restatement == reference files: OK')
+
+
 def main():
     mods = install_shim()
     gd = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(gd, exist_ok=True)
     # batch/size chosen so that the deepest BatchNorm still sees >= 32 samples per channel (bf16 parity
     # of the HIP path is checked against these same vectors)
+    if '--retrieval-only' in sys.argv:
+        return golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))
     if '--metric-only' in sys.argv:
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
     if '--unsup-only' in sys.argv:
@@ -458,6 +577,7 @@ def main():
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     golden_dice(os.path.join(gd, 'dice_loss.npz'))
     golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
+    golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))
 
 
 if __name__ == '__main__':

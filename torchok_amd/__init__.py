@@ -7,7 +7,7 @@ Everything numeric runs in hand-written HIP kernels for gfx950 behind the C ABI 
 (torchok_amd/lib/libtok_gfx950.so, built by __graft_entry__.build()).  No CPU fallback exists.
 """
 from . import constructor  # noqa: F401
-from . import models, losses, metrics, optim, tasks  # noqa: F401
+from . import models, losses, metrics, retrieval, optim, tasks  # noqa: F401
 from .constructor import (BACKBONES, HEADS, LOSSES, METRICS, NECKS, OPTIMIZERS, POOLINGS, SCHEDULERS, TASKS)  # noqa: F401
 from .constructor.config import load_config  # noqa: F401
 
