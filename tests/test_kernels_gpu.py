@@ -310,7 +310,7 @@ def test_gap_colsum(libs):
     assert relerr(dv[id(out)], out) < 1e-4
 
 
-@pytest.mark.parametrize('rows,classes', [(256, 1000), (7, 10), (64, 11318), (70001, 19)])
+@pytest.mark.parametrize('rows,classes', [(256, 1000), (7, 10), (64, 11318), (70001, 19), (20000, 64), (16384, 3), (16500, 33)])
 def test_softmax_ce(libs, rows, classes):
     ld = (classes + 7) // 8 * 8
     z = (rnd(rows, ld) * 3).to(BF16)

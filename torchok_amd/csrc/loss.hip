@@ -33,6 +33,71 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
   }
 }
 
+// Few classes, many rows (segmentation logits: 4 M pixel rows x 19 classes): one THREAD per row, the row in
+// registers through 16-byte loads (ld <= 64); a wavefront per row would leave most of its lanes idle.
+__global__ __launch_bounds__(256) void ce_fwd_small_kernel(const bf16* __restrict__ logits,
+                                                           const int64_t* __restrict__ target, int rows, int classes,
+                                                           int ld, int64_t ignore_index, float* __restrict__ lse,
+                                                           float* __restrict__ row_loss) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const bf16* z = logits + (size_t)row * ld;
+  const int nv = ld >> 3;
+  float v[64];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nv) {
+      const bf16x8 q = ldg16(z + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i * 8 + e] = (i * 8 + e < classes) ? bf2f(q[e]) : -INFINITY;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i * 8 + e] = -INFINITY;
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) mx = fmaxf(mx, v[c]);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) s += (c < classes) ? expf(v[c] - mx) : 0.f;
+  const float l = mx + logf(s);
+  lse[row] = l;
+  const int64_t t = target[row];
+  row_loss[row] = (t == ignore_index || t < 0 || t >= classes) ? 0.f : l - bf2f(z[t]);
+}
+
+__global__ __launch_bounds__(256) void ce_bwd_small_kernel(const bf16* __restrict__ logits,
+                                                           const int64_t* __restrict__ target,
+                                                           const float* __restrict__ lse, const float* __restrict__ loss,
+                                                           const float* __restrict__ gscale, int rows, int classes, int ld,
+                                                           int64_t ignore_index, bf16* __restrict__ dlogits) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= rows) return;
+  const int64_t t = target[row];
+  const bool valid = t != ignore_index;
+  const float g = valid ? (gscale ? gscale[0] : 1.f) / loss[1] : 0.f;
+  const float l = lse[row];
+  const bf16* z = logits + (size_t)row * ld;
+  bf16* d = dlogits + (size_t)row * ld;
+  const int nv = ld >> 3;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < nv) {
+      const bf16x8 q = ldg16(z + i * 8);
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = i * 8 + e;
+        float w = 0.f;
+        if (valid && c < classes) w = (expf(bf2f(q[e]) - l) - (c == t ? 1.f : 0.f)) * g;
+        o[e] = f2bf(w);
+      }
+      stg16(d + i * 8, o);
+    }
+  }
+}
+
 // deterministic mean over valid rows in two fixed-order stages: up to 512 blocks each reduce one contiguous
 // chunk into a (sum, count) double pair kept in the caller's loss buffer, then one block folds the pairs
 constexpr int CE_PARTS = (TOK_CE_LOSS_FLOATS - 2) / 4;   // (sum, count) doubles
@@ -241,14 +306,23 @@ extern "C" int tok_dice_bwd(const void* logits, const void* target, const float*
   return TOK_OK;
 }
 
+// thread-per-row kernels: rows of at most 64 bf16 in whole 16-byte vectors, enough rows to fill the chip
+static inline bool ce_small(const void* logits, int rows, int ld) {
+  return ld <= 64 && (ld & 7) == 0 && rows >= 16384 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
+}
+
 extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
                                   int64_t ignore_index, float* lse, float* row_loss, float* loss,
                                   void* stream) {
   TOK_CHECK_ARG(logits && target && lse && row_loss && loss, "tok_softmax_ce_fwd: null pointer");
   TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_softmax_ce_fwd: bad sizes");
   hipStream_t st = tok_stream(stream);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16*)logits, target, rows,
-                     classes, ld, ignore_index, lse, row_loss);
+  if (ce_small(logits, rows, ld))
+    hipLaunchKernelGGL(ce_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16*)logits, target, rows,
+                       classes, ld, ignore_index, lse, row_loss);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16*)logits, target, rows,
+                       classes, ld, ignore_index, lse, row_loss);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd");
   double* part = reinterpret_cast<double*>(loss + 2);   // loss holds TOK_CE_LOSS_FLOATS floats, 8-byte aligned
   TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_softmax_ce_fwd: loss must be 8-byte aligned");
@@ -267,9 +341,13 @@ extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, con
                                   int64_t ignore_index, void* dlogits, void* stream) {
   TOK_CHECK_ARG(logits && target && lse && loss && dlogits, "tok_softmax_ce_bwd: null pointer");
   TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_softmax_ce_bwd: bad sizes");
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, tok_stream(stream),
-                     (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index,
-                     (bf16*)dlogits);
+  if (ce_small(logits, rows, ld) && (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0)
+    hipLaunchKernelGGL(ce_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, tok_stream(stream),
+                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, (bf16*)dlogits);
+  else
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, tok_stream(stream),
+                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index,
+                       (bf16*)dlogits);
   TOK_CHECK_LAUNCH("tok_softmax_ce_bwd");
   return TOK_OK;
 }
