@@ -360,6 +360,23 @@ int tok_triplet_bwd(const void* anchor, const void* positive, const void* negati
                     const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
                     void* d_anchor, void* d_positive, void* d_negative, void* stream);
 
+/* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
+ * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:
+ * softmax(q k^T / sqrt(32)) v on unshifted windows, no cosine normalisation (ds_scratch / dscale_part unused).
+ * ChannelAttention (davit.py:131-165): A = softmax_rows((k * scale)^T v) per (image, head) over all tokens of the
+ * image, out = q A^T.  tok_chan_gram: out[u] = f(scale * X_u^T Y_u), u = image * heads + head, X / Y the 32-wide head
+ * slices of bf16 token matrices (row pitches ldx / ldy, pointers already offset to the q / k / v block), fp32
+ * [images*heads][32][32]; mode 0: f = id, 1: row softmax, 2: softmax backward A o (G - rowsum(G o A)) with A = a_in.
+ * tok_chan_apply: out[n][h*32+i] = scale * sum_j M[u][i][j] x[n][h*32+j] (transposed != 0: M[u][j][i]).           */
+int tok_chan_gram(const void* x, int ldx, const void* y, int ldy, int rows_per_image, int images, int heads,
+                  float scale, int mode, const float* a_in, float* out, void* stream);
+int tok_chan_apply(const void* x, int ldx, const float* m, int transposed, float scale, int rows_per_image,
+                   int images, int heads, void* out, int ldo, void* stream);
+/* out (+)= a + row_scale[row / rows_per_sample] * b on bf16 [rows][ld]; a and row_scale may be NULL.  The pre-norm
+ * residual x + drop_path(f(norm(x))) of davit.py:262-271,330-366 and its backward (db = row_scale * dout).         */
+int tok_scale_rows_add(const void* a, const void* b, const float* row_scale, int rows_per_sample, void* out,
+                       int accumulate, int64_t rows, int ld, void* stream);
+
 /* ---- retrieval meters (validation path) -------------------------------------------------------
  * IndexBasedMeter.compute (metrics/index_base_metric.py:170-270) with exact_index=True: the faiss flat index
  * (:523-545) is an exhaustive search = similarity matrix + k best per row; the ranx metric functions bound by

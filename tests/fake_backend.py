@@ -827,10 +827,15 @@ class FakeTok:
         x = _t(qkv, (b, h, w, ld), BF16)[..., :3 * c].float().clone().requires_grad_(True)
         xw = self._win(x, b, h, w, ws, shift).view(-1, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
         q, k, v = xw[0], xw[1], xw[2]
-        ls = _t(logit_scale, (heads,), torch.float32).clone().requires_grad_(True)
-        bi = _t(bias, (heads, n, n), torch.float32).clone().requires_grad_(True)
-        attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
-        attn = attn * torch.clamp(ls, max=math.log(100.0)).exp()[None, :, None, None] + bi[None]
+        if logit_scale is None:        # plain mode: softmax(q k^T / sqrt(head_dim)) v
+            ls = torch.zeros(heads, requires_grad=True)
+            bi = torch.zeros(heads, n, n, requires_grad=True)
+            attn = (q * (c // heads) ** -0.5) @ k.transpose(-2, -1) + 0 * ls[None, :, None, None] + 0 * bi[None]
+        else:
+            ls = _t(logit_scale, (heads,), torch.float32).clone().requires_grad_(True)
+            bi = _t(bias, (heads, n, n), torch.float32).clone().requires_grad_(True)
+            attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
+            attn = attn * torch.clamp(ls, max=math.log(100.0)).exp()[None, :, None, None] + bi[None]
         if mask is not None:
             m = _t(mask, (nw, n, n), torch.float32)
             attn = (attn.view(b, nw, heads, n, n) + m[None, :, None]).view(-1, heads, n, n)
@@ -862,6 +867,8 @@ class FakeTok:
         d = _t(dqkv, (b, h, w, ld), BF16)
         d.zero_()
         d[..., :3 * c] = _bf(gx)
+        if logit_scale is None:
+            return 0
         # the stand-in reports the reduced gradients in row 0 of the scratch buffers (their colsums are what is used)
         sc = _t(ds_scratch, (b * nw, heads, n, n), torch.float32)
         sc.zero_()
@@ -869,6 +876,52 @@ class FakeTok:
         dp = _t(dscale_part, (b * nw, heads), torch.float32)
         dp.zero_()
         dp[0] = gls
+        return 0
+
+    # ---- DaViT channel attention / pre-norm residual -------------------------------------------------------------------
+    @staticmethod
+    def _heads(p, ld, rpi, images, heads):
+        """bf16 [images*rpi][ld] at p -> float [images, heads, rpi, 32] view of the first heads*32 columns."""
+        n = images * rpi
+        flat = _t(p, ((n - 1) * ld + heads * 32,), BF16)
+        m = torch.as_strided(flat, (n, heads * 32), (ld, 1)).float()
+        return m.view(images, rpi, heads, 32).permute(0, 2, 1, 3)
+
+    def tok_chan_gram(self, x, ldx, y, ldy, rpi, images, heads, scale, mode, a_in, out, st):
+        xs, ys = self._heads(x, ldx, rpi, images, heads), self._heads(y, ldy, rpi, images, heads)
+        g = scale * (xs.transpose(-1, -2) @ ys).reshape(images * heads, 32, 32)
+        if mode == 1:
+            g = g.softmax(-1)
+        elif mode == 2:
+            a = _t(a_in, (images * heads, 32, 32), torch.float32)
+            g = a * (g - (g * a).sum(-1, keepdim=True))
+        _t(out, (images * heads, 32, 32), torch.float32).copy_(g)
+        return 0
+
+    def tok_chan_apply(self, x, ldx, m, transposed, scale, rpi, images, heads, out, ldo, st):
+        xs = self._heads(x, ldx, rpi, images, heads)                     # [img, h, n, 32]
+        mm = _t(m, (images, heads, 32, 32), torch.float32)
+        if not transposed:
+            mm = mm.transpose(-1, -2)                                    # out = x M^T
+        o = scale * (xs @ mm)                                            # [img, h, n, 32]
+        n = images * rpi
+        flat = _t(out, ((n - 1) * ldo + heads * 32,), BF16)
+        dst = torch.as_strided(flat, (n, heads * 32), (ldo, 1))
+        dst.copy_(_bf(o.permute(0, 2, 1, 3).reshape(n, heads * 32)))
+        return 0
+
+    def tok_scale_rows_add(self, a, b, row_scale, rps, out, accumulate, rows, ld, st):
+        bv = _t(b, (rows, ld), BF16).float()
+        if row_scale is not None:
+            samples = (rows + rps - 1) // rps
+            rs = _t(row_scale, (samples,), torch.float32)
+            bv = bv * rs.repeat_interleave(rps)[:rows, None]
+        if a is not None:
+            bv = bv + _t(a, (rows, ld), BF16).float()
+        o = _t(out, (rows, ld), BF16)
+        if accumulate:
+            bv = bv + o.float()
+        o.copy_(_bf(bv))
         return 0
 
     def tok_cpb_bias_fwd(self, table, ld, index, heads, n, bias, st):

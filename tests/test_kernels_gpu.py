@@ -72,6 +72,8 @@ CONV_CASES = [
     (1, 7, 7, 512, 512, 3, 1, 1),      # deep K (4608)
     (4, 1, 1, 2048, 1000, 1, 1, 0),    # linear 2048 -> 1000
     (1, 20, 20, 48, 96, 3, 1, 1),      # HRNet-like widths (taps straddle BK)
+    (2, 16, 16, 96, 192, 2, 2, 0),     # DaViT patch embed 2x2 s2 (davit.py:62-64)
+    (3, 14, 14, 384, 768, 2, 2, 0),
 ]
 
 
@@ -925,3 +927,83 @@ def test_triplet_kernels(libs, rows, d, ld, swap):
                                                   f(outs[1]), f(outs[2]), None])
     for o in outs:
         assert relerr(dv[id(o)].float(), o.float()) < 6e-3
+
+
+# ---- DaViT ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('b,h,w,heads,ws', [(2, 8, 8, 3, 4), (3, 14, 14, 6, 7), (9, 7, 7, 2, 7)])
+def test_window_attention_plain_mode(libs, b, h, w, heads, ws):
+    """logit_scale == bias == NULL: softmax(q k^T / sqrt(32)) v of DaViT's WindowAttention (davit.py:168-207)."""
+    lib, fake = libs
+    c = heads * 32
+    n, nw = ws * ws, (h // ws) * (w // ws)
+    qkv = rnd(b * h * w, 3 * c).to(BF16)
+    out, lse = torch.empty(b * h * w, c, dtype=BF16), torch.empty(b * nw * heads * n)
+    dv = both(libs, 'tok_window_attn_fwd', lambda d: [d(qkv), b, h, w, c, heads, ws, 0, 3 * c, None, None, None, d(out),
+                                                      d(lse), None])
+    x = qkv.float().view(b, h // ws, ws, w // ws, ws, 3, heads, 32).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, -1, heads, n, 32)
+    ref = torch.softmax(x[0] @ x[1].transpose(-1, -2) / 32 ** 0.5, -1) @ x[2]                  # torch fp32 restatement
+    ref = ref.view(b, h // ws, w // ws, heads, ws, ws, 32).permute(0, 1, 4, 2, 5, 3, 6).reshape(b * h * w, c)
+    assert relerr(out.float(), ref) < 1e-2 and relerr(dv[id(out)].float(), ref) < 1e-2
+    assert relerr(dv[id(lse)], lse) < 3e-3
+    g = rnd(b * h * w, c, seed=7).to(BF16)
+    P = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    dq_h = torch.empty(b * h * w, 3 * c, dtype=BF16)
+    assert fake.tok_window_attn_bwd(P(qkv), P(g), b, h, w, c, heads, ws, 0, 3 * c, None, None, None, P(lse), P(dq_h), None,
+                                    None, None) == 0
+    dq_d = torch.empty(b * h * w, 3 * c, dtype=BF16, device='cuda')
+    qd, gd = qkv.cuda(), g.cuda()
+    assert lib.tok_window_attn_bwd(P(qd), P(gd), b, h, w, c, heads, ws, 0, 3 * c, None, None, None, P(dv[id(lse)]), P(dq_d),
+                                   None, None, torch.cuda.current_stream().cuda_stream) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert relerr(dq_d.float(), dq_h.float()) < 3e-2
+    ls = torch.zeros(heads, device='cuda')
+    assert lib.tok_window_attn_fwd(P(qd), b, h, w, c, heads, ws, 0, 3 * c, P(ls), None, None, P(dv[id(out)]), P(dv[id(lse)]),
+                                   None) != 0                                              # scale without bias: refused
+
+
+@pytest.mark.parametrize('images,rpi,heads,pad', [(2, 100, 3, 0), (3, 49, 6, 8), (1, 3136, 3, 0), (5, 1, 2, 0)])
+def test_channel_attention_kernels(libs, images, rpi, heads, pad):
+    c = heads * 32
+    ld = 3 * c + pad
+    n = images * rpi
+    qkv = rnd(n, ld).to(BF16)
+    P = lambda t_, off=0: t_.data_ptr() + 2 * off   # noqa: E731
+    scale = 32 ** -0.5
+    for mode in (0, 1):
+        a = torch.empty(images * heads, 32, 32)
+        dv = both(libs, 'tok_chan_gram', lambda d: (lambda q_: [q_.data_ptr() + 2 * c, ld, q_.data_ptr() + 4 * c, ld, rpi,
+                                                                images, heads, scale, mode, None, d(a), None])(d(qkv)))
+        k = qkv[:, c:2 * c].float().view(images, rpi, heads, 32).permute(0, 2, 1, 3)
+        v = qkv[:, 2 * c:3 * c].float().view(images, rpi, heads, 32).permute(0, 2, 1, 3)
+        ref = (scale * k.transpose(-1, -2) @ v).reshape(-1, 32, 32)                       # torch fp32 restatement
+        ref = ref.softmax(-1) if mode else ref
+        assert relerr(a, ref) < 1e-5 and relerr(dv[id(a)], ref) < 1e-4
+    attn = a
+    gm = torch.empty_like(attn)
+    g = rnd(n, c, seed=3).to(BF16)
+    dv = both(libs, 'tok_chan_gram', lambda d: [d(g), c, d(qkv), ld, rpi, images, heads, 1.0, 2, d(attn), d(gm), None])
+    assert relerr(dv[id(gm)], gm) < 1e-4
+    for transposed in (0, 1):
+        out = torch.zeros(n, ld, dtype=BF16)
+        dv = both(libs, 'tok_chan_apply', lambda d: [d(qkv), ld, d(attn), transposed, 0.5, rpi, images, heads,
+                                                     d(out).data_ptr() + 2 * c, ld, None])
+        q = qkv[:, :c].float().view(images, rpi, heads, 32).permute(0, 2, 1, 3)
+        m = attn.view(images, heads, 32, 32)
+        ref = 0.5 * (q @ (m if transposed else m.transpose(-1, -2)))
+        ref = ref.permute(0, 2, 1, 3).reshape(n, c)
+        assert relerr(out[:, c:2 * c].float(), ref) < 5e-3 and relerr(dv[id(out)][:, c:2 * c].float(), ref) < 5e-3
+        assert float(dv[id(out)][:, :c].abs().max()) == 0 and float(dv[id(out)][:, 2 * c:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('rows,ld,rps,with_a,acc', [(37, 96, 0, 1, 0), (64, 768, 16, 1, 0), (50, 24, 10, 0, 1),
+                                                    (200704, 96, 3136, 1, 0)])
+def test_scale_rows_add(libs, rows, ld, rps, with_a, acc):
+    a, b = rnd(rows, ld).to(BF16), rnd(rows, ld, seed=1).to(BF16)
+    out = rnd(rows, ld, seed=2).to(BF16)
+    rs = (torch.rand((rows + rps - 1) // rps, generator=torch.Generator().manual_seed(0)) < 0.7).float() / 0.7 if rps else None
+    want = b.float() * (rs.repeat_interleave(rps)[:rows, None] if rps else 1.0) + (a.float() if with_a else 0) + \
+        (out.float() if acc else 0)
+    dv = both(libs, 'tok_scale_rows_add', lambda d: [d(a) if with_a else None, d(b), d(rs) if rps else None, rps, d(out), acc,
+                                                     rows, ld, None])
+    assert torch.equal(out, want.to(BF16))
+    assert relerr(dv[id(out)].float(), want) < 3e-3          # fp32 fma contraction may move one bf16 ulp

@@ -225,6 +225,90 @@ def golden_swin(out_path, seed=51):
     print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params, restatement == reference files: OK')
 
 
+def golden_davit(out_path, seed=71):
+    """ClassificationTask wiring over the reference's OWN davit.py — its only in-tree transformer: every class in that
+    file is reference code, the stubs cover just `timm.models.layers.{DropPath, trunc_normal_, to_2tuple}` and
+    `build_model_with_cfg`.  drop_path_rate > 0 in training mode: the stochastic-depth draws are part of the step.
+    Asserts oracle/davit_ref.py is bit-identical (features, logits, gradients)."""
+    import oracle.davit_ref as D
+    import oracle.swin_ref as S
+    lay = sys.modules['timm.models.layers']
+    lay.trunc_normal_, lay.to_2tuple, lay.DropPath = S.trunc_normal_, S.to_2tuple, timm_min.DropPath
+    if 'torchok.models.modules' not in sys.modules:
+        _fake_pkg('torchok.models.modules', f'{REF}/models/modules')
+        _fake_pkg('torchok.models.modules.bricks', f'{REF}/models/modules/bricks')
+    _load('torchok.models.modules.bricks.mlp', f'{REF}/models/modules/bricks/mlp.py')
+    # timm's build_model_with_cfg keeps pretrained_cfg / pretrained_filter_fn for its checkpoint loader
+    h = sys.modules['timm.models.helpers']
+    h.build_model_with_cfg = lambda cls, variant, pretrained, pretrained_cfg=None, pretrained_filter_fn=None, **kw_: \
+        timm_min.build_model_with_cfg(cls, variant, pretrained, **kw_)
+    davit = _load('torchok.models.backbones.davit', f'{REF}/models/backbones/davit.py')
+    pooling = sys.modules['torchok.models.poolings.classification.pooling']
+    head = sys.modules['torchok.models.heads.classification.classification_head']
+    kw = dict(img_size=128, window_size=4, drop_path_rate=0.2)
+    classes, batch = 10, 4
+
+    class RefCls(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = davit.davit_t(pretrained=False, in_channels=3, **kw)
+            self.pooling = pooling.Pooling(in_channels=self.backbone.out_channels)
+            self.head = head.ClassificationHead(in_channels=self.pooling.out_channels, num_classes=classes)
+
+    torch.manual_seed(seed)
+    task = RefCls().train()
+    sd = deterministic_state(task.state_dict(), seed)
+    task.load_state_dict(sd)
+    ora = D.davit_t(window_size=4, drop_path_rate=0.2).train()
+    bsd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
+    assert set(ora.state_dict()) == set(bsd), 'state_dict keys differ: restated wiring != reference'
+    ora.load_state_dict(bsd)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, 128, 128, generator=g).half().float()
+    y = torch.randint(0, classes, (batch,), generator=g)
+    task.eval(), ora.eval()
+    feats = task.backbone.forward_features(x)
+    ofeats = ora.forward_features(x)
+    assert all(torch.equal(a, b) for a, b in zip(feats, ofeats))
+    task.train(), ora.train()
+    torch.manual_seed(seed + 2)
+    state = torch.get_rng_state()
+    last = task.backbone(x)
+    pred = task.head(task.pooling(last), y)
+    loss = nn.functional.cross_entropy(pred, y)
+    loss.backward()
+    torch.set_rng_state(state)
+    olast = ora(x)
+    assert torch.equal(last, olast)
+    nn.functional.cross_entropy(task.head(task.pooling(olast), y), y).backward()
+    # the per-sample stochastic-depth factors, in draw order (2 per block): what a device RNG cannot reproduce
+    torch.set_rng_state(state)
+    dpr = [m.drop_prob for m in task.backbone.modules() if type(m).__name__ == 'DropPath' for _ in range(2)]
+    draws = np.stack([(torch.empty(batch, 1, 1).bernoulli_(1 - p) / (1 - p)).reshape(-1).numpy() if p > 0
+                      else np.ones(batch, np.float32) for p in dpr])
+    grads = {n: p.grad.clone() for n, p in task.named_parameters() if p.grad is not None}
+    for n, p in ora.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, grads['backbone.' + n]), n
+    opt = torch.optim.AdamW(task.parameters(), lr=1e-3, weight_decay=0.05)
+    opt.step()
+    names = [n for n, _ in task.named_parameters() if n in grads]
+    no_grad = [n for n, _ in task.named_parameters() if n not in grads]
+    small = [n for n in names if grads[n].numel() <= 768][:80]
+    np.savez_compressed(
+        out_path, seed=seed, num_classes=classes, x=x.half().numpy(), y=y.numpy(), drop_scales=draws,
+        feat_shapes=np.array([list(f.shape) for f in feats[1:]]),
+        feat_sumsq=np.array([float((f.double() ** 2).sum()) for f in feats[1:]]),
+        eval_last_feature=feats[-1].detach().numpy(),
+        last_feature=last.detach().numpy(), prediction=pred.detach().numpy(), loss=float(loss.detach()),
+        param_names=np.array(names), no_grad_names=np.array(no_grad),
+        grad_norm=np.array([float(grads[n].double().norm()) for n in names]),
+        post_step_norm=np.array([float(task.get_parameter(n).double().norm()) for n in names]),
+        small_names=np.array(small), **{f'grad__{n}': grads[n].numpy() for n in small})
+    print(f'wrote {out_path}: loss {float(loss.detach()):.6f}, {len(names)} params with gradients, {len(no_grad)} without, '
+          f'restatement == reference files: OK')
+
+
 def golden_dice(out_path):
     """DiceLoss outputs and input gradients from the reference's own losses/segmentation/dice.py (imports as is)."""
     _fake_pkg('torchok.losses.segmentation', f'{REF}/losses/segmentation')
@@ -565,6 +649,8 @@ def main():
         return golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     if '--dice-only' in sys.argv:
         return golden_dice(os.path.join(gd, 'dice_loss.npz'))
+    if '--davit-only' in sys.argv:
+        return golden_davit(os.path.join(gd, 'davit_cls_step.npz'))
     if '--swin-only' in sys.argv:
         return golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     if '--hrnet-only' in sys.argv:
@@ -575,6 +661,7 @@ def main():
     golden_metric(os.path.join(gd, 'metric_heads.npz'))
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
+    golden_davit(os.path.join(gd, 'davit_cls_step.npz'))
     golden_dice(os.path.join(gd, 'dice_loss.npz'))
     golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int kind, const bf16* __re
 // window attention.  One wave per (image, window, head); lane = query row (rows loop for N > 64).
 struct AttnArgs {
   int B, H, W, C, heads, ws, shift, nWx, nW, N, ld;   // ld: row pitch of qkv (>= 3C); head_dim = 32
+  int plain;   // 1: softmax(q k^T / sqrt(head_dim)) v — no cosine normalisation, logit scale, bias (DaViT, davit.py:168-207)
 };
 
 constexpr int HD = 32;
@@ -453,19 +454,19 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
   const int bg = blockIdx.x / (a.heads * a.nW);
   const int N = a.N;
   const int l15 = lane & 15, g = lane >> 4, qi = wv;
-  const float scale = expf(fminf(logit_scale[h], 4.605170185988092f));
+  const float scale = a.plain ? 0.17677669529663687f : expf(fminf(logit_scale[h], 4.605170185988092f));
   // additive logit terms of this wave's query tile (position bias + shift mask; -inf on padding): loaded once per
   // workgroup, reused for every image it walks.  element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
   float addt[4][4];
   {
-    const float* bh = bias + (size_t)h * N * N;
+    const float* bh = bias ? bias + (size_t)h * N * N : nullptr;
     const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const int i = qi * 16 + 4 * g + reg, j = kj * 16 + l15;
-        addt[reg][kj] = (i < N && j < N) ? bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
+        addt[reg][kj] = (i < N && j < N) ? (bh ? bh[i * N + j] : 0.f) + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
       }
   }
   for (int bb = 0; bb < bpw; ++bb) {
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       const int t = lane;
       bf16x8 r8[4];
       const bf16* src = qkv + token_row(a, b, win, t < N ? t : 0) * a.ld + h * HD + wv * a.C;
-      load_head_row(src, t < N, wv < 2, r8);
+      load_head_row(src, t < N, wv < 2 && !a.plain, r8);
       put_row(wv == 0 ? qs : (wv == 1 ? ks : nullptr), wv == 2 ? vt : nullptr, t, r8);
     }
     __syncthreads();
@@ -581,11 +582,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   const int h = blockIdx.x % a.heads;
   const int win = (blockIdx.x / a.heads) % a.nW;
   const int bg = blockIdx.x / (a.heads * a.nW);
-  const float raw_ls = logit_scale[h];
-  const float scale = expf(fminf(raw_ls, 4.605170185988092f));
-  const float* bh = bias + (size_t)h * N * N;
+  const float raw_ls = a.plain ? 0.f : logit_scale[h];
+  const float scale = a.plain ? 0.17677669529663687f : expf(fminf(raw_ls, 4.605170185988092f));
+  const float* bh = bias ? bias + (size_t)h * N * N : nullptr;
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
-  float* dS = ds_scratch + (size_t)blockIdx.x * N * N;
+  float* dS = ds_scratch ? ds_scratch + (size_t)blockIdx.x * N * N : nullptr;
   float dsc = 0.f;
   float addt[4][4];        // position bias + shift mask of this wave's query tile (-inf on padding), loaded once
 #pragma unroll
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) {
       const int i = wv * 16 + 4 * g + reg, j = kj * 16 + l15;
-      addt[reg][kj] = (i < N && j < N) ? bh[i * N + j] + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
+      addt[reg][kj] = (i < N && j < N) ? (bh ? bh[i * N + j] : 0.f) + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
     }
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       bf16x8 r8[4];
       const int64_t row = token_row(a, b, win, t < N ? t : 0);
       const bf16* src = wv < 3 ? qkv + row * a.ld + h * HD + wv * a.C : dout + row * a.C + h * HD;
-      const float inv = load_head_row(src, t < N, wv < 2, r8);
+      const float inv = load_head_row(src, t < N, wv < 2 && !a.plain, r8);
       if (wv == 0) { put_row(qs, qt, t, r8); qinv[t] = inv; }
       else if (wv == 1) { put_row(ks, kt, t, r8); kinv[t] = inv; }
       else if (wv == 2) put_row(vs, nullptr, t, r8);
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       for (int kj = 0; kj < 4; ++kj) {
         const int j = kj * 16 + l15;
         const float ds = p[kj] * (dp[kj][reg] - dl);
-        if (i < N && j < N) {
+        if (dS != nullptr && i < N && j < N) {
           float* dd = dS + (size_t)i * N + j;
           *dd = bb == 0 ? ds : *dd + ds;
         }
@@ -698,8 +699,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
           for (int dj = 0; dj < 2; ++dj) {
             const int d = dj * 16 + l15;
-            dr[d] = f2bf((dq[dj][reg] - qn[dj] * dotq) * qi_);
-            dr[a.C + d] = f2bf((dk[dj][reg] - kn[dj] * dotk) * ki_);
+            dr[d] = f2bf(a.plain ? dq[dj][reg] : (dq[dj][reg] - qn[dj] * dotq) * qi_);
+            dr[a.C + d] = f2bf(a.plain ? dk[dj][reg] : (dk[dj][reg] - kn[dj] * dotk) * ki_);
             dr[2 * a.C + d] = f2bf(dv[dj][reg]);
           }
         }
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   dsc = wave_sum(dsc);
   if (lane == 0) wsum[wv] = dsc;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0 && dscale_part != nullptr)
     dscale_part[blockIdx.x] = raw_ls < 4.605170185988092f ? (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale : 0.f;
 }
 
@@ -905,7 +906,7 @@ bool fill_attn(AttnArgs& a, int B, int H, int W, int C, int heads, int ws, int s
   if (B <= 0 || H <= 0 || W <= 0 || heads <= 0 || ws <= 0 || C != heads * HD || H % ws || W % ws || shift < 0 ||
       shift >= ws || ld < 3 * C || (ld & 7)) return false;
   a.B = B; a.H = H; a.W = W; a.C = C; a.heads = heads; a.ws = ws; a.shift = shift;
-  a.nWx = W / ws; a.nW = (H / ws) * a.nWx; a.N = ws * ws; a.ld = ld;
+  a.nWx = W / ws; a.nW = (H / ws) * a.nWx; a.N = ws * ws; a.ld = ld; a.plain = 0;
   return true;
 }
 
@@ -1011,9 +1012,13 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
                                    const float* logit_scale, const float* bias, const float* mask, void* out,
                                    float* lse, void* stream) {
   AttnArgs a;
-  TOK_CHECK_ARG(qkv && logit_scale && bias && out && lse && fill_attn(a, batch, h, w, c, heads, ws, shift, ld),
+  TOK_CHECK_ARG(qkv && out && lse && fill_attn(a, batch, h, w, c, heads, ws, shift, ld),
                 "tok_window_attn_fwd: bad args (head_dim must be 32, h/w multiples of the window)");
-  if (a.N <= 64 && !tok_attn_scalar()) {
+  TOK_CHECK_ARG((logit_scale == nullptr) == (bias == nullptr), "tok_window_attn_fwd: logit_scale and bias go together");
+  a.plain = logit_scale == nullptr;
+  TOK_CHECK_ARG(!a.plain || (a.N <= 64 && !mask && shift == 0),
+                "tok_window_attn_fwd: the plain mode covers unshifted windows of up to 64 tokens");
+  if (a.N <= 64 && (a.plain || !tok_attn_scalar())) {
     const int bpw = attn_bpw(a);
     const int groups = tok_cdiv(batch, bpw) * a.nW * heads;
     hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(groups), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
@@ -1044,9 +1049,12 @@ extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch,
                                    int shift, int ld, const float* logit_scale, const float* bias, const float* mask,
                                    const float* lse, void* dqkv, float* ds_scratch, float* dscale_part, void* stream) {
   AttnArgs a;
-  TOK_CHECK_ARG(qkv && dout && logit_scale && bias && lse && dqkv && ds_scratch && dscale_part &&
-                fill_attn(a, batch, h, w, c, heads, ws, shift, ld), "tok_window_attn_bwd: bad args");
-  if (a.N <= 64 && !tok_attn_scalar()) {
+  TOK_CHECK_ARG(qkv && dout && lse && dqkv && fill_attn(a, batch, h, w, c, heads, ws, shift, ld),
+                "tok_window_attn_bwd: bad args");
+  a.plain = logit_scale == nullptr;
+  TOK_CHECK_ARG(a.plain ? (!bias && !mask && shift == 0 && a.N <= 64) : (bias && ds_scratch && dscale_part),
+                "tok_window_attn_bwd: bad args (plain mode: no bias / mask / shift, windows of up to 64 tokens)");
+  if (a.N <= 64 && (a.plain || !tok_attn_scalar())) {
     const int bpw = attn_bpw(a);
     const int waves = tok_cdiv(batch, bpw) * a.nW * heads;
     static bool attr_m = false;

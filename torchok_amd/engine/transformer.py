@@ -330,12 +330,19 @@ class _WindowAttnNode(Node):
         nw = (h // ws) * (w // ws)
         qkv = self.qkv
         dev = g.device
-        rows = lib.tok_window_attn_bwd_rows(b, h, w, heads, ws)
-        scratch = torch.empty((rows, heads * n * n), dtype=F32, device=dev)
-        dscale = torch.empty((rows, heads), dtype=F32, device=dev)
         tgt, acc = grad_target(qkv)
         if acc:
             raise RuntimeError('window_attention: qkv has a single consumer')
+        if self.logit_scale is None:       # plain scaled-dot-product windows (DaViT): no bias / scale gradients
+            _C.check(lib.tok_window_attn_bwd(ptr(qkv.data), ptr(g), b, h, w, c, heads, ws, shift, qkv.cp, None, None, None,
+                                             ptr(self.lse), ptr(tgt), None, None, st), 'tok_window_attn_bwd')
+            if qkv.cp != 3 * c:
+                tgt[:, 3 * c:] = 0
+            self.out.grad = None
+            return
+        rows = lib.tok_window_attn_bwd_rows(b, h, w, heads, ws)
+        scratch = torch.empty((rows, heads * n * n), dtype=F32, device=dev)
+        dscale = torch.empty((rows, heads), dtype=F32, device=dev)
         _C.check(lib.tok_window_attn_bwd(ptr(qkv.data), ptr(g), b, h, w, c, heads, ws, shift, qkv.cp,
                                          ptr(self.logit_scale), ptr(self.bias), ptr(self.mask), ptr(self.lse), ptr(tgt),
                                          ptr(scratch), ptr(dscale), st), 'tok_window_attn_bwd')
@@ -364,11 +371,15 @@ class _WindowAttnNode(Node):
 
 
 def window_attention(region: Region, qkv: TTensor, geo: Tuple[int, int, int, int, int, int, int],
-                     logit_scale: nn.Parameter, bias: torch.Tensor, bias_node, mask: Optional[torch.Tensor]) -> TTensor:
-    """qkv rows [B*H*W][3C] -> attention output rows [B*H*W][C]; geo = (B, H, W, C, heads, window, shift)."""
+                     logit_scale: Optional[nn.Parameter] = None, bias: Optional[torch.Tensor] = None, bias_node=None,
+                     mask: Optional[torch.Tensor] = None) -> TTensor:
+    """qkv rows [B*H*W][3C] -> attention output rows [B*H*W][C]; geo = (B, H, W, C, heads, window, shift).
+    logit_scale / bias given: SwinV2 cosine attention; both None: softmax(q k^T / sqrt(head_dim)) v (DaViT)."""
     b, h, w, c, heads, ws, shift = geo
     if c != heads * 32:
-        raise NotImplementedError('window_attention: head_dim 32 (every SwinV2 variant of the reference)')
+        raise NotImplementedError('window_attention: head_dim 32 (every SwinV2 / DaViT variant of the reference)')
+    if (logit_scale is None) != (bias is None):
+        raise ValueError('window_attention: logit_scale and bias go together')
     lib, st = _C.lib(), stream_ptr()
     n = ws * ws
     nw = (h // ws) * (w // ws)
@@ -377,7 +388,8 @@ def window_attention(region: Region, qkv: TTensor, geo: Tuple[int, int, int, int
     lse = torch.empty(b * nw * heads * n, dtype=F32, device=dev)
     _C.check(lib.tok_window_attn_fwd(ptr(qkv.data), b, h, w, c, heads, ws, shift, qkv.cp, ptr(logit_scale), ptr(bias),
                                      ptr(mask), ptr(out_data), ptr(lse), st), 'tok_window_attn_fwd')
-    req = region.grad_mode and (qkv.requires_grad or logit_scale.requires_grad or bias_node is not None)
+    req = region.grad_mode and (qkv.requires_grad or (logit_scale is not None and logit_scale.requires_grad) or
+                                bias_node is not None)
     out = TTensor(out_data, c, requires_grad=req)
     if req:
         node = _WindowAttnNode()
@@ -426,5 +438,111 @@ def patch_merge(region: Region, x: TTensor, b: int, h: int, w: int) -> TTensor:
         node.x, node.out, node.geo = x, out, (b, h, w, c)
         out.node = node
         x.uses += 1
+        region.add(node)
+    return out
+
+
+# ---- DaViT: channel attention and the pre-norm residual ------------------------------------------------------------------------
+class _ChannelAttnNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None or not self.qkv.requires_grad:
+            return
+        images, rpi, heads, c, scale = self.geo
+        qkv, ld = self.qkv, self.qkv.cp
+        q, k, v = (ptr(qkv.data) + 2 * o for o in (0, c, 2 * c))
+        tgt, acc = grad_target(qkv)
+        if acc:
+            raise RuntimeError('channel_attention: qkv has a single consumer')
+        dq, dk, dv = (ptr(tgt) + 2 * o for o in (0, c, 2 * c))
+        ds = torch.empty_like(self.attn)
+        # dA = dout^T q, through the softmax: dS = A o (dA - rowsum(dA o A))
+        _C.check(lib.tok_chan_gram(ptr(g), g.stride(0), q, ld, rpi, images, heads, 1.0, 2, ptr(self.attn), ptr(ds), st),
+                 'tok_chan_gram')
+        _C.check(lib.tok_chan_apply(ptr(g), g.stride(0), ptr(self.attn), 1, 1.0, rpi, images, heads, dq, ld, st),
+                 'tok_chan_apply')                                   # dq = dout A
+        _C.check(lib.tok_chan_apply(v, ld, ptr(ds), 0, scale, rpi, images, heads, dk, ld, st), 'tok_chan_apply')   # dk
+        _C.check(lib.tok_chan_apply(k, ld, ptr(ds), 1, scale, rpi, images, heads, dv, ld, st), 'tok_chan_apply')   # dv
+        if ld != 3 * c:
+            tgt[:, 3 * c:] = 0
+        self.out.grad = None
+
+    def release(self):
+        self.qkv = self.out = self.attn = None
+
+
+def channel_attention(region: Region, qkv: TTensor, images: int, rows_per_image: int, heads: int) -> TTensor:
+    """davit.py:152-165 on qkv rows [B*N][3C]: A = softmax((k * scale)^T v) per (image, head), out = q A^T."""
+    c = heads * 32
+    if qkv.c != 3 * c:
+        raise NotImplementedError('channel_attention: head_dim 32 (every DaViT variant of the reference)')
+    lib, st = _C.lib(), stream_ptr()
+    dev = qkv.data.device
+    ld = qkv.cp
+    scale = 32 ** -0.5
+    q, k, v = (ptr(qkv.data) + 2 * o for o in (0, c, 2 * c))
+    attn = torch.empty((images * heads, 32, 32), dtype=F32, device=dev)
+    _C.check(lib.tok_chan_gram(k, ld, v, ld, rows_per_image, images, heads, scale, 1, None, ptr(attn), st), 'tok_chan_gram')
+    out_data = torch.empty((images * rows_per_image, c), dtype=BF16, device=dev)
+    _C.check(lib.tok_chan_apply(q, ld, ptr(attn), 0, 1.0, rows_per_image, images, heads, ptr(out_data), c, st),
+             'tok_chan_apply')
+    req = region.grad_mode and qkv.requires_grad
+    out = TTensor(out_data, c, requires_grad=req)
+    if req:
+        node = _ChannelAttnNode()
+        node.qkv, node.out, node.attn, node.geo = qkv, out, attn, (images, rows_per_image, heads, c, scale)
+        out.node = node
+        qkv.uses += 1
+        region.add(node)
+    return out
+
+
+class _ResidualNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None:
+            return
+        a, b = self.a, self.b
+        rows, cp = _rows(b), b.cp
+        if b.requires_grad:
+            tgt, acc = grad_target(b)
+            _C.check(lib.tok_scale_rows_add(None, ptr(g), ptr(self.row_scale), self.rps, ptr(tgt), acc, rows, cp, st),
+                     'tok_scale_rows_add')
+        if a.requires_grad:
+            if not (self.out.grad_owned and donate_grad(a, g.view(a.data.shape))):
+                tgt, acc = grad_target(a)
+                _C.check(lib.tok_act_bwd(2, ptr(g), ptr(g), ptr(tgt), acc, g.numel(), st), 'tok_act_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.a = self.b = self.out = self.row_scale = None
+
+
+def residual_add(region: Region, a: TTensor, b: TTensor, row_scale: Optional[torch.Tensor] = None,
+                 rows_per_sample: int = 0) -> TTensor:
+    """out = a + row_scale[sample] * b — `x + drop_path(f(x))` with the stochastic-depth keep/scale vector applied in place."""
+    lib, st = _C.lib(), stream_ptr()
+    rows, cp = _rows(b), b.cp
+    if a.data.shape != b.data.shape:
+        raise ValueError(f'residual_add: {tuple(a.data.shape)} vs {tuple(b.data.shape)}')
+    out_data = torch.empty_like(b.data)
+    _C.check(lib.tok_scale_rows_add(ptr(a.data), ptr(b.data), ptr(row_scale), rows_per_sample, ptr(out_data), 0, rows, cp, st),
+             'tok_scale_rows_add')
+    req = region.grad_mode and (a.requires_grad or b.requires_grad)
+    out = TTensor(out_data, b.c, requires_grad=req)
+    if req:
+        node = _ResidualNode()
+        node.a, node.b, node.out, node.row_scale, node.rps = a, b, out, row_scale, rows_per_sample
+        out.node = node
+        if a.requires_grad:
+            a.uses += 1
+        if b.requires_grad:
+            b.uses += 1
         region.add(node)
     return out

@@ -1,1 +1,1 @@
-from . import hrnet, resnet, swin  # noqa: F401
+from . import davit, hrnet, resnet, swin  # noqa: F401
