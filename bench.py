@@ -60,18 +60,22 @@ def build_seg_task(backbone: str, num_classes: int, h: int, w: int):
     return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
 
 
-ALG_FLOPS_PER_IMG = {('swinv2_custom', 224): 26.94e9}             # SwinV2-T 224 (window 7)
+ALG_FLOPS_PER_IMG = {('swinv2_custom', 224): 26.94e9,            # SwinV2-T 224 (window 7)
+                     # DaViT-T 224: 4.496 GMAC forward (linears 12*T*C^2 per block, window 98*T*C + channel 64*T*C attention,
+                     # patch embeds, head) x 2 x 3 (forward + dgrad + wgrad)
+                     ('davit_t', 224): 26.98e9}
 MFMA_PEAK_BF16 = 2.5e15
 
 
-def build_swin_task(num_classes: int, res: int):
+def build_swin_task(num_classes: int, res: int, backbone: str = 'swinv2_custom'):
     """SwinV2-T (embed 96, depths 2-2-6-2, heads 3-6-12-24, window 7) + ClassificationTask + AdamW
-    (secondary workload: `--backbone swinv2_custom --res 224 --batch 128`; never the default line)."""
+    (secondary workload: `--backbone swinv2_custom --res 224 --batch 128`; never the default line).  `davit_t`: the
+    reference's in-tree DaViT-T under the same task / optimizer."""
     import torchok_amd as T
     from torchok_amd.constructor.config import apply_schema
     cfg = apply_schema({
         'task': {'name': 'ClassificationTask',
-                 'params': {'backbone_name': 'swinv2_custom',
+                 'params': {'backbone_name': backbone,
                             'backbone_params': {'pretrained': False, 'in_channels': 3, 'img_size': res, 'window_size': 7,
                                                 'drop_path_rate': 0.1},
                             'pooling_name': 'Pooling', 'head_name': 'ClassificationHead',
@@ -181,11 +185,11 @@ def main():
     torch.manual_seed(1234)
     seg = args.backbone.startswith('hrnet')
     width = args.width or args.res
-    swin = args.backbone.startswith('swinv2')
-    if swin and args.backbone != 'swinv2_custom':
-        raise SystemExit('bench.py: the SwinV2 workload is swinv2_custom (SwinV2-T geometry, window 7) at --res')
+    swin = args.backbone.startswith('swinv2') or args.backbone.startswith('davit')
+    if swin and args.backbone not in ('swinv2_custom', 'davit_t'):
+        raise SystemExit('bench.py: the transformer workloads are swinv2_custom (SwinV2-T geometry, window 7) and davit_t at --res')
     task = (build_seg_task(args.backbone, args.classes, args.res, width) if seg
-            else build_swin_task(args.classes, args.res) if swin
+            else build_swin_task(args.classes, args.res, args.backbone) if swin
             else build_task(args.backbone, args.classes)).cuda().train()
     opt = task.configure_optimizers()[0]['optimizer']
     reducer = None
@@ -274,7 +278,7 @@ def main():
             'config': {'workload': (f'{args.backbone} + SegmentationTask(HRNetSegmentationNeck, SegmentationHead '
                                     f'{args.classes}) + CrossEntropyLoss + SGD(momentum 0.9, wd 5e-4), synthetic '
                                     f'3x{args.res}x{width} bf16, batch {args.batch}/GPU') if seg else
-                                   (f'SwinV2-T(window 7, drop_path 0.1) + ClassificationTask(Pooling, ClassificationHead '
+                                   (f'{"DaViT-T" if args.backbone == "davit_t" else "SwinV2-T"}(window 7, drop_path 0.1) + ClassificationTask(Pooling, ClassificationHead '
                                     f'{args.classes}) + CrossEntropyLoss + AdamW, synthetic 3x{args.res}x{args.res} bf16, '
                                     f'batch {args.batch}/GPU') if swin else
                                    f'{args.backbone} + ClassificationTask(Pooling, ClassificationHead {args.classes}) '
