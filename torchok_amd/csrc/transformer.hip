@@ -523,6 +523,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
       pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
+    // the 16 x 32 output tile goes back through this wave's own (now consumed) P rows so that a lane stores 16 bytes
+    // of one token instead of sixteen lanes storing 2 bytes each
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj) {
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -532,10 +534,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kt], vf, o, 0, 0, 0);
       }
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = qi * 16 + 4 * g + reg;
-        if (i < N) out[token_row(a, b, win, i) * a.C + h * HD + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
-      }
+      for (int reg = 0; reg < 4; ++reg)
+        ps[(qi * 16 + 4 * g + reg) * PPITCH + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int i = qi * 16 + (lane >> 2), ch = (lane & 3) * 8;
+      if (i < N)
+        stg16(out + token_row(a, b, win, i) * a.C + h * HD + ch, *reinterpret_cast<const bf16x8*>(ps + i * PPITCH + ch));
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -693,16 +700,28 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
         }
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) { dotq += __shfl_xor(dotq, off, 64); dotk += __shfl_xor(dotk, off, 64); }
-        if (t < N) {
-          bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD;
-          const float qi_ = qinv[t], ki_ = kinv[t];
+        {
+          // rows mt*16.. of dS, dS^T and P^T were read by this wave only (its A fragments above): they take the
+          // 16 x 32 dq / dk / dv tiles so that the global stores below are 16 bytes per lane
+          const float qi_ = qinv[t < 64 ? t : 0], ki_ = kinv[t < 64 ? t : 0];
 #pragma unroll
           for (int dj = 0; dj < 2; ++dj) {
             const int d = dj * 16 + l15;
-            dr[d] = f2bf(a.plain ? dq[dj][reg] : (dq[dj][reg] - qn[dj] * dotq) * qi_);
-            dr[a.C + d] = f2bf(a.plain ? dk[dj][reg] : (dk[dj][reg] - kn[dj] * dotk) * ki_);
-            dr[2 * a.C + d] = f2bf(dv[dj][reg]);
+            dsr[t * PPITCH + d] = f2bf(a.plain ? dq[dj][reg] : (dq[dj][reg] - qn[dj] * dotq) * qi_);
+            dst[t * PPITCH + d] = f2bf(a.plain ? dk[dj][reg] : (dk[dj][reg] - kn[dj] * dotk) * ki_);
+            pt[t * PPITCH + d] = f2bf(dv[dj][reg]);
           }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int t = mt * 16 + (lane >> 2), ch = (lane & 3) * 8;
+        if (t < N) {
+          bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD + ch;
+          stg16(dr, *reinterpret_cast<const bf16x8*>(dsr + t * PPITCH + ch));
+          stg16(dr + a.C, *reinterpret_cast<const bf16x8*>(dst + t * PPITCH + ch));
+          stg16(dr + 2 * a.C, *reinterpret_cast<const bf16x8*>(pt + t * PPITCH + ch));
         }
       }
     }
