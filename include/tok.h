@@ -360,6 +360,16 @@ int tok_triplet_bwd(const void* anchor, const void* positive, const void* negati
                     const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
                     void* d_anchor, void* d_positive, void* d_negative, void* stream);
 
+/* ---- GEMM + activation (Mlp.fc1 -> GELU -> fc2 of the transformer blocks: [timm] Mlp, modules/bricks/mlp.py:37-41) ----
+ * tok_conv_fwd_act: y = conv(x, w) + bias AND y_act = act(y) from one launch (the backward needs y, the next layer
+ * y_act).  tok_conv_dgrad_act: dx = conv_dgrad(dy) * act'(act_x) — the dgrad of the layer AFTER the activation writes the
+ * gradient of the activation's INPUT.  Pointwise layers only (1x1, stride 1, no padding); kind 0 ReLU, 1 GELU (erf).
+ * Same arithmetic as tok_conv_fwd + tok_act_fwd resp. tok_conv_dgrad + tok_act_bwd on the bf16-rounded GEMM result.       */
+int tok_conv_fwd_act(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, void* y_act,
+                     int kind, void* stream);
+int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const void* act_x, int kind,
+                       void* dx, void* stream);
+
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:
  * softmax(q k^T / sqrt(32)) v on unshifted windows, no cosine normalisation (ds_scratch / dscale_part unused).

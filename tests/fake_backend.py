@@ -141,6 +141,16 @@ class FakeTok:
             out.copy_(gi.to(BF16))
         return 0
 
+    def tok_conv_fwd_act(self, d, x, w, bias, y, y_act, kind, st):
+        rc = self.tok_conv_fwd(d, x, w, bias, y, None, st)
+        dd = _desc(d)
+        return rc or self.tok_act_fwd(kind, y, y_act, dd.n * dd.p * dd.q * dd.k, st)
+
+    def tok_conv_dgrad_act(self, d, dy, wd, act_x, kind, dx, st):
+        rc = self.tok_conv_dgrad(d, dy, wd, dx, 0, st)
+        dd = _desc(d)
+        return rc or self.tok_act_bwd(kind, dx, act_x, dx, 0, dd.n * dd.h * dd.w * dd.c, st)
+
     def tok_conv_dgrad_stat_rows(self, d):
         return 2
 

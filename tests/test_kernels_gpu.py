@@ -1007,3 +1007,36 @@ def test_scale_rows_add(libs, rows, ld, rps, with_a, acc):
                                                      rows, ld, None])
     assert torch.equal(out, want.to(BF16))
     assert relerr(dv[id(out)].float(), want) < 3e-3          # fp32 fma contraction may move one bf16 ulp
+
+
+@pytest.mark.parametrize('rows,c,k', [(1000, 96, 384), (802, 384, 96), (4096, 768, 3072), (77, 24, 40)])
+@pytest.mark.parametrize('kind', [0, 1])
+def test_gemm_activation_epilogues_equal_the_unfused_pair(libs, rows, c, k, kind):
+    """tok_conv_fwd_act == tok_conv_fwd + tok_act_fwd and tok_conv_dgrad_act == tok_conv_dgrad + tok_act_bwd, bit for bit
+    (the epilogue applies the activation to the bf16-rounded GEMM result, exactly what the separate launch reads)."""
+    lib = libs[0]
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: t_.data_ptr()   # noqa: E731
+    d = _desc(rows, 1, 1, c, k, 1, 1, 0)
+    x = rnd(rows, c).to(BF16).cuda()
+    w = (rnd(k, c, seed=1) * c ** -0.5).to(BF16).cuda()
+    bias = rnd(k, seed=2).cuda()
+    y0, y1, a0, a1 = (torch.empty(rows, k, dtype=BF16, device='cuda') for _ in range(4))
+    assert lib.tok_conv_fwd(d, P(x), P(w), P(bias), P(y0), None, st) == 0
+    assert lib.tok_act_fwd(kind, P(y0), P(a0), y0.numel(), st) == 0
+    assert lib.tok_conv_fwd_act(d, P(x), P(w), P(bias), P(y1), P(a1), kind, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(a0, a1)
+    # backward of the NEXT layer (k -> c2): its dgrad produces d(act(y)); fused: d(y) directly
+    c2 = 64
+    d2 = _desc(rows, 1, 1, k, c2, 1, 1, 0)
+    g = rnd(rows, c2, seed=3).to(BF16).cuda()
+    wd = (rnd(k, c2, seed=4) * c2 ** -0.5).to(BF16).cuda()           # dgrad pack [C=k][1][1][K=c2]
+    da, dy0, dy1 = (torch.empty(rows, k, dtype=BF16, device='cuda') for _ in range(3))
+    assert lib.tok_conv_dgrad(d2, P(g), P(wd), P(da), 0, st) == 0
+    assert lib.tok_act_bwd(kind, P(da), P(y0), P(dy0), 0, da.numel(), st) == 0
+    assert lib.tok_conv_dgrad_act(d2, P(g), P(wd), P(y0), kind, P(dy1), st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dy0, dy1)
+    d3 = _desc(2, 8, 8, 16, 16, 3, 1, 1)
+    assert lib.tok_conv_fwd_act(d3, P(x), P(w), None, P(y1), P(a1), kind, st) != 0         # 3x3: refused

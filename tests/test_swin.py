@@ -176,3 +176,35 @@ def test_training_loop_learns_and_side_stream_is_transparent(monkeypatch):
     assert losses[0] == losses[1]
     for n in finals[0]:
         assert torch.equal(finals[0][n], finals[1][n]), n
+
+
+@pytest.mark.gpu
+def test_fused_activation_epilogues_leave_training_bit_identical(monkeypatch):
+    """fc1 + GELU in one launch and GELU' in fc2's dgrad epilogue (engine.transformer.FUSE_ACT) against the separate
+    activation launches: 5 AdamW steps, identical losses and parameters."""
+    from helpers import cls_config
+    from torchok_amd.engine import transformer as ET
+    finals = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ET, 'FUSE_ACT', fuse)
+        cfg = cls_config('swinv2_custom', 5, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                         backbone_params=dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0),
+                         inputs_shape=(3, 64, 64))
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 9)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(4)
+        x, y = torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 5, (8,), generator=g).cuda()
+        losses = []
+        for it in range(5):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad()
+            out['loss'].backward()
+            opt.step()
+            losses.append(float(out['loss'].detach()))
+        finals.append((losses, {n: p.detach().clone() for n, p in task.named_parameters()}))
+    assert finals[0][0] == finals[1][0]
+    for n in finals[0][1]:
+        assert torch.equal(finals[0][1][n], finals[1][1][n]), n

@@ -52,6 +52,9 @@ struct ConvArgs {
   bf16* y;
   const float* bias;
   float* stats;  // [2][stat_rows][K] or null
+  bf16* y2;                // PWM 3 forward: act(y) is stored here beside the pre-activation y (fc1 -> GELU)
+  const bf16* act_x;       // PWM 3 dgrad: pre-activation of the tensor whose gradient is produced: dx = dy * act'(act_x)
+  int act;                 // 0 ReLU, 1 GELU (erf)
   const bf16* bn_y;        // dgrad + BatchNorm-backward statistics: raw conv output of the unit that
   const uint8_t* bn_mask;  // produced the tensor whose gradient this launch completes, and its ReLU bits
   int H, W, C;   // gathered tensor
@@ -94,6 +97,7 @@ template <int BM, int BN, int IN_DIV, bool C4, int PWM>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool PW = PWM != 0;    // PWM 1: pointwise; 2: pointwise with streaming (non-temporal) stores
   constexpr bool NTS = PWM == 2;
+  constexpr bool ACT = PWM == 3;   // pointwise with a fused activation epilogue (forward: second output; dgrad: * act')
   // DMA: global -> LDS directly (buffer_load ... lds), no staging registers and no ds_write pass
   // (LDS stores run at ~80 B/clk/CU: the register-staged loop was LDS-write bound on deep-K layers).
   // The LDS image of a wave instruction is lane-linear, so the XOR swizzle is applied to the SOURCE:
@@ -412,6 +416,29 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+            if (ACT) {
+              // same arithmetic as tok_act_fwd / tok_act_bwd on the bf16-rounded GEMM result: bit-identical to the
+              // unfused pair of launches, minus one read (forward) or one write + one read (backward) of the tensor
+              const size_t eoff = opix * a.K + nb + half * 32;
+              if (a.act_x != nullptr) {
+                const bf16x8 hx = ldg16(a.act_x + eoff);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = bf2f(hx[e]);
+                  const float dd = a.act == 0 ? (f > 0.f ? 1.f : 0.f) : gelu_d(f);
+                  o[e] = f2bf(bf2f(o[e]) * dd);
+                }
+              }
+              if (a.y2 != nullptr) {
+                bf16x8 o2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  const float f = bf2f(o[e]);
+                  o2[e] = f2bf(a.act == 0 ? fmaxf(f, 0.f) : gelu_f(f));
+                }
+                stg16(a.y2 + eoff, o2);
+              }
+            }
             if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(yp + half * 32));
             else stg16(yp + half * 32, o);
             if (a.stats != nullptr) {
@@ -706,8 +733,13 @@ int launch(ConvArgs& a, hipStream_t st) {
       // (PWM 2 = streaming / non-temporal output stores: +5..25 % on the write-heavy layers in
       //  isolation, but the consumer BatchNorm pass then misses the 256 MB Infinity Cache and the
       //  whole step loses 2 % — measured, so it stays off)
+      if (a.y2 != nullptr || a.act_x != nullptr) return launch_pw<BM, BN, 1, false, 3>(a, st);
       return launch_pw<BM, BN, 1, false, 1>(a, st);
     }
+  }
+  if (a.y2 != nullptr || a.act_x != nullptr) {
+    tok_set_error("fused activation epilogue: 1x1 / stride 1 / no padding layers only");
+    return TOK_ERR_INVALID;
   }
   return launch_pw<BM, BN, IN_DIV, C4, 0>(a, st);
 }
@@ -778,7 +810,7 @@ int check_fused(const tok_bn_fused* bn, int k, bool fwd, const char* who) {
   return 0;
 }
 int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
-                  const tok_bn_fused* bn, void* stream);
+                  const tok_bn_fused* bn, void* stream, void* y_act = nullptr, int act = 0);
 }  // namespace
 
 extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w,
@@ -794,7 +826,7 @@ extern "C" int tok_conv_fwd_bn(const tok_conv_desc* d, const void* x, const void
 
 namespace {
 int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
-                  const tok_bn_fused* bn, void* stream) {
+                  const tok_bn_fused* bn, void* stream, void* y_act, int act) {
   if (int e = check_desc(d, "tok_conv_fwd")) return e;
   TOK_CHECK_ARG(x && w && y, "tok_conv_fwd: null pointer");
   ConvArgs a = {};
@@ -805,6 +837,7 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
     a.fin = *bn;
   }
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.bias = bias; a.stats = stats;
+  a.y2 = (bf16*)y_act; a.act = act;
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad;
   a.P = d->p; a.Q = d->q; a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q;
@@ -816,13 +849,15 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   a.x_bytes = (uint32_t)xb; a.w_bytes = (uint32_t)wb;
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
+  int rc;
   if (pick_bn(d->k, a.Ktot, a.gridM) == 64) {
     a.gridN = tok_cdiv(d->k, 64);
-    if (c4) launch<128, 64, 1, true>(a, st); else launch<128, 64, 1, false>(a, st);
+    rc = c4 ? launch<128, 64, 1, true>(a, st) : launch<128, 64, 1, false>(a, st);
   } else {
     a.gridN = tok_cdiv(d->k, 128);
-    if (c4) launch<128, 128, 1, true>(a, st); else launch<128, 128, 1, false>(a, st);
+    rc = c4 ? launch<128, 128, 1, true>(a, st) : launch<128, 128, 1, false>(a, st);
   }
+  if (rc) return rc;
   TOK_CHECK_LAUNCH("tok_conv_fwd");
   return TOK_OK;
 }
@@ -872,7 +907,7 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
 
 int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who,
-               const tok_bn_fused* bn = nullptr) {
+               const tok_bn_fused* bn = nullptr, const void* act_x = nullptr, int act = 0) {
   if (int e = check_desc(d, who)) return e;
   TOK_CHECK_ARG(dy && w_dgrad && dx, "%s: null pointer", who);
   ConvArgs a = {};
@@ -881,6 +916,7 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
   a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr;
   a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask;
   a.accumulate = accumulate;
+  a.act_x = (const bf16*)act_x; a.act = act;
   if (bn != nullptr) {
     if (int e = check_fused(bn, d->c, false, who)) return e;
     TOK_CHECK_ARG(tok_cdiv(d->c, 64) <= 64, "%s: more than 64 channel tiles", who);
@@ -888,16 +924,27 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     a.fin = *bn;
   }
   hipStream_t st = tok_stream(stream);
-  if (pl.bn_tile == 64) {
-    if (d->stride == 1) launch<128, 64, 1, false>(a, st); else launch<128, 64, 2, false>(a, st);
-  } else {
-    if (d->stride == 1) launch<128, 128, 1, false>(a, st); else launch<128, 128, 2, false>(a, st);
-  }
+  int rc;
+  if (pl.bn_tile == 64) rc = d->stride == 1 ? launch<128, 64, 1, false>(a, st) : launch<128, 64, 2, false>(a, st);
+  else rc = d->stride == 1 ? launch<128, 128, 1, false>(a, st) : launch<128, 128, 2, false>(a, st);
+  if (rc) return rc;
   TOK_CHECK_LAUNCH(who);
   return TOK_OK;
 }
 
 }  // namespace
+
+extern "C" int tok_conv_fwd_act(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y,
+                                void* y_act, int kind, void* stream) {
+  TOK_CHECK_ARG(y_act != nullptr && (kind == 0 || kind == 1), "tok_conv_fwd_act: y_act and kind 0 (ReLU) / 1 (GELU)");
+  return conv_fwd_impl(d, x, w, bias, y, nullptr, nullptr, stream, y_act, kind);
+}
+
+extern "C" int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const void* act_x, int kind,
+                                  void* dx, void* stream) {
+  TOK_CHECK_ARG(act_x != nullptr && (kind == 0 || kind == 1), "tok_conv_dgrad_act: act_x and kind 0 (ReLU) / 1 (GELU)");
+  return dgrad_impl(d, dy, w_dgrad, dx, 0, nullptr, nullptr, nullptr, stream, "tok_conv_dgrad_act", nullptr, act_x, kind);
+}
 
 extern "C" int tok_conv_dgrad(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                               int accumulate, void* stream) {

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <math.h>
 #include "../../include/tok.h"
 
 typedef __bf16 bf16;
@@ -48,6 +49,13 @@ __device__ __forceinline__ bf16x8 ldg16(const bf16* p) {
   return *reinterpret_cast<const bf16x8*>(p);
 }
 __device__ __forceinline__ void stg16(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
+
+// exact (erf) GELU and its derivative: one definition for tok_act_fwd/_bwd and the fused GEMM epilogues, so that the
+// fused and the unfused paths give the same bits
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
 
 __device__ __forceinline__ bf16x8 zero8() {
   bf16x8 z;

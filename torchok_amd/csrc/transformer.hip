@@ -272,10 +272,7 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------
 // activations (kind 0 = ReLU, 1 = GELU erf)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_d(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
+// gelu_f / gelu_d: tok_common.h (shared with the GEMM epilogues of conv_igemm.hip)
 
 __global__ __launch_bounds__(256) void act_fwd_kernel(int kind, const bf16* __restrict__ x, bf16* __restrict__ out,
                                                       size_t n8) {

@@ -12,6 +12,7 @@ window_attention     WindowAttention.forward between qkv and proj, with roll / w
 patch_merge          PatchMerging's strided 2x2 gather + cat
 reshape              .view between (B, H, W, C) maps and (B*H*W, C) token rows (zero copy)
 """
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -117,18 +118,35 @@ class _LinearNode(Node):
             else:
                 run_wgrad()
         if x.requires_grad:
-            tgt, acc = grad_target(x)
-            _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+            an = x.node
+            if (FUSE_ACT and isinstance(an, _ActNode) and an.out is x and an.kind in (RELU, GELU) and x.uses == 1 and
+                    x.grad is None and an.x.requires_grad and an.x.uses == 1 and an.x.grad is None):
+                # this layer consumes act(h) and nothing else does: its dgrad epilogue multiplies by act'(h) and writes
+                # d(h) — the gradient of act(h) is never materialised, the activation node finds nothing to do
+                tgt, _ = grad_target(an.x)
+                _C.check(lib.tok_conv_dgrad_act(d, ptr(g), ptr(self.pk.dgrad), ptr(an.x.data), an.kind, ptr(tgt), st),
+                         'tok_conv_dgrad_act')
+            else:
+                tgt, acc = grad_target(x)
+                _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
         self.out.grad = None
 
     def release(self):
         self.x = self.out = self.pk = None
 
 
+# GELU / ReLU in the epilogues of the GEMMs around it (tok_conv_fwd_act / tok_conv_dgrad_act).  Bit-identical to the separate
+# launches and measured NEUTRAL on MI355X (SwinV2-T B=256: 29.0 vs 29.0 ms/step, DaViT-T 27.4 vs 27.1): the erf / exp
+# arithmetic of 128 values per lane stretches the GEMM epilogue by what the deleted passes cost (their reads were served by
+# the 256 MB Infinity Cache).  Off by default; TOK_FUSE_ACT=1 turns it on.
+FUSE_ACT = os.environ.get('TOK_FUSE_ACT', '0') == '1'
+
+
 def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Optional[torch.Tensor] = None,
-              bias_sinks: Sequence[Tuple[nn.Parameter, int]] = ()) -> TTensor:
+              bias_sinks: Sequence[Tuple[nn.Parameter, int]] = (), act: Optional[int] = None):
     """y = x W^T + bias_vec.  `bias_vec` is an fp32 vector of the (padded) output width; `bias_sinks` lists the
-    parameters it was assembled from as (param, start column) — their gradients are column sums of dy."""
+    parameters it was assembled from as (param, start column) — their gradients are column sums of dy.
+    act = RELU / GELU: returns act(y) instead, produced by the same launch (y is kept for the backward)."""
     lib, st = _C.lib(), stream_ptr()
     k, c = weight.shape
     n, cp = x.shape
@@ -143,7 +161,13 @@ def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Option
         bias_vec = b
     d = _C.ConvDesc(n, 1, 1, cp, kp, 1, 1, 1, 1, 1, 0, 1)
     y = torch.empty((n, kp), dtype=BF16, device=x.data.device)
-    _C.check(lib.tok_conv_fwd(d, ptr(x.data), ptr(pk.fwd), ptr(bias_vec), ptr(y), None, st), 'tok_conv_fwd')
+    y_act = None
+    if act is not None and FUSE_ACT:
+        y_act = torch.empty_like(y)
+        _C.check(lib.tok_conv_fwd_act(d, ptr(x.data), ptr(pk.fwd), ptr(bias_vec), ptr(y), ptr(y_act), act, st),
+                 'tok_conv_fwd_act')
+    else:
+        _C.check(lib.tok_conv_fwd(d, ptr(x.data), ptr(pk.fwd), ptr(bias_vec), ptr(y), None, st), 'tok_conv_fwd')
     req = region.grad_mode and (x.requires_grad or weight.requires_grad or any(p.requires_grad for p, _ in bias_sinks))
     out = TTensor(y, k, requires_grad=req)
     if req:
@@ -154,13 +178,15 @@ def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Option
         if x.requires_grad:
             x.uses += 1
         region.add(node)
-    return out
+    if act is None:
+        return out
+    return activation(region, out, act, precomputed=y_act)
 
 
-def linear_module(region: Region, x: TTensor, fc: nn.Linear) -> TTensor:
+def linear_module(region: Region, x: TTensor, fc: nn.Linear, act: Optional[int] = None) -> TTensor:
     if fc.bias is None:
-        return linear_op(region, x, fc.weight)
-    return linear_op(region, x, fc.weight, fc.bias.detach(), [(fc.bias, 0)])
+        return linear_op(region, x, fc.weight, act=act)
+    return linear_op(region, x, fc.weight, fc.bias.detach(), [(fc.bias, 0)], act=act)
 
 
 # ---- layer norm (+ residual, + stochastic depth) ---------------------------------------------------------------------
@@ -269,9 +295,13 @@ class _ActNode(Node):
         self.x = self.out = None
 
 
-def activation(region: Region, x: TTensor, kind: int) -> TTensor:
-    y = torch.empty_like(x.data)
-    _C.check(_C.lib().tok_act_fwd(kind, ptr(x.data), ptr(y), y.numel(), stream_ptr()), 'tok_act_fwd')
+def activation(region: Region, x: TTensor, kind: int, precomputed: Optional[torch.Tensor] = None) -> TTensor:
+    """act(x); `precomputed` = act(x) already produced by the epilogue of the GEMM that made x."""
+    if precomputed is not None:
+        y = precomputed
+    else:
+        y = torch.empty_like(x.data)
+        _C.check(_C.lib().tok_act_fwd(kind, ptr(x.data), ptr(y), y.numel(), stream_ptr()), 'tok_act_fwd')
     req = region.grad_mode and x.requires_grad
     out = TTensor(y, x.c, requires_grad=req)
     if req:

@@ -68,8 +68,7 @@ class Mlp(nn.Module):
         self.drop2 = nn.Dropout(drop)
 
     def run(self, r, x):
-        h = ET.linear_module(r, x, self.fc1)
-        h = ET.activation(r, h, ET.GELU)
+        h = ET.linear_module(r, x, self.fc1, act=ET.GELU)      # fc1 + GELU: one launch; fc2's dgrad applies GELU'
         return ET.linear_module(r, h, self.fc2)
 
 
