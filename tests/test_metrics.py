@@ -127,3 +127,62 @@ def test_jaccard_index_and_legacy_forms(dev):
     a = T.METRICS.get('Accuracy')().to(dev)
     a.update(preds=logits.to(dev), target=tgt.to(dev))
     assert a.num_classes == c and np.allclose(float(a.compute()), (pred == t).mean(), rtol=1e-6)
+
+
+def test_reference_metric_manager_known_answers():
+    """tests/base_tests/metrics/metric_manager/test_metric_manager.py of the reference, case for case: user metrics
+    registered in METRICS (plain modules with update / compute / reset instead of torchmetrics.Metric), 5 updates with
+    `predict <- embedding`, `target <- target`; expected logs {'train/MockSumMetric': 5}, {'train/moc_sum': 5,
+    'train/MockConstantMetric': 0}, {'train/MockDictMetric_target_shape': 10, 'train/MockDictMetric_embedding_size': 512},
+    and an exception for a metric whose compute() cannot be called."""
+    from torch import nn
+
+    class _Mock(nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            self.reset()
+
+        def update(self, predict, target):
+            self.sum += 1
+
+        def reset(self):
+            self.sum = torch.tensor(0)
+
+    class MockSumMetric(_Mock):
+        def compute(self):
+            return self.sum
+
+    class MockConstantMetric(_Mock):
+        def compute(self):
+            return torch.tensor(0)
+
+    class MockDictMetric(_Mock):
+        def compute(self):
+            return {'target_shape': torch.tensor(10), 'embedding_size': torch.tensor(512)}
+
+    class MockRaiseMetric(_Mock):
+        def compute(self, memory_block):
+            return torch.tensor([1, 2])
+
+    registered = []
+    try:
+        for cls in (MockSumMetric, MockConstantMetric, MockDictMetric, MockRaiseMetric):
+            T.METRICS.register_class(cls)
+            registered.append(cls.__name__)
+        mapping = dict(predict='embedding', target='target')
+
+        def run(names, tags):
+            mm = MetricsManager([dict(name=n, mapping=mapping, tag=t, phases=[Phase.TRAIN]) for n, t in zip(names, tags)])
+            for _ in range(5):
+                mm.update(Phase.TRAIN, embedding=torch.rand(4, 512), target=torch.rand(4, 10))
+            return {k: int(v) for k, v in mm.on_epoch_end(Phase.TRAIN).items()}
+        assert run(['MockSumMetric'], [None]) == {'train/MockSumMetric': 5}
+        assert run(['MockSumMetric', 'MockConstantMetric'], ['moc_sum', None]) == \
+            {'train/moc_sum': 5, 'train/MockConstantMetric': 0}
+        assert run(['MockDictMetric'], [None]) == {'train/MockDictMetric_target_shape': 10,
+                                                   'train/MockDictMetric_embedding_size': 512}
+        with pytest.raises(Exception):
+            run(['MockRaiseMetric'], [None])
+    finally:
+        for n in registered:
+            T.METRICS.entrypoints.pop(n, None)
