@@ -1,7 +1,7 @@
 """CPU restatement of the reference's in-tree DaViT: plain PyTorch fp32, each piece citing
 torchok/models/backbones/davit.py.  TEST INFRASTRUCTURE ONLY.
 
-Pinned by tests/golden/davit_cls_step.npz: tools/gen_golden.py imports the reference's OWN davit.py (its timm imports —
+Pinned by tests/golden/davit_cls_step.npz: tests/golden/gen_golden.py imports the reference's OWN davit.py (its timm imports —
 DropPath, trunc_normal_, to_2tuple, build_model_with_cfg — stubbed by oracle/timm_min.py; everything else in that file
 is in-tree code), runs a ClassificationTask training step and asserts this restatement is bit-identical to it
 (features, logits, loss, every gradient, the post-step parameters).  Parameter names equal the reference's."""

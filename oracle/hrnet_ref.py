@@ -3,7 +3,7 @@
     (absent offline; semantics per SURVEY.md App. A.2) — imported by `torchok/models/backbones/hrnet.py:13`
   * wiring of `torchok/models/backbones/hrnet.py:52-260` (HighResolutionNet),
     `necks/segmentation/hrnet.py:16-43`, `heads/segmentation/base.py:12-42`, `tasks/segmentation.py:60-93`
-TEST INFRASTRUCTURE ONLY.  Pinned by tests/golden/hrnet_seg_step.npz (tools/gen_golden.py runs the reference's
+TEST INFRASTRUCTURE ONLY.  Pinned by tests/golden/hrnet_seg_step.npz (tests/golden/gen_golden.py runs the reference's
 own hrnet.py / neck / head on the stubbed timm and asserts this file reproduces it bit for bit)."""
 import torch
 import torch.nn as nn

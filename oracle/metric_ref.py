@@ -1,6 +1,6 @@
 """CPU restatement of the metric-learning rows of the hot path: fp32, plain
 PyTorch ops, each function citing the reference lines it follows.  TEST INFRASTRUCTURE ONLY.
-Pinned by tests/golden/metric_heads.npz, which tools/gen_golden.py writes by running the reference's
+Pinned by tests/golden/metric_heads.npz, which tests/golden/gen_golden.py writes by running the reference's
 own arcface_head.py / linear_head.py / pairwise.py (and the body of calc_relevance_matrix)."""
 import math
 

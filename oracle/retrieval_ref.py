@@ -10,7 +10,7 @@ Third-party pieces the reference calls and that are absent here, restated from t
 Pinned by (a) the reference's OWN known-answer tables for these meters
 (`tests/base_tests/metrics/representation/data.py`: CLASSIFICATION_ANSWERS, REPRESENTATION_ANSWERS,
 REPRESENTATION_QUERY_AS_RELEVANT_ANSWERS), copied as data into tests/golden/retrieval_known_answers.npz, and
-(b) tests/golden/retrieval_meters.npz, which tools/gen_golden.py writes by driving the reference's own
+(b) tests/golden/retrieval_meters.npz, which tests/golden/gen_golden.py writes by driving the reference's own
 `prepare_classification_data` / `prepare_representation_data` / `query_generator` / `clear_faiss_output` /
 `process_data_for_metric_func` (index_base_metric.py, representation_ranx.py) on random data.
 

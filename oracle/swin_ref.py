@@ -2,7 +2,7 @@
   * [timm 0.6.13] `timm.models.swin_transformer_v2` pieces the reference imports (`swin.py:18-20`): PatchEmbed,
     PatchMerging, BasicLayer (SwinTransformerBlock, WindowAttention, Mlp, window_partition / window_reverse) and
     `timm.models.layers.{trunc_normal_, to_2tuple, DropPath}` — absent offline, semantics per SURVEY.md App. A.3
-  * the wiring of `torchok/models/backbones/swin.py:71-256` is NOT restated here: tools/gen_golden.py and the tests
+  * the wiring of `torchok/models/backbones/swin.py:71-256` is NOT restated here: tests/golden/gen_golden.py and the tests
     run the reference's own SwinTransformerV2 class on top of these pieces; `SwinV2` below is the same wiring for
     boxes without /root/reference (asserted bit-identical to it at fixture generation).
 TEST INFRASTRUCTURE ONLY."""

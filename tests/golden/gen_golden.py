@@ -24,7 +24,7 @@ import sys
 import types
 
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 REF = '/root/reference/torchok'

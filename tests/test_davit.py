@@ -1,5 +1,5 @@
 """DaViT row: the reference's in-tree Dual Attention Transformer against oracle/davit_ref.py and
-tests/golden/davit_cls_step.npz (one training step of the reference's OWN davit.py, tools/gen_golden.py).
+tests/golden/davit_cls_step.npz (one training step of the reference's OWN davit.py, tests/golden/gen_golden.py).
 Each test runs on the host stand-in and, marked gpu, through libtok_gfx950.so."""
 import copy
 import os

@@ -1,5 +1,5 @@
 """HIP path vs the committed golden vectors (generated from the reference's own files by
-tools/gen_golden.py).  bf16 tolerances: logits/loss tight-ish, gradient norms loose (ReLU-mask /
+tests/golden/gen_golden.py).  bf16 tolerances: logits/loss tight-ish, gradient norms loose (ReLU-mask /
 argmax flips under bf16 rounding; see test_resnet_gpu.py for the autocast yardstick)."""
 import os
 

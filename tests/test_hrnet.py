@@ -1,6 +1,6 @@
 """HRNet segmentation rows (SURVEY.md §8 a12-a14 + a10 on (N,C,H,W) logits): HighResolutionNet,
 HRNetSegmentationNeck, SegmentationHead, SegmentationTask against tests/golden/hrnet_seg_step.npz (one training
-step of the reference's own hrnet.py / neck / head, tools/gen_golden.py) and oracle/hrnet_ref.py.
+step of the reference's own hrnet.py / neck / head, tests/golden/gen_golden.py) and oracle/hrnet_ref.py.
 Each test runs on the host stand-in and, marked gpu, through libtok_gfx950.so."""
 import copy
 import os

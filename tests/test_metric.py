@@ -1,6 +1,6 @@
 """Metric-learning rows: ArcFaceHead, LinearHead(normalize), ContrastiveLoss,
 PairwiseLearnTask against tests/golden/metric_heads.npz (outputs of the reference's own files,
-tools/gen_golden.py) and against oracle/metric_ref.py.
+tests/golden/gen_golden.py) and against oracle/metric_ref.py.
 
 Every test runs twice: on the host stand-in (tests/fake_backend.py; checks the host logic on a CPU box)
 and, marked gpu, through libtok_gfx950.so on the MI355X.  Tolerances are bf16 ones (activations and

@@ -1,5 +1,5 @@
 """Pin the oracle (CPU): oracle/torchok_ref.py must reproduce the golden vectors that
-tools/gen_golden.py produced by running the REFERENCE's own resnet.py / pooling.py /
+tests/golden/gen_golden.py produced by running the REFERENCE's own resnet.py / pooling.py /
 classification_head.py / losses/base.py (on the restated timm subset) — inputs, logits, loss,
 all parameter-gradient norms, small gradients in full, post-SGD-step parameters, BN running stats."""
 import os

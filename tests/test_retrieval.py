@@ -2,7 +2,7 @@
 
 * the oracle (oracle/retrieval_ref.py) against the reference's OWN known-answer tables
   (tests/golden/retrieval_known_answers.npz = tests/base_tests/metrics/representation/data.py as data) and against
-  tests/golden/retrieval_meters.npz (the reference's files driven on random data by tools/gen_golden.py);
+  tests/golden/retrieval_meters.npz (the reference's files driven on random data by tests/golden/gen_golden.py);
 * the meters (torchok_amd/retrieval.py) against both, on the host stand-in and, marked gpu, through libtok_gfx950.so;
 * the search kernels on their own against torch fp32, and a 4096-vector case against the oracle."""
 import os

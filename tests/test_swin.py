@@ -1,5 +1,5 @@
 """SwinV2 row: SwinTransformerV2 backbone (+ ClassificationTask) against oracle/swin_ref.py and
-tests/golden/swinv2_cls_step.npz (one training step of the reference's own swin.py, tools/gen_golden.py).
+tests/golden/swinv2_cls_step.npz (one training step of the reference's own swin.py, tests/golden/gen_golden.py).
 Each test runs on the host stand-in and, marked gpu, through libtok_gfx950.so."""
 import copy
 import os
