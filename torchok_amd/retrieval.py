@@ -11,7 +11,7 @@ runs on the host, and one float per group comes back.
 
 Differences, all deliberate:
   * ``normalize_vectors`` makes unit-length ROWS (what the reference's known-answer tests and its "IP = cosine" contract
-    require); the shipped line (:190) divides by per-column norms.  See oracle/retrieval_ref.py.
+    require); the shipped line (:190) divides by per-column norms.
   * ``exact_index=False`` (faiss IVF, approximate) is not provided.
   * ``search_batch_size`` / ``use_batching_search`` only chunk the faiss requests in the reference (the result does not
     depend on them); accepted and ignored — the chunk is chosen from the size of the similarity matrix.
