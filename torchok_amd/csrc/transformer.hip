@@ -592,6 +592,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
   float* dS = ds_scratch ? ds_scratch + (size_t)blockIdx.x * N * N : nullptr;
   float dsc = 0.f;
+  float dsa[4][4];         // d(logits) of this wave's query tile summed over the images the workgroup walks (-> d(bias))
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) dsa[reg][kj] = 0.f;
   float addt[4][4];        // position bias + shift mask of this wave's query tile (-inf on padding), loaded once
 #pragma unroll
   for (int reg = 0; reg < 4; ++reg)
@@ -647,10 +652,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       for (int kj = 0; kj < 4; ++kj) {
         const int j = kj * 16 + l15;
         const float ds = p[kj] * (dp[kj][reg] - dl);
-        if (dS != nullptr && i < N && j < N) {
-          float* dd = dS + (size_t)i * N + j;
-          *dd = bb == 0 ? ds : *dd + ds;
-        }
+        dsa[reg][kj] += ds;
         dsc = fmaf(ds, sc[kj][reg], dsc);
         const bf16 dsb = f2bf(ds * scale);     // d(qn kn^T) = d(logits) * scale
         dsr[i * PPITCH + j] = dsb;
@@ -723,6 +725,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       }
     }
     __syncthreads();                     // before the next image overwrites the staging
+  }
+  if (dS != nullptr) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+#pragma unroll
+      for (int kj = 0; kj < 4; ++kj) {
+        const int i = wv * 16 + 4 * g + reg, j = kj * 16 + l15;
+        if (i < N && j < N) dS[(size_t)i * N + j] = dsa[reg][kj];
+      }
   }
   dsc = wave_sum(dsc);
   if (lane == 0) wsum[wv] = dsc;
