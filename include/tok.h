@@ -360,6 +360,20 @@ int tok_triplet_bwd(const void* anchor, const void* positive, const void* negati
                     const float* gscale, int rows, int d, int ld, float margin, float eps, int swap,
                     void* d_anchor, void* d_positive, void* d_negative, void* stream);
 
+/* ---- stem: BatchNorm + ReLU + max-pool in one pass (resnet.py:541-546: conv1 -> bn1 -> act1 -> maxpool) ---------------
+ * tok_bn_relu_maxpool_fwd == tok_bn_act_fwd(relu) followed by tok_maxpool3x3s2_fwd without storing the activated map;
+ * tok_bn_pool_bwd_reduce / _apply == tok_maxpool3x3s2_bwd followed by tok_bn_bwd_reduce / tok_bn_bwd_apply without
+ * storing d(activated map): y fp bf16 [n][h][w][c] raw conv output, dpool / argmax [n][p][q][c] of the pooled map,
+ * partial fp32 [2][tok_bn_bwd_rows(n*h*w, c)][c] (xhat form: tok_bn_bwd_finalize with dzy_form = 0).  Bit-identical to
+ * the unfused launches.                                                                                          */
+int tok_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, int n, int h, int w, int c,
+                            void* pooled, uint8_t* argmax, void* stream);
+int tok_bn_pool_bwd_reduce(const void* dpool, const uint8_t* argmax, const void* y, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, int n, int h, int w, int c,
+                           float* partial, void* stream);
+int tok_bn_pool_bwd_apply(const void* dpool, const uint8_t* argmax, const void* y, const float* scale,
+                          const float* shift, const float* coef, int n, int h, int w, int c, void* dy, void* stream);
+
 /* ---- GEMM + activation (Mlp.fc1 -> GELU -> fc2 of the transformer blocks: [timm] Mlp, modules/bricks/mlp.py:37-41) ----
  * tok_conv_fwd_act: y = conv(x, w) + bias AND y_act = act(y) from one launch (the backward needs y, the next layer
  * y_act).  tok_conv_dgrad_act: dx = conv_dgrad(dy) * act'(act_x) — the dgrad of the layer AFTER the activation writes the

@@ -347,6 +347,29 @@ class FakeTok:
         out.copy_(((res + out.float()) if accumulate else res).to(BF16))
         return 0
 
+    # ---- stem: BatchNorm + ReLU + max-pool fused == the unfused entry points chained through scratch tensors ----------
+    def tok_bn_relu_maxpool_fwd(self, y, scale, shift, n, h, w, c, pooled, argmax, st):
+        z = torch.empty(n * h * w, c, dtype=BF16)
+        self.tok_bn_act_fwd(y, scale, shift, None, 1, z.data_ptr(), None, n * h * w, c, st)
+        return self.tok_maxpool3x3s2_fwd(z.data_ptr(), pooled, argmax, n, h, w, c, st)
+
+    def _pool_dz(self, dpool, argmax, y, scale, shift, n, h, w, c):
+        m = n * h * w
+        dz = torch.empty(m, c, dtype=BF16)
+        self.tok_maxpool3x3s2_bwd(dpool, argmax, dz.data_ptr(), 0, n, h, w, c, None)
+        z = torch.empty(m, c, dtype=BF16)
+        mask = torch.empty(m, c // 8, dtype=torch.uint8)
+        self.tok_bn_act_fwd(y, scale, shift, None, 1, z.data_ptr(), mask.data_ptr(), m, c, None)
+        return dz, mask
+
+    def tok_bn_pool_bwd_reduce(self, dpool, argmax, y, scale, shift, mean, rstd, n, h, w, c, partial, st):
+        dz, mask = self._pool_dz(dpool, argmax, y, scale, shift, n, h, w, c)
+        return self.tok_bn_bwd_reduce(dz.data_ptr(), y, mask.data_ptr(), scale, shift, mean, rstd, 1, n * h * w, c, partial, st)
+
+    def tok_bn_pool_bwd_apply(self, dpool, argmax, y, scale, shift, coef, n, h, w, c, dy, st):
+        dz, mask = self._pool_dz(dpool, argmax, y, scale, shift, n, h, w, c)
+        return self.tok_bn_bwd_apply(dz.data_ptr(), y, mask.data_ptr(), scale, shift, coef, 1, dy, None, 0, n * h * w, c, st)
+
     def tok_gap_fwd(self, x, y, n, hw, c, st):
         _t(y, (n, c), BF16).copy_((_t(x, (n, hw, c), BF16).float().sum(1) * (1.0 / hw)).to(BF16))
         return 0

@@ -1040,3 +1040,41 @@ def test_gemm_activation_epilogues_equal_the_unfused_pair(libs, rows, c, k, kind
     assert torch.equal(dy0, dy1)
     d3 = _desc(2, 8, 8, 16, 16, 3, 1, 1)
     assert lib.tok_conv_fwd_act(d3, P(x), P(w), None, P(y1), P(a1), kind, st) != 0         # 3x3: refused
+
+
+@pytest.mark.parametrize('n,h,w,c', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128), (4, 112, 112, 64)])
+def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
+    """tok_bn_relu_maxpool_fwd == tok_bn_act_fwd + tok_maxpool3x3s2_fwd; tok_bn_pool_bwd_reduce / _apply ==
+    tok_maxpool3x3s2_bwd + tok_bn_bwd_reduce / tok_bn_bwd_apply — bit for bit, partial rows included."""
+    lib = libs[0]
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    m = n * h * w
+    p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = rnd(m, c).to(BF16).cuda()
+    scale, shift = (rnd(c, seed=1) * 0.5 + 1).cuda(), (rnd(c, seed=2) * 0.3).cuda()
+    mean, rstd = (rnd(c, seed=3) * 0.1).cuda(), (rnd(c, seed=4).abs() + 0.5).cuda()
+    z = torch.empty(m, c, dtype=BF16, device='cuda')
+    mask = torch.empty(m, c // 8, dtype=torch.uint8, device='cuda')
+    pooled0, pooled1 = (torch.empty(n, p, q, c, dtype=BF16, device='cuda') for _ in range(2))
+    idx0, idx1 = (torch.empty(n, p, q, c, dtype=torch.uint8, device='cuda') for _ in range(2))
+    assert lib.tok_bn_act_fwd(P(y), P(scale), P(shift), None, 1, P(z), P(mask), m, c, st) == 0
+    assert lib.tok_maxpool3x3s2_fwd(P(z), P(pooled0), P(idx0), n, h, w, c, st) == 0
+    assert lib.tok_bn_relu_maxpool_fwd(P(y), P(scale), P(shift), n, h, w, c, P(pooled1), P(idx1), st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(pooled0, pooled1) and torch.equal(idx0, idx1)
+    g = rnd(n * p * q, c, seed=5).to(BF16).cuda()
+    dz = torch.empty(m, c, dtype=BF16, device='cuda')
+    rows = lib.tok_bn_bwd_rows(m, c)
+    part0, part1 = (torch.zeros(2, rows, c, device='cuda') for _ in range(2))
+    assert lib.tok_maxpool3x3s2_bwd(P(g), P(idx0), P(dz), 0, n, h, w, c, st) == 0
+    assert lib.tok_bn_bwd_reduce(P(dz), P(y), P(mask), P(scale), P(shift), P(mean), P(rstd), 1, m, c, P(part0), st) == 0
+    assert lib.tok_bn_pool_bwd_reduce(P(g), P(idx0), P(y), P(scale), P(shift), P(mean), P(rstd), n, h, w, c, P(part1),
+                                      st) == 0, lib.tok_last_error()
+    coef = torch.stack([rnd(c, seed=6), rnd(c, seed=7) * 0.1, rnd(c, seed=8) * 0.01]).cuda()
+    dy0, dy1 = (torch.empty(m, c, dtype=BF16, device='cuda') for _ in range(2))
+    assert lib.tok_bn_bwd_apply(P(dz), P(y), P(mask), P(scale), P(shift), P(coef), 1, P(dy0), None, 0, m, c, st) == 0
+    assert lib.tok_bn_pool_bwd_apply(P(g), P(idx0), P(y), P(scale), P(shift), P(coef), n, h, w, c, P(dy1), st) == 0, \
+        lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(part0, part1) and torch.equal(dy0, dy1)

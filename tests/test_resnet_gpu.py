@@ -193,3 +193,35 @@ def test_hipgraph_replay_equals_eager():
     assert results[0][0] == results[1][0]
     for k in results[0][1]:
         assert torch.equal(results[0][1][k], results[1][1][k]), k
+
+
+def test_fused_stem_pool_leaves_training_bit_identical(monkeypatch):
+    """bn1 + ReLU + max-pool as one pass (engine.functional.FUSE_STEM_POOL; ResNet.forward only — forward_features still
+    returns act1) against the unfused chain: 6 SGD steps, identical losses, parameters and BatchNorm buffers."""
+    from torchok_amd.engine import functional as EF
+    finals = []
+    for fuse in (True, False):
+        monkeypatch.setattr(EF, 'FUSE_STEM_POOL', fuse)
+        cfg = cls_config('resnet18', 6, opt_params={'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4})
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 3)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(11)
+        x, y = torch.randn(16, 3, 64, 64, generator=g).cuda(), torch.randint(0, 6, (16,), generator=g).cuda()
+        losses = []
+        for it in range(6):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad(set_to_none=True)
+            out['loss'].backward()
+            opt.step()
+            losses.append(float(out['loss'].detach()))
+        torch.cuda.synchronize()
+        state = {n: v.detach().clone() for n, v in task.state_dict().items() if not n.startswith('input_tensors')}
+        finals.append((losses, state))
+        feats = task.backbone.forward_features(x)
+        assert tuple(feats[1].shape) == (16, 64, 32, 32)                 # act1 is still there when asked for
+    assert finals[0][0] == finals[1][0]
+    for n in finals[0][1]:
+        assert torch.equal(finals[0][1][n], finals[1][1][n]), n

@@ -115,6 +115,9 @@ PROTOTYPES = {
     'tok_ntxent_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P]),
     'tok_triplet_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     'tok_triplet_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
+    'tok_bn_relu_maxpool_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'tok_bn_pool_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    'tok_bn_pool_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_conv_fwd_act': (c_int, [_PD, _P, _P, _P, _P, _P, c_int, _P]),
     'tok_conv_dgrad_act': (c_int, [_PD, _P, _P, _P, c_int, _P, _P]),
     'tok_chan_gram': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),

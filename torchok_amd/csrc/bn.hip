@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             const float yf = bf2f(v[e]);
             const float dz = ((bits >> e) & 1u) ? bf2f(g[e]) : 0.f;
             s1[e] += dz;
-            s2[e] += dz * ((yf - mu[e]) * rs[e]);
+            s2[e] = fmaf(dz, (yf - mu[e]) * rs[e], s2[e]);
           }
         } else {
 #pragma unroll
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             float dz = bf2f(g[e]);
             if (relu && !(fmaf(yf, sc[e], sh[e]) > 0.f)) dz = 0.f;
             s1[e] += dz;
-            s2[e] += dz * ((yf - mu[e]) * rs[e]);
+            s2[e] = fmaf(dz, (yf - mu[e]) * rs[e], s2[e]);
           }
         }
       }
@@ -360,6 +360,184 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+
+// ---- stem: BatchNorm + ReLU + 3x3/s2/p1 max-pool as ONE pass (forward) and pool-gather + BatchNorm backward as the
+// reduce / apply pair (backward).  The activated map z = relu(bn(y)) (ResNet stem: 112 x 112 x 64 per image, the largest
+// tensor of the network) is never written: forward reads y and writes the pooled map + tap indices, backward rebuilds
+// d(z) per position from the <= 4 windows that contain it.  Arithmetic and summation order are those of
+// bn_act_fwd -> maxpool_fwd resp. maxpool_bwd -> bn_bwd_reduce -> bn_bwd_apply, so the results are bit-identical.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, bf16* __restrict__ out,
+                                                                  uint8_t* __restrict__ argmax, int N, int H, int W, int C,
+                                                                  int P, int Q) {
+  const int cg_total = C >> 3;
+  const size_t total = (size_t)N * P * Q * cg_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    size_t pix = i / cg_total;
+    const int q = (int)(pix % Q);
+    pix /= Q;
+    const int p = (int)(pix % P);
+    const int n = (int)(pix / P);
+    float sc[8], sh[8];
+    load8f(scale + cg * 8, sc);
+    load8f(shift + cg * 8, sh);
+    float best[8];
+    int idx[8];
+    bool first = true;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int h = 2 * p - 1 + r;
+      if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int w = 2 * q - 1 + s;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const bf16x8 v = ldg16(y + (((size_t)n * H + h) * W + w) * C + cg * 8);
+        if (first) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; idx[e] = r * 3 + s; }
+          first = false;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = bf2f(f2bf(fmaxf(fmaf(bf2f(v[e]), sc[e], sh[e]), 0.f)));   // the bf16 value bn_act_fwd stores
+          if (f > best[e] || f != f) { best[e] = f; idx[e] = r * 3 + s; }
+        }
+      }
+    }
+    bf16x8 o;
+    uint64_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[e] = f2bf(best[e]);
+      packed |= (uint64_t)(idx[e] & 0xff) << (8 * e);
+    }
+    const size_t off = (((size_t)n * P + p) * Q + q) * C + cg * 8;
+    stg16(out + off, o);
+    *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+  }
+}
+
+// d(z) of input position m (8 channels), as maxpool_bwd would have stored it (bf16) and the ReLU mask applied
+__device__ __forceinline__ void pooled_dz(const bf16* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                                          const bf16x8 yv, const float (&sc)[8], const float (&sh)[8], int n, int h,
+                                          int w, int C, int P, int Q, int cg, float (&dz)[8]) {
+  float g[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = 0.f;
+  // the <= 2 x 2 windows that contain (h, w): all four (tap index, gradient) pairs are loaded unconditionally (clamped
+  // addresses) so that the eight loads are in flight together; a window that does not exist contributes nothing.
+  // Accumulation order (p outer, q inner) is that of maxpool_bwd_kernel.
+  const int p0 = h >> 1, p1 = (h + 1) >> 1, q0 = w >> 1, q1 = (w + 1) >> 1;
+  const bool vp[2] = {p0 < P, p1 != p0 && p1 < P}, vq[2] = {q0 < Q, q1 != q0 && q1 < Q};
+  const int pc[2] = {p0 < P ? p0 : P - 1, vp[1] ? p1 : (p0 < P ? p0 : P - 1)};
+  const int qc[2] = {q0 < Q ? q0 : Q - 1, vq[1] ? q1 : (q0 < Q ? q0 : Q - 1)};
+  uint64_t packed[4];
+  bf16x8 d[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const size_t off = (((size_t)n * P + pc[a]) * Q + qc[b]) * C + cg * 8;
+      packed[a * 2 + b] = *reinterpret_cast<const uint64_t*>(argmax + off);
+      d[a * 2 + b] = ldg16(dpool + off);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const bool valid = vp[a] && vq[b];
+      const int tap = (h - (2 * pc[a] - 1)) * 3 + (w - (2 * qc[b] - 1));
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        g[e] += (valid && (int)((packed[a * 2 + b] >> (8 * e)) & 0xff) == tap) ? bf2f(d[a * 2 + b][e]) : 0.f;
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool on = bf2f(f2bf(fmaxf(fmaf(bf2f(yv[e]), sc[e], sh[e]), 0.f))) > 0.f;
+    dz[e] = on ? bf2f(f2bf(g[e])) : 0.f;
+  }
+}
+
+// REDUCE: partial[2][gridDim.x][C] = (sum dz, sum dz * xhat), geometry and order of bn_bwd_reduce_kernel
+// else:   dy = c1 * dz + c2 * y + c3, geometry of bn_bwd_apply_kernel
+template <bool REDUCE>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const bf16* __restrict__ dpool,
+                                                          const uint8_t* __restrict__ argmax, const bf16* __restrict__ y,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ coef, int64_t M, int H, int W, int C,
+                                                          int P, int Q, int cge, int rpb, float* __restrict__ partial,
+                                                          bf16* __restrict__ dy) {
+  __shared__ float red[REDUCE ? 2 : 1][REDUCE ? 256 : 1][8];
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < rpb) {
+      float sc[8], sh[8], a[8], b[8], c3[8];
+      load8f(scale + cg * 8, sc);
+      load8f(shift + cg * 8, sh);
+      if (REDUCE) {
+        load8f(mean + cg * 8, a);
+        load8f(rstd + cg * 8, b);
+      } else {
+        load8f(coef + cg * 8, a);
+        load8f(coef + C + cg * 8, b);
+        load8f(coef + 2 * C + cg * 8, c3);
+      }
+      // (n, h, w) of row m advance with the row stride: no division inside the loop
+      const int64_t m0 = (int64_t)blockIdx.x * rpb + rl, step = (int64_t)gridDim.x * rpb;
+      int w = (int)(m0 % W), h = (int)((m0 / W) % H), n = (int)(m0 / ((int64_t)W * H));
+      const int dw = (int)(step % W), dh = (int)((step / W) % H), dn = (int)(step / ((int64_t)W * H));
+      for (int64_t m = m0; m < M; m += step) {
+        const size_t off = (size_t)m * C + cg * 8;
+        const bf16x8 v = ldg16(y + off);
+        float dz[8];
+        pooled_dz(dpool, argmax, v, sc, sh, n, h, w, C, P, Q, cg, dz);
+        w += dw;
+        if (w >= W) { w -= W; ++h; }
+        h += dh;
+        if (h >= H) { h -= H; ++n; }
+        n += dn;
+        if (REDUCE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += dz[e];
+            s2[e] = fmaf(dz[e], (bf2f(v[e]) - a[e]) * b[e], s2[e]);
+          }
+        } else {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(a[e], dz[e], fmaf(b[e], bf2f(v[e]), c3[e])));
+          stg16(dy + off, o);
+        }
+      }
+    }
+    if (REDUCE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+      __syncthreads();
+      if (rl == 0) {
+        for (int r = 1; r < rpb; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += red[0][r * cge + cgl][e]; s2[e] += red[1][r * cge + cgl][e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          partial[((size_t)0 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s1[e];
+          partial[((size_t)1 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s2[e];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace
 
 static int stream_cap() {   // blocks of the elementwise kernels (TOK_BN_BLOCKS overrides).  1024 = 4 per CU = half the wave slots: the
@@ -460,5 +638,48 @@ extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* 
                      tok_stream(stream), (const bf16*)dout, (const bf16*)y, mask, scale, shift,
                      coef, relu, (bf16*)dy, (bf16*)dshortcut, dshortcut_accumulate, m, c, g.cge, g.rpb);
   TOK_CHECK_LAUNCH("tok_bn_bwd_apply");
+  return TOK_OK;
+}
+
+// ---- stem: BatchNorm + ReLU + max-pool fused (see the kernels) ---------------------------------------------------------------
+extern "C" int tok_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, int n, int h, int w, int c,
+                                       void* pooled, uint8_t* argmax, void* stream) {
+  TOK_CHECK_ARG(y && scale && shift && pooled && argmax && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0,
+                "tok_bn_relu_maxpool_fwd: bad args");
+  const int p = (h + 2 - 3) / 2 + 1, q = (w + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)n * p * q * (c >> 3);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)y,
+                     scale, shift, (bf16*)pooled, argmax, n, h, w, c, p, q);
+  TOK_CHECK_LAUNCH("tok_bn_relu_maxpool_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_pool_bwd_reduce(const void* dpool, const uint8_t* argmax, const void* y, const float* scale,
+                                      const float* shift, const float* mean, const float* rstd, int n, int h, int w, int c,
+                                      float* partial, void* stream) {
+  TOK_CHECK_ARG(dpool && argmax && y && scale && shift && mean && rstd && partial && n > 0 && h > 0 && w > 0 && c > 0 &&
+                c % 8 == 0, "tok_bn_pool_bwd_reduce: bad args");
+  const int64_t m = (int64_t)n * h * w;
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_pool_bwd_kernel<true>, dim3(stream_blocks(m, g, kReduceCap)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)dpool, argmax, (const bf16*)y, scale, shift, mean, rstd, (const float*)nullptr, m, h, w, c,
+                     (h + 2 - 3) / 2 + 1, (w + 2 - 3) / 2 + 1, g.cge, g.rpb, partial, (bf16*)nullptr);
+  TOK_CHECK_LAUNCH("tok_bn_pool_bwd_reduce");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_pool_bwd_apply(const void* dpool, const uint8_t* argmax, const void* y, const float* scale,
+                                     const float* shift, const float* coef, int n, int h, int w, int c, void* dy,
+                                     void* stream) {
+  TOK_CHECK_ARG(dpool && argmax && y && scale && shift && coef && dy && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0,
+                "tok_bn_pool_bwd_apply: bad args");
+  const int64_t m = (int64_t)n * h * w;
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_pool_bwd_kernel<false>, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)dpool, argmax, (const bf16*)y, scale, shift, (const float*)nullptr, (const float*)nullptr,
+                     coef, m, h, w, c, (h + 2 - 3) / 2 + 1, (w + 2 - 3) / 2 + 1, g.cge, g.rpb, (float*)nullptr, (bf16*)dy);
+  TOK_CHECK_LAUNCH("tok_bn_pool_bwd_apply");
   return TOK_OK;
 }

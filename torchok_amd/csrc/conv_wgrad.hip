@@ -255,7 +255,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     const int k = (int)(rest / R);
     const size_t src = (((size_t)k * R + r) * S_pad + s) * C_pad + c;
     float t = 0.f;
-    for (int sp = 0; sp < splitM; ++sp) t += ws[(size_t)sp * slab + src];
+    for (int sp = 0; sp < splitM; sp += 8) {       // 8 loads in flight, additions in split order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(sp + u < splitM ? sp + u : splitM - 1) * slab + src];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += sp + u < splitM ? v[u] : 0.f;
+    }
     dw[i] = accumulate ? dw[i] + t : t;
   }
 }
@@ -321,7 +327,10 @@ Plan make_plan(const tok_conv_desc* d) {
   p.MS = (M >= 100000 && p.TN == 128 && p.TK == 128) ? 64 : 32;
   const long long max_split = (M + 8 * p.MS - 1) / (8 * p.MS);   // at least 8 steps per workgroup
   if (split > max_split) split = max_split;
-  if (split > 256) split = 256;
+  // (512 only for the stem — 2 tiles over 3.2 M pixels at B = 256: 512 workgroups left every CU with 2 and the launch
+  //  latency-bound; every other layer keeps its partition, and with it its summation order)
+  const long long cap = (d->c == 4 && tiles <= 2) ? 512 : 256;
+  if (split > cap) split = cap;
   if (split < 1) split = 1;
   long long chunk = (M + split - 1) / split;
   chunk = ((chunk + p.MS - 1) / p.MS) * p.MS;

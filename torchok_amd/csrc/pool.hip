@@ -74,24 +74,32 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16* __restrict
     float g[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[e] = 0.f;
-    // windows p with 2p-1 <= h <= 2p+1
-    const int p_lo = h >> 1, p_hi = (h + 1) >> 1;
-    const int q_lo = w >> 1, q_hi = (w + 1) >> 1;
-    for (int p = p_lo; p <= p_hi; ++p) {
-      if (p >= P) continue;
-      const int r = h - (2 * p - 1);
-      for (int q = q_lo; q <= q_hi; ++q) {
-        if (q >= Q) continue;
-        const int s = w - (2 * q - 1);
-        const int tap = r * 3 + s;
-        const size_t off = (((size_t)n * P + p) * Q + q) * C + cg * 8;
-        const uint64_t packed = *reinterpret_cast<const uint64_t*>(argmax + off);
-        const bf16x8 d = ldg16(dy + off);
+    // windows p with 2p-1 <= h <= 2p+1: at most 2 x 2; all four (tap index, gradient) pairs are loaded unconditionally
+    // (clamped addresses: the eight loads are in flight together), a window that does not exist contributes nothing
+    const int p0 = h >> 1, p1 = (h + 1) >> 1, q0 = w >> 1, q1 = (w + 1) >> 1;
+    const bool vp[2] = {p0 < P, p1 != p0 && p1 < P}, vq[2] = {q0 < Q, q1 != q0 && q1 < Q};
+    const int pc[2] = {p0 < P ? p0 : P - 1, vp[1] ? p1 : (p0 < P ? p0 : P - 1)};
+    const int qc[2] = {q0 < Q ? q0 : Q - 1, vq[1] ? q1 : (q0 < Q ? q0 : Q - 1)};
+    uint64_t packed[4];
+    bf16x8 d[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const size_t off = (((size_t)n * P + pc[a]) * Q + qc[b]) * C + cg * 8;
+        packed[a * 2 + b] = *reinterpret_cast<const uint64_t*>(argmax + off);
+        d[a * 2 + b] = ldg16(dy + off);
+      }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const bool valid = vp[a] && vq[b];
+        const int tap = (h - (2 * pc[a] - 1)) * 3 + (w - (2 * qc[b] - 1));
 #pragma unroll
         for (int e = 0; e < 8; ++e)
-          if ((int)((packed >> (8 * e)) & 0xff) == tap) g[e] += bf2f(d[e]);
+          g[e] += (valid && (int)((packed[a * 2 + b] >> (8 * e)) & 0xff) == tap) ? bf2f(d[a * 2 + b][e]) : 0.f;
       }
-    }
     const size_t xoff = (((size_t)n * H + h) * W + w) * C + cg * 8;
     bf16x8 o;
     if (accumulate) {

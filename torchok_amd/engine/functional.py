@@ -220,15 +220,16 @@ class _ConvBnActNode(Node):
         self.fused_partial = None   # (partial, rows) when a consumer's dgrad epilogue did our BN-bwd reduce
         self.fused_coef = None      # apply coefficients when that dgrad also finalized (tok_conv_dgrad_bn)
         self.coef = None
+        self.pool = None            # tap indices of the fused 3x3/s2 max-pool: `out` is the POOLED map, z was never stored
 
     def release(self):
         self.x = self.out = self.shortcut = None
-        self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = None
+        self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = self.pool = None
         self.mean = self.rstd = self.scale = self.shift = None
 
     def wants_fused_bwd_stats(self) -> bool:
         """Can the kernel that completes d(out) also reduce sum(dz), sum(dz*y) for this unit?"""
-        return self.bn is not None and self.batch_stats and (not self.relu or self.mask is not None)
+        return self.bn is not None and self.batch_stats and (not self.relu or self.mask is not None) and self.pool is None
 
     def _finalize_bwd(self, lib, st, g, mask, m, kp, g_need, b_need):
         """sum(dz), sum(dz*xhat) -> dgamma, dbeta, apply coefficients (stand-alone reduce / finalize launches)."""
@@ -240,9 +241,15 @@ class _ConvBnActNode(Node):
         else:
             rows = lib.tok_bn_bwd_rows(m, kp)
             partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
-            _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale), ptr(self.shift),
-                                           ptr(self.mean), ptr(self.rstd), int(self.relu), m, kp, ptr(partial), st),
-                     'tok_bn_bwd_reduce')
+            if self.pool is not None:
+                n_, h_, w_, _ = self.y.shape
+                _C.check(lib.tok_bn_pool_bwd_reduce(ptr(g), ptr(self.pool), ptr(self.y), ptr(self.scale), ptr(self.shift),
+                                                    ptr(self.mean), ptr(self.rstd), n_, h_, w_, kp, ptr(partial), st),
+                         'tok_bn_pool_bwd_reduce')
+            else:
+                _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale), ptr(self.shift),
+                                               ptr(self.mean), ptr(self.rstd), int(self.relu), m, kp, ptr(partial), st),
+                         'tok_bn_bwd_reduce')
         coef = torch.empty((3, kp), dtype=F32, device=g.device)
         gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
         bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
@@ -316,9 +323,14 @@ class _ConvBnActNode(Node):
                     else:
                         tgt, ds_acc = grad_target(sc)
                         ds_ptr = ptr(tgt)
-                _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
-                                              ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
-                                              ds_acc, m, kp, st), 'tok_bn_bwd_apply')
+                if self.pool is not None:
+                    n_, h_, w_, _ = self.y.shape
+                    _C.check(lib.tok_bn_pool_bwd_apply(ptr(g), ptr(self.pool), ptr(self.y), ptr(self.scale), ptr(self.shift),
+                                                       ptr(coef), n_, h_, w_, kp, ptr(dy), st), 'tok_bn_pool_bwd_apply')
+                else:
+                    _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
+                                                  ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
+                                                  ds_acc, m, kp, st), 'tok_bn_bwd_apply')
             else:
                 dy = None
         else:
@@ -396,10 +408,17 @@ class _ConvBnActNode(Node):
                 _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
 
 
+FUSE_STEM_POOL = os.environ.get('TOK_FUSE_STEM_POOL', '1') != '0'
+
+
 def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None,
-                relu: bool = False, shortcut: Optional[TTensor] = None) -> TTensor:
+                relu: bool = False, shortcut: Optional[TTensor] = None, pool: bool = False) -> TTensor:
     """out = act(bn(conv(x)) (+ shortcut)).  `conv` is an nn.Conv2d or nn.Linear used purely as
-    the parameter container (state_dict names stay those of the reference)."""
+    the parameter container (state_dict names stay those of the reference).
+    pool=True (BatchNorm + ReLU, no shortcut): out = maxpool3x3/s2/p1(act(bn(conv(x)))) with the activated map never
+    stored (the ResNet stem when only the pooled map is consumed)."""
+    if pool and (bn is None or not relu or shortcut is not None or x.data.dim() != 4):
+        raise ValueError('conv_bn_act(pool=True): BatchNorm + ReLU on a 4-D input, no shortcut')
     await_ready(x, shortcut)
     lib, st = _C.lib(), stream_ptr()
     if isinstance(conv, nn.Linear):
@@ -465,12 +484,19 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             _C.check(lib.tok_bn_eval_coeffs(ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
                                             ptr(bn.running_var), float(bn.eps), kp, bn.num_features, ptr(scale), ptr(shift), st),
                      'tok_bn_eval_coeffs')
-        out_data = torch.empty_like(y)
         mask = None
-        if relu and region.grad_mode and batch_stats:
-            mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev)   # ReLU bits for the backward pass
-        _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
-                                    int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
+        if pool:
+            p2, q2 = (d.p + 2 - 3) // 2 + 1, (d.q + 2 - 3) // 2 + 1
+            out_data = torch.empty((d.n, p2, q2, kp), dtype=BF16, device=dev)
+            node.pool = torch.empty((d.n, p2, q2, kp), dtype=torch.uint8, device=dev)
+            _C.check(lib.tok_bn_relu_maxpool_fwd(ptr(y), ptr(scale), ptr(shift), d.n, d.p, d.q, kp, ptr(out_data),
+                                                 ptr(node.pool), st), 'tok_bn_relu_maxpool_fwd')
+        else:
+            out_data = torch.empty_like(y)
+            if relu and region.grad_mode and batch_stats:
+                mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev)   # ReLU bits for the backward pass
+            _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
+                                        int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
         node.mask = mask
         node.mean, node.rstd, node.scale, node.shift = mean, rstd, scale, shift
     else:

@@ -210,12 +210,16 @@ class ResNet(BaseBackbone):
                 if hasattr(m, 'zero_init_last'):
                     m.zero_init_last()
 
-    def _run(self, r, x: torch.Tensor):
+    def _run(self, r, x: torch.Tensor, all_features: bool = True):
         t = r.input(x, c_pad_to=4 if x.shape[1] <= 4 else 8)
         feats = []
-        t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True)
-        feats.append(t)
-        t = EF.max_pool_3x3_s2(r, t)
+        if all_features or not EF.FUSE_STEM_POOL:
+            t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True)
+            feats.append(t)                      # 'act1', the first entry of feature_info
+            t = EF.max_pool_3x3_s2(r, t)
+        else:
+            # nobody asked for act1: bn1 + ReLU + max-pool in one pass, the 112 x 112 activated map is never stored
+            t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True, pool=True)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             t = layer(t)
             feats.append(t)
@@ -223,7 +227,7 @@ class ResNet(BaseBackbone):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         with engine.region() as r:
-            feats = self._run(r, x)
+            feats = self._run(r, x, all_features=False)
             return r.output(feats[-1])
 
     def forward_features(self, x: torch.Tensor) -> List[torch.Tensor]:
