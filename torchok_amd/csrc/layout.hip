@@ -116,9 +116,15 @@ __global__ __launch_bounds__(256) void pack_both_kernel(const float* __restrict_
   }
 }
 
-// every weight of a model in ONE launch: block b serves item i (largest block_start <= b) and covers 1024
-// consecutive indices of that item's max(forward, dgrad) pack index space
+// every weight of a model in ONE launch: block b serves item i (largest block_start <= b) and one 32 (k) x 32 (c) tile of
+// one filter tap (r, s) of it.  The tile is read once from the fp32 master in 128-byte row segments, goes through LDS, and
+// leaves as the forward pack [k][r][s_pad][c_pad] (rows of c) AND the tap-flipped transposed dgrad pack [c][r][s][k_pad]
+// (rows of k) in 64-byte segments — the element-wise version gathered the dgrad pack with one cache line per lane.
+__device__ __forceinline__ int pack_tiles_k(const tok_pack_item& it) { return (it.k_pad + 31) >> 5; }
+__device__ __forceinline__ int pack_tiles_c(const tok_pack_item& it) { return (it.c_pad + 31) >> 5; }
+
 __global__ __launch_bounds__(256) void pack_batched_kernel(const tok_pack_item* __restrict__ items, int n_items) {
+  __shared__ float tile[32][33];
   int lo = 0, hi = n_items - 1;
   const int b = blockIdx.x;
   while (lo < hi) {
@@ -130,33 +136,34 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const tok_pack_item* 
   bf16* __restrict__ fwd = (bf16*)it.dst_fwd;
   bf16* __restrict__ dgr = (bf16*)it.dst_dgrad;
   const int k = it.k, r = it.r, s = it.s, c = it.c, k_pad = it.k_pad, s_pad = it.s_pad, c_pad = it.c_pad;
-  const size_t total_f = fwd ? (size_t)k_pad * r * s_pad * c_pad : 0;
-  const size_t total_d = dgr ? (size_t)c_pad * r * s * k_pad : 0;
-  const size_t base = (size_t)(b - it.block_start) * 1024;
+  const int tk = pack_tiles_k(it), tc = pack_tiles_c(it);
+  int t = b - it.block_start;                 // ((rr * s_pad + ss) * tk + kt) * tc + ct
+  const int ct = t % tc; t /= tc;
+  const int kt = t % tk; t /= tk;
+  const int ss = t % s_pad, rr = t / s_pad;
+  const int k0 = kt * 32, c0 = ct * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const size_t i = base + u * 256 + threadIdx.x;
-    if (i < total_f) {
-      const int cc = (int)(i % c_pad);
-      size_t rest = i / c_pad;
-      const int ss = (int)(rest % s_pad);
-      rest /= s_pad;
-      const int rr = (int)(rest % r);
-      const int kk = (int)(rest / r);
-      float v = 0.f;
-      if (kk < k && ss < s && cc < c) v = src[(((size_t)kk * r + rr) * s + ss) * c + cc];
-      fwd[i] = f2bf(v);
+  for (int j = 0; j < 4; ++j) {
+    const int kk = k0 + ty + 8 * j, cc = c0 + tx;
+    float v = 0.f;
+    if (kk < k && ss < s && cc < c) v = src[(((size_t)kk * r + rr) * s + ss) * c + cc];
+    tile[ty + 8 * j][tx] = v;
+  }
+  __syncthreads();
+  if (fwd != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kk = k0 + ty + 8 * j, cc = c0 + tx;
+      if (kk < k_pad && cc < c_pad) fwd[(((size_t)kk * r + rr) * s_pad + ss) * c_pad + cc] = f2bf(tile[ty + 8 * j][tx]);
     }
-    if (i < total_d) {
-      const int kk = (int)(i % k_pad);
-      size_t rest = i / k_pad;
-      const int ss = (int)(rest % s);
-      rest /= s;
-      const int rr = (int)(rest % r);
-      const int cc = (int)(rest / r);
-      float v = 0.f;
-      if (kk < k && cc < c) v = src[(((size_t)kk * r + (r - 1 - rr)) * s + (s - 1 - ss)) * c + cc];
-      dgr[i] = f2bf(v);
+  }
+  if (dgr != nullptr && ss < s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = c0 + ty + 8 * j, kk = k0 + tx;
+      if (cc < c_pad && kk < k_pad)
+        dgr[(((size_t)cc * r + (r - 1 - rr)) * s + (s - 1 - ss)) * k_pad + kk] = f2bf(tile[tx][ty + 8 * j]);
     }
   }
 }
@@ -234,9 +241,9 @@ extern "C" int tok_pack_weight_both(const float* src, int k, int r, int s, int c
 
 extern "C" int tok_pack_item_blocks(const tok_pack_item* item) {
   if (!item) return 0;
-  const size_t tf = item->dst_fwd ? (size_t)item->k_pad * item->r * item->s_pad * item->c_pad : 0;
-  const size_t td = item->dst_dgrad ? (size_t)item->c_pad * item->r * item->s * item->k_pad : 0;
-  return (int)(((tf > td ? tf : td) + 1023) / 1024);
+  const long long tiles = (long long)((item->k_pad + 31) / 32) * ((item->c_pad + 31) / 32) * item->r * item->s_pad;
+  if (tiles <= 0 || tiles >= (1ll << 30)) return TOK_ERR_INVALID;
+  return (int)tiles;
 }
 
 extern "C" int tok_pack_weights_batched(const tok_pack_item* items_dev, int n_items, int total_blocks, void* stream) {

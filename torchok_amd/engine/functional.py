@@ -168,7 +168,11 @@ def repack_after_step(params, cache: dict, arena_sig) -> None:
             k, r, s, c, kp, sp, cp = pk.dims
             it = _C.PackItem(p.data_ptr(), pk.fwd.data_ptr(), pk.dgrad.data_ptr() if pk.dgrad is not None else None,
                              k, r, s, c, kp, sp, cp, block)
-            block += _C.lib().tok_pack_item_blocks(ctypes.byref(it))
+            nb = _C.lib().tok_pack_item_blocks(ctypes.byref(it))
+            if nb <= 0:                       # a pack of 2^31 elements or more: refreshed on its own by the forward
+                skipped.append(pk)
+                continue
+            block += nb
             items.append(it)
             entries.append((p, pk))
         dev = None
