@@ -367,7 +367,12 @@ int tok_triplet_bwd(const void* anchor, const void* positive, const void* negati
  * partial fp32 [2][tok_bn_bwd_rows(n*h*w, c)][c] (xhat form: tok_bn_bwd_finalize with dzy_form = 0).  Bit-identical to
  * the unfused launches.                                                                                          */
 int tok_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, int n, int h, int w, int c,
-                            void* pooled, uint8_t* argmax, void* stream);
+                            void* pooled, uint8_t* argmax, void* ypool, void* stream);
+/* ypool (optional, bf16 [n][p][q][c]): the raw conv output at each winning tap.  With it the backward sums can be taken in
+ * the pooled domain — partial fp32 [2][tok_bn_bwd_rows(m_pooled, c)][c], 3 pooled-size reads instead of a 4-window gather
+ * per input position; equal to tok_bn_pool_bwd_reduce up to the bf16 rounding of positions hit by several windows.    */
+int tok_bn_pool_bwd_reduce_pooled(const void* dpool, const void* pooled, const void* ypool, const float* mean,
+                                  const float* rstd, int64_t m_pooled, int c, float* partial, void* stream);
 int tok_bn_pool_bwd_reduce(const void* dpool, const uint8_t* argmax, const void* y, const float* scale,
                            const float* shift, const float* mean, const float* rstd, int n, int h, int w, int c,
                            float* partial, void* stream);

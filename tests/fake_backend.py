@@ -348,10 +348,26 @@ class FakeTok:
         return 0
 
     # ---- stem: BatchNorm + ReLU + max-pool fused == the unfused entry points chained through scratch tensors ----------
-    def tok_bn_relu_maxpool_fwd(self, y, scale, shift, n, h, w, c, pooled, argmax, st):
+    def tok_bn_relu_maxpool_fwd(self, y, scale, shift, n, h, w, c, pooled, argmax, ypool, st):
         z = torch.empty(n * h * w, c, dtype=BF16)
         self.tok_bn_act_fwd(y, scale, shift, None, 1, z.data_ptr(), None, n * h * w, c, st)
-        return self.tok_maxpool3x3s2_fwd(z.data_ptr(), pooled, argmax, n, h, w, c, st)
+        rc = self.tok_maxpool3x3s2_fwd(z.data_ptr(), pooled, argmax, n, h, w, c, st)
+        if ypool is not None:
+            p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            tap = _t(argmax, (n, p, q, c), torch.uint8).long()
+            ih = 2 * torch.arange(p).view(1, p, 1, 1) - 1 + tap // 3
+            iw = 2 * torch.arange(q).view(1, 1, q, 1) - 1 + tap % 3
+            yv = _t(y, (n, h * w, c), BF16)
+            _t(ypool, (n, p * q, c), BF16).copy_(torch.gather(yv, 1, (ih * w + iw).view(n, p * q, c)))
+        return rc
+
+    def tok_bn_pool_bwd_reduce_pooled(self, dpool, pooled, ypool, mean, rstd, mp, c, partial, st):
+        g = _t(dpool, (mp, c), BF16).float() * (_t(pooled, (mp, c), BF16).float() > 0)
+        xhat = (_t(ypool, (mp, c), BF16).float() - _t(mean, (c,), torch.float32)) * _t(rstd, (c,), torch.float32)
+        p = _t(partial, (2, 1, c), torch.float32)
+        p[0, 0] = g.sum(0)
+        p[1, 0] = (g * xhat).sum(0)
+        return 0
 
     def _pool_dz(self, dpool, argmax, y, scale, shift, n, h, w, c):
         m = n * h * w

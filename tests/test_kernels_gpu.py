@@ -1060,7 +1060,9 @@ def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     idx0, idx1 = (torch.empty(n, p, q, c, dtype=torch.uint8, device='cuda') for _ in range(2))
     assert lib.tok_bn_act_fwd(P(y), P(scale), P(shift), None, 1, P(z), P(mask), m, c, st) == 0
     assert lib.tok_maxpool3x3s2_fwd(P(z), P(pooled0), P(idx0), n, h, w, c, st) == 0
-    assert lib.tok_bn_relu_maxpool_fwd(P(y), P(scale), P(shift), n, h, w, c, P(pooled1), P(idx1), st) == 0, lib.tok_last_error()
+    ypool = torch.empty(n, p, q, c, dtype=BF16, device='cuda')
+    assert lib.tok_bn_relu_maxpool_fwd(P(y), P(scale), P(shift), n, h, w, c, P(pooled1), P(idx1), P(ypool), st) == 0, \
+        lib.tok_last_error()
     torch.cuda.synchronize()
     assert torch.equal(pooled0, pooled1) and torch.equal(idx0, idx1)
     g = rnd(n * p * q, c, seed=5).to(BF16).cuda()
@@ -1076,5 +1078,23 @@ def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     assert lib.tok_bn_bwd_apply(P(dz), P(y), P(mask), P(scale), P(shift), P(coef), 1, P(dy0), None, 0, m, c, st) == 0
     assert lib.tok_bn_pool_bwd_apply(P(g), P(idx0), P(y), P(scale), P(shift), P(coef), n, h, w, c, P(dy1), st) == 0, \
         lib.tok_last_error()
+    # pooled-domain sums: equal up to the bf16 rounding of positions that several windows hit
+    rows_p = lib.tok_bn_bwd_rows(n * p * q, c)
+    part2 = torch.zeros(2, rows_p, c, device='cuda')
+    assert lib.tok_bn_pool_bwd_reduce_pooled(P(g), P(pooled1), P(ypool), P(mean), P(rstd), n * p * q, c, P(part2), st) == 0, \
+        lib.tok_last_error()
     torch.cuda.synchronize()
     assert torch.equal(part0, part1) and torch.equal(dy0, dy1)
+    ih = 2 * torch.arange(p).view(1, p, 1, 1) - 1 + idx1.cpu().long() // 3
+    iw = 2 * torch.arange(q).view(1, 1, q, 1) - 1 + idx1.cpu().long() % 3
+    want_y = torch.gather(y.cpu().view(n, h * w, c), 1, (ih * w + iw).view(n, p * q, c)).view(n, p, q, c)
+    assert torch.equal(ypool.cpu(), want_y)
+    # the pooled-domain sums are the exact ones (no bf16 rounding of a position's summed gradient in between); the
+    # position-domain sums of the unfused chain scatter around them by that rounding: ~2^-9 |g| sqrt(positions)
+    gz = g.double().cpu().view(-1, c) * (pooled1.double().cpu().view(-1, c) > 0)
+    xh = (ypool.double().cpu().view(-1, c) - mean.double().cpu()) * rstd.double().cpu()
+    exact = torch.stack([gz.sum(0), (gz * xh).sum(0)])
+    b = part2.double().sum(1).cpu()
+    assert float((b - exact).abs().max()) < 1e-4 * float(exact.abs().max()) + 1e-4
+    a = part0.double().sum(1).cpu()
+    assert float((a - exact).abs().max()) < 2.0 ** -7 * (m ** 0.5) * 4

@@ -200,6 +200,7 @@ def test_fused_stem_pool_leaves_training_bit_identical(monkeypatch):
     returns act1) against the unfused chain: 6 SGD steps, identical losses, parameters and BatchNorm buffers."""
     from torchok_amd.engine import functional as EF
     finals = []
+    monkeypatch.setattr(EF, 'STEM_POOLED_STATS', False)      # position-domain sums: the bit-identical form
     for fuse in (True, False):
         monkeypatch.setattr(EF, 'FUSE_STEM_POOL', fuse)
         cfg = cls_config('resnet18', 6, opt_params={'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4})
@@ -225,3 +226,28 @@ def test_fused_stem_pool_leaves_training_bit_identical(monkeypatch):
     assert finals[0][0] == finals[1][0]
     for n in finals[0][1]:
         assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+
+
+def test_pooled_domain_stem_statistics_match_the_position_domain(monkeypatch):
+    """engine.functional.STEM_POOLED_STATS (default): the BatchNorm-backward sums of the fused stem taken over the pooled
+    elements.  One backward pass from the same state: every gradient above the stem is bit-identical, conv1 / bn1 agree
+    to the bf16 rounding the position-domain form applies where several windows hit one position."""
+    from torchok_amd.engine import functional as EF
+    grads = []
+    for pooled in (True, False):
+        monkeypatch.setattr(EF, 'STEM_POOLED_STATS', pooled)
+        cfg = cls_config('resnet18', 6)
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 3)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        g = torch.Generator().manual_seed(11)
+        x, y = torch.randn(32, 3, 96, 96, generator=g).cuda(), torch.randint(0, 6, (32,), generator=g).cuda()
+        task.training_step({'image': x, 'target': y}, 0)['loss'].backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.detach().float().clone() for n, p in task.named_parameters()})
+    for n in grads[0]:
+        if n.startswith('backbone.conv1') or n.startswith('backbone.bn1'):
+            assert rel_err(grads[0][n], grads[1][n]) < 1e-2, n
+        else:
+            assert torch.equal(grads[0][n], grads[1][n]), n

@@ -115,7 +115,8 @@ PROTOTYPES = {
     'tok_ntxent_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, _P, _P]),
     'tok_triplet_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
     'tok_triplet_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P]),
-    'tok_bn_relu_maxpool_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'tok_bn_relu_maxpool_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    'tok_bn_pool_bwd_reduce_pooled': (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P]),
     'tok_bn_pool_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_bn_pool_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_conv_fwd_act': (c_int, [_PD, _P, _P, _P, _P, _P, c_int, _P]),

@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __restrict__ y,
                                                                   const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, bf16* __restrict__ out,
-                                                                  uint8_t* __restrict__ argmax, int N, int H, int W, int C,
-                                                                  int P, int Q) {
+                                                                  uint8_t* __restrict__ argmax, bf16* __restrict__ ypool,
+                                                                  int N, int H, int W, int C, int P, int Q) {
   const int cg_total = C >> 3;
   const size_t total = (size_t)N * P * Q * cg_total;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
     float sc[8], sh[8];
     load8f(scale + cg * 8, sc);
     load8f(shift + cg * 8, sh);
-    float best[8];
+    float best[8], ybest[8];
     int idx[8];
     bool first = true;
 #pragma unroll
@@ -397,13 +397,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
         const bf16x8 v = ldg16(y + (((size_t)n * H + h) * W + w) * C + cg * 8);
         if (first) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; idx[e] = r * 3 + s; }
+          for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; ybest[e] = 0.f; idx[e] = r * 3 + s; }
           first = false;
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = bf2f(f2bf(fmaxf(fmaf(bf2f(v[e]), sc[e], sh[e]), 0.f)));   // the bf16 value bn_act_fwd stores
-          if (f > best[e] || f != f) { best[e] = f; idx[e] = r * 3 + s; }
+          if (f > best[e] || f != f) { best[e] = f; ybest[e] = bf2f(v[e]); idx[e] = r * 3 + s; }
         }
       }
     }
@@ -417,6 +417,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16* __
     const size_t off = (((size_t)n * P + p) * Q + q) * C + cg * 8;
     stg16(out + off, o);
     *reinterpret_cast<uint64_t*>(argmax + off) = packed;
+    if (ypool != nullptr) {      // raw conv output at the winning tap: the backward statistics read it instead of gathering y
+      bf16x8 yo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) yo[e] = f2bf(ybest[e]);
+      stg16(ypool + off, yo);
+    }
   }
 }
 
@@ -538,6 +544,58 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const bf16* __restrict
   }
 }
 
+
+// BatchNorm-backward sums of the stem taken in the POOLED domain: every pooled element sends its gradient to exactly one
+// position (its winning tap), so sum dz = sum over pooled elements with pooled > 0 of dpool, and sum dz * xhat the same with
+// the raw conv output of that tap (ypool, written by the forward).  Reads 3 pooled-size tensors (1/4 of y each) instead
+// of gathering four windows per input position.  Differs from the position-domain sums only by the bf16 rounding the
+// unfused chain applies when several windows hit one position.  partial[2][gridDim.x][C], geometry of bn_bwd_reduce.
+__global__ __launch_bounds__(256) void bn_pool_bwd_reduce_pooled_kernel(const bf16* __restrict__ dpool,
+                                                                        const bf16* __restrict__ pooled,
+                                                                        const bf16* __restrict__ ypool,
+                                                                        const float* __restrict__ mean,
+                                                                        const float* __restrict__ rstd, int64_t M, int C,
+                                                                        int cge, int rpb, float* __restrict__ partial) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  const int cg_total = C >> 3;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < rpb) {
+      float mu[8], rs[8];
+      load8f(mean + cg * 8, mu);
+      load8f(rstd + cg * 8, rs);
+      for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
+        const size_t off = (size_t)m * C + cg * 8;
+        const bf16x8 g = ldg16(dpool + off), z = ldg16(pooled + off), yv = ldg16(ypool + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dz = bf2f(z[e]) > 0.f ? bf2f(g[e]) : 0.f;
+          s1[e] += dz;
+          s2[e] = fmaf(dz, (bf2f(yv[e]) - mu[e]) * rs[e], s2[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+    __syncthreads();
+    if (rl == 0) {
+      for (int r = 1; r < rpb; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += red[0][r * cge + cgl][e]; s2[e] += red[1][r * cge + cgl][e]; }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        partial[((size_t)0 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s1[e];
+        partial[((size_t)1 * gridDim.x + blockIdx.x) * C + cg * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 static int stream_cap() {   // blocks of the elementwise kernels (TOK_BN_BLOCKS overrides).  1024 = 4 per CU = half the wave slots: the
@@ -643,7 +701,7 @@ extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* 
 
 // ---- stem: BatchNorm + ReLU + max-pool fused (see the kernels) ---------------------------------------------------------------
 extern "C" int tok_bn_relu_maxpool_fwd(const void* y, const float* scale, const float* shift, int n, int h, int w, int c,
-                                       void* pooled, uint8_t* argmax, void* stream) {
+                                       void* pooled, uint8_t* argmax, void* ypool, void* stream) {
   TOK_CHECK_ARG(y && scale && shift && pooled && argmax && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0,
                 "tok_bn_relu_maxpool_fwd: bad args");
   const int p = (h + 2 - 3) / 2 + 1, q = (w + 2 - 3) / 2 + 1;
@@ -651,7 +709,7 @@ extern "C" int tok_bn_relu_maxpool_fwd(const void* y, const float* scale, const 
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)y,
-                     scale, shift, (bf16*)pooled, argmax, n, h, w, c, p, q);
+                     scale, shift, (bf16*)pooled, argmax, (bf16*)ypool, n, h, w, c, p, q);
   TOK_CHECK_LAUNCH("tok_bn_relu_maxpool_fwd");
   return TOK_OK;
 }
@@ -681,5 +739,17 @@ extern "C" int tok_bn_pool_bwd_apply(const void* dpool, const uint8_t* argmax, c
                      (const bf16*)dpool, argmax, (const bf16*)y, scale, shift, (const float*)nullptr, (const float*)nullptr,
                      coef, m, h, w, c, (h + 2 - 3) / 2 + 1, (w + 2 - 3) / 2 + 1, g.cge, g.rpb, (float*)nullptr, (bf16*)dy);
   TOK_CHECK_LAUNCH("tok_bn_pool_bwd_apply");
+  return TOK_OK;
+}
+
+extern "C" int tok_bn_pool_bwd_reduce_pooled(const void* dpool, const void* pooled, const void* ypool, const float* mean,
+                                             const float* rstd, int64_t m_pooled, int c, float* partial, void* stream) {
+  TOK_CHECK_ARG(dpool && pooled && ypool && mean && rstd && partial && m_pooled > 0 && c > 0 && c % 8 == 0,
+                "tok_bn_pool_bwd_reduce_pooled: bad args");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_pooled_kernel, dim3(stream_blocks(m_pooled, g, kReduceCap)), dim3(256), 0,
+                     tok_stream(stream), (const bf16*)dpool, (const bf16*)pooled, (const bf16*)ypool, mean, rstd, m_pooled, c,
+                     g.cge, g.rpb, partial);
+  TOK_CHECK_LAUNCH("tok_bn_pool_bwd_reduce_pooled");
   return TOK_OK;
 }

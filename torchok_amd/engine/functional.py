@@ -225,10 +225,11 @@ class _ConvBnActNode(Node):
         self.fused_coef = None      # apply coefficients when that dgrad also finalized (tok_conv_dgrad_bn)
         self.coef = None
         self.pool = None            # tap indices of the fused 3x3/s2 max-pool: `out` is the POOLED map, z was never stored
+        self.ypool = None           # raw conv output at the winning taps (pooled-domain BatchNorm-backward sums)
 
     def release(self):
         self.x = self.out = self.shortcut = None
-        self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = self.pool = None
+        self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = self.pool = self.ypool = None
         self.mean = self.rstd = self.scale = self.shift = None
 
     def wants_fused_bwd_stats(self) -> bool:
@@ -244,13 +245,22 @@ class _ConvBnActNode(Node):
             dzy = 1
         else:
             rows = lib.tok_bn_bwd_rows(m, kp)
-            partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
-            if self.pool is not None:
+            if self.pool is not None and self.ypool is not None:
+                # sums over the pooled elements (each feeds exactly one position): 3 pooled-size reads, no gather
+                mp = self.out.data.numel() // kp
+                rows = lib.tok_bn_bwd_rows(mp, kp)
+                partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
+                _C.check(lib.tok_bn_pool_bwd_reduce_pooled(ptr(g), ptr(self.out.data), ptr(self.ypool), ptr(self.mean),
+                                                           ptr(self.rstd), mp, kp, ptr(partial), st),
+                         'tok_bn_pool_bwd_reduce_pooled')
+            elif self.pool is not None:
+                partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
                 n_, h_, w_, _ = self.y.shape
                 _C.check(lib.tok_bn_pool_bwd_reduce(ptr(g), ptr(self.pool), ptr(self.y), ptr(self.scale), ptr(self.shift),
                                                     ptr(self.mean), ptr(self.rstd), n_, h_, w_, kp, ptr(partial), st),
                          'tok_bn_pool_bwd_reduce')
             else:
+                partial = torch.empty((2, rows, kp), dtype=F32, device=g.device)
                 _C.check(lib.tok_bn_bwd_reduce(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale), ptr(self.shift),
                                                ptr(self.mean), ptr(self.rstd), int(self.relu), m, kp, ptr(partial), st),
                          'tok_bn_bwd_reduce')
@@ -413,6 +423,7 @@ class _ConvBnActNode(Node):
 
 
 FUSE_STEM_POOL = os.environ.get('TOK_FUSE_STEM_POOL', '1') != '0'
+STEM_POOLED_STATS = os.environ.get('TOK_STEM_POOLED_STATS', '1') != '0'   # BatchNorm-backward sums of the fused stem in the pooled domain
 
 
 def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None,
@@ -493,8 +504,10 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             p2, q2 = (d.p + 2 - 3) // 2 + 1, (d.q + 2 - 3) // 2 + 1
             out_data = torch.empty((d.n, p2, q2, kp), dtype=BF16, device=dev)
             node.pool = torch.empty((d.n, p2, q2, kp), dtype=torch.uint8, device=dev)
+            if STEM_POOLED_STATS and region.grad_mode and batch_stats:
+                node.ypool = torch.empty_like(out_data)
             _C.check(lib.tok_bn_relu_maxpool_fwd(ptr(y), ptr(scale), ptr(shift), d.n, d.p, d.q, kp, ptr(out_data),
-                                                 ptr(node.pool), st), 'tok_bn_relu_maxpool_fwd')
+                                                 ptr(node.pool), ptr(node.ypool), st), 'tok_bn_relu_maxpool_fwd')
         else:
             out_data = torch.empty_like(y)
             if relu and region.grad_mode and batch_stats:
