@@ -119,29 +119,34 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16* __restrict__ 
 
 // Per-lane fold of partial rows rl, rl+64, ... for both sums: 8 loads in flight (the serial version was bound by the
 // load latency: 12 dependent round trips on 768 rows), additions in row order so the result does not depend on it.
+// RL = row lanes of the block (256 / channels per block).
+template <int RL>
 __device__ __forceinline__ void fold_rows(const float* __restrict__ p, int rows, int C, int c, int rl, double& a1,
                                           double& a2) {
   const float* p1 = p + c;
   const float* p2 = p + (size_t)rows * C + c;
-  for (int r = rl; r < rows; r += 256) {
+  for (int r = rl; r < rows; r += 4 * RL) {
     float v1[4], v2[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int ru = r + 64 * u;
+      const int ru = r + RL * u;
       const int rc = ru < rows ? ru : rows - 1;      // unconditional loads (a branch would serialise them)
       v1[u] = p1[(size_t)rc * C];
       v2[u] = p2[(size_t)rc * C];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bool live = r + 64 * u < rows;
+      const bool live = r + RL * u < rows;
       a1 += live ? (double)v1[u] : 0.0;
       a2 += live ? (double)v2[u] : 0.0;
     }
   }
 }
 
-// 4 channels per block, 64 row-lanes each; fp64 accumulation across partial rows.
+// CW channels per block, 256 / CW row-lanes each; fp64 accumulation across partial rows.  CW = 4 keeps many blocks
+// for narrow layers; CW = 16 (64-byte row segments) for the wide ones, whose 16-byte segments made the fold
+// transaction-bound (2048 channels x 768 rows: 78 us).
+template <int CW>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows,
                                                           double inv_count, double unbias, int C, int Creal,
                                                           const float* __restrict__ gamma,
@@ -151,20 +156,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* mean, float* rstd, float* scale,
                                                           float* shift) {
   __shared__ double red[2][256];
+  constexpr int RL = 256 / CW;
   const int tid = threadIdx.x;
-  const int cl = tid & 3, rl = tid >> 2;
-  const int c = blockIdx.x * 4 + cl;
+  const int cl = tid % CW, rl = tid / CW;
+  const int c = blockIdx.x * CW + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    fold_rows(stats, rows, C, c, rl, a1, a2);
+    fold_rows<RL>(stats, rows, C, c, rl, a1, a2);
   }
   red[0][tid] = a1;
   red[1][tid] = a2;
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
+  for (int s = RL / 2; s > 0; s >>= 1) {
     if (rl < s) {
-      red[0][tid] += red[0][tid + s * 4];
-      red[1][tid] += red[1][tid + s * 4];
+      red[0][tid] += red[0][tid + s * CW];
+      red[1][tid] += red[1][tid + s * CW];
     }
     __syncthreads();
   }
@@ -264,25 +270,27 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
   }
 }
 
+template <int CW>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int rows, double inv_m, int C, int Creal, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* dgamma, float* dbeta,
     float* coef, int accumulate, int dzy_form) {
   __shared__ double red[2][256];
+  constexpr int RL = 256 / CW;
   const int tid = threadIdx.x;
-  const int cl = tid & 3, rl = tid >> 2;
-  const int c = blockIdx.x * 4 + cl;
+  const int cl = tid % CW, rl = tid / CW;
+  const int c = blockIdx.x * CW + cl;
   double a1 = 0.0, a2 = 0.0;
   if (c < C) {
-    fold_rows(partial, rows, C, c, rl, a1, a2);
+    fold_rows<RL>(partial, rows, C, c, rl, a1, a2);
   }
   red[0][tid] = a1;
   red[1][tid] = a2;
   __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
+  for (int s = RL / 2; s > 0; s >>= 1) {
     if (rl < s) {
-      red[0][tid] += red[0][tid + s * 4];
-      red[1][tid] += red[1][tid + s * 4];
+      red[0][tid] += red[0][tid + s * CW];
+      red[1][tid] += red[1][tid + s * CW];
     }
     __syncthreads();
   }
@@ -615,9 +623,14 @@ extern "C" int tok_bn_finalize(const float* stats, int rows, int64_t count, int 
   TOK_CHECK_ARG(rows > 0 && count > 0 && c > 0 && c_real > 0 && c_real <= c, "tok_bn_finalize: bad sizes");
   TOK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "tok_bn_finalize: running stats");
   const double unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), stats, rows,
-                     1.0 / (double)count, unbias, c, c_real, gamma, beta, running_mean, running_var, nbt,
-                     momentum, eps, mean, rstd, scale, shift);
+  if (c >= 512)
+    hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3((c + 15) / 16), dim3(256), 0, tok_stream(stream), stats, rows,
+                       1.0 / (double)count, unbias, c, c_real, gamma, beta, running_mean, running_var, nbt,
+                       momentum, eps, mean, rstd, scale, shift);
+  else
+    hipLaunchKernelGGL(bn_finalize_kernel<4>, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), stats, rows,
+                       1.0 / (double)count, unbias, c, c_real, gamma, beta, running_mean, running_var, nbt,
+                       momentum, eps, mean, rstd, scale, shift);
   TOK_CHECK_LAUNCH("tok_bn_finalize");
   return TOK_OK;
 }
@@ -679,8 +692,12 @@ extern "C" int tok_bn_bwd_finalize(const float* partial, int rows, int64_t m, in
                                    float* coef, int accumulate, int dzy_form, void* stream) {
   TOK_CHECK_ARG(partial && gamma && mean && rstd && coef, "tok_bn_bwd_finalize: null pointer");
   TOK_CHECK_ARG(c > 0 && c_real > 0 && c_real <= c, "tok_bn_bwd_finalize: bad sizes");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), partial,
-                     rows, 1.0 / (double)m, c, c_real, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
+  if (c >= 512)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((c + 15) / 16), dim3(256), 0, tok_stream(stream), partial,
+                       rows, 1.0 / (double)m, c, c_real, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((c + 3) / 4), dim3(256), 0, tok_stream(stream), partial,
+                       rows, 1.0 / (double)m, c, c_real, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy_form);
   TOK_CHECK_LAUNCH("tok_bn_bwd_finalize");
   return TOK_OK;
 }
