@@ -272,16 +272,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
       }
       ok = ok && ((unsigned)hh < (unsigned)a.H);
       if (C4) {
-        bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
-        if (ok) {
-          const bf16* ptr = a.x + ((size_t)(pix[i] + hh * a.W + ww)) * 4;
-          if ((unsigned)ww < (unsigned)a.W) lo = *reinterpret_cast<const bf16x4*>(ptr);
-          if ((unsigned)(ww + 1) < (unsigned)a.W) hi = *reinterpret_cast<const bf16x4*>(ptr + 4);
-        }
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
-        ra[i] = v;
+        // two 8-byte pixels (s, s+1 of the padded filter row) as unconditional buffer loads: a tap outside the image takes
+        // an out-of-range offset and comes back as zeros (the branchy form put an s_waitcnt in front of every load)
+        const uint32_t base = (uint32_t)(pix[i] + hh * a.W + ww) * 8u;
+        const uint32_t off_lo = (ok && (unsigned)ww < (unsigned)a.W) ? base : 0xFFFFFFF0u;
+        const uint32_t off_hi = (ok && (unsigned)(ww + 1) < (unsigned)a.W) ? base + 8u : 0xFFFFFFF0u;
+        const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(xsrd, off_lo, 0, 0);
+        const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(xsrd, off_hi, 0, 0);
+        const u32x4 both = {lo[0], lo[1], hi[0], hi[1]};
+        ra[i] = __builtin_bit_cast(bf16x8, both);
       } else {
         // buffer load: padding taps / rows past M / K tail use an out-of-range offset, which the
         // buffer unit answers with zeros — one unconditional instruction per row, no zero-fill VALU
