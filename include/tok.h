@@ -406,6 +406,33 @@ int tok_chan_apply(const void* x, int ldx, const float* m, int transposed, float
 int tok_scale_rows_add(const void* a, const void* b, const float* row_scale, int rows_per_sample, void* out,
                        int accumulate, int64_t rows, int ld, void* stream);
 
+/* ---- object-contextual representations (heads/segmentation/ocr.py) -------------------------------------------
+ * SpatialGather_Module (:23-46): p = softmax over the PIXELS of the auxiliary logits, context[k] = sum_n p[n][k] x[n];
+ * ObjectAttentionBlock (:49-104): sim = softmax_k(q key^T / sqrt(C_key)), context[n] = sum_k sim[n][k] value[k].
+ * Building blocks (K <= 64 classes; x / out bf16 pixel tensors [images][n][ld], m bf16 class matrices [images][k][ldm],
+ * w / p fp32 [images][n][k]):
+ *   tok_pix_class_matmul  out[b][n][k]  = scale * sum_c x[b][n][c] m[b][k][c]
+ *   tok_class_pix_expand  out[b][n][c] (+)= scale * sum_k w[b][n][k] m[b][k][c]
+ *   tok_weighted_pool     out[b][k][c] (+)= scale * sum_n w[b][n][k] x[b][n][c]   (k * c <= 4096; partial fp32
+ *                         [images][tok_weighted_pool_chunks(n)][k][c], fixed-order fold)
+ *   tok_softmax_rows_f32 / _bwd_f32   softmax over the k entries of a row and its backward p o (dp - <p, dp>)
+ *   tok_softmax_cols_fwd / _bwd       softmax over the n pixels of every (image, class) of bf16 logits * scale
+ *   tok_channel_scale     out (+)= x * s[b][c]   (Dropout2d of SpatialOCR, :121-124, and its backward)            */
+int tok_pix_class_matmul(const void* x, int ldx, const void* m, int ldm, int images, int n, int k, int c, float scale,
+                         float* out, void* stream);
+int tok_class_pix_expand(const float* w, const void* m, int ldm, int images, int n, int k, int c, float scale, void* out,
+                         int ldo, int accumulate, void* stream);
+int tok_weighted_pool_chunks(int n);
+int tok_weighted_pool(const float* w, const void* x, int ldx, int images, int n, int k, int c, float scale, float* partial,
+                      void* out, int ldo, int accumulate, void* stream);
+int tok_softmax_rows_f32(const float* x, int64_t rows, int k, float* out, void* stream);
+int tok_softmax_rows_bwd_f32(const float* p, const float* dp, int64_t rows, int k, float* dx, void* stream);
+int tok_softmax_cols_fwd(const void* logits, int ld, int images, int n, int k, float scale, float* p, void* stream);
+int tok_softmax_cols_bwd(const float* p, const float* dp, int images, int n, int k, float scale, void* dlogits, int ld,
+                         int accumulate, void* stream);
+int tok_channel_scale(const void* x, const float* s, void* out, int accumulate, int images, int n, int c, int ld,
+                      void* stream);
+
 /* ---- retrieval meters (validation path) -------------------------------------------------------
  * IndexBasedMeter.compute (metrics/index_base_metric.py:170-270) with exact_index=True: the faiss flat index
  * (:523-545) is an exhaustive search = similarity matrix + k best per row; the ranx metric functions bound by

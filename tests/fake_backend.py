@@ -497,6 +497,73 @@ class FakeTok:
             o[:, :d] = _bf(val * act)
         return 0
 
+    # ---- object-contextual representations --------------------------------------------------------------------------------
+    @staticmethod
+    def _strided(p, rows, ld, c, dtype=BF16):
+        flat = _t(p, ((rows - 1) * ld + c,), dtype)
+        return torch.as_strided(flat, (rows, c), (ld, 1))
+
+    def tok_pix_class_matmul(self, x, ldx, m, ldm, images, n, k, c, scale, out, st):
+        xv = self._strided(x, images * n, ldx, c).float().view(images, n, c)
+        mv = self._strided(m, images * k, ldm, c).float().view(images, k, c)
+        _t(out, (images, n, k), torch.float32).copy_(scale * xv @ mv.transpose(1, 2))
+        return 0
+
+    def tok_class_pix_expand(self, w, m, ldm, images, n, k, c, scale, out, ldo, accumulate, st):
+        wv = _t(w, (images, n, k), torch.float32)
+        mv = self._strided(m, images * k, ldm, c).float().view(images, k, c)
+        o = _t(out, (images * n, ldo), BF16)
+        res = (scale * wv @ mv).reshape(images * n, c)
+        cp = (c + 7) // 8 * 8
+        if accumulate:
+            o[:, :c] = _bf(res + o[:, :c].float())
+        else:
+            o[:, :cp] = 0
+            o[:, :c] = _bf(res)
+        return 0
+
+    def tok_weighted_pool_chunks(self, n):
+        return max(1, (n + 511) // 512)
+
+    def tok_weighted_pool(self, w, x, ldx, images, n, k, c, scale, partial, out, ldo, accumulate, st):
+        wv = _t(w, (images, n, k), torch.float32)
+        xv = self._strided(x, images * n, ldx, c).float().view(images, n, c)
+        res = (scale * wv.transpose(1, 2) @ xv).reshape(images * k, c)
+        o = self._strided(out, images * k, ldo, c)
+        o.copy_(_bf(res + (o.float() if accumulate else 0)))
+        return 0
+
+    def tok_softmax_rows_f32(self, x, rows, k, out, st):
+        _t(out, (rows, k), torch.float32).copy_(_t(x, (rows, k), torch.float32).softmax(-1))
+        return 0
+
+    def tok_softmax_rows_bwd_f32(self, p, dp, rows, k, dx, st):
+        pv, dv = _t(p, (rows, k), torch.float32), _t(dp, (rows, k), torch.float32)
+        _t(dx, (rows, k), torch.float32).copy_(pv * (dv - (pv * dv).sum(-1, keepdim=True)))
+        return 0
+
+    def tok_softmax_cols_fwd(self, logits, ld, images, n, k, scale, p, st):
+        lv = self._strided(logits, images * n, ld, k).float().view(images, n, k)
+        _t(p, (images, n, k), torch.float32).copy_((scale * lv).softmax(1))
+        return 0
+
+    def tok_softmax_cols_bwd(self, p, dp, images, n, k, scale, dlogits, ld, accumulate, st):
+        pv, dv = _t(p, (images, n, k), torch.float32), _t(dp, (images, n, k), torch.float32)
+        res = scale * pv * (dv - (pv * dv).sum(1, keepdim=True))
+        o = _t(dlogits, (images * n, ld), BF16)
+        full = torch.zeros(images * n, ld)
+        full[:, :k] = res.reshape(images * n, k)
+        o.copy_(_bf(full + (o.float() if accumulate else 0)))
+        return 0
+
+    def tok_channel_scale(self, x, s, out, accumulate, images, n, c, ld, st):
+        xv = _t(x, (images, n, ld), BF16).float()
+        sv = torch.zeros(images, 1, ld)
+        sv[:, 0, :c] = _t(s, (images, c), torch.float32)
+        o = _t(out, (images, n, ld), BF16)
+        o.copy_(_bf(xv * sv + (o.float() if accumulate else 0)))
+        return 0
+
     # ---- retrieval meters ------------------------------------------------------------------------------------------------
     def tok_sim_matrix(self, q, g, nq, ng, d, ldq, ldg, metric, out, ldo, st):
         qv = _t(q, (nq, ldq), torch.float32)[:, :d]

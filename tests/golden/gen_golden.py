@@ -309,6 +309,57 @@ def golden_davit(out_path, seed=71):
           f'restatement == reference files: OK')
 
 
+def golden_ocr(out_path, seed=81):
+    """OCRSegmentationHead: the reference's OWN heads/segmentation/ocr.py and modules/bricks/convbnact.py (in-tree files, torch
+    only) in training mode — both outputs, the channel-dropout factors it drew, every gradient of an (out, out_aux) loss;
+    asserts oracle/ocr_ref.py is bit-identical."""
+    import oracle.ocr_ref as O
+    if 'torchok.models.modules' not in sys.modules:
+        _fake_pkg('torchok.models.modules', f'{REF}/models/modules')
+        _fake_pkg('torchok.models.modules.bricks', f'{REF}/models/modules/bricks')
+    if 'torchok.models.modules.bricks.convbnact' not in sys.modules:
+        _load('torchok.models.modules.bricks.convbnact', f'{REF}/models/modules/bricks/convbnact.py')
+    if 'torchok.models.heads.segmentation' not in sys.modules:
+        _fake_pkg('torchok.models.heads.segmentation', f'{REF}/models/heads/segmentation')
+    ocr = _load('torchok.models.heads.segmentation.ocr', f'{REF}/models/heads/segmentation/ocr.py')
+    cin, classes, batch, h, w = 48, 7, 4, 16, 24
+    torch.manual_seed(seed)
+    ref = ocr.OCRSegmentationHead(in_channels=cin, num_classes=classes).train()
+    ora = O.OCRSegmentationHead(cin, classes).train()
+    assert set(ref.state_dict()) == set(ora.state_dict()), 'state_dict keys differ: restated wiring != reference'
+    sd = deterministic_state(ref.state_dict(), seed)
+    ref.load_state_dict(sd)
+    ora.load_state_dict(sd)
+    g = torch.Generator().manual_seed(seed + 1)
+    image = torch.zeros(batch, 3, 4 * h, 4 * w)
+    feats = torch.randn(batch, cin, h, w, generator=g).half().float()
+    wo, wa = torch.randn(batch, classes, 4 * h, 4 * w, generator=g), torch.randn(batch, classes, 4 * h, 4 * w, generator=g)
+    outs = []
+    for m in (ref, ora):
+        torch.manual_seed(seed + 2)
+        x = feats.clone().requires_grad_(True)
+        out, aux = m([image, x])
+        ((out * wo).sum() + 0.4 * (aux * wa).sum()).backward()
+        outs.append((out.detach(), aux.detach(), x.grad.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    for (n, p), (n2, p2) in zip(ref.named_parameters(), ora.named_parameters()):
+        assert n == n2 and torch.equal(p.grad, p2.grad), n
+    torch.manual_seed(seed + 2)
+    drop = torch.empty(batch, 128, 1, 1).bernoulli_(0.95).div_(0.95).reshape(batch, 128)
+    ref.eval()
+    with torch.no_grad():
+        ev = ref([image, feats])
+    names = [n for n, _ in ref.named_parameters()]
+    np.savez_compressed(
+        out_path, seed=seed, in_channels=cin, num_classes=classes, feats=feats.numpy(), image_hw=np.array([4 * h, 4 * w]),
+        weight_seed=seed + 1,        # w_out / w_aux: the two randn draws that follow `feats` on torch.Generator(weight_seed)
+        drop_scale=drop.numpy(), out=outs[0][0].half().numpy(), out_aux=outs[0][1].half().numpy(),
+        d_feats=outs[0][2].numpy(), eval_out=ev.half().numpy(), param_names=np.array(names),
+        grad_norm=np.array([float(p.grad.double().norm()) for _, p in ref.named_parameters()]),
+        **{f'grad__{n}': p.grad.numpy() for n, p in ref.named_parameters() if p.numel() <= 4096})
+    print(f'wrote {out_path}: {len(names)} params, restatement == reference files: OK')
+
+
 def golden_dice(out_path):
     """DiceLoss outputs and input gradients from the reference's own losses/segmentation/dice.py (imports as is)."""
     _fake_pkg('torchok.losses.segmentation', f'{REF}/losses/segmentation')
@@ -649,6 +700,8 @@ def main():
         return golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     if '--dice-only' in sys.argv:
         return golden_dice(os.path.join(gd, 'dice_loss.npz'))
+    if '--ocr-only' in sys.argv:
+        return golden_ocr(os.path.join(gd, 'ocr_head_step.npz'))
     if '--davit-only' in sys.argv:
         return golden_davit(os.path.join(gd, 'davit_cls_step.npz'))
     if '--swin-only' in sys.argv:
@@ -662,6 +715,7 @@ def main():
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))
     golden_davit(os.path.join(gd, 'davit_cls_step.npz'))
+    golden_ocr(os.path.join(gd, 'ocr_head_step.npz'))
     golden_dice(os.path.join(gd, 'dice_loss.npz'))
     golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))

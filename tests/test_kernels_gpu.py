@@ -1098,3 +1098,51 @@ def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     assert float((b - exact).abs().max()) < 1e-4 * float(exact.abs().max()) + 1e-4
     a = part0.double().sum(1).cpu()
     assert float((a - exact).abs().max()) < 2.0 ** -7 * (m ** 0.5) * 4
+
+
+# ---- OCR head: pixel <-> class products ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize('images,n,k,c,pad', [(2, 100, 7, 48, 0), (3, 384, 19, 128, 0), (1, 1000, 19, 64, 8), (2, 33, 3, 20, 8)])
+def test_ocr_building_blocks(libs, images, n, k, c, pad):
+    cp = (c + 7) // 8 * 8 + pad
+    x = rnd(images * n, cp).to(BF16)
+    m = rnd(images * k, cp, seed=1).to(BF16)
+    w = rnd(images, n, k, seed=2).softmax(-1).contiguous()
+    out = torch.empty(images, n, k)
+    dv = both(libs, 'tok_pix_class_matmul', lambda d: [d(x), cp, d(m), cp, images, n, k, c, 0.5, d(out), None])
+    ref = 0.5 * x.float().view(images, n, cp)[..., :c] @ m.float().view(images, k, cp)[..., :c].transpose(1, 2)
+    assert relerr(out, ref) < 1e-5 and relerr(dv[id(out)], ref) < 1e-4
+    for acc in (0, 1):
+        o = rnd(images * n, cp, seed=3).to(BF16)
+        o0 = o.clone()
+        dv = both(libs, 'tok_class_pix_expand', lambda d: [d(w), d(m), cp, images, n, k, c, 2.0, d(o), cp, acc, None])
+        ref = (2.0 * w @ m.float().view(images, k, cp)[..., :c]).reshape(images * n, c) + (o0.float()[:, :c] if acc else 0)
+        assert relerr(o.float()[:, :c], ref) < 5e-3 and relerr(dv[id(o)].float()[:, :c], ref) < 5e-3
+    lib = libs[0]
+    chunks = lib.tok_weighted_pool_chunks(n)
+    part = torch.empty(images, chunks, k, c)
+    for acc in (0, 1):
+        o = rnd(images * k, cp, seed=4).to(BF16)
+        o0 = o.clone()
+        dv = both(libs, 'tok_weighted_pool', lambda d: [d(w), d(x), cp, images, n, k, c, 0.25, d(part), d(o), cp, acc, None])
+        ref = (0.25 * w.transpose(1, 2) @ x.float().view(images, n, cp)[..., :c]).reshape(images * k, c) + \
+            (o0.float()[:, :c] if acc else 0)
+        assert relerr(o.float()[:, :c], ref) < 5e-3 and relerr(dv[id(o)].float()[:, :c], ref) < 5e-3
+    logits = (rnd(images * n, cp, seed=5) * 2).to(BF16)
+    p = torch.empty(images, n, k)
+    dv = both(libs, 'tok_softmax_cols_fwd', lambda d: [d(logits), cp, images, n, k, 1.0, d(p), None])
+    ref = logits.float().view(images, n, cp)[..., :k].softmax(1)
+    assert relerr(p, ref) < 1e-5 and relerr(dv[id(p)], ref) < 1e-4
+    dp = rnd(images, n, k, seed=6)
+    dl = torch.ones(images * n, cp, dtype=BF16)
+    dv = both(libs, 'tok_softmax_cols_bwd', lambda d: [d(p), d(dp), images, n, k, 1.0, d(dl), cp, 0, None])
+    assert relerr(dv[id(dl)].float(), dl.float()) < 5e-3 and float(dv[id(dl)][:, k:].abs().max()) == 0
+    sm = torch.empty(images, n, k)
+    dv = both(libs, 'tok_softmax_rows_f32', lambda d: [d(out), images * n, k, d(sm), None])
+    assert relerr(dv[id(sm)], out.softmax(-1)) < 1e-5
+    dx = torch.empty(images, n, k)
+    dv = both(libs, 'tok_softmax_rows_bwd_f32', lambda d: [d(sm), d(dp), images * n, k, d(dx), None])
+    assert relerr(dv[id(dx)], dx) < 1e-5
+    s = rnd(images, c, seed=7)
+    y = torch.empty(images * n, cp, dtype=BF16)
+    dv = both(libs, 'tok_channel_scale', lambda d: [d(x), d(s), d(y), 0, images, n, c, cp, None])
+    assert relerr(dv[id(y)].float(), y.float()) < 5e-3

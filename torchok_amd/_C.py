@@ -124,6 +124,15 @@ PROTOTYPES = {
     'tok_chan_gram': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     'tok_chan_apply': (c_int, [_P, c_int, _P, c_int, c_float, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_scale_rows_add': (c_int, [_P, _P, _P, c_int, _P, c_int, c_int64, c_int, _P]),
+    'tok_pix_class_matmul': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'tok_class_pix_expand': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P]),
+    'tok_weighted_pool_chunks': (c_int, [c_int]),
+    'tok_weighted_pool': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, c_int, _P]),
+    'tok_softmax_rows_f32': (c_int, [_P, c_int64, c_int, _P, _P]),
+    'tok_softmax_rows_bwd_f32': (c_int, [_P, _P, c_int64, c_int, _P, _P]),
+    'tok_softmax_cols_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
+    'tok_softmax_cols_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P]),
+    'tok_channel_scale': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_sim_matrix': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     'tok_topk_rows': (c_int, [_P, c_int, c_int, c_int64, c_int, _P, _P, _P]),
     'tok_retrieval_nrel': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
