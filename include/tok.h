@@ -413,7 +413,7 @@ int tok_scale_rows_add(const void* a, const void* b, const float* row_scale, int
  * w / p fp32 [images][n][k]):
  *   tok_pix_class_matmul  out[b][n][k]  = scale * sum_c x[b][n][c] m[b][k][c]
  *   tok_class_pix_expand  out[b][n][c] (+)= scale * sum_k w[b][n][k] m[b][k][c]
- *   tok_weighted_pool     out[b][k][c] (+)= scale * sum_n w[b][n][k] x[b][n][c]   (k * c <= 4096; partial fp32
+ *   tok_weighted_pool     out[b][k][c] (+)= scale * sum_n w[b][n][k] x[b][n][c]   (k * c <= 10240; partial fp32
  *                         [images][tok_weighted_pool_chunks(n)][k][c], fixed-order fold)
  *   tok_softmax_rows_f32 / _bwd_f32   softmax over the k entries of a row and its backward p o (dp - <p, dp>)
  *   tok_softmax_cols_fwd / _bwd       softmax over the n pixels of every (image, class) of bf16 logits * scale

@@ -1101,7 +1101,7 @@ def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
 
 
 # ---- OCR head: pixel <-> class products ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize('images,n,k,c,pad', [(2, 100, 7, 48, 0), (3, 384, 19, 128, 0), (1, 1000, 19, 64, 8), (2, 33, 3, 20, 8)])
+@pytest.mark.parametrize('images,n,k,c,pad', [(2, 100, 7, 48, 0), (3, 384, 19, 128, 0), (1, 1000, 19, 64, 8), (2, 33, 3, 20, 8), (2, 700, 19, 512, 0)])
 def test_ocr_building_blocks(libs, images, n, k, c, pad):
     cp = (c + 7) // 8 * 8 + pad
     x = rnd(images * n, cp).to(BF16)

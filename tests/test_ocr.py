@@ -88,5 +88,5 @@ def test_eval_returns_one_tensor(dev):
 
 def test_limits(dev):
     with pytest.raises(NotImplementedError):
-        T.HEADS.get('OCRSegmentationHead')(in_channels=16, num_classes=40).to(dev).train()(
-            [torch.zeros(1, 3, 16, 16, device=dev), torch.randn(1, 16, 4, 4, device=dev)])     # 40 x 128 > 4096
+        T.HEADS.get('OCRSegmentationHead')(in_channels=16, num_classes=40, ocr_mid_channels=512).to(dev).train()(
+            [torch.zeros(1, 3, 16, 16, device=dev), torch.randn(2, 16, 4, 4, device=dev)])     # 40 x 512 > 10240

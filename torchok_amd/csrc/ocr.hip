@@ -86,20 +86,20 @@ __global__ __launch_bounds__(256) void class_pix_expand_kernel(const float* __re
 
 // partial[b][chunk][k][c]: block (chunk, b) folds its pixel chunk; thread owns the (k, c) pairs tid, tid + 256, ...
 __global__ __launch_bounds__(256) void weighted_pool_partial_kernel(const float* __restrict__ w, const bf16* __restrict__ x,
-                                                                    int ldx, int N, int K, int C, int chunk,
+                                                                    int ldx, int N, int K, int C, int chunk, int stage,
                                                                     float* __restrict__ partial) {
-  extern __shared__ float sm[];                    // xs[32][C] then ws[32][K]
+  extern __shared__ float sm[];                    // xs[stage][C] then ws[stage][K]
   float* xs = sm;
-  float* ws = sm + 32 * C;
+  float* ws = sm + stage * C;
   const int b = blockIdx.y;
   const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
   const int kc = K * C;
-  constexpr int MAXP = 16;                         // K * C <= 4096
+  constexpr int MAXP = 40;                         // K * C <= 10240 (19 classes x 512 channels of HRNet-OCR)
   float acc[MAXP];
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) acc[p] = 0.f;
-  for (int nb = n0; nb < n1; nb += 32) {
-    const int rows = min(32, n1 - nb);
+  for (int nb = n0; nb < n1; nb += stage) {
+    const int rows = min(stage, n1 - nb);
     for (int i = threadIdx.x; i < rows * C; i += 256)
       xs[i] = bf2f(x[((size_t)b * N + nb + i / C) * ldx + (i % C)]);
     for (int i = threadIdx.x; i < rows * K; i += 256) ws[i] = w[((size_t)b * N + nb) * K + i];
@@ -276,12 +276,14 @@ extern "C" int tok_weighted_pool(const float* w, const void* x, int ldx, int ima
                                  float* partial, void* out, int ldo, int accumulate, void* stream) {
   TOK_CHECK_ARG(w && x && partial && out && images > 0 && n > 0 && k > 0 && k <= KMAX && c > 0 && ldx >= c && ldo >= c,
                 "tok_weighted_pool: bad args (at most 64 classes)");
-  TOK_CHECK_ARG(k * c <= 4096 && images <= 65535, "tok_weighted_pool: K * C = %d exceeds 4096", k * c);
+  TOK_CHECK_ARG(k * c <= 10240 && images <= 65535, "tok_weighted_pool: K * C = %d exceeds 10240", k * c);
   const int chunks = tok_weighted_pool_chunks(n);
-  const size_t smem = (size_t)32 * (c + k) * sizeof(float);
+  const int stage = c <= 256 ? 32 : 16;           // pixel rows staged in LDS per pass (<= 64 KB)
+  const size_t smem = (size_t)stage * (c + k) * sizeof(float);
+  TOK_CHECK_ARG(smem <= 64 * 1024, "tok_weighted_pool: %d channels do not fit the LDS stage", c);
   hipStream_t st = tok_stream(stream);
   hipLaunchKernelGGL(weighted_pool_partial_kernel, dim3(chunks, images), dim3(256), smem, st, w, (const bf16*)x, ldx, n, k, c,
-                     512, partial);
+                     512, stage, partial);
   TOK_CHECK_LAUNCH("tok_weighted_pool(partial)");
   hipLaunchKernelGGL(weighted_pool_fold_kernel, dim3((k * c + 255) / 256, images), dim3(256), 0, st, partial, chunks, k, c,
                      scale, (bf16*)out, ldo, accumulate);

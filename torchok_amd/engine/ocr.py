@@ -65,8 +65,8 @@ def spatial_gather(region: Region, feats: TTensor, logits: TTensor, scale: float
     lib, st = _C.lib(), stream_ptr()
     b, npix, ldf = _geo(feats)
     k = logits.c
-    if k > 64 or k * feats.c > 4096:
-        raise NotImplementedError(f'spatial_gather: at most 64 classes and classes x channels <= 4096 (got {k} x {feats.c})')
+    if k > 64 or k * feats.c > 10240:
+        raise NotImplementedError(f'spatial_gather: at most 64 classes and classes x channels <= 10240 (got {k} x {feats.c})')
     dev = feats.data.device
     p = torch.empty((b, npix, k), dtype=F32, device=dev)
     _C.check(lib.tok_softmax_cols_fwd(ptr(logits.data), logits.cp, b, npix, k, scale, ptr(p), st), 'tok_softmax_cols_fwd')
@@ -127,8 +127,8 @@ def object_attention(region: Region, q: TTensor, key: TTensor, value: TTensor, s
     k, c = key.shape[1], q.c
     if key.shape[0] != b or value.shape[:2] != key.shape[:2] or key.c != c or value.c != c:
         raise ValueError('object_attention: key / value must be (B, K, 1, C) with the channels of q')
-    if k > 64 or k * c > 4096:
-        raise NotImplementedError(f'object_attention: at most 64 classes and classes x channels <= 4096 (got {k} x {c})')
+    if k > 64 or k * c > 10240:
+        raise NotImplementedError(f'object_attention: at most 64 classes and classes x channels <= 10240 (got {k} x {c})')
     dev = q.data.device
     logit = torch.empty((b, npix, k), dtype=F32, device=dev)
     _C.check(lib.tok_pix_class_matmul(ptr(q.data), ldq, ptr(key.data), key.cp, b, npix, k, c, scale, ptr(logit), st),
