@@ -433,6 +433,16 @@ int tok_softmax_cols_bwd(const float* p, const float* dp, int images, int n, int
 int tok_channel_scale(const void* x, const float* s, void* out, int accumulate, int images, int n, int c, int ld,
                       void* stream);
 
+/* Depthwise 3x3 / stride 1 / pad 1 convolution with bias (ConvPosEnc.proj, davit.py:101-106; only reached with
+ * cpe_act=True).  x / out bf16 NHWC [n][h][w][ld], w fp32 [c][3][3] (the master), bias fp32 [c] or NULL.  flip = 1 applies
+ * the tap-flipped filter (the data gradient).  tok_dwconv3x3_wgrad: dw fp32 [c][3][3], db fp32 [c]; partial fp32
+ * [tok_dwconv3x3_wgrad_blocks(n, h)][c][10], fixed-order fold.                                                        */
+int tok_dwconv3x3(const void* x, const float* w, const float* bias, void* out, int accumulate, int flip, int n, int h, int wd,
+                  int c, int ld, void* stream);
+int tok_dwconv3x3_wgrad_blocks(int n, int h);
+int tok_dwconv3x3_wgrad(const void* x, const void* dout, int n, int h, int wd, int c, int ld, float* partial, float* dw,
+                        float* db, int accumulate, void* stream);
+
 /* ---- retrieval meters (validation path) -------------------------------------------------------
  * IndexBasedMeter.compute (metrics/index_base_metric.py:170-270) with exact_index=True: the faiss flat index
  * (:523-545) is an exhaustive search = similarity matrix + k best per row; the ranx metric functions bound by

@@ -564,6 +564,37 @@ class FakeTok:
         o.copy_(_bf(xv * sv + (o.float() if accumulate else 0)))
         return 0
 
+    # ---- depthwise 3x3 (DaViT ConvPosEnc with activation) -----------------------------------------------------------
+    def tok_dwconv3x3(self, x, w, bias, out, accumulate, flip, n, h, wd, c, ld, st):
+        xv = _t(x, (n, h, wd, ld), BF16)[..., :c].float().permute(0, 3, 1, 2)
+        wv = _t(w, (c, 1, 3, 3), torch.float32)
+        if flip:
+            wv = wv.flip(2, 3)
+        b = _t(bias, (c,), torch.float32) if bias is not None else None
+        y = F.conv2d(xv, wv, b, padding=1, groups=c).permute(0, 2, 3, 1)
+        o = _t(out, (n, h, wd, ld), BF16)
+        if accumulate:
+            o[..., :c] = _bf(y + o[..., :c].float())
+        else:
+            o.zero_()
+            o[..., :c] = _bf(y)
+        return 0
+
+    def tok_dwconv3x3_wgrad_blocks(self, n, h):
+        return 1
+
+    def tok_dwconv3x3_wgrad(self, x, dout, n, h, wd, c, ld, partial, dw, db, accumulate, st):
+        xv = _t(x, (n, h, wd, ld), BF16)[..., :c].float().permute(0, 3, 1, 2).contiguous()
+        gv = _t(dout, (n, h, wd, ld), BF16)[..., :c].float().permute(0, 3, 1, 2).contiguous()
+        gw = torch.nn.grad.conv2d_weight(xv, (c, 1, 3, 3), gv, padding=1, groups=c).reshape(c, 9)
+        if dw is not None:
+            t = _t(dw, (c, 9), torch.float32)
+            t.copy_(gw + (t if accumulate else 0))
+        if db is not None:
+            t = _t(db, (c,), torch.float32)
+            t.copy_(gv.sum((0, 2, 3)) + (t if accumulate else 0))
+        return 0
+
     # ---- retrieval meters ------------------------------------------------------------------------------------------------
     def tok_sim_matrix(self, q, g, nq, ng, d, ldq, ldg, metric, out, ldo, st):
         qv = _t(q, (nq, ldq), torch.float32)[:, :d]

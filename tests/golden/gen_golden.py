@@ -263,6 +263,19 @@ def golden_davit(out_path, seed=71):
     bsd = {k[len('backbone.'):]: v for k, v in sd.items() if k.startswith('backbone.')}
     assert set(ora.state_dict()) == set(bsd), 'state_dict keys differ: restated wiring != reference'
     ora.load_state_dict(bsd)
+    # cpe_act=True (ConvPosEnc with its GELU residual): restatement == reference on features and gradients, too
+    rc = davit.davit_t(pretrained=False, in_channels=3, img_size=128, window_size=4, drop_path_rate=0.0, cpe_act=True).train()
+    oc = D.davit_t(window_size=4, drop_path_rate=0.0, cpe_act=True).train()
+    csd = deterministic_state(rc.state_dict(), seed + 5)
+    rc.load_state_dict(csd)
+    oc.load_state_dict(csd)
+    xc = torch.randn(2, 3, 128, 128, generator=torch.Generator().manual_seed(seed + 6))
+    fr, fo = rc.forward_features(xc), oc.forward_features(xc)
+    assert all(torch.equal(a, b) for a, b in zip(fr, fo))
+    sum(f.sum() for f in fr[1:]).backward()
+    sum(f.sum() for f in fo[1:]).backward()
+    for (n, p), (n2, p2) in zip(rc.named_parameters(), oc.named_parameters()):
+        assert n == n2 and p.grad is not None and torch.equal(p.grad, p2.grad), n
     g = torch.Generator().manual_seed(seed + 1)
     x = torch.randn(batch, 3, 128, 128, generator=g).half().float()
     y = torch.randint(0, classes, (batch,), generator=g)

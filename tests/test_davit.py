@@ -42,8 +42,6 @@ def test_structure():
     assert sum(p.numel() for p in D.davit_t().parameters()) == sum(p.numel() for p in m.parameters())
     assert [tuple(getattr(T.BACKBONES.get(n)(pretrained=False), 'embed_dims')) for n in ('davit_s', 'davit_b')] == \
         [(96, 192, 384, 768), (128, 256, 512, 1024)]
-    with pytest.raises(NotImplementedError):
-        T.BACKBONES.get('davit_t')(pretrained=False, cpe_act=True)
     with pytest.raises(RuntimeError):
         T.BACKBONES.get('davit_t')(pretrained=True)
 
@@ -75,6 +73,35 @@ def test_forward_features_and_backward_vs_oracle(dev):
     assert all('cpe' in n for n in g32 if g32[n] is None)        # ConvPosEnc without activation: inert (davit.py:124-128)
     yard = {n: rel_err(dict(ac.named_parameters())[n].grad, g32[n]) for n in live}
     errs = {n: rel_err(dict(m.named_parameters())[n].grad, g32[n]) for n in live}
+    assert np.median(list(errs.values())) < 1.5 * np.median(list(yard.values())) + 1e-2
+    bad = [n for n in errs if errs[n] > 1.5 * yard[n] + 0.08]
+    assert len(bad) <= 0.05 * len(errs), [(n, errs[n], yard[n]) for n in bad][:8]
+
+
+def test_conv_pos_enc_with_activation(dev):
+    """cpe_act=True: x + GELU(depthwise3x3(x)) before each attention / MLP — forward features and every gradient (the
+    cpe parameters now receive one) against the oracle, torch's bf16 autocast run as the yardstick."""
+    m, ref = _pair(window_size=4, drop_path_rate=0.0, cpe_act=True)
+    m.to(dev).train()
+    ref.train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 128, 128, generator=g)
+    feats = m.forward_features(x.to(dev))
+    rfeats = ref.forward_features(x)
+    for i, (a, b) in enumerate(zip(feats[1:], rfeats[1:])):
+        assert rel_err(a.float(), b) < 2e-2, i
+    w = [torch.randn(f.shape, generator=g) for f in rfeats[1:]]
+    sum((f.float() * wi.to(dev)).sum() for f, wi in zip(feats[1:], w)).backward()
+    sum((f * wi).sum() for f, wi in zip(rfeats[1:], w)).backward()
+    ac = copy.deepcopy(ref)
+    ac.zero_grad()
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        af = ac.forward_features(x)
+    sum((f.float() * wi).sum() for f, wi in zip(af[1:], w)).backward()
+    g32 = {n: p.grad for n, p in ref.named_parameters()}
+    assert all(v is not None for v in g32.values()) and all(p.grad is not None for p in m.parameters())
+    yard = {n: rel_err(p.grad, g32[n]) for n, p in ac.named_parameters()}
+    errs = {n: rel_err(p.grad.float(), g32[n]) for n, p in m.named_parameters()}
     assert np.median(list(errs.values())) < 1.5 * np.median(list(yard.values())) + 1e-2
     bad = [n for n in errs if errs[n] > 1.5 * yard[n] + 0.08]
     assert len(bad) <= 0.05 * len(errs), [(n, errs[n], yard[n]) for n in bad][:8]

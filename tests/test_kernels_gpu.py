@@ -1146,3 +1146,26 @@ def test_ocr_building_blocks(libs, images, n, k, c, pad):
     y = torch.empty(images * n, cp, dtype=BF16)
     dv = both(libs, 'tok_channel_scale', lambda d: [d(x), d(s), d(y), 0, images, n, c, cp, None])
     assert relerr(dv[id(y)].float(), y.float()) < 5e-3
+
+
+@pytest.mark.parametrize('n,h,w,c,ld', [(2, 8, 8, 96, 96), (1, 7, 9, 20, 24), (3, 14, 14, 384, 384)])
+def test_depthwise_3x3(libs, n, h, w, c, ld):
+    """ConvPosEnc.proj (davit.py:101-106): forward, data gradient (flipped taps), weight / bias gradient."""
+    x = rnd(n * h * w, ld).to(BF16)
+    x[:, c:] = 0
+    wt, b = rnd(c, 9, seed=1) * 0.3, rnd(c, seed=2)
+    out = torch.empty(n * h * w, ld, dtype=BF16)
+    dv = both(libs, 'tok_dwconv3x3', lambda d: [d(x), d(wt), d(b), d(out), 0, 0, n, h, w, c, ld, None])
+    ref = torch.nn.functional.conv2d(x.float().view(n, h, w, ld)[..., :c].permute(0, 3, 1, 2), wt.view(c, 1, 3, 3), b, padding=1,
+                                     groups=c).permute(0, 2, 3, 1).reshape(-1, c)
+    assert relerr(out.float()[:, :c], ref) < 5e-3 and relerr(dv[id(out)].float()[:, :c], ref) < 5e-3
+    g = rnd(n * h * w, ld, seed=3).to(BF16)
+    g[:, c:] = 0
+    dx = torch.empty(n * h * w, ld, dtype=BF16)
+    dv = both(libs, 'tok_dwconv3x3', lambda d: [d(g), d(wt), None, d(dx), 0, 1, n, h, w, c, ld, None])
+    assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
+    lib = libs[0]
+    part = torch.empty(lib.tok_dwconv3x3_wgrad_blocks(n, h), c, 10)
+    dw, db = torch.empty(c, 9), torch.empty(c)
+    dv = both(libs, 'tok_dwconv3x3_wgrad', lambda d: [d(x), d(g), n, h, w, c, ld, d(part), d(dw), d(db), 0, None])
+    assert relerr(dv[id(dw)], dw) < 1e-4 and relerr(dv[id(db)], db) < 1e-4

@@ -133,6 +133,9 @@ PROTOTYPES = {
     'tok_softmax_cols_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_float, _P, _P]),
     'tok_softmax_cols_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, c_int, c_int, _P]),
     'tok_channel_scale': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_dwconv3x3': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_dwconv3x3_wgrad_blocks': (c_int, [c_int, c_int]),
+    'tok_dwconv3x3_wgrad': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P]),
     'tok_sim_matrix': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     'tok_topk_rows': (c_int, [_P, c_int, c_int, c_int64, c_int, _P, _P, _P]),
     'tok_retrieval_nrel': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),

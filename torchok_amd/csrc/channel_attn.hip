@@ -178,3 +178,133 @@ extern "C" int tok_scale_rows_add(const void* a, const void* b, const float* row
   TOK_CHECK_LAUNCH("tok_scale_rows_add");
   return TOK_OK;
 }
+
+// ---- depthwise 3x3 / stride 1 / pad 1 convolution with bias (ConvPosEnc.proj, davit.py:101-106) -------------------------------
+// NHWC bf16, weights fp32 [C][3][3] (the master itself: 9 values per channel), thread = (pixel, 8 channels).
+namespace {
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, bf16* out, int accumulate, int flip,
+                                                        int N, int H, int W, int C, int ld) {
+  const int cg_total = ld >> 3;
+  const size_t total = (size_t)N * H * W * cg_total;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cg = (int)(i % cg_total);
+    size_t pix = i / cg_total;
+    const int wq = (int)(pix % W);
+    pix /= W;
+    const int hq = (int)(pix % H);
+    const int n = (int)(pix / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cg * 8 + e;
+      acc[e] = (bias != nullptr && c < C) ? bias[c] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hh = hq + r - 1;
+      if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ww = wq + s - 1;
+        if ((unsigned)ww >= (unsigned)W) continue;
+        const bf16x8 v = ldg16(x + (((size_t)n * H + hh) * W + ww) * ld + cg * 8);
+        const int tap = flip ? (2 - r) * 3 + (2 - s) : r * 3 + s;      // flip: the data gradient (correlation -> convolution)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = cg * 8 + e;
+          if (c < C) acc[e] = fmaf(bf2f(v[e]), w[c * 9 + tap], acc[e]);
+        }
+      }
+    }
+    const size_t off = (((size_t)n * H + hq) * W + wq) * ld + cg * 8;
+    bf16x8 o;
+    if (accumulate) {
+      const bf16x8 old = ldg16(out + off);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] + bf2f(old[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    }
+    stg16(out + off, o);
+  }
+}
+
+// partial[block][c][10]: 9 tap sums of x * dout and the sum of dout (bias gradient); one block per row chunk
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_partial_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dout,
+                                                                      int N, int H, int W, int C, int ld, int rows_per_block,
+                                                                      float* __restrict__ partial) {
+  // thread = (channel c = tid % Cb, row lane); channels beyond 256 handled by the cb loop
+  const int total_rows = N * H;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(total_rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[t] = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      const int n = row / H, hq = row - n * H;
+      for (int wq = 0; wq < W; ++wq) {
+        const float g = bf2f(dout[(((size_t)n * H + hq) * W + wq) * ld + c]);
+        acc[9] += g;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int hh = hq + r - 1;
+          if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const int ww = wq + s - 1;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            acc[r * 3 + s] = fmaf(g, bf2f(x[(((size_t)n * H + hh) * W + ww) * ld + c]), acc[r * 3 + s]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) partial[((size_t)blockIdx.x * C + c) * 10 + t] = acc[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_fold_kernel(const float* __restrict__ partial, int blocks, int C,
+                                                                   float* dw, float* db, int accumulate) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 10) return;
+  const int c = i / 10, t = i - c * 10;
+  double a = 0.0;
+  for (int b = 0; b < blocks; ++b) a += (double)partial[((size_t)b * C + c) * 10 + t];
+  float* dst = t < 9 ? (dw ? dw + c * 9 + t : nullptr) : (db ? db + c : nullptr);
+  if (dst) *dst = (float)a + (accumulate ? *dst : 0.f);
+}
+
+}  // namespace
+
+extern "C" int tok_dwconv3x3(const void* x, const float* w, const float* bias, void* out, int accumulate, int flip, int n, int h,
+                             int wd, int c, int ld, void* stream) {
+  TOK_CHECK_ARG(x && w && out && n > 0 && h > 0 && wd > 0 && c > 0 && ld >= c && (ld & 7) == 0, "tok_dwconv3x3: bad args");
+  const size_t total = (size_t)n * h * wd * (ld >> 3);
+  size_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)x, w, bias,
+                     (bf16*)out, accumulate, flip, n, h, wd, c, ld);
+  TOK_CHECK_LAUNCH("tok_dwconv3x3");
+  return TOK_OK;
+}
+
+extern "C" int tok_dwconv3x3_wgrad_blocks(int n, int h) { return n <= 0 || h <= 0 ? TOK_ERR_INVALID : (n * h < 1024 ? n * h : 1024); }
+
+extern "C" int tok_dwconv3x3_wgrad(const void* x, const void* dout, int n, int h, int wd, int c, int ld, float* partial,
+                                   float* dw, float* db, int accumulate, void* stream) {
+  TOK_CHECK_ARG(x && dout && partial && (dw || db) && n > 0 && h > 0 && wd > 0 && c > 0 && ld >= c,
+                "tok_dwconv3x3_wgrad: bad args");
+  const int blocks = tok_dwconv3x3_wgrad_blocks(n, h);
+  const int rpb = tok_cdiv(n * h, blocks);
+  hipStream_t st = tok_stream(stream);
+  hipLaunchKernelGGL(dwconv3x3_wgrad_partial_kernel, dim3(tok_cdiv(n * h, rpb)), dim3(256), 0, st, (const bf16*)x,
+                     (const bf16*)dout, n, h, wd, c, ld, rpb, partial);
+  TOK_CHECK_LAUNCH("tok_dwconv3x3_wgrad(partial)");
+  hipLaunchKernelGGL(dwconv3x3_wgrad_fold_kernel, dim3(tok_cdiv(c * 10, 256)), dim3(256), 0, st, partial,
+                     tok_cdiv(n * h, rpb), c, dw, db, accumulate);
+  TOK_CHECK_LAUNCH("tok_dwconv3x3_wgrad(fold)");
+  return TOK_OK;
+}

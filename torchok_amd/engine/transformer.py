@@ -576,3 +576,59 @@ def residual_add(region: Region, a: TTensor, b: TTensor, row_scale: Optional[tor
             b.uses += 1
         region.add(node)
     return out
+
+
+# ---- DaViT ConvPosEnc with activation: depthwise 3x3 + bias ------------------------------------------------------------------
+class _DwConvNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        g = self.out.grad
+        if g is None:
+            return
+        x, conv = self.x, self.conv
+        n, h, w, ld = x.shape
+        w_need, b_need = conv.weight.requires_grad, conv.bias is not None and conv.bias.requires_grad
+        if w_need or b_need:
+            blocks = lib.tok_dwconv3x3_wgrad_blocks(n, h)
+            partial = torch.empty((blocks, x.c, 10), dtype=F32, device=g.device)
+            ws, wm = param_grad_target(conv.weight) if w_need else (None, 0)
+            bs, bm = param_grad_target(conv.bias) if b_need else (None, 0)
+            if wm == 2 or bm == 2 or (w_need and b_need and wm != bm):
+                raise NotImplementedError('dwconv3x3: foreign .grad tensors on the depthwise parameters')
+            _C.check(lib.tok_dwconv3x3_wgrad(ptr(x.data), ptr(g), n, h, w, x.c, ld, ptr(partial), ptr(ws), ptr(bs),
+                                             1 if (wm == 1 or bm == 1) else 0, st), 'tok_dwconv3x3_wgrad')
+            if w_need:
+                commit_param_grad(conv.weight, ws, wm)
+            if b_need:
+                commit_param_grad(conv.bias, bs, bm)
+        if x.requires_grad:
+            tgt, acc = grad_target(x)
+            _C.check(lib.tok_dwconv3x3(ptr(g), ptr(conv.weight), None, ptr(tgt), acc, 1, n, h, w, x.c, ld, st), 'tok_dwconv3x3')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def dwconv3x3(region: Region, x: TTensor, conv: nn.Conv2d) -> TTensor:
+    """Depthwise 3x3 / stride 1 / pad 1 convolution (+ bias) on a (B, H, W, C) map."""
+    c = x.c
+    if (conv.groups != c or conv.in_channels != c or conv.out_channels != c or tuple(conv.kernel_size) != (3, 3) or
+            tuple(conv.stride) != (1, 1) or tuple(conv.padding) != (1, 1) or not conv.weight.is_contiguous()):
+        raise NotImplementedError('dwconv3x3: depthwise 3x3, stride 1, padding 1')
+    n, h, w, ld = x.shape
+    y = torch.empty_like(x.data)
+    _C.check(_C.lib().tok_dwconv3x3(ptr(x.data), ptr(conv.weight), ptr(conv.bias), ptr(y), 0, 0, n, h, w, c, ld, stream_ptr()),
+             'tok_dwconv3x3')
+    req = region.grad_mode and (x.requires_grad or conv.weight.requires_grad)
+    out = TTensor(y, c, requires_grad=req)
+    if req:
+        node = _DwConvNode()
+        node.x, node.out, node.conv = x, out, conv
+        out.node = node
+        if x.requires_grad:
+            x.uses += 1
+        region.add(node)
+    return out

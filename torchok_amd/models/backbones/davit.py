@@ -13,8 +13,8 @@ arithmetic inside the attention kernel; the channel attention streams the token 
 ``ConvPosEnc`` as shipped: with ``use_act=False`` (the default of every entrypoint) its forward computes the depthwise
 convolution and then returns the INPUT unchanged (:124-128: the sum is inside ``if self.activation is not None``), so
 ``cpe.*.proj`` never influences the output and never receives a gradient.  The same holds here — the parameters
-exist (checkpoint compatibility), nothing is computed.  ``cpe_act=True`` would need a depthwise convolution kernel and
-raises NotImplementedError.
+exist (checkpoint compatibility), nothing is computed.  With ``cpe_act=True`` the depthwise 3x3 convolution runs
+(``engine.transformer.dwconv3x3``) and ``x + GELU(conv(x))`` is what the block sees.
 """
 import itertools
 import logging
@@ -63,19 +63,24 @@ class PatchEmbed(nn.Module):
 
 
 class ConvPosEnc(nn.Module):
-    """Parameters only — see the module docstring."""
+    """davit.py:89-128.  Without activation: parameters only (see the module docstring).  With it:
+    x + GELU(depthwise3x3(x)) on the (B, H, W, C) view of the tokens."""
 
     def __init__(self, dim: int, kernel_size: int = 3, use_act: bool = False, norm_layer: Optional[str] = None):
         super().__init__()
-        if use_act:
-            raise NotImplementedError('torchok_amd DaViT: cpe_act=True needs a depthwise convolution kernel')
+        if kernel_size != 3 or norm_layer is not None:
+            raise NotImplementedError('torchok_amd DaViT ConvPosEnc: kernel 3, no normalisation (what the blocks use)')
         self.proj = nn.Conv2d(dim, dim, kernel_size, 1, kernel_size // 2, groups=dim)
         self.norm_layer = norm_layer
-        if norm_layer == 'batch':
-            self.norm = nn.BatchNorm2d(dim)
-        elif norm_layer == 'layer':
-            self.norm = nn.LayerNorm(dim)
-        self.activation = None
+        self.activation = nn.GELU() if use_act else None
+
+    def run(self, r, x, batch: int, size: Tuple[int, int]):
+        if self.activation is None:
+            return x                                            # :124-128: the sum sits inside `if self.activation`
+        h, w = size
+        feat = ET.dwconv3x3(r, ET.reshape(r, x, (batch, h, w, x.cp)), self.proj)
+        feat = ET.activation(r, ET.reshape(r, feat, (batch * h * w, x.cp)), ET.GELU)
+        return ET.residual_add(r, x, feat)
 
 
 class ChannelAttention(nn.Module):
@@ -111,9 +116,11 @@ class WindowAttention(nn.Module):
 class _Block(nn.Module):
     """x = x + drop_path(attn(norm1(x)));  x = x + drop_path(mlp(norm2(x)))  with the two (inert) ConvPosEnc in between."""
 
-    def _tail(self, r, x, cur, batch: int, tokens: int):
+    def _tail(self, r, x, cur, batch: int, size: Tuple[int, int]):
         dev = x.data.device
+        tokens = size[0] * size[1]
         x = ET.residual_add(r, x, cur, _scale_of(self.drop_path, batch, dev), tokens)
+        x = self.cpe[1].run(r, x, batch, size)
         if self.ffn:
             m = self.mlp.run(r, ET.layer_norm(r, x, self.norm2))
             x = ET.residual_add(r, x, m, _scale_of(self.drop_path, batch, dev), tokens)
@@ -137,8 +144,9 @@ class ChannelBlock(_Block):
 
     def run(self, r, x, batch: int, size: Tuple[int, int]):
         tokens = size[0] * size[1]
+        x = self.cpe[0].run(r, x, batch, size)
         cur = self.attn.run(r, ET.layer_norm(r, x, self.norm1), batch, tokens)
-        return self._tail(r, x, cur, batch, tokens)
+        return self._tail(r, x, cur, batch, size)
 
 
 class SpatialBlock(_Block):
@@ -161,8 +169,9 @@ class SpatialBlock(_Block):
         if h % self.window_size or w % self.window_size:
             raise NotImplementedError(f'torchok_amd DaViT SpatialBlock: {h}x{w} tokens are not a multiple of the window '
                                       f'{self.window_size} (the zero-padded windows of davit.py:336-340 are not provided)')
+        x = self.cpe[0].run(r, x, batch, size)
         cur = self.attn.run(r, ET.layer_norm(r, x, self.norm1), batch, size, self.window_size)
-        return self._tail(r, x, cur, batch, h * w)
+        return self._tail(r, x, cur, batch, size)
 
 
 class DaViT(BaseBackbone):
