@@ -174,8 +174,12 @@ def main():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # TOK_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, bucketed gradient all-reduce, barriers) with one
+    # rank — the way to exercise it on a 1-GPU box; the numbers it prints include the reducer's overhead
+    dist_on = world > 1 or os.environ.get('TOK_BENCH_FORCE_DIST') == '1'
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     import __graft_entry__ as ge
@@ -193,7 +197,7 @@ def main():
             else build_task(args.backbone, args.classes)).cuda().train()
     opt = task.configure_optimizers()[0]['optimizer']
     reducer = None
-    if world > 1:
+    if dist_on:
         from torchok_amd.dist import GradientAllReducer
         reducer = GradientAllReducer(opt)
 
@@ -225,7 +229,7 @@ def main():
     for i in range(args.warmup):
         loss = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -235,13 +239,13 @@ def main():
         loss = step(args.warmup + i)
         evs[i + 1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
-    final_loss = float(loss)
-    if world > 1:
+    final_loss = float(loss.detach())
+    if dist_on:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -291,7 +295,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
