@@ -242,6 +242,16 @@ int tok_dice_fwd(const void* logits, const void* target, int64_t rows, int class
 int tok_dice_bwd(const void* logits, const void* target, const float* coef, const float* gscale, int64_t rows,
                  int classes, int ld, int mode, void* dlogits, void* stream);
 
+/* BCEWithLogitsLoss with an ignore value (losses/classification/binary_cross_entropy.py:13-59; its forward :50-59 drops
+ * the elements whose target equals ignore_index, then F.binary_cross_entropy_with_logits over the rest, 'mean' or 'sum';
+ * nothing selected -> 0).  logits bf16 [rows][ld], target fp32 [rows][classes] (dense), loss as in tok_softmax_ce_fwd:
+ * TOK_CE_LOSS_FLOATS floats, [0] = loss, [1] = number of selected elements.
+ * backward: dlogits bf16 [rows][ld] = (sigmoid(x) - t) * gscale[0] / (mean ? n_selected : 1), 0 elsewhere.          */
+int tok_bce_logits_fwd(const void* logits, const float* target, int64_t rows, int classes, int ld,
+                       float ignore_value, int mean, float* loss, void* stream);
+int tok_bce_logits_bwd(const void* logits, const float* target, const float* loss, const float* gscale,
+                       int64_t rows, int classes, int ld, float ignore_value, int mean, void* dlogits, void* stream);
+
 /* On-device classification statistics behind the Accuracy / F1Score metrics the reference configs log every step
  * (metrics/metrics_manager.py:147-158, classification_cifar10.yaml:134-150; torchmetrics itself is third-party):
  * counts int64 [3][classes] += {true positives, predicted, actual} per class.  Predictions are bf16 logits

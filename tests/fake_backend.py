@@ -737,6 +737,27 @@ class FakeTok:
         d[:, :classes] = _bf(dz * g)
         return 0
 
+    def tok_bce_logits_fwd(self, logits, target, rows, classes, ld, ignore_value, mean, loss, st):
+        x = _t(logits, (rows, ld), BF16).float()[:, :classes]
+        t = _t(target, (rows, classes), torch.float32)
+        sel = t != ignore_value
+        el = ((1 - t) * x - torch.nn.functional.logsigmoid(x))[sel].double()
+        o = _t(loss, (2,), torch.float32)
+        n = int(sel.sum())
+        o[0] = float((el.sum() / n if mean else el.sum())) if n else 0.0
+        o[1] = float(n)
+        return 0
+
+    def tok_bce_logits_bwd(self, logits, target, loss, gscale, rows, classes, ld, ignore_value, mean, dlogits, st):
+        x = _t(logits, (rows, ld), BF16).float()[:, :classes]
+        t = _t(target, (rows, classes), torch.float32)
+        n = float(_t(loss, (2,), torch.float32)[1])
+        g = float(_t(gscale, (1,), torch.float32)[0]) * ((1.0 / n if n else 0.0) if mean else 1.0)
+        d = _t(dlogits, (rows, ld), BF16)
+        d.zero_()
+        d[:, :classes] = _bf(torch.where(t != ignore_value, (torch.sigmoid(x) - t) * g, torch.zeros(())))
+        return 0
+
     # ---- metric-learning head / loss ---------------------------------------------------------------
     def tok_l2norm_fwd(self, x, y, inv_norm, rows, c, ld, is_f32, eps, st):
         dt = torch.float32 if is_f32 else BF16

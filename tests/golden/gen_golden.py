@@ -397,6 +397,36 @@ def golden_dice(out_path):
     print('wrote', out_path)
 
 
+def golden_bce(out_path):
+    """BCEWithLogitsLoss (ignore value) outputs and input gradients from the reference's own
+    losses/classification/binary_cross_entropy.py (imports as is: torch + the registry)."""
+    _fake_pkg('torchok.losses.classification', f'{REF}/losses/classification')
+    mod = _load('torchok.losses.classification.binary_cross_entropy', f'{REF}/losses/classification/binary_cross_entropy.py')
+    g = torch.Generator().manual_seed(91)
+    out = {}
+    x = (torch.randn(37, 21, generator=g) * 3).bfloat16().float()          # 21 classes: row pitch 24 on the device
+    t = (torch.rand(37, 21, generator=g) < 0.3).float()
+    t[torch.rand(37, 21, generator=g) < 0.25] = -1                         # ignored labels
+    x4 = (torch.randn(2, 5, 6, 8, generator=g) * 2).bfloat16().float()     # any shape goes through the mask
+    t4 = (torch.rand(2, 5, 6, 8, generator=g) < 0.5).float()
+    t4[torch.rand(2, 5, 6, 8, generator=g) < 0.1] = -1
+    for tag, (xi, ti) in (('a', (x, t)), ('b', (x4, t4))):
+        for red in ('mean', 'sum'):
+            xv = xi.clone().requires_grad_(True)
+            L = mod.BCEWithLogitsLoss(reduction=red)(xv, ti)
+            L.backward()
+            out[f'{tag}_{red}_loss'], out[f'{tag}_{red}_dx'] = float(L.detach()), xv.grad.numpy()
+    xv = x.clone().requires_grad_(True)
+    L = mod.BCEWithLogitsLoss(ignore_index=0)(xv, t.clamp_min(0))          # ignoring the negatives: only t == 1 counts
+    L.backward()
+    out['ign0_loss'], out['ign0_dx'] = float(L.detach()), xv.grad.numpy()
+    L = mod.BCEWithLogitsLoss()(x, torch.full_like(t, -1))                 # nothing selected -> 0 (:58-59)
+    out['empty_loss'] = float(L)
+    out.update(x=x.numpy(), t=t.numpy(), x4=x4.numpy(), t4=t4.numpy())
+    np.savez_compressed(out_path, **out)
+    print('wrote', out_path)
+
+
 def golden_unsupervised(out_path):
     """NT_XentLoss from the reference's own losses/representation/unsupervised.py; TripletMarginLoss is torch's class
     (what the reference registers, losses/__init__.py:39)."""
@@ -711,6 +741,8 @@ def main():
         return golden_metric(os.path.join(gd, 'metric_heads.npz'))
     if '--unsup-only' in sys.argv:
         return golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
+    if '--bce-only' in sys.argv:
+        return golden_bce(os.path.join(gd, 'bce_loss.npz'))
     if '--dice-only' in sys.argv:
         return golden_dice(os.path.join(gd, 'dice_loss.npz'))
     if '--ocr-only' in sys.argv:
@@ -730,6 +762,7 @@ def main():
     golden_davit(os.path.join(gd, 'davit_cls_step.npz'))
     golden_ocr(os.path.join(gd, 'ocr_head_step.npz'))
     golden_dice(os.path.join(gd, 'dice_loss.npz'))
+    golden_bce(os.path.join(gd, 'bce_loss.npz'))
     golden_unsupervised(os.path.join(gd, 'unsupervised_losses.npz'))
     golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))
 

@@ -84,6 +84,8 @@ PROTOTYPES = {
     'tok_dice_rows': (c_int, [c_int64]),
     'tok_dice_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_int, _P, c_int, _P, _P, _P, _P]),
     'tok_dice_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P]),
+    'tok_bce_logits_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, c_float, c_int, _P, _P]),
+    'tok_bce_logits_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P, _P]),
     'tok_cls_stats_update': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P]),
     'tok_l2norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'tok_l2norm_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -353,6 +353,101 @@ extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, con
 }
 
 namespace {
+// BCEWithLogitsLoss with an ignore value (losses/classification/binary_cross_entropy.py:50-59): elements whose target
+// equals `ignore` are dropped, the rest take  (1 - t) x - log_sigmoid(x)  in fp32 (ATen's formula), mean or sum.
+// Stage 1: one contiguous chunk of the row-major element range per block -> (sum, count) doubles; stage 2 folds them in
+// fixed order.  Element e lives at logits[(e / classes) * ld + e % classes].
+__device__ __forceinline__ float bce_elem(float x, float t) {
+  const float ls = fminf(x, 0.f) - log1pf(expf(-fabsf(x)));   // log_sigmoid(x)
+  return (1.f - t) * x - ls;
+}
+
+__global__ __launch_bounds__(256) void bce_partial_kernel(const bf16* __restrict__ logits, const float* __restrict__ target,
+                                                          int64_t n, int classes, int ld, float ignore, int64_t chunk,
+                                                          double* __restrict__ part) {
+  const int64_t e0 = (int64_t)blockIdx.x * chunk;
+  const int64_t e1 = e0 + chunk < n ? e0 + chunk : n;
+  double s = 0.0, cnt = 0.0;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const float t = target[e];
+    if (t != ignore) {
+      const int64_t r = e / classes;
+      const int c = (int)(e - r * classes);
+      s += (double)bce_elem(bf2f(logits[r * ld + c]), t);
+      cnt += 1.0;
+    }
+  }
+  block_reduce2(s, cnt);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void bce_final_kernel(const double* __restrict__ part, int nparts, int mean, float* loss) {
+  double s = 0.0, cnt = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) { s += part[2 * i]; cnt += part[2 * i + 1]; }
+  block_reduce2(s, cnt);
+  if (threadIdx.x == 0) {
+    // nothing selected: the reference returns a zero (binary_cross_entropy.py:58-59), not 0/0
+    loss[0] = cnt > 0.0 ? (float)(mean ? s / cnt : s) : 0.f;
+    loss[1] = (float)cnt;
+  }
+}
+
+// d loss / d x = (sigmoid(x) - t) * gscale / (mean ? n_valid : 1) on the selected elements, 0 elsewhere and in the pad
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const bf16* __restrict__ logits, const float* __restrict__ target,
+                                                      const float* __restrict__ loss, const float* __restrict__ gscale,
+                                                      int64_t rows, int classes, int ld, float ignore, int mean,
+                                                      bf16* __restrict__ dlogits) {
+  const float nv = loss[1];
+  const float g = gscale[0] * (mean ? (nv > 0.f ? 1.f / nv : 0.f) : 1.f);
+  const int64_t total = rows * ld;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / ld;
+    const int c = (int)(i - r * ld);
+    float d = 0.f;
+    if (c < classes) {
+      const float t = target[r * classes + c];
+      if (t != ignore) {
+        const float x = bf2f(logits[i]);
+        d = (1.f / (1.f + expf(-x)) - t) * g;
+      }
+    }
+    dlogits[i] = f2bf(d);
+  }
+}
+}  // namespace
+
+extern "C" int tok_bce_logits_fwd(const void* logits, const float* target, int64_t rows, int classes, int ld,
+                                  float ignore_value, int mean, float* loss, void* stream) {
+  TOK_CHECK_ARG(logits && target && loss, "tok_bce_logits_fwd: null pointer");
+  TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_bce_logits_fwd: bad sizes");
+  TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_bce_logits_fwd: loss must be 8-byte aligned");
+  hipStream_t st = tok_stream(stream);
+  double* part = reinterpret_cast<double*>(loss + 2);   // loss holds TOK_CE_LOSS_FLOATS floats
+  const int64_t n = rows * classes;
+  const int nparts = n < 8192 ? 1 : (int)(tok_cdiv(n, (int64_t)8192) < CE_PARTS ? tok_cdiv(n, (int64_t)8192) : CE_PARTS);
+  const int64_t chunk = tok_cdiv(n, (int64_t)nparts);
+  hipLaunchKernelGGL(bce_partial_kernel, dim3(nparts), dim3(256), 0, st, (const bf16*)logits, target, n, classes, ld,
+                     ignore_value, chunk, part);
+  TOK_CHECK_LAUNCH("tok_bce_logits_fwd(partial)");
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, part, nparts, mean, loss);
+  TOK_CHECK_LAUNCH("tok_bce_logits_fwd(final)");
+  return TOK_OK;
+}
+
+extern "C" int tok_bce_logits_bwd(const void* logits, const float* target, const float* loss, const float* gscale,
+                                  int64_t rows, int classes, int ld, float ignore_value, int mean, void* dlogits,
+                                  void* stream) {
+  TOK_CHECK_ARG(logits && target && loss && gscale && dlogits, "tok_bce_logits_bwd: null pointer");
+  TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_bce_logits_bwd: bad sizes");
+  const int64_t total = rows * ld;
+  const int blocks = (int)(tok_cdiv(total, (int64_t)256) < 4096 ? tok_cdiv(total, (int64_t)256) : 4096);
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(blocks), dim3(256), 0, tok_stream(stream), (const bf16*)logits, target, loss,
+                     gscale, rows, classes, ld, ignore_value, mean, (bf16*)dlogits);
+  TOK_CHECK_LAUNCH("tok_bce_logits_bwd");
+  return TOK_OK;
+}
+
+namespace {
 // classification statistics for the on-device metrics: per class c: counts[0][c] += [argmax == c == target],
 // counts[1][c] += [argmax == c], counts[2][c] += [target == c]  (int64 atomics: exact, order-independent)
 __global__ __launch_bounds__(256) void cls_stats_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
