@@ -285,6 +285,13 @@ int tok_contrastive_bwd(const void* e1, const void* e2, const float* R, const fl
                         const float* gscale, int n1, int n2, int d, int ld, float margin, void* de1,
                         void* de2, int same_tensor, void* stream);
 
+/* BasePairwiseLoss.regularize (pairwise.py:28-46) on the first embedding matrix, bf16 [n][ld]: mode 1 'L1' reg_i = sum_c |e_ic|,
+ * mode 2 'L2' reg_i = ||e_i||_2; row_reg fp32 [n] (saved), out[0] = mean_i reg_i.
+ * backward: de bf16 [n][ld] = gscale[0] * coeff * (sign(e) | e / reg_i), pad columns zero.                       */
+int tok_embed_reg_fwd(const void* e, int n, int d, int ld, int mode, float* row_reg, float* out, void* stream);
+int tok_embed_reg_bwd(const void* e, const float* row_reg, const float* gscale, float coeff, int n, int d, int ld,
+                      int mode, void* de, void* stream);
+
 /* ---- multi-resolution glue (HRNet) ------------------------------------------------------------
  * [timm 0.6.13] HighResolutionModule.forward: out = relu(sum_j up_j(t_j)), where term j is an NHWC
  * bf16 tensor at (h >> s_j, w >> s_j) and up_j the nearest-neighbour nn.Upsample(scale_factor=2^s_j)

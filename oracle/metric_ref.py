@@ -48,8 +48,14 @@ def relevance_matrix(y, num_classes):
     return torch.where(inter > 0, 1., 0.)
 
 
-def contrastive_loss(emb1, emb2, R, margin, reduction='mean'):
-    """pairwise.py:126-136 + :48-64 (reg=None)."""
+def contrastive_loss(emb1, emb2, R, margin, reduction='mean', reg=None, eps=1e-3):
+    """pairwise.py:126-136 (calc_loss) + :28-46 (regularize: eps * sum|emb1| or eps * ||emb1||_2 per row) + :48-64."""
     S = torch.cdist(emb1, emb2, p=2)
     L = ((1. - R) * F.relu(margin - S).pow(2) + R * S.pow(2)).sum(1)
+    if reg == 'L1':
+        L = L + eps * emb1.abs().sum(1)
+    elif reg == 'L2':
+        L = L + eps * torch.norm(emb1, p=None, dim=1)
+    elif reg is not None:
+        raise ValueError(f'Unknown regularization type: {reg}')
     return L.mean() if reduction == 'mean' else L.sum()

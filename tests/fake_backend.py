@@ -815,6 +815,23 @@ class FakeTok:
         _t(R, (na, nb), torch.float32).copy_((a[:, None] == b[None, :]).float())
         return 0
 
+    def tok_embed_reg_fwd(self, e, n, d, ld, mode, row_reg, out, st):
+        x = _t(e, (n, ld), BF16).float()[:, :d]
+        rr = x.abs().sum(1) if mode == 1 else x.pow(2).sum(1).sqrt()
+        _t(row_reg, (n,), torch.float32).copy_(rr)
+        _t(out, (1,), torch.float32)[0] = float(rr.double().mean())
+        return 0
+
+    def tok_embed_reg_bwd(self, e, row_reg, gscale, coeff, n, d, ld, mode, de, st):
+        x = _t(e, (n, ld), BF16).float()[:, :d]
+        g = float(_t(gscale, (1,), torch.float32)[0]) * coeff
+        rr = _t(row_reg, (n,), torch.float32)
+        v = torch.sign(x) * g if mode == 1 else torch.where(rr[:, None] > 0, g * x / rr[:, None], torch.zeros(()))
+        out = _t(de, (n, ld), BF16)
+        out.zero_()
+        out[:, :d] = _bf(v)
+        return 0
+
     def tok_contrastive_fwd(self, e1, e2, R, n1, n2, d, ld, margin, S, row_loss, loss, st):
         a = _t(e1, (n1, ld), BF16)[:, :d].float()
         b = _t(e2, (n2, ld), BF16)[:, :d].float()

@@ -521,6 +521,13 @@ def golden_metric(out_path):
     R2 = (lab[:, None] == lab2[None, :]).float()
     L2 = cl(emb1=e1, emb2=e2, R=R2)
     L2.backward()
+    for tag, kw in (('l1', dict(reg='L1')), ('l2', dict(reg='L2', eps=0.05)), ('sum', dict(reduction='sum')),
+                    ('l1sum', dict(reg='L1', reduction='sum', eps=0.01))):
+        ei = e.detach().clone().requires_grad_(True)
+        Lr = pw.ContrastiveLoss(margin=1.0, **kw)(emb1=ei, emb2=ei, R=R)
+        Lr.backward()
+        assert torch.equal(Lr.detach(), M.contrastive_loss(e.detach(), e.detach(), R, 1.0, **kw))
+        out[f'con_{tag}_loss'], out[f'con_{tag}_de'] = float(Lr), ei.grad.numpy()
     out.update(con_lab=lab.numpy(), con_R=R.numpy(), con_e=e.detach().numpy(), con_loss=float(L), con_de=e.grad.numpy(),
                con_e2=e2.detach().numpy(), con_R2=R2.numpy(), con_loss2=float(L2), con_de1=e1.grad.numpy(),
                con_de2=e2.grad.numpy())

@@ -521,6 +521,38 @@ def test_contrastive(libs, n1, n2, dim, ld, same):
         assert relerr(dv[id(de2)].float(), de2.float()) < 6e-3
 
 
+@pytest.mark.parametrize('n,dim,ld,mode', [(16, 24, 24, 1), (33, 20, 24, 2), (512, 512, 512, 2), (7, 100, 104, 1)])
+def test_embed_regulariser(libs, n, dim, ld, mode):
+    e = torch.zeros(n, ld)
+    e[:, :dim] = rnd(n, dim, seed=n)
+    e[0] = 0                                   # a zero row: the L2 gradient is defined as 0 there
+    e = e.to(BF16)
+    rr, out = torch.empty(n), torch.empty(1)
+    dv = both(libs, 'tok_embed_reg_fwd', lambda d: [d(e), n, dim, ld, mode, d(rr), d(out), None])
+    assert relerr(dv[id(rr)], rr) < 1e-5 and relerr(dv[id(out)], out) < 1e-5
+    gs, de = torch.tensor([0.3]), torch.empty(n, ld, dtype=BF16)
+    dv = both(libs, 'tok_embed_reg_bwd', lambda d: [d(e), d(rr), d(gs), 1.0 / n, n, dim, ld, mode, d(de), None])
+    assert relerr(dv[id(de)].float(), de.float()) < 6e-3
+    assert float(dv[id(de)][0].abs().max()) == 0.0 and (ld == dim or float(dv[id(de)][:, dim:].abs().max()) == 0.0)
+
+
+@pytest.mark.parametrize('rows,classes,ld,mean', [(37, 21, 24, 1), (4096, 80, 80, 1), (5, 1, 8, 0), (100000, 19, 24, 0)])
+def test_bce_logits_ignore(libs, rows, classes, ld, mean):
+    z = torch.zeros(rows, ld)
+    z[:, :classes] = rnd(rows, classes, scale=3.0, seed=rows)
+    z = z.to(BF16)
+    g = torch.Generator().manual_seed(classes)
+    tgt = (torch.rand(rows, classes, generator=g) < 0.3).float()
+    tgt[torch.rand(rows, classes, generator=g) < 0.2] = -1
+    loss = torch.empty(2050)
+    dv = both(libs, 'tok_bce_logits_fwd', lambda d: [d(z), d(tgt), rows, classes, ld, -1.0, mean, d(loss), None])
+    assert relerr(dv[id(loss)][:2], loss[:2]) < 2e-6 and float(dv[id(loss)][1]) == float((tgt != -1).sum())
+    gs, dz = torch.tensor([1.3]), torch.empty(rows, ld, dtype=BF16)
+    dv = both(libs, 'tok_bce_logits_bwd', lambda d: [d(z), d(tgt), d(loss), d(gs), rows, classes, ld, -1.0, mean, d(dz), None])
+    assert relerr(dv[id(dz)].float(), dz.float()) < 6e-3
+    assert ld == classes or float(dv[id(dz)][:, classes:].abs().max()) == 0.0
+
+
 # ---- multi-resolution glue (resample.hip) ------------------------------------------------------------------
 @pytest.mark.parametrize('n,h,w,c,shifts,relu', [(2, 16, 16, 16, (0, 1, 2, 3), 1), (2, 8, 24, 48, (0, 0, 1), 1),
                                                (1, 32, 32, 32, (0, 0), 1), (3, 8, 8, 64, (0, 2), 0)])

@@ -138,6 +138,23 @@ def test_contrastive_loss_memory_bank(dev):
         T.LOSSES.get('ContrastiveLoss')(margin=1.0, reduction='max')
 
 
+@pytest.mark.parametrize('tag,kw', [('l1', dict(reg='L1')), ('l2', dict(reg='L2', eps=0.05)), ('sum', dict(reduction='sum')),
+                                    ('l1sum', dict(reg='L1', reduction='sum', eps=0.01))])
+def test_contrastive_regularisers_and_sum(dev, tag, kw):
+    """BasePairwiseLoss.regularize / apply_reduction (pairwise.py:28-64) against the reference's own outputs + gradients."""
+    e = t(GOLD['con_e'], dev).to(torch.bfloat16).requires_grad_(True)
+    R = t(GOLD['con_R'], dev)
+    loss = T.LOSSES.get('ContrastiveLoss')(margin=1.0, **kw)(emb1=e, emb2=e, R=R)
+    er = e.detach().float().cpu().requires_grad_(True)          # oracle at the bf16-rounded embeddings: kernel error only
+    lo = M.contrastive_loss(er, er, R.cpu(), 1.0, **kw)
+    lo.backward()
+    assert abs(float(loss.detach()) - float(lo)) < 1e-4 * float(lo)
+    assert abs(float(loss.detach()) - float(GOLD[f'con_{tag}_loss'])) < 2e-2 * float(GOLD[f'con_{tag}_loss'])
+    loss.backward()
+    assert rel_err(e.grad.float(), er.grad) < 1e-2
+    assert rel_err(e.grad.float(), torch.from_numpy(GOLD[f'con_{tag}_de'])) < 3e-2
+
+
 def _pairwise_cfg():
     from torchok_amd.constructor.config import apply_schema
     return apply_schema({

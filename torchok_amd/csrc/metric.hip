@@ -344,6 +344,62 @@ extern "C" int tok_arcface_margin_bwd(const void* cosine, const int64_t* target,
   return TOK_OK;
 }
 
+namespace {
+// BasePairwiseLoss.regularize (pairwise.py:28-46): per embedding row sum|e| ('L1') or ||e||_2 ('L2'); a wavefront per row
+__global__ __launch_bounds__(256) void embed_reg_fwd_kernel(const bf16* __restrict__ e, int n, int d, int ld, int mode,
+                                                            float* __restrict__ row_reg) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = bf2f(e[(size_t)row * ld + c]);
+    s += mode == 1 ? fabsf(v) : v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) row_reg[row] = mode == 1 ? s : sqrtf(s);
+}
+
+// d reg_i / d e_ic = sign(e_ic) ('L1') or e_ic / ||e_i|| ('L2', 0 for a zero row), times gscale * coeff; pad columns zeroed
+__global__ __launch_bounds__(256) void embed_reg_bwd_kernel(const bf16* __restrict__ e, const float* __restrict__ row_reg,
+                                                            const float* __restrict__ gscale, float coeff, int n, int d,
+                                                            int ld, int mode, bf16* __restrict__ de) {
+  const float g = gscale[0] * coeff;
+  const size_t total = (size_t)n * ld;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / ld);
+    const int c = (int)(i - (size_t)row * ld);
+    float v = 0.f;
+    if (c < d) {
+      const float x = bf2f(e[i]);
+      if (mode == 1) v = x > 0.f ? g : (x < 0.f ? -g : 0.f);
+      else { const float nr = row_reg[row]; v = nr > 0.f ? g * x / nr : 0.f; }
+    }
+    de[i] = f2bf(v);
+  }
+}
+}  // namespace
+
+extern "C" int tok_embed_reg_fwd(const void* e, int n, int d, int ld, int mode, float* row_reg, float* out, void* stream) {
+  TOK_CHECK_ARG(e && row_reg && out && n > 0 && d > 0 && ld >= d && (mode == 1 || mode == 2), "tok_embed_reg_fwd: bad args");
+  hipStream_t st = tok_stream(stream);
+  hipLaunchKernelGGL(embed_reg_fwd_kernel, dim3((n + 3) / 4), dim3(256), 0, st, (const bf16*)e, n, d, ld, mode, row_reg);
+  TOK_CHECK_LAUNCH("tok_embed_reg_fwd");
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_reg, n, out);
+  TOK_CHECK_LAUNCH("tok_embed_reg_fwd(mean)");
+  return TOK_OK;
+}
+
+extern "C" int tok_embed_reg_bwd(const void* e, const float* row_reg, const float* gscale, float coeff, int n, int d,
+                                 int ld, int mode, void* de, void* stream) {
+  TOK_CHECK_ARG(e && row_reg && gscale && de && n > 0 && d > 0 && ld >= d && (mode == 1 || mode == 2),
+                "tok_embed_reg_bwd: bad args");
+  hipLaunchKernelGGL(embed_reg_bwd_kernel, dim3(grid_for((size_t)n * ld)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)e, row_reg, gscale, coeff, n, d, ld, mode, (bf16*)de);
+  TOK_CHECK_LAUNCH("tok_embed_reg_bwd");
+  return TOK_OK;
+}
+
 extern "C" int tok_relevance_matrix(const int64_t* labels_a, const int64_t* labels_b, int na, int nb, float* R,
                                     void* stream) {
   TOK_CHECK_ARG(labels_a && labels_b && R && na > 0 && nb > 0, "tok_relevance_matrix: bad args");

@@ -18,6 +18,8 @@ F32 = torch.float32
 
 
 def _geo(x: TTensor):
+    if len(x.shape) == 2:             # (rows, channels) embeddings: one pixel per row
+        return x.shape[0], 1, x.shape[1]
     n, h, w, cp = x.shape
     return n, h * w, cp
 

@@ -73,20 +73,60 @@ class _Contrastive(torch.autograd.Function):
         return fin(de1, dt1), fin(de2, dt2), None, None
 
 
+class _EmbedReg(torch.autograd.Function):
+    """mean_i reg_i of BasePairwiseLoss.regularize (pairwise.py:28-46): 'L1' sum|e_i| or 'L2' ||e_i||_2."""
+
+    @staticmethod
+    def forward(ctx, emb: Tensor, mode: int):
+        require_device(emb)
+        e = emb.detach()
+        if e.dtype != BF16 or e.stride(1) != 1:
+            e = e.to(BF16).contiguous()
+        n, d = e.shape
+        row_reg = torch.empty(n, dtype=torch.float32, device=e.device)
+        out = torch.empty(1, dtype=torch.float32, device=e.device)
+        _C.check(_C.lib().tok_embed_reg_fwd(ptr(e), n, d, e.stride(0), mode, ptr(row_reg), ptr(out), stream_ptr()),
+                 'tok_embed_reg_fwd')
+        ctx.saved = (e, row_reg, mode, emb.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        e, row_reg, mode, dt = ctx.saved
+        n, d = e.shape
+        ld = pad8(d)
+        if e.stride(0) != ld:
+            ec = torch.zeros((n, ld), dtype=BF16, device=e.device)
+            ec[:, :d] = e
+        else:
+            ec = e
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        de = torch.empty((n, ld), dtype=BF16, device=e.device)
+        _C.check(_C.lib().tok_embed_reg_bwd(ptr(ec), ptr(row_reg), ptr(gs), 1.0 / n, n, d, ld, mode, ptr(de), stream_ptr()),
+                 'tok_embed_reg_bwd')
+        ctx.saved = None
+        if ld != d:
+            mark_padded(de)
+            de = de[:, :d]
+        return (de if dt == BF16 else de.to(dt)), None
+
+
 @LOSSES.register_class
 class ContrastiveLoss(nn.Module):
     def __init__(self, margin: float, reg: Optional[str] = None, reduction: Optional[str] = 'mean',
                  eps: Optional[float] = 1e-3):
         super().__init__()
-        if reg is not None:
-            if reg not in ('L1', 'L2'):
-                raise ValueError(f'Unknown regularization type: {reg}')
-            raise NotImplementedError('torchok_amd ContrastiveLoss: embedding regularisers are not built')
-        if reduction != 'mean':
-            if reduction != 'sum':
-                raise ValueError(f'Unknown reduction type: {reduction}')
-            raise NotImplementedError("torchok_amd ContrastiveLoss: reduction='mean' only")
+        if reg not in (None, 'L1', 'L2'):
+            raise ValueError(f'Unknown regularization type: {reg}')
+        if reduction not in ('mean', 'sum'):
+            raise ValueError(f'Unknown reduction type: {reduction}')
         self.margin, self.reg, self.reduction, self.eps = margin, reg, reduction, eps
 
     def forward(self, emb1: Tensor, emb2: Tensor, R: Tensor) -> Tensor:
-        return _Contrastive.apply(emb1, emb2, R, self.margin)
+        # mean over the rows of (pair term + eps * regulariser of emb1), pairwise.py:101-103; 'sum' = mean * rows
+        loss = _Contrastive.apply(emb1, emb2, R, self.margin)
+        if self.reg is not None:
+            loss = loss + self.eps * _EmbedReg.apply(emb1, 1 if self.reg == 'L1' else 2)
+        if self.reduction == 'sum':
+            loss = loss * emb1.shape[0]
+        return loss

@@ -10,6 +10,7 @@ from ... import engine
 from ...constructor import HEADS
 from ...engine import functional as EF
 from ...engine import metric as EM
+from ...engine import ocr as EO
 from ..base import BaseModel
 
 
@@ -21,11 +22,22 @@ class LinearHead(BaseModel):
         self.normalize = normalize
         self.fc = nn.Linear(in_channels, out_channels, bias=bias)
 
+    def draw_dropout(self, rows: int, device) -> Optional[Tensor]:
+        """Keep/scale factors of F.dropout on the (rows, in_channels) embedding: one Bernoulli(1 - p) draw per element,
+        kept elements scaled by 1 / (1 - p); None outside training or at p = 0 (linear_head.py:27-28)."""
+        if not (self.drop_rate > 0. and self.training):
+            return None
+        if self.drop_rate >= 1.:
+            return torch.zeros((rows, self.in_channels), dtype=torch.float32, device=device)
+        keep = 1. - self.drop_rate
+        return torch.empty((rows, self.in_channels), dtype=torch.float32, device=device).bernoulli_(keep).div_(keep)
+
     def forward(self, x: Tensor, targets: Optional[Tensor] = None) -> Tensor:
-        if self.drop_rate > 0. and self.training:
-            raise NotImplementedError('torchok_amd LinearHead: dropout is not built (p = 0 in all hot-path configs)')
         with engine.region() as r:
-            y = EF.linear(r, r.input(x), self.fc)
+            xin = r.input(x)
+            # an embedding row is an image of one pixel: element dropout = the per-(image, channel) scale kernel
+            xin = EO.channel_dropout(r, xin, self.draw_dropout(xin.shape[0], xin.data.device))
+            y = EF.linear(r, xin, self.fc)
             if self.normalize:
                 y = EM.l2_normalize(r, y)
             return r.output(y)
