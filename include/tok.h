@@ -230,6 +230,15 @@ int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* l
                        const float* loss, const float* gscale, int rows, int classes, int ld,
                        int64_t ignore_index, void* dlogits, void* stream);
 
+/* the same with torch's label_smoothing in [0, 1]: row loss = (1 - s)(lse - z_t) + s (lse - mean_c z_c), and
+ * dlogits = (softmax - (1 - s) onehot - s / classes) * gscale[0] / n_valid.  s = 0 is tok_softmax_ce_fwd/_bwd bit for bit. */
+int tok_softmax_ce_smooth_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
+                              int64_t ignore_index, float label_smoothing, float* lse, float* row_loss,
+                              float* loss, void* stream);
+int tok_softmax_ce_smooth_bwd(const void* logits, const int64_t* target, const float* lse, const float* loss,
+                              const float* gscale, int rows, int classes, int ld, int64_t ignore_index,
+                              float label_smoothing, void* dlogits, void* stream);
+
 /* DiceLoss (losses/segmentation/dice.py:86-188) on bf16 logits rows [rows][ld] (pixels of the channel-last logits).
  * mode 0 'multiclass': softmax + one_hot(target int64 [rows]); mode 1 'binary': sigmoid of column 0, target float32
  * [rows], classes = 1.  dims=(0, 2) statistics per class, `1 - dice` or `-log(dice)`, classes without true pixels
@@ -277,6 +286,9 @@ int tok_arcface_margin_bwd(const void* cosine, const int64_t* target, const void
 /* PairwiseLearnTask.calc_relevance_matrix for 1-D labels (pairwise_task.py:87-107): exact.   */
 int tok_relevance_matrix(const int64_t* labels_a, const int64_t* labels_b, int na, int nb, float* R,
                          void* stream);
+/* the same for multi-label matrices ya fp32 [na][classes], yb [nb][classes] (:103-105): R_ij = [sum_c ya_ic yb_jc > 0] */
+int tok_relevance_matrix_multilabel(const float* ya, const float* yb, int na, int nb, int classes, float* R,
+                                    void* stream);
 /* ContrastiveLoss (losses/representation/pairwise.py:126-136, mean reduction, no regulariser):
  * S = cdist(e1, e2) [n1][n2] (saved), loss[0] = mean_i sum_j (1-R)relu(mu-S)^2 + R S^2.      */
 int tok_contrastive_fwd(const void* e1, const void* e2, const float* R, int n1, int n2, int d, int ld,

@@ -407,12 +407,18 @@ class FakeTok:
 
     # ---- loss -------------------------------------------------------------------------------------
     def tok_softmax_ce_fwd(self, logits, target, rows, classes, ld, ignore_index, lse, row_loss, loss, st):
+        return self.tok_softmax_ce_smooth_fwd(logits, target, rows, classes, ld, ignore_index, 0.0, lse, row_loss, loss, st)
+
+    def tok_softmax_ce_smooth_fwd(self, logits, target, rows, classes, ld, ignore_index, smooth, lse, row_loss, loss, st):
         z = _t(logits, (rows, ld), BF16).float()[:, :classes]
         t = _t(target, (rows,), torch.int64)
         l = torch.logsumexp(z, 1)
         valid = t != ignore_index
         tt = t.clamp(0, classes - 1)
-        rl = torch.where(valid, l - z.gather(1, tt[:, None])[:, 0], torch.zeros(()))
+        nll = l - z.gather(1, tt[:, None])[:, 0]
+        if smooth:
+            nll = (1 - smooth) * nll + smooth * (l - z.mean(1))
+        rl = torch.where(valid, nll, torch.zeros(()))
         _t(lse, (rows,), torch.float32).copy_(l)
         _t(row_loss, (rows,), torch.float32).copy_(rl)
         o = _t(loss, (2,), torch.float32)
@@ -422,17 +428,21 @@ class FakeTok:
         return 0
 
     def tok_softmax_ce_bwd(self, logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, dlogits, st):
+        return self.tok_softmax_ce_smooth_bwd(logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, 0.0,
+                                              dlogits, st)
+
+    def tok_softmax_ce_smooth_bwd(self, logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, smooth,
+                                  dlogits, st):
         z = _t(logits, (rows, ld), BF16).float()[:, :classes]
         t = _t(target, (rows,), torch.int64)
         l = _t(lse, (rows,), torch.float32)
         nv = _t(loss, (2,), torch.float32)[1]
         gs = _t(gscale, (1,), torch.float32)[0] if gscale is not None else 1.0
         valid = (t != ignore_index)
-        p = torch.exp(z - l[:, None])
-        p[torch.arange(rows)[valid], t[valid]] -= 1.0
+        p = torch.exp(z - l[:, None]) - smooth / classes
+        p[torch.arange(rows)[valid], t[valid]] -= 1.0 - smooth
         p = p * (gs / nv) * valid[:, None]
-        rows_out = classes + (-classes) % 8
-        d = _t(dlogits, (rows, rows_out), BF16)
+        d = _t(dlogits, (rows, ld), BF16)        # d(logits) in the row pitch of the logits
         d.zero_()
         d[:, :classes] = p.to(BF16)
         return 0
@@ -813,6 +823,11 @@ class FakeTok:
     def tok_relevance_matrix(self, la, lb, na, nb, R, st):
         a, b = _t(la, (na,), torch.int64), _t(lb, (nb,), torch.int64)
         _t(R, (na, nb), torch.float32).copy_((a[:, None] == b[None, :]).float())
+        return 0
+
+    def tok_relevance_matrix_multilabel(self, ya, yb, na, nb, classes, R, st):
+        a, b = _t(ya, (na, classes), torch.float32), _t(yb, (nb, classes), torch.float32)
+        _t(R, (na, nb), torch.float32).copy_((a @ b.t() > 0).float())
         return 0
 
     def tok_embed_reg_fwd(self, e, n, d, ld, mode, row_reg, out, st):

@@ -521,6 +521,10 @@ def golden_metric(out_path):
     R2 = (lab[:, None] == lab2[None, :]).float()
     L2 = cl(emb1=e1, emb2=e2, R=R2)
     L2.backward()
+    ml = (torch.rand(n, 9, generator=torch.Generator().manual_seed(77)) < 0.2).float()     # multi-label rows, some empty
+    Rml = calc_rel(_Self(), ml)
+    assert torch.equal(Rml, M.relevance_matrix(ml, 9))
+    out.update(con_ml=ml.numpy(), con_Rml=Rml.numpy())
     for tag, kw in (('l1', dict(reg='L1')), ('l2', dict(reg='L2', eps=0.05)), ('sum', dict(reduction='sum')),
                     ('l1sum', dict(reg='L1', reduction='sum', eps=0.01))):
         ei = e.detach().clone().requires_grad_(True)

@@ -54,3 +54,37 @@ def test_tag_access_and_missing_mapping():
         jl['loss2']
     with pytest.raises(ValueError):
         jl(x=X)            # 'y' missing from the model outputs (losses/base.py:110-112)
+
+
+@pytest.mark.parametrize('shape', [(33, 10), (3, 5, 6, 7)])
+@pytest.mark.parametrize('kw', [dict(label_smoothing=0.1), dict(reduction='sum'), dict(label_smoothing=0.2, reduction='sum',
+                                                                                      ignore_index=2)])
+def test_cross_entropy_label_smoothing_and_sum(fake_backend, shape, kw):
+    """CrossEntropyLoss(label_smoothing, reduction='sum') against torch.nn.CrossEntropyLoss — the class the reference
+    registers under this name (losses/__init__.py:26) — on bf16-exact logits: loss <= 1e-5, gradient = bf16 storage."""
+    _ce_options_case('cpu', shape, kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(33, 10), (3, 5, 6, 7), (4096, 1000)])
+@pytest.mark.parametrize('kw', [dict(label_smoothing=0.1), dict(reduction='sum'), dict(label_smoothing=0.2, reduction='sum',
+                                                                                      ignore_index=2)])
+def test_cross_entropy_label_smoothing_and_sum_gpu(shape, kw):
+    _ce_options_case('cuda', shape, kw)
+
+
+def _ce_options_case(dev, shape, kw):
+    import torchok_amd as T
+    g = torch.Generator().manual_seed(len(shape))
+    x = (torch.randn(*shape, generator=g) * 2).bfloat16()
+    classes = shape[1]
+    t = torch.randint(0, classes, (shape[0],) + tuple(shape[2:]), generator=g)
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(**kw)(xr, t)
+    ref.backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss = T.LOSSES.get('CrossEntropyLoss')(**kw)(xd, t.to(dev))
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * abs(float(ref.detach()))
+    loss.backward()
+    err = (xd.grad.float().cpu() - xr.grad).abs().max() / xr.grad.abs().max()
+    assert float(err) < 5e-3

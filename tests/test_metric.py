@@ -185,6 +185,11 @@ def test_pairwise_task_step(dev):
     assert set(out) == {'emb1', 'emb2', 'R', 'target'} and out['emb1'] is out['emb2']
     assert np.array_equal(out['R'].cpu().numpy(), M.relevance_matrix(lab, 6).numpy())      # exact
     assert out['R'].dtype == torch.float32
+    # multi-label targets (pairwise_task.py:103-105): any shared class, exact; rows without a label match nothing
+    ml = torch.from_numpy(GOLD['con_ml']).to(dev)
+    assert np.array_equal(task.calc_relevance_matrix(ml).cpu().numpy(), GOLD['con_Rml'])
+    assert np.array_equal(task.calc_relevance_matrix(ml.long()).cpu().numpy(), GOLD['con_Rml'])
+    assert np.array_equal(M.relevance_matrix(torch.from_numpy(GOLD['con_ml']), 9).numpy(), GOLD['con_Rml'])
 
     ref = Rf.ClassificationModel('resnet18', 32).train()      # same backbone/pooling/fc wiring, 32-d output
     ref.load_state_dict(sd)

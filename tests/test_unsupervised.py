@@ -33,6 +33,13 @@ def test_nt_xent(dev):
     assert rel_err(e2.grad.float(), torch.from_numpy(GOLD['ntx_d2'])) < 1e-2
     with pytest.raises(NotImplementedError):
         T.LOSSES.get('NT_XentLoss')()(e1, e2, emb_m=e1)
+    # reduction='sum' (CrossEntropyLoss over the 2B rows of the similarity matrix, unsupervised.py:22,52) = mean * 2B
+    rows = 2 * e1.shape[0]
+    e1.grad = e2.grad = None
+    ls = T.LOSSES.get('NT_XentLoss')(reduction='sum', temperature=0.2)(emb1=e1, emb2=e2)
+    assert abs(float(ls.detach()) - rows * float(GOLD['ntx_loss'])) < 1e-3 * rows * float(GOLD['ntx_loss'])
+    ls.backward()
+    assert rel_err(e1.grad.float(), rows * torch.from_numpy(GOLD['ntx_d1'])) < 1e-2
 
 
 @pytest.mark.parametrize('tag,kw', [('tri', dict(margin=1.0)), ('tri_swap', dict(margin=0.5, swap=True))])
@@ -43,6 +50,11 @@ def test_triplet_margin(dev, tag, kw):
     loss.backward()
     for t, k in ((a, '_da'), (p, '_dp'), (n, '_dn')):
         assert rel_err(t.grad.float(), torch.from_numpy(GOLD[tag + k])) < 1e-2, k
+    a.grad = None
+    ls = T.LOSSES.get('TripletMarginLoss')(reduction='sum', **kw)(anchor=a, positive=p, negative=n)    # = mean * rows
+    assert abs(float(ls.detach()) - a.shape[0] * float(GOLD[tag + '_loss'])) < 1e-3 * a.shape[0] * float(GOLD[tag + '_loss'])
+    ls.backward()
+    assert rel_err(a.grad.float(), a.shape[0] * torch.from_numpy(GOLD[tag + '_da'])) < 1e-2
 
 
 def _cfg(task, loss, mapping, loss_params=None):

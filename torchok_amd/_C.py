@@ -81,11 +81,14 @@ PROTOTYPES = {
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
     'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
+    'tok_softmax_ce_smooth_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, _P, _P]),
+    'tok_softmax_ce_smooth_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P]),
     'tok_dice_rows': (c_int, [c_int64]),
     'tok_dice_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_int, _P, c_int, _P, _P, _P, _P]),
     'tok_dice_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P]),
     'tok_bce_logits_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, c_float, c_int, _P, _P]),
     'tok_bce_logits_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_float, c_int, _P, _P]),
+    'tok_relevance_matrix_multilabel': (c_int, [_P, _P, c_int, c_int, c_int, _P, _P]),
     'tok_embed_reg_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'tok_embed_reg_bwd': (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_cls_stats_update': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P]),

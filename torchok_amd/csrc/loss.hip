@@ -13,7 +13,7 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ logits,
                                                      const int64_t* __restrict__ target, int rows,
-                                                     int classes, int ld, int64_t ignore_index,
+                                                     int classes, int ld, int64_t ignore_index, float smooth,
                                                      float* __restrict__ lse, float* __restrict__ row_loss) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -22,14 +22,20 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
   float mx = -INFINITY;
   for (int c = lane; c < classes; c += 64) mx = fmaxf(mx, bf2f(z[c]));
   mx = wave_max(mx);
-  float s = 0.f;
-  for (int c = lane; c < classes; c += 64) s += expf(bf2f(z[c]) - mx);
+  float s = 0.f, zs = 0.f;
+  for (int c = lane; c < classes; c += 64) { const float v = bf2f(z[c]); s += expf(v - mx); zs += v; }
   s = wave_sum(s);
   const float l = mx + logf(s);
+  if (smooth != 0.f) zs = wave_sum(zs);   // label smoothing: + smooth * mean_c(-log p_c) = smooth * (lse - mean_c z_c)
   if (lane == 0) {
     lse[row] = l;
     const int64_t t = target[row];
-    row_loss[row] = (t == ignore_index || t < 0 || t >= classes) ? 0.f : l - bf2f(z[t]);
+    float rl = 0.f;
+    if (!(t == ignore_index || t < 0 || t >= classes)) {
+      rl = l - bf2f(z[t]);
+      if (smooth != 0.f) rl = (1.f - smooth) * rl + smooth * (l - zs / (float)classes);
+    }
+    row_loss[row] = rl;
   }
 }
 
@@ -37,8 +43,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
 // registers through 16-byte loads (ld <= 64); a wavefront per row would leave most of its lanes idle.
 __global__ __launch_bounds__(256) void ce_fwd_small_kernel(const bf16* __restrict__ logits,
                                                            const int64_t* __restrict__ target, int rows, int classes,
-                                                           int ld, int64_t ignore_index, float* __restrict__ lse,
-                                                           float* __restrict__ row_loss) {
+                                                           int ld, int64_t ignore_index, float smooth,
+                                                           float* __restrict__ lse, float* __restrict__ row_loss) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const bf16* z = logits + (size_t)row * ld;
@@ -64,14 +70,24 @@ __global__ __launch_bounds__(256) void ce_fwd_small_kernel(const bf16* __restric
   const float l = mx + logf(s);
   lse[row] = l;
   const int64_t t = target[row];
-  row_loss[row] = (t == ignore_index || t < 0 || t >= classes) ? 0.f : l - bf2f(z[t]);
+  float rl = 0.f;
+  if (!(t == ignore_index || t < 0 || t >= classes)) {
+    rl = l - bf2f(z[t]);
+    if (smooth != 0.f) {
+      float zs = 0.f;
+#pragma unroll
+      for (int c = 0; c < 64; ++c) zs += (c < classes) ? v[c] : 0.f;
+      rl = (1.f - smooth) * rl + smooth * (l - zs / (float)classes);
+    }
+  }
+  row_loss[row] = rl;
 }
 
 __global__ __launch_bounds__(256) void ce_bwd_small_kernel(const bf16* __restrict__ logits,
                                                            const int64_t* __restrict__ target,
                                                            const float* __restrict__ lse, const float* __restrict__ loss,
                                                            const float* __restrict__ gscale, int rows, int classes, int ld,
-                                                           int64_t ignore_index, bf16* __restrict__ dlogits) {
+                                                           int64_t ignore_index, float smooth, bf16* __restrict__ dlogits) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const int64_t t = target[row];
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(256) void ce_bwd_small_kernel(const bf16* __restric
       for (int e = 0; e < 8; ++e) {
         const int c = i * 8 + e;
         float w = 0.f;
-        if (valid && c < classes) w = (expf(bf2f(q[e]) - l) - (c == t ? 1.f : 0.f)) * g;
+        if (valid && c < classes) w = (expf(bf2f(q[e]) - l) - (c == t ? 1.f - smooth : 0.f) - smooth / (float)classes) * g;
         o[e] = f2bf(w);
       }
       stg16(d + i * 8, o);
@@ -144,7 +160,8 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16* __restrict__ lo
                                                      const float* __restrict__ lse,
                                                      const float* __restrict__ loss,
                                                      const float* __restrict__ gscale, int rows, int classes,
-                                                     int ld, int64_t ignore_index, bf16* __restrict__ dlogits) {
+                                                     int ld, int64_t ignore_index, float smooth,
+                                                     bf16* __restrict__ dlogits) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -156,7 +173,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16* __restrict__ lo
   bf16* d = dlogits + (size_t)row * ld;
   for (int c = lane; c < ld; c += 64) {
     float v = 0.f;
-    if (valid && c < classes) v = (expf(bf2f(z[c]) - l) - (c == t ? 1.f : 0.f)) * g;
+    if (valid && c < classes) v = (expf(bf2f(z[c]) - l) - (c == t ? 1.f - smooth : 0.f) - smooth / (float)classes) * g;
     d[c] = f2bf(v);
   }
 }
@@ -311,18 +328,19 @@ static inline bool ce_small(const void* logits, int rows, int ld) {
   return ld <= 64 && (ld & 7) == 0 && rows >= 16384 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
 }
 
-extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
-                                  int64_t ignore_index, float* lse, float* row_loss, float* loss,
-                                  void* stream) {
+extern "C" int tok_softmax_ce_smooth_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
+                                         int64_t ignore_index, float label_smoothing, float* lse, float* row_loss,
+                                         float* loss, void* stream) {
   TOK_CHECK_ARG(logits && target && lse && row_loss && loss, "tok_softmax_ce_fwd: null pointer");
   TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_softmax_ce_fwd: bad sizes");
+  TOK_CHECK_ARG(label_smoothing >= 0.f && label_smoothing <= 1.f, "tok_softmax_ce_fwd: label_smoothing outside [0, 1]");
   hipStream_t st = tok_stream(stream);
   if (ce_small(logits, rows, ld))
     hipLaunchKernelGGL(ce_fwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16*)logits, target, rows,
-                       classes, ld, ignore_index, lse, row_loss);
+                       classes, ld, ignore_index, label_smoothing, lse, row_loss);
   else
     hipLaunchKernelGGL(ce_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, (const bf16*)logits, target, rows,
-                       classes, ld, ignore_index, lse, row_loss);
+                       classes, ld, ignore_index, label_smoothing, lse, row_loss);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd");
   double* part = reinterpret_cast<double*>(loss + 2);   // loss holds TOK_CE_LOSS_FLOATS floats, 8-byte aligned
   TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_softmax_ce_fwd: loss must be 8-byte aligned");
@@ -336,20 +354,32 @@ extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int
   return TOK_OK;
 }
 
-extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* lse,
-                                  const float* loss, const float* gscale, int rows, int classes, int ld,
-                                  int64_t ignore_index, void* dlogits, void* stream) {
+extern "C" int tok_softmax_ce_fwd(const void* logits, const int64_t* target, int rows, int classes, int ld,
+                                  int64_t ignore_index, float* lse, float* row_loss, float* loss, void* stream) {
+  return tok_softmax_ce_smooth_fwd(logits, target, rows, classes, ld, ignore_index, 0.f, lse, row_loss, loss, stream);
+}
+
+extern "C" int tok_softmax_ce_smooth_bwd(const void* logits, const int64_t* target, const float* lse,
+                                         const float* loss, const float* gscale, int rows, int classes, int ld,
+                                         int64_t ignore_index, float label_smoothing, void* dlogits, void* stream) {
   TOK_CHECK_ARG(logits && target && lse && loss && dlogits, "tok_softmax_ce_bwd: null pointer");
   TOK_CHECK_ARG(rows > 0 && classes > 0 && ld >= classes, "tok_softmax_ce_bwd: bad sizes");
   if (ce_small(logits, rows, ld) && (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0)
     hipLaunchKernelGGL(ce_bwd_small_kernel, dim3((rows + 255) / 256), dim3(256), 0, tok_stream(stream),
-                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, (bf16*)dlogits);
+                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, label_smoothing,
+                       (bf16*)dlogits);
   else
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, tok_stream(stream),
-                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index,
+                       (const bf16*)logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, label_smoothing,
                        (bf16*)dlogits);
   TOK_CHECK_LAUNCH("tok_softmax_ce_bwd");
   return TOK_OK;
+}
+
+extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, const float* lse,
+                                  const float* loss, const float* gscale, int rows, int classes, int ld,
+                                  int64_t ignore_index, void* dlogits, void* stream) {
+  return tok_softmax_ce_smooth_bwd(logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, 0.f, dlogits, stream);
 }
 
 namespace {

@@ -115,6 +115,18 @@ __global__ void relevance_kernel(const int64_t* __restrict__ la, const int64_t* 
   if (i < na * nb) R[i] = la[i / nb] == lb[i % nb] ? 1.f : 0.f;
 }
 
+// multi-label form (pairwise_task.py:103-105): R_ij = [ sum_c ya_ic * yb_jc > 0 ] on fp32 label matrices
+__global__ void relevance_ml_kernel(const float* __restrict__ ya, const float* __restrict__ yb, int na, int nb, int classes,
+                                    float* __restrict__ R) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= na * nb) return;
+  const float* a = ya + (size_t)(idx / nb) * classes;
+  const float* b = yb + (size_t)(idx % nb) * classes;
+  float s = 0.f;
+  for (int c = 0; c < classes; ++c) s = fmaf(a[c], b[c], s);
+  R[idx] = s > 0.f ? 1.f : 0.f;
+}
+
 // ---- contrastive loss: L_i = sum_j (1-R_ij) relu(mu - S_ij)^2 + R_ij S_ij^2,  S = ||e1_i - e2_j|| --------
 // one wave per (i, j) pair strip: wave handles row i, loops j; lanes stride the embedding dim
 __global__ __launch_bounds__(256) void contrastive_fwd_kernel(const bf16* __restrict__ e1, const bf16* __restrict__ e2,
@@ -406,6 +418,15 @@ extern "C" int tok_relevance_matrix(const int64_t* labels_a, const int64_t* labe
   hipLaunchKernelGGL(relevance_kernel, dim3((na * nb + 255) / 256), dim3(256), 0, tok_stream(stream), labels_a,
                      labels_b, na, nb, R);
   TOK_CHECK_LAUNCH("tok_relevance_matrix");
+  return TOK_OK;
+}
+
+extern "C" int tok_relevance_matrix_multilabel(const float* ya, const float* yb, int na, int nb, int classes, float* R,
+                                               void* stream) {
+  TOK_CHECK_ARG(ya && yb && R && na > 0 && nb > 0 && classes > 0, "tok_relevance_matrix_multilabel: bad args");
+  hipLaunchKernelGGL(relevance_ml_kernel, dim3((na * nb + 255) / 256), dim3(256), 0, tok_stream(stream), ya, yb, na, nb,
+                     classes, R);
+  TOK_CHECK_LAUNCH("tok_relevance_matrix_multilabel");
   return TOK_OK;
 }
 

@@ -62,8 +62,9 @@ class _NTXent(torch.autograd.Function):
 class NT_XentLoss(nn.Module):
     def __init__(self, reduction: str = 'mean', temperature: float = 1.0) -> None:
         super().__init__()
-        if reduction != 'mean':
-            raise NotImplementedError("torchok_amd NT_XentLoss: reduction='mean'")
+        if reduction not in ('mean', 'sum'):
+            raise NotImplementedError("torchok_amd NT_XentLoss: reduction 'mean' or 'sum'")
+        self.reduction = reduction
         self.temperature = temperature
 
     def forward(self, emb1, emb2, emb_m=None):
@@ -71,7 +72,8 @@ class NT_XentLoss(nn.Module):
             raise NotImplementedError('torchok_amd NT_XentLoss: the memory-bank form (emb_m) is not built')
         if emb1.shape != emb2.shape or emb1.dim() != 2:
             raise ValueError(f'NT_XentLoss expects two (B, D) embeddings, got {tuple(emb1.shape)} and {tuple(emb2.shape)}')
-        return _NTXent.apply(emb1, emb2, self.temperature)
+        loss = _NTXent.apply(emb1, emb2, self.temperature)
+        return loss if self.reduction == 'mean' else loss * (2 * emb1.shape[0])    # CrossEntropyLoss over the 2B rows
 
 
 class _Triplet(torch.autograd.Function):
@@ -104,14 +106,15 @@ class _Triplet(torch.autograd.Function):
 
 @LOSSES.register_class
 class TripletMarginLoss(nn.Module):
-    """torch.nn.TripletMarginLoss semantics (p = 2, mean reduction)."""
+    """torch.nn.TripletMarginLoss semantics (p = 2, mean or sum reduction)."""
 
     def __init__(self, margin: float = 1.0, p: float = 2.0, eps: float = 1e-6, swap: bool = False, size_average=None,
                  reduce=None, reduction: str = 'mean'):
         super().__init__()
-        if p != 2 or reduction != 'mean' or size_average is not None or reduce is not None:
-            raise NotImplementedError("torchok_amd TripletMarginLoss: p=2, reduction='mean'")
-        self.margin, self.p, self.eps, self.swap = margin, p, eps, swap
+        if p != 2 or reduction not in ('mean', 'sum') or size_average is not None or reduce is not None:
+            raise NotImplementedError("torchok_amd TripletMarginLoss: p=2, reduction 'mean' or 'sum'")
+        self.margin, self.p, self.eps, self.swap, self.reduction = margin, p, eps, swap, reduction
 
     def forward(self, anchor: Tensor, positive: Tensor, negative: Tensor) -> Tensor:
-        return _Triplet.apply(anchor, positive, negative, self.margin, self.eps, self.swap)
+        loss = _Triplet.apply(anchor, positive, negative, self.margin, self.eps, self.swap)
+        return loss if self.reduction == 'mean' else loss * anchor.shape[0]

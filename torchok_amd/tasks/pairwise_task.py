@@ -48,4 +48,11 @@ class PairwiseLearnTask(ClassificationTask):
             _C.check(_C.lib().tok_relevance_matrix(ptr(lab), ptr(lab), n, n, ptr(R), stream_ptr()),
                      'tok_relevance_matrix')
             return R
-        raise NotImplementedError('torchok_amd PairwiseLearnTask: multi-label relevance matrices are not built')
+        if y.ndim != 2:
+            raise ValueError(f'calc_relevance_matrix: labels (N,) or a multi-label matrix (N, L), got {tuple(y.shape)}')
+        lab = y.to(torch.float32).contiguous()
+        n, classes = lab.shape
+        R = torch.empty((n, n), dtype=torch.float32, device=y.device)
+        _C.check(_C.lib().tok_relevance_matrix_multilabel(ptr(lab), ptr(lab), n, n, classes, ptr(R), stream_ptr()),
+                 'tok_relevance_matrix_multilabel')
+        return R
