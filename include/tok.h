@@ -241,7 +241,7 @@ int tok_softmax_ce_smooth_bwd(const void* logits, const int64_t* target, const f
 
 /* DiceLoss (losses/segmentation/dice.py:86-188) on bf16 logits rows [rows][ld] (pixels of the channel-last logits).
  * mode 0 'multiclass': softmax + one_hot(target int64 [rows]); mode 1 'binary': sigmoid of column 0, target float32
- * [rows], classes = 1.  dims=(0, 2) statistics per class, `1 - dice` or `-log(dice)`, classes without true pixels
+ * [rows], classes = 1; mode 2 'multilabel': sigmoid per class, target float32 [rows][classes].  dims=(0, 2) statistics per class, `1 - dice` or `-log(dice)`, classes without true pixels
  * masked, mean over the (selected) classes.  partial fp32 [tok_dice_rows(rows)][3][classes] (scratch), loss fp32 [1],
  * coef fp32 [2][classes] (saved: d loss / d p = coef[0][c] * y + coef[1][c]).                                      */
 int tok_dice_rows(int64_t rows);

@@ -704,6 +704,8 @@ class FakeTok:
         z = _t(logits, (rows, ld), BF16)[:, :classes].float()
         if mode == 0:
             return z.softmax(1), F.one_hot(_t(target, (rows,), torch.int64), classes).float()
+        if mode == 2:
+            return torch.sigmoid(z), _t(target, (rows, classes), torch.float32)
         return torch.sigmoid(z), _t(target, (rows,), torch.float32)[:, None]
 
     def tok_dice_fwd(self, logits, target, rows, classes, ld, mode, smooth, eps, log_loss, sel, n_sel, partial, loss,

@@ -393,6 +393,14 @@ def golden_dice(out_path):
     L = dice.DiceLoss('binary', smooth=0.5)(zi, tb)
     L.backward()
     out.update(bin_loss=float(L.detach()), bin_dz=zi.grad.numpy(), z=z.numpy(), t=t.numpy(), zb=zb.numpy(), tb=tb.numpy())
+    tm = (torch.rand(3, 5, 12, 10, generator=g) < 0.3).float()       # multilabel targets on the logits z; class 3 stays empty
+    tm[:, 3] = 0
+    for tag, kw in (('ml', dict(smooth=0.5)), ('ml_log_sel', dict(log_loss=True, smooth=1.0, classes=torch.tensor([1, 3, 4])))):
+        zi = z.clone().bfloat16().float().requires_grad_(True)
+        L = dice.DiceLoss('multilabel', **kw)(zi, tm)
+        L.backward()
+        out[tag + '_loss'], out[tag + '_dz'] = float(L.detach()), zi.grad.numpy()
+    out['tm'] = tm.numpy()
     np.savez_compressed(out_path, **out)
     print('wrote', out_path)
 

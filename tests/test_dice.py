@@ -32,6 +32,20 @@ def test_multiclass(dev, tag, kw):
     assert rel_err(z.grad.float(), torch.from_numpy(GOLD[tag + '_dz'])) < 1e-2     # bf16 gradient storage
 
 
+@pytest.mark.parametrize('tag,kw', [('ml', dict(smooth=0.5)), ('ml_log_sel', dict(log_loss=True, smooth=1.0, classes=[1, 3, 4]))])
+def test_multilabel(dev, tag, kw):
+    """'multilabel' (dice.py:143,166-168): a sigmoid per class against dense (N, C, H, W) targets; the empty class is masked."""
+    z = torch.from_numpy(GOLD['z']).to(dev).to(torch.bfloat16).requires_grad_(True)
+    t = torch.from_numpy(GOLD['tm']).to(dev)
+    loss = T.LOSSES.get('DiceLoss')('multilabel', **kw)(z, t)
+    assert abs(float(loss.detach()) - float(GOLD[tag + '_loss'])) < 2e-3 * abs(float(GOLD[tag + '_loss'])) + 1e-5
+    loss.backward()
+    assert rel_err(z.grad.float(), torch.from_numpy(GOLD[tag + '_dz'])) < 1e-2     # bf16 gradient storage
+    assert float(z.grad[:, 3].abs().max()) == 0.0                                  # no true pixel: no gradient
+    with pytest.raises(ValueError):
+        T.LOSSES.get('DiceLoss')('multilabel')(z.detach(), t[:, :4])
+
+
 def test_binary_and_errors(dev):
     z = torch.from_numpy(GOLD['zb']).to(dev).to(torch.bfloat16).requires_grad_(True)
     t = torch.from_numpy(GOLD['tb']).to(dev)

@@ -896,12 +896,16 @@ def test_fused_bn_finalize_equals_standalone(libs, case):
 
 
 @pytest.mark.parametrize('rows,classes,ld,mode,log_loss,sel', [(5000, 19, 24, 0, 0, None), (777, 5, 8, 0, 1, [0, 3]),
-                                                              (4099, 1, 8, 1, 0, None), (100000, 3, 8, 0, 0, None)])
+                                                              (4099, 1, 8, 1, 0, None), (100000, 3, 8, 0, 0, None),
+                                                              (3001, 19, 24, 2, 0, None), (640, 6, 8, 2, 1, [1, 5])])
 def test_dice(libs, rows, classes, ld, mode, log_loss, sel):
     lib, fake = libs
     z = (rnd(rows, ld) * 2).to(BF16)
     if mode == 0:
         t = torch.randint(0, max(classes - 1, 1), (rows,), generator=torch.Generator().manual_seed(2))   # last class empty
+    elif mode == 2:
+        t = (torch.rand(rows, classes, generator=torch.Generator().manual_seed(2)) < 0.3).float()
+        t[:, classes - 1] = 0                                                                             # last class empty
     else:
         t = (torch.rand(rows, generator=torch.Generator().manual_seed(2)) < 0.3).float()
     selt = torch.tensor(sel) if sel else None

@@ -184,7 +184,7 @@ namespace {
 
 // ---- Dice loss (losses/segmentation/dice.py:86-188) ------------------------------------------------------------------
 // mode 0 (multiclass): p = softmax(logits) per pixel row, y = one_hot(target);  mode 1 (binary): p = sigmoid(logit 0),
-// y = target (float).  Per class: I = sum p*y, P = sum p, Y = sum y.  One wave per pixel row, lane = class; every lane
+// y = target (float);  mode 2 (multilabel): p = sigmoid(logit c), y = target[row][c] (float).  Per class: I = sum p*y, P = sum p, Y = sum y.  One wave per pixel row, lane = class; every lane
 // keeps its class's three sums in registers over all the rows of its wave; waves -> block partial row (fixed order).
 __global__ __launch_bounds__(256) void dice_fwd_kernel(const bf16* __restrict__ logits, const void* __restrict__ target,
                                                        int64_t rows, int classes, int ld, int mode,
@@ -202,6 +202,11 @@ __global__ __launch_bounds__(256) void dice_fwd_kernel(const bf16* __restrict__ 
       const float den = wave_sum(e);
       p = e / den;
       y = (lane < classes && ((const int64_t*)target)[row] == lane) ? 1.f : 0.f;
+    } else if (mode == 2) {            // multilabel: a sigmoid per class, dense fp32 targets [rows][classes]
+      if (lane < classes) {
+        p = 1.f / (1.f + expf(-bf2f(z[lane])));
+        y = ((const float*)target)[row * classes + lane];
+      }
     } else if (lane == 0) {
       p = 1.f / (1.f + expf(-bf2f(z[0])));
       y = ((const float*)target)[row];
@@ -278,6 +283,14 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const bf16* __restrict__ 
     if (lane < classes) dp = (((const int64_t*)target)[row] == lane ? coef[lane] : 0.f) + coef[classes + lane];
     const float dot = wave_sum(p * dp);
     if (lane < ld) d[lane] = f2bf(lane < classes ? p * (dp - dot) * g : 0.f);
+  } else if (mode == 2) {
+    if (lane < classes) {
+      const float p = 1.f / (1.f + expf(-bf2f(z[lane])));
+      const float dp = coef[lane] * ((const float*)target)[row * classes + lane] + coef[classes + lane];
+      d[lane] = f2bf(p * (1.f - p) * dp * g);
+    } else if (lane < ld) {
+      d[lane] = f2bf(0.f);
+    }
   } else {
     if (lane == 0) {
       const float p = 1.f / (1.f + expf(-bf2f(z[0])));
@@ -300,7 +313,7 @@ extern "C" int tok_dice_fwd(const void* logits, const void* target, int64_t rows
                             float smooth, float eps, int log_loss, const int64_t* class_sel, int n_sel, float* partial,
                             float* loss, float* coef, void* stream) {
   TOK_CHECK_ARG(logits && target && partial && loss && coef && rows > 0 && classes > 0 && classes <= 64 && ld >= classes &&
-                ld <= 64 && (mode == 0 || (mode == 1 && classes == 1)), "tok_dice_fwd: bad args (<= 64 classes)");
+                ld <= 64 && (mode == 0 || mode == 2 || (mode == 1 && classes == 1)), "tok_dice_fwd: bad args (<= 64 classes)");
   TOK_CHECK_ARG(!class_sel || n_sel > 0, "tok_dice_fwd: empty class selection");
   hipStream_t st = tok_stream(stream);
   const int g = tok_dice_rows(rows);

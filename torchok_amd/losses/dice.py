@@ -1,6 +1,6 @@
 """DiceLoss on the fused Dice kernels (reference ``torchok/losses/segmentation/dice.py:86-188``; used next to
 CrossEntropyLoss by the shipped HRNet recipe, ``examples/configs/segmentation_sweet_pepper.yaml:16-27``).
-'multiclass' (softmax + one-hot) and 'binary' (sigmoid) modes, from logits."""
+'multiclass' (softmax + one-hot), 'binary' (sigmoid) and 'multilabel' (sigmoid per class) modes, from logits."""
 from typing import List
 
 import torch
@@ -35,6 +35,11 @@ class _Dice(torch.autograd.Function):
             n, classes, h, w = logits.shape
             z, ld = _pixel_rows(logits, classes)
             tgt = target.reshape(-1).to(torch.int64).contiguous()
+            ctx.view = (n, h, w, classes)
+        elif mode == 2:   # multilabel: (N, C, H, W) logits and targets; the targets follow the logits into pixel rows
+            n, classes, h, w = logits.shape
+            z, ld = _pixel_rows(logits, classes)
+            tgt = target.detach().permute(0, 2, 3, 1).to(torch.float32).contiguous().view(n * h * w, classes)
             ctx.view = (n, h, w, classes)
         else:   # binary: (N, H, W) logits — column 0 of the one-class head output, or any tensor
             classes = 1
@@ -71,7 +76,7 @@ class _Dice(torch.autograd.Function):
         _C.check(_C.lib().tok_dice_bwd(ptr(z), ptr(tgt), ptr(coef), ptr(gs), rows, classes, ld, mode, ptr(d), stream_ptr()),
                  'tok_dice_bwd')
         ctx.saved = None
-        if mode == 0:
+        if mode in (0, 2):
             n, h, w, c = ctx.view
             if ld == pad8(c) != c:
                 mark_padded(d)
@@ -93,19 +98,21 @@ class DiceLoss(nn.Module):
         super().__init__()
         if classes is not None and mode == BINARY_MODE:
             raise ValueError('DiceLoss initialize. Masking classes is not supported with mode=binary')
-        if mode == MULTILABEL_MODE or not from_logits:
-            raise NotImplementedError("torchok_amd DiceLoss: 'multiclass' and 'binary' modes, from logits")
+        if not from_logits:
+            raise NotImplementedError('torchok_amd DiceLoss: from logits only (the activation is fused into the kernels)')
         self.mode = mode
         self.classes = None if classes is None else torch.as_tensor(list(classes), dtype=torch.long)
         self.from_logits, self.smooth, self.eps, self.log_loss = from_logits, smooth, eps, log_loss
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
-        if self.mode == BINARY_MODE and input.shape != target.shape:
+        if self.mode in (BINARY_MODE, MULTILABEL_MODE) and input.shape != target.shape:
             raise ValueError(f"Shapes of input {input.shape} and target {target.shape} tensors don't match!")
         if self.mode == MULTICLASS_MODE and input[:, 0].shape != target.shape:
             raise ValueError(f"Shapes of input {input.shape} and target {target.shape} tensors don't match!")
         sel = None
         if self.classes is not None:
             sel = self.classes.to(input.device)
-        return _Dice.apply(input, target, 0 if self.mode == MULTICLASS_MODE else 1, self.smooth, self.eps,
-                           self.log_loss, sel)
+        if self.mode == MULTILABEL_MODE and input.dim() != 4:
+            raise NotImplementedError("torchok_amd DiceLoss 'multilabel': (N, C, H, W) logits")
+        mode = {MULTICLASS_MODE: 0, BINARY_MODE: 1, MULTILABEL_MODE: 2}[self.mode]
+        return _Dice.apply(input, target, mode, self.smooth, self.eps, self.log_loss, sel)
