@@ -25,7 +25,7 @@ def make_blocks(block_fn, channels, block_repeats, inplanes, **kwargs):
         blocks = []
         for block_idx in range(num_blocks):
             blocks.append(block_fn(inplanes, planes, stride if block_idx == 0 else 1,
-                                   downsample if block_idx == 0 else None))
+                                   downsample if block_idx == 0 else None, **kwargs))
             inplanes = planes * block_fn.expansion
         stages.append((f'layer{stage_idx + 1}', nn.Sequential(*blocks)))
         feature_info.append(dict(num_chs=inplanes, reduction=net_stride, module=f'layer{stage_idx + 1}'))
@@ -33,13 +33,13 @@ def make_blocks(block_fn, channels, block_repeats, inplanes, **kwargs):
 
 
 class ResNet(nn.Module):
-    def __init__(self, block, layers, in_channels=3, zero_init_last=True):
+    def __init__(self, block, layers, in_channels=3, zero_init_last=True, base_width=64):
         super().__init__()
         self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)  # :488
         self.bn1 = nn.BatchNorm2d(64)
         self.act1 = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)                          # :510
-        stages, _ = make_blocks(block, [64, 128, 256, 512], layers, 64)
+        stages, _ = make_blocks(block, [64, 128, 256, 512], layers, 64, base_width=base_width)     # :515-518
         for s in stages:
             self.add_module(*s)
         self.out_channels = 512 * block.expansion
@@ -80,7 +80,17 @@ def resnet50(**kw):
     return ResNet(T.Bottleneck, [3, 4, 6, 3], **kw)
 
 
-BACKBONES = dict(resnet18=resnet18, resnet34=resnet34, resnet50=resnet50)
+def resnet26(**kw):                                   # resnet.py:623-628
+    return ResNet(T.Bottleneck, [2, 2, 2, 2], **kw)
+
+
+def wide_resnet50_2(**kw):                            # resnet.py:756-765: bottleneck width x2, outer 1x1 widths unchanged
+    return ResNet(T.Bottleneck, [3, 4, 6, 3], base_width=128, **kw)
+
+
+BACKBONES = dict(resnet18=resnet18, resnet34=resnet34, resnet50=resnet50, resnet26=resnet26,
+                 wide_resnet50_2=wide_resnet50_2, tv_resnet34=resnet34, tv_resnet50=resnet50, ssl_resnet18=resnet18,
+                 swsl_resnet50=resnet50)
 
 
 class ClassificationModel(nn.Module):

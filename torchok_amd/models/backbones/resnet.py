@@ -12,7 +12,8 @@ pass), activations stay NHWC bf16 in HBM between units, and the whole backbone i
 autograd node.  The nn.Conv2d / nn.BatchNorm2d children are parameter containers only.
 
 Only the plain (v1.5) family is built: no SE / anti-aliasing / drop-block / avg-down / deep stem
-(the other 84 registered variants of the reference are outside the hot-path scope).
+(plus the other plain-architecture entrypoints at the end of the file; the d/s/t-stem, grouped, SE/ECA, blur-pool and
+RS variants of the reference are outside the hot-path scope).
 """
 import math
 from typing import List
@@ -275,3 +276,27 @@ def resnet101(pretrained=False, **kwargs):
 @BACKBONES.register_class
 def resnet152(pretrained=False, **kwargs):
     return _create_resnet('resnet152', pretrained, **dict(block=Bottleneck, layers=[3, 8, 36, 3], **kwargs))
+
+
+# ---- further plain v1.5 entrypoints of the reference (same blocks, other depths / bottleneck widths; the tv_ / ssl_ /
+# swsl_ names differ from their plain twins only in the pretrained weights they would download) ----------------------
+def _plain(name, block, layers, doc, default_pretrained=False, **fixed):
+    def entry(pretrained=default_pretrained, **kwargs):
+        return _create_resnet(name, pretrained, **dict(block=block, layers=layers, **fixed, **kwargs))
+    entry.__name__ = entry.__qualname__ = name
+    entry.__doc__ = doc
+    return BACKBONES.register_class(entry)
+
+
+resnet26 = _plain('resnet26', Bottleneck, [2, 2, 2, 2], 'resnet.py:623-628')
+resnet200 = _plain('resnet200', Bottleneck, [3, 24, 36, 3], 'resnet.py:707-712')
+tv_resnet34 = _plain('tv_resnet34', BasicBlock, [3, 4, 6, 3], 'resnet.py:724-729')
+tv_resnet50 = _plain('tv_resnet50', Bottleneck, [3, 4, 6, 3], 'resnet.py:732-737')
+tv_resnet101 = _plain('tv_resnet101', Bottleneck, [3, 4, 23, 3], 'resnet.py:740-745')
+tv_resnet152 = _plain('tv_resnet152', Bottleneck, [3, 8, 36, 3], 'resnet.py:748-753')
+wide_resnet50_2 = _plain('wide_resnet50_2', Bottleneck, [3, 4, 6, 3], 'resnet.py:756-765 (bottleneck width x 2)', base_width=128)
+wide_resnet101_2 = _plain('wide_resnet101_2', Bottleneck, [3, 4, 23, 3], 'resnet.py:768-776', base_width=128)
+ssl_resnet18 = _plain('ssl_resnet18', BasicBlock, [2, 2, 2, 2], 'resnet.py:881-888', default_pretrained=True)
+ssl_resnet50 = _plain('ssl_resnet50', Bottleneck, [3, 4, 6, 3], 'resnet.py:891-898', default_pretrained=True)
+swsl_resnet18 = _plain('swsl_resnet18', BasicBlock, [2, 2, 2, 2], 'resnet.py:942-949', default_pretrained=True)
+swsl_resnet50 = _plain('swsl_resnet50', Bottleneck, [3, 4, 6, 3], 'resnet.py:953-960', default_pretrained=True)
