@@ -211,6 +211,10 @@ int tok_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int n, int h, 
                          void* stream);
 int tok_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int accumulate,
                          int n, int h, int w, int c, void* stream);
+/* AvgPool2d(2, stride 2, ceil_mode=True, count_include_pad=False) of [timm] downsample_avg (avg_down shortcut of the
+ * d-variant ResNets, resnet.py:598-603,...): NHWC bf16 [n][h][w][c] -> [n][ceil(h/2)][ceil(w/2)][c], c % 8 == 0.       */
+int tok_avgpool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, void* stream);
+int tok_avgpool2x2_bwd(const void* dy, void* dx, int accumulate, int n, int h, int w, int c, void* stream);
 int tok_gap_fwd(const void* x, void* y, int n, int hw, int c, void* stream);
 int tok_gap_bwd(const void* dy, void* dx, int accumulate, int n, int hw, int c, void* stream);
 

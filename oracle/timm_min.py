@@ -125,8 +125,18 @@ def downsample_conv(in_channels, out_channels, kernel_size, stride=1, dilation=1
                                    dilation=first_dilation, bias=False), norm_layer(out_channels))
 
 
-def downsample_avg(*a, **k):
-    raise NotImplementedError
+def downsample_avg(in_channels, out_channels, kernel_size, stride=1, dilation=1, first_dilation=None, norm_layer=None):
+    """[timm 0.6.13] resnet.downsample_avg: AvgPool2d(2, stride, ceil_mode=True,
+    count_include_pad=False) where the block strides (Identity at stride 1), then a 1x1 stride-1 conv and the norm."""
+    norm_layer = norm_layer or nn.BatchNorm2d
+    avg_stride = stride if dilation == 1 else 1
+    if stride == 1 and dilation == 1:
+        pool = nn.Identity()
+    else:
+        assert avg_stride != 1 or dilation == 1, 'AvgPool2dSame (dilated avg_down) is not restated'
+        pool = nn.AvgPool2d(2, avg_stride, ceil_mode=True, count_include_pad=False)
+    return nn.Sequential(pool, nn.Conv2d(in_channels, out_channels, 1, stride=1, padding=0, bias=False),
+                         norm_layer(out_channels))
 
 
 class SelectAdaptivePool2d(nn.Module):

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 from . import timm_min as T
 
 
-def make_blocks(block_fn, channels, block_repeats, inplanes, **kwargs):
+def make_blocks(block_fn, channels, block_repeats, inplanes, avg_down=False, **kwargs):
     # resnet.py:363-405 with reduce_first=1, output_stride=32, down_kernel_size=1, no drop
     stages, feature_info = [], []
     net_stride = 4
@@ -21,7 +21,8 @@ def make_blocks(block_fn, channels, block_repeats, inplanes, **kwargs):
         net_stride *= stride
         downsample = None
         if stride != 1 or inplanes != planes * block_fn.expansion:
-            downsample = T.downsample_conv(inplanes, planes * block_fn.expansion, kernel_size=1, stride=stride)
+            down = T.downsample_avg if avg_down else T.downsample_conv                                # :383-387
+            downsample = down(inplanes, planes * block_fn.expansion, kernel_size=1, stride=stride)
         blocks = []
         for block_idx in range(num_blocks):
             blocks.append(block_fn(inplanes, planes, stride if block_idx == 0 else 1,
@@ -33,13 +34,22 @@ def make_blocks(block_fn, channels, block_repeats, inplanes, **kwargs):
 
 
 class ResNet(nn.Module):
-    def __init__(self, block, layers, in_channels=3, zero_init_last=True, base_width=64):
+    def __init__(self, block, layers, in_channels=3, zero_init_last=True, base_width=64, stem_width=64, stem_type='',
+                 avg_down=False):
         super().__init__()
-        self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)  # :488
+        if 'deep' in stem_type:                                                                  # :472-486
+            chs = (3 * (stem_width // 4), stem_width) if 'tiered' in stem_type else (stem_width, stem_width)
+            self.conv1 = nn.Sequential(
+                nn.Conv2d(in_channels, chs[0], 3, stride=2, padding=1, bias=False), nn.BatchNorm2d(chs[0]), nn.ReLU(inplace=True),
+                nn.Conv2d(chs[0], chs[1], 3, stride=1, padding=1, bias=False), nn.BatchNorm2d(chs[1]), nn.ReLU(inplace=True),
+                nn.Conv2d(chs[1], stem_width * 2, 3, stride=1, padding=1, bias=False))
+            assert stem_width * 2 == 64
+        else:
+            self.conv1 = nn.Conv2d(in_channels, 64, kernel_size=7, stride=2, padding=3, bias=False)  # :488
         self.bn1 = nn.BatchNorm2d(64)
         self.act1 = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)                          # :510
-        stages, _ = make_blocks(block, [64, 128, 256, 512], layers, 64, base_width=base_width)     # :515-518
+        stages, _ = make_blocks(block, [64, 128, 256, 512], layers, 64, avg_down=avg_down, base_width=base_width)     # :515-518
         for s in stages:
             self.add_module(*s)
         self.out_channels = 512 * block.expansion
@@ -88,7 +98,19 @@ def wide_resnet50_2(**kw):                            # resnet.py:756-765: bottl
     return ResNet(T.Bottleneck, [3, 4, 6, 3], base_width=128, **kw)
 
 
-BACKBONES = dict(resnet18=resnet18, resnet34=resnet34, resnet50=resnet50, resnet26=resnet26,
+def resnet18d(**kw):                                  # resnet.py:597-603
+    return ResNet(T.BasicBlock, [2, 2, 2, 2], stem_width=32, stem_type='deep', avg_down=True, **kw)
+
+
+def resnet26t(**kw):                                  # resnet.py:631-637
+    return ResNet(T.Bottleneck, [2, 2, 2, 2], stem_width=32, stem_type='deep_tiered', avg_down=True, **kw)
+
+
+def resnet50d(**kw):                                  # resnet.py:656-662
+    return ResNet(T.Bottleneck, [3, 4, 6, 3], stem_width=32, stem_type='deep', avg_down=True, **kw)
+
+
+BACKBONES = dict(resnet18d=resnet18d, resnet26t=resnet26t, resnet50d=resnet50d, resnet18=resnet18, resnet34=resnet34, resnet50=resnet50, resnet26=resnet26,
                  wide_resnet50_2=wide_resnet50_2, tv_resnet34=resnet34, tv_resnet50=resnet50, ssl_resnet18=resnet18,
                  swsl_resnet50=resnet50)
 

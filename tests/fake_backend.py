@@ -386,6 +386,21 @@ class FakeTok:
         dz, mask = self._pool_dz(dpool, argmax, y, scale, shift, n, h, w, c)
         return self.tok_bn_bwd_apply(dz.data_ptr(), y, mask.data_ptr(), scale, shift, coef, 1, dy, None, 0, n * h * w, c, st)
 
+    def tok_avgpool2x2_fwd(self, x, y, n, h, w, c, st):
+        xin = _t(x, (n, h, w, c), BF16).float().permute(0, 3, 1, 2)
+        out = F.avg_pool2d(xin, 2, 2, ceil_mode=True, count_include_pad=False)
+        _t(y, (n, (h + 1) // 2, (w + 1) // 2, c), BF16).copy_(_bf(out.permute(0, 2, 3, 1)))
+        return 0
+
+    def tok_avgpool2x2_bwd(self, dy, dx, accumulate, n, h, w, c, st):
+        g = _t(dy, (n, (h + 1) // 2, (w + 1) // 2, c), BF16).float()
+        hh, ww = torch.arange(h), torch.arange(w)
+        cnt = (torch.where(2 * (hh // 2) + 1 < h, 2, 1)[:, None] * torch.where(2 * (ww // 2) + 1 < w, 2, 1)[None, :]).float()
+        gx = g[:, hh // 2][:, :, ww // 2] / cnt[None, :, :, None]
+        d = _t(dx, (n, h, w, c), BF16)
+        d.copy_(_bf(d.float() + gx) if accumulate else _bf(gx))
+        return 0
+
     def tok_gap_fwd(self, x, y, n, hw, c, st):
         _t(y, (n, c), BF16).copy_((_t(x, (n, hw, c), BF16).float().sum(1) * (1.0 / hw)).to(BF16))
         return 0

@@ -521,6 +521,21 @@ def test_contrastive(libs, n1, n2, dim, ld, same):
         assert relerr(dv[id(de2)].float(), de2.float()) < 6e-3
 
 
+@pytest.mark.parametrize('n,h,w,c', [(2, 8, 8, 16), (3, 9, 5, 64), (1, 1, 7, 8), (4, 56, 56, 256)])
+def test_avgpool2x2(libs, n, h, w, c):
+    x = rnd(n, h, w, c, seed=h).to(BF16)
+    y = torch.empty(n, (h + 1) // 2, (w + 1) // 2, c, dtype=BF16)
+    dv = both(libs, 'tok_avgpool2x2_fwd', lambda d: [d(x), d(y), n, h, w, c, None])
+    assert relerr(dv[id(y)].float(), y.float()) < 4e-3
+    ref = torch.nn.functional.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2, ceil_mode=True, count_include_pad=False)
+    assert relerr(dv[id(y)].float().cpu(), ref.permute(0, 2, 3, 1)) < 4e-3
+    dy = rnd(*y.shape, seed=3).to(BF16)
+    for acc in (0, 1):
+        dx = rnd(n, h, w, c, seed=9).to(BF16)
+        dv = both(libs, 'tok_avgpool2x2_bwd', lambda d: [d(dy), d(dx), acc, n, h, w, c, None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < 6e-3
+
+
 @pytest.mark.parametrize('n,dim,ld,mode', [(16, 24, 24, 1), (33, 20, 24, 2), (512, 512, 512, 2), (7, 100, 104, 1)])
 def test_embed_regulariser(libs, n, dim, ld, mode):
     e = torch.zeros(n, ld)

@@ -1,5 +1,5 @@
-"""The further plain v1.5 ResNet entrypoints of the reference (resnet.py:623-628, 707-776, 881-960): other depths and the
-wide bottleneck (base_width 128).  Same blocks and kernels as resnet18/50, so the checks are: the parameter tree equals
+"""The further ResNet entrypoints of the reference (resnet.py:597-776, 881-960): other depths, the wide bottleneck
+(base_width 128) and the 'd' / 't' variants (deep 3x3 stem, average-pool shortcut projections).  Same blocks and kernels as resnet18/50, so the checks are: the parameter tree equals
 the oracle's (timm's BasicBlock / Bottleneck restated in oracle/timm_min.py), and a training step of the two new
 shapes of layer — [2,2,2,2] bottlenecks and 2x-wide 3x3s — stays inside the bf16 yardstick of the fp32 oracle."""
 import copy
@@ -22,10 +22,11 @@ def dev(request):
 
 
 def test_registered_names_and_parameter_trees(fake_backend):
-    names = ['resnet26', 'resnet200', 'tv_resnet34', 'tv_resnet50', 'tv_resnet101', 'tv_resnet152', 'wide_resnet50_2',
+    names = ['resnet18d', 'resnet34d', 'resnet26d', 'resnet26t', 'resnet50d', 'resnet50t', 'resnet101d', 'resnet152d',
+             'resnet200d', 'resnet26', 'resnet200', 'tv_resnet34', 'tv_resnet50', 'tv_resnet101', 'tv_resnet152', 'wide_resnet50_2',
              'wide_resnet101_2', 'ssl_resnet18', 'ssl_resnet50', 'swsl_resnet18', 'swsl_resnet50']
     assert all(n in T.BACKBONES.entrypoints for n in names)
-    for n in ('resnet26', 'wide_resnet50_2', 'tv_resnet34', 'tv_resnet50', 'ssl_resnet18', 'swsl_resnet50'):
+    for n in ('resnet18d', 'resnet26t', 'resnet50d', 'resnet26', 'wide_resnet50_2', 'tv_resnet34', 'tv_resnet50', 'ssl_resnet18', 'swsl_resnet50'):
         mine = T.BACKBONES.get(n)(pretrained=False, in_channels=3)
         ref = R.BACKBONES[n]()
         assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == \
@@ -39,8 +40,9 @@ def test_registered_names_and_parameter_trees(fake_backend):
         T.BACKBONES.get('ssl_resnet18')()          # the reference default asks for a download (pretrained=True)
 
 
-@pytest.mark.parametrize('backbone', ['resnet26', 'wide_resnet50_2'])
-def test_training_step_vs_oracle(dev, backbone):
+# resnet18d / resnet26t at 72 px: 18 -> 9 -> 5 -> 3 feature maps, so the ceil-mode average pool meets odd sizes
+@pytest.mark.parametrize('backbone,size', [('resnet26', 64), ('wide_resnet50_2', 64), ('resnet18d', 72), ('resnet26t', 72)])
+def test_training_step_vs_oracle(dev, backbone, size):
     torch.manual_seed(0)
     cfg = cls_config(backbone, 10, backbone_params={'zero_init_last': False})
     task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
@@ -49,7 +51,7 @@ def test_training_step_vs_oracle(dev, backbone):
     copy_state(ref, task)
     task.to(dev).train()
     ref.train()
-    x, y = torch.randn(16, 3, 64, 64), torch.randint(0, 10, (16,))
+    x, y = torch.randn(16, 3, size, size), torch.randint(0, 10, (16,))
     ref2 = copy.deepcopy(ref)
     with torch.autocast('cpu', dtype=torch.bfloat16):
         o = ref2.forward_with_gt({'image': x, 'target': y})

@@ -76,6 +76,8 @@ PROTOTYPES = {
     'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
     'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_avgpool2x2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'tok_avgpool2x2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_gap_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'tok_gap_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),

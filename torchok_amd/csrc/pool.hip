@@ -279,6 +279,87 @@ extern "C" int tok_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void*
   return TOK_OK;
 }
 
+namespace {
+// AvgPool2d(2, stride 2, ceil_mode=True, count_include_pad=False) — the 'avg_down' shortcut of the d-variant ResNets
+// ([timm] downsample_avg): output ceil(h/2) x ceil(w/2); a window hanging over the edge averages its valid pixels only.
+// One thread per (image, output pixel, 8 channels); NHWC bf16, 16-byte accesses.
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int n, int h,
+                                                           int w, int c) {
+  const int p = (h + 1) >> 1, q = (w + 1) >> 1, c8 = c >> 3;
+  const size_t total = (size_t)n * p * q * c8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % c8);
+    size_t t = i / c8;
+    const int oq = (int)(t % q); t /= q;
+    const int op = (int)(t % p);
+    const int b = (int)(t / p);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int hh = 2 * op + dh, ww = 2 * oq + dw;
+        if (hh < h && ww < w) {
+          const bf16x8 v = ldg16(x + (((size_t)b * h + hh) * w + ww) * c + cc * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+          ++cnt;
+        }
+      }
+    const float inv = 1.f / (float)cnt;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] * inv);
+    stg16(y + i * 8, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16* __restrict__ dy, bf16* __restrict__ dx, int accumulate,
+                                                           int n, int h, int w, int c) {
+  const int p = (h + 1) >> 1, q = (w + 1) >> 1, c8 = c >> 3;
+  const size_t total = (size_t)n * h * w * c8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % c8);
+    size_t t = i / c8;
+    const int ww = (int)(t % w); t /= w;
+    const int hh = (int)(t % h);
+    const int b = (int)(t / h);
+    const int op = hh >> 1, oq = ww >> 1;
+    const int cnt = ((2 * op + 1 < h) ? 2 : 1) * ((2 * oq + 1 < w) ? 2 : 1);
+    const float inv = 1.f / (float)cnt;
+    const bf16x8 g = ldg16(dy + (((size_t)b * p + op) * q + oq) * c + cc * 8);
+    bf16x8 o;
+    if (accumulate) {
+      const bf16x8 old = ldg16(dx + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(old[e]) + bf2f(g[e]) * inv);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(bf2f(g[e]) * inv);
+    }
+    stg16(dx + i * 8, o);
+  }
+}
+}  // namespace
+
+extern "C" int tok_avgpool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, void* stream) {
+  TOK_CHECK_ARG(x && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_avgpool2x2_fwd: bad args");
+  const size_t total = (size_t)n * ((h + 1) / 2) * ((w + 1) / 2) * (c / 8);
+  hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, tok_stream(stream), (const bf16*)x, (bf16*)y,
+                     n, h, w, c);
+  TOK_CHECK_LAUNCH("tok_avgpool2x2_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_avgpool2x2_bwd(const void* dy, void* dx, int accumulate, int n, int h, int w, int c, void* stream) {
+  TOK_CHECK_ARG(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_avgpool2x2_bwd: bad args");
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(grid_for((size_t)n * h * w * (c / 8))), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)dy, (bf16*)dx, accumulate, n, h, w, c);
+  TOK_CHECK_LAUNCH("tok_avgpool2x2_bwd");
+  return TOK_OK;
+}
+
 extern "C" int tok_gap_fwd(const void* x, void* y, int n, int hw, int c, void* stream) {
   TOK_CHECK_ARG(x && y && n > 0 && hw > 0 && c > 0 && c % 8 == 0, "tok_gap_fwd: bad args");
   hipLaunchKernelGGL(gap_fwd_kernel, dim3((n * (c / 8) + 255) / 256), dim3(256), 0, tok_stream(stream),

@@ -581,6 +581,40 @@ def max_pool_3x3_s2(region: Region, x: TTensor) -> TTensor:
     return out
 
 
+# ---- 2x2 average pool (avg_down shortcuts) ---------------------------------------------------------------------
+
+class _AvgPool2Node(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        n, h, w, c = self.x.shape
+        tgt, acc = grad_target(self.x)
+        _C.check(_C.lib().tok_avgpool2x2_bwd(ptr(g), ptr(tgt), acc, n, h, w, c, stream_ptr()), 'tok_avgpool2x2_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = None
+
+
+def avg_pool_2x2(region: Region, x: TTensor) -> TTensor:
+    """AvgPool2d(2, stride 2, ceil_mode=True, count_include_pad=False) ([timm] downsample_avg)."""
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=BF16, device=x.data.device)
+    _C.check(_C.lib().tok_avgpool2x2_fwd(ptr(x.data), ptr(y), n, h, w, c, stream_ptr()), 'tok_avgpool2x2_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, x.c, requires_grad=req)
+    if req:
+        node = _AvgPool2Node()
+        node.x, node.out = x, out
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out
+
+
 # ---- global average pool --------------------------------------------------------------------------------
 
 class _GapNode(Node):

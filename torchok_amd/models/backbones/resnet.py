@@ -119,6 +119,10 @@ def _run_downsample(r, x, downsample):
     without activation (necks/classification/hrnet.py:62-69)."""
     if hasattr(downsample, 'run'):
         return downsample.run(r, x)
+    if len(downsample) == 3:       # [timm] downsample_avg: (AvgPool2d | Identity, 1x1 conv, norm)
+        if isinstance(downsample[0], nn.AvgPool2d):
+            x = EF.avg_pool_2x2(r, x)
+        return EF.conv_bn_act(r, x, downsample[1], downsample[2], relu=False)
     return EF.conv_bn_act(r, x, downsample[0], downsample[1], relu=False)
 
 
@@ -140,10 +144,21 @@ def downsample_conv(in_channels, out_channels, kernel_size, stride=1, dilation=1
         norm_layer(out_channels))
 
 
+def downsample_avg(in_channels, out_channels, kernel_size, stride=1, dilation=1, first_dilation=None, norm_layer=None):
+    """[timm] downsample_avg: 2x2 average pool (only where the block strides) -> 1x1 stride-1 conv -> norm."""
+    norm_layer = norm_layer or nn.BatchNorm2d
+    pool = nn.Identity()
+    if stride != 1:
+        if stride != 2 or dilation != 1:
+            raise NotImplementedError('torchok_amd ResNet: avg_down with stride 2, no dilation')
+        pool = nn.AvgPool2d(2, stride, ceil_mode=True, count_include_pad=False)
+    return nn.Sequential(pool, nn.Conv2d(in_channels, out_channels, 1, stride=1, padding=0, bias=False),
+                         norm_layer(out_channels))
+
+
 def make_blocks(block_fn, channels, block_repeats, inplanes, reduce_first=1, output_stride=32,
                 down_kernel_size=1, avg_down=False, drop_block_rate=0., drop_path_rate=0., **kwargs):
-    _unsupported(avg_down=avg_down, drop_block_rate=drop_block_rate, drop_path_rate=drop_path_rate,
-                 output_stride=output_stride != 32)
+    _unsupported(drop_block_rate=drop_block_rate, drop_path_rate=drop_path_rate, output_stride=output_stride != 32)
     no_downsample_stages = kwargs.pop('no_downsample_stages', [0])
     stages, feature_info = [], []
     net_stride = 4
@@ -153,8 +168,9 @@ def make_blocks(block_fn, channels, block_repeats, inplanes, reduce_first=1, out
         net_stride *= stride
         downsample = None
         if stride != 1 or inplanes != planes * block_fn.expansion:
-            downsample = downsample_conv(inplanes, planes * block_fn.expansion, kernel_size=down_kernel_size,
-                                         stride=stride, norm_layer=kwargs.get('norm_layer'))
+            make = downsample_avg if avg_down else downsample_conv
+            downsample = make(inplanes, planes * block_fn.expansion, kernel_size=down_kernel_size,
+                              stride=stride, norm_layer=kwargs.get('norm_layer'))
         blocks = []
         for block_idx in range(num_blocks):
             blocks.append(block_fn(inplanes, planes, stride if block_idx == 0 else 1,
@@ -174,10 +190,20 @@ class ResNet(BaseBackbone):
         block_args = block_args or dict()
         if output_stride not in (8, 16, 32):
             raise ValueError('`output_stride` must be in (8, 16, 32)')
-        _unsupported(stem_type=bool(stem_type), replace_stem_pool=replace_stem_pool, aa_layer=aa_layer,
-                     act_layer=act_layer is not nn.ReLU, norm_layer=norm_layer is not nn.BatchNorm2d)
-        inplanes = 64
-        self.conv1 = nn.Conv2d(in_channels, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
+        _unsupported(stem_type=stem_type not in ('', 'deep', 'deep_tiered'), replace_stem_pool=replace_stem_pool,
+                     aa_layer=aa_layer, act_layer=act_layer is not nn.ReLU, norm_layer=norm_layer is not nn.BatchNorm2d)
+        deep_stem = 'deep' in stem_type
+        inplanes = stem_width * 2 if deep_stem else 64
+        if deep_stem:      # three 3x3 convs (resnet.py:475-486): conv1 becomes a Sequential, bn1 / act1 follow its last conv
+            stem_chs = (3 * (stem_width // 4), stem_width) if 'tiered' in stem_type else (stem_width, stem_width)
+            self.conv1 = nn.Sequential(
+                nn.Conv2d(in_channels, stem_chs[0], 3, stride=2, padding=1, bias=False), norm_layer(stem_chs[0]),
+                act_layer(inplace=True),
+                nn.Conv2d(stem_chs[0], stem_chs[1], 3, stride=1, padding=1, bias=False), norm_layer(stem_chs[1]),
+                act_layer(inplace=True),
+                nn.Conv2d(stem_chs[1], inplanes, 3, stride=1, padding=1, bias=False))
+        else:
+            self.conv1 = nn.Conv2d(in_channels, inplanes, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(inplanes)
         self.act1 = act_layer(inplace=True)
         self.feature_info = [dict(num_chs=inplanes, reduction=2, module='act1')]
@@ -214,13 +240,18 @@ class ResNet(BaseBackbone):
     def _run(self, r, x: torch.Tensor, all_features: bool = True):
         t = r.input(x, c_pad_to=4 if x.shape[1] <= 4 else 8)
         feats = []
+        last = self.conv1
+        if isinstance(self.conv1, nn.Sequential):            # deep stem: two conv-bn-relu units in front of the last conv
+            t = EF.conv_bn_act(r, t, self.conv1[0], self.conv1[1], relu=True)
+            t = EF.conv_bn_act(r, t, self.conv1[3], self.conv1[4], relu=True)
+            last = self.conv1[6]
         if all_features or not EF.FUSE_STEM_POOL:
-            t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True)
+            t = EF.conv_bn_act(r, t, last, self.bn1, relu=True)
             feats.append(t)                      # 'act1', the first entry of feature_info
             t = EF.max_pool_3x3_s2(r, t)
         else:
             # nobody asked for act1: bn1 + ReLU + max-pool in one pass, the 112 x 112 activated map is never stored
-            t = EF.conv_bn_act(r, t, self.conv1, self.bn1, relu=True, pool=True)
+            t = EF.conv_bn_act(r, t, last, self.bn1, relu=True, pool=True)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             t = layer(t)
             feats.append(t)
@@ -300,3 +331,15 @@ ssl_resnet18 = _plain('ssl_resnet18', BasicBlock, [2, 2, 2, 2], 'resnet.py:881-8
 ssl_resnet50 = _plain('ssl_resnet50', Bottleneck, [3, 4, 6, 3], 'resnet.py:891-898', default_pretrained=True)
 swsl_resnet18 = _plain('swsl_resnet18', BasicBlock, [2, 2, 2, 2], 'resnet.py:942-949', default_pretrained=True)
 swsl_resnet50 = _plain('swsl_resnet50', Bottleneck, [3, 4, 6, 3], 'resnet.py:953-960', default_pretrained=True)
+# 'd' = deep stem (three 3x3 convs, width 32) + average-pool shortcut projections; 't' = tiered deep stem (24, 32)
+_D = dict(stem_width=32, stem_type='deep', avg_down=True)
+_T = dict(stem_width=32, stem_type='deep_tiered', avg_down=True)
+resnet18d = _plain('resnet18d', BasicBlock, [2, 2, 2, 2], 'resnet.py:597-603', **_D)
+resnet34d = _plain('resnet34d', BasicBlock, [3, 4, 6, 3], 'resnet.py:614-620', **_D)
+resnet26d = _plain('resnet26d', Bottleneck, [2, 2, 2, 2], 'resnet.py:640-645', **_D)
+resnet26t = _plain('resnet26t', Bottleneck, [2, 2, 2, 2], 'resnet.py:631-637', **_T)
+resnet50d = _plain('resnet50d', Bottleneck, [3, 4, 6, 3], 'resnet.py:656-662', **_D)
+resnet50t = _plain('resnet50t', Bottleneck, [3, 4, 6, 3], 'resnet.py:665-671', **_T)
+resnet101d = _plain('resnet101d', Bottleneck, [3, 4, 23, 3], 'resnet.py:682-687', **_D)
+resnet152d = _plain('resnet152d', Bottleneck, [3, 8, 36, 3], 'resnet.py:698-704', **_D)
+resnet200d = _plain('resnet200d', Bottleneck, [3, 24, 36, 3], 'resnet.py:715-721', **_D)
