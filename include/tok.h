@@ -513,6 +513,10 @@ int tok_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   void* shadow_bf16, size_t count, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int decoupled /*AdamW*/, int64_t step,
                   int maximize, void* stream);
+/* torch.optim.RMSprop (registered at optim/optimizers/__init__.py:16): square_avg / momentum_buf / grad_avg start at 0 */
+int tok_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
+                     size_t count, float lr, float alpha, float eps, float weight_decay, float momentum,
+                     int centered, int maximize, void* stream);
 int tok_fill_f32(float* dst, float value, size_t count, void* stream);
 int tok_scale_f32(float* dst, float factor, size_t count, void* stream);
 

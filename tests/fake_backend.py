@@ -1193,6 +1193,28 @@ class FakeTok:
             _t(shadow, (count,), BF16).copy_(p)
         return 0
 
+    def tok_rmsprop_step(self, param, grad, sq, mbuf, gavg, count, lr, alpha, eps, wd, momentum, centered, maximize, st):
+        self.calls.append('rmsprop_step')
+        p, g = _t(param, (count,), torch.float32), _t(grad, (count,), torch.float32)
+        s_ = _t(sq, (count,), torch.float32)
+        d = -g if maximize else g.clone()
+        if wd != 0:
+            d = d + wd * p
+        s_.mul_(alpha).addcmul_(d, d, value=1 - alpha)
+        if centered:
+            ga = _t(gavg, (count,), torch.float32)
+            ga.lerp_(d, 1 - alpha)
+            avg = torch.addcmul(s_, ga, ga, value=-1).sqrt_().add_(eps)
+        else:
+            avg = s_.sqrt().add_(eps)
+        if momentum > 0:
+            b = _t(mbuf, (count,), torch.float32)
+            b.mul_(momentum).addcdiv_(d, avg)
+            p.add_(b, alpha=-lr)
+        else:
+            p.addcdiv_(d, avg, value=-lr)
+        return 0
+
     def tok_adam_step(self, param, grad, m, v, shadow, count, lr, b1, b2, eps, wd, decoupled, step, maximize, st):
         self.calls.append('adam_step')
         p, g = _t(param, (count,), torch.float32), _t(grad, (count,), torch.float32)

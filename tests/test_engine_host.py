@@ -102,6 +102,42 @@ def test_fused_adam_equals_torch_adam(fake_backend):
             assert rel_err(p, rp[n]) < 1e-5, (it, n)
 
 
+@pytest.mark.parametrize('kw', [dict(lr=1e-2), dict(lr=1e-2, momentum=0.9, weight_decay=1e-4), dict(lr=5e-3, centered=True, alpha=0.9),
+                                dict(lr=5e-3, centered=True, momentum=0.5, eps=1e-6)])
+def test_fused_rmsprop_equals_torch_rmsprop(fake_backend, kw):
+    _rmsprop_case('cpu', kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw', [dict(lr=1e-2), dict(lr=5e-3, centered=True, momentum=0.5, weight_decay=1e-4)])
+def test_fused_rmsprop_equals_torch_rmsprop_gpu(kw):
+    _rmsprop_case('cuda', kw)
+
+
+def _rmsprop_case(dev, kw):
+    torch.manual_seed(3)
+    task, ref = _pair(optimizer='RMSprop', opt_params=kw)
+    task.to(dev)
+    opt = task.configure_optimizers()[0]['optimizer']
+    assert type(opt).__name__ == 'RMSprop' and type(opt).__module__.startswith('torchok_amd')
+    ropt = torch.optim.RMSprop(ref.parameters(), **kw)
+    x, y = torch.randn(4, 3, 32, 32).to(dev), torch.randint(0, 10, (4,)).to(dev)
+    rp = dict(ref.named_parameters())
+    for it in range(3):
+        out = task.training_step({'image': x, 'target': y}, it)
+        opt.zero_grad()
+        out['loss'].backward()
+        for n, p in task.named_parameters():        # same gradients on both sides
+            rp[n].grad = p.grad.detach().float().cpu().clone().contiguous()
+        opt.step()
+        ropt.step()
+        for n, p in task.named_parameters():
+            assert rel_err(p, rp[n]) < 2e-5, (it, n)
+    sd = opt.state_dict()
+    assert 'square_avg' in sd['state'][0] and ('momentum_buffer' in sd['state'][0]) == (kw.get('momentum', 0) > 0)
+    assert ('grad_avg' in sd['state'][0]) == bool(kw.get('centered', False))
+
+
 def test_frozen_parameters_get_no_grad_and_are_skipped(fake_backend):
     """FreezeUnfreeze-style freezing (reference callbacks/freeze_unfreeze.py): frozen params keep
     grad None, stay in the optimizer, and are not updated (torch semantics: grad None => skip)."""

@@ -149,6 +149,7 @@ PROTOTYPES = {
     'tok_topk_rows': (c_int, [_P, c_int, c_int, c_int64, c_int, _P, _P, _P]),
     'tok_retrieval_nrel': (c_int, [_P, _P, c_int, c_int, _P, _P, c_int, _P, _P]),
     'tok_retrieval_eval': (c_int, [c_int, _P, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    'tok_rmsprop_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, c_int, _P]),
     'tok_sgd_step': (c_int, [_P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,

@@ -54,6 +54,37 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// torch.optim.RMSprop (_single_tensor_rmsprop): g += wd * p; sq = alpha * sq + (1 - alpha) g^2; centered: ga = lerp(ga, g,
+// 1 - alpha), avg = sqrt(sq - ga^2) + eps, else avg = sqrt(sq) + eps; momentum: buf = m * buf + g / avg, p -= lr * buf,
+// else p -= lr * g / avg.  State arrays start at zero (the arena allocates them zeroed).
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                               float* __restrict__ buf, float* __restrict__ ga, size_t n, float lr, float alpha, float eps,
+                               float wd, float momentum, int centered, int maximize) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float w = p[i];
+    float d = maximize ? -g[i] : g[i];
+    if (wd != 0.f) d = fmaf(wd, w, d);
+    const float s = alpha * sq[i] + (1.f - alpha) * d * d;
+    sq[i] = s;
+    float avg;
+    if (centered) {
+      const float a = ga[i] + (d - ga[i]) * (1.f - alpha);
+      ga[i] = a;
+      avg = sqrtf(s - a * a) + eps;
+    } else {
+      avg = sqrtf(s) + eps;
+    }
+    if (momentum > 0.f) {
+      const float b = momentum * buf[i] + d / avg;
+      buf[i] = b;
+      w -= lr * b;
+    } else {
+      w -= lr * (d / avg);
+    }
+    p[i] = w;
+  }
+}
+
 __global__ void fill_kernel(float* dst, float v, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     dst[i] = v;
@@ -92,6 +123,17 @@ extern "C" int tok_adam_step(float* param, const float* grad, float* exp_avg, fl
                      exp_avg, exp_avg_sq, (bf16*)shadow_bf16, count, lr, beta1, beta2, eps, weight_decay,
                      decoupled, (float)((double)lr / bc1), (float)sqrt(bc2), maximize);
   TOK_CHECK_LAUNCH("tok_adam_step");
+  return TOK_OK;
+}
+
+extern "C" int tok_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
+                                size_t count, float lr, float alpha, float eps, float weight_decay, float momentum,
+                                int centered, int maximize, void* stream) {
+  TOK_CHECK_ARG(param && grad && square_avg && count > 0, "tok_rmsprop_step: bad args");
+  TOK_CHECK_ARG((momentum <= 0.f || momentum_buf) && (!centered || grad_avg), "tok_rmsprop_step: state buffer missing");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(count)), dim3(256), 0, tok_stream(stream), param, grad, square_avg,
+                     momentum_buf, grad_avg, count, lr, alpha, eps, weight_decay, momentum, centered, maximize);
+  TOK_CHECK_LAUNCH("tok_rmsprop_step");
   return TOK_OK;
 }
 

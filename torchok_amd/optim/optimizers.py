@@ -219,3 +219,75 @@ class AdamW(_AdamBase):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, **kw):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+
+
+@OPTIMIZERS.register_class
+class RMSprop(_ArenaOptimizer):
+    """torch.optim.RMSprop semantics (the class the reference registers, optim/optimizers/__init__.py:16) on the flat
+    arena: one launch per run of parameters; square_avg / momentum_buffer / grad_avg are arena state slots 0 / 1 / 2."""
+    _n_state = 3
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0., momentum=0., centered=False,
+                 capturable: bool = False, foreach=None, maximize: bool = False, differentiable: bool = False):
+        if lr < 0.0:
+            raise ValueError(f'Invalid learning rate: {lr}')
+        if eps < 0.0:
+            raise ValueError(f'Invalid epsilon value: {eps}')
+        if momentum < 0.0:
+            raise ValueError(f'Invalid momentum value: {momentum}')
+        if weight_decay < 0.0:
+            raise ValueError(f'Invalid weight_decay value: {weight_decay}')
+        if alpha < 0.0:
+            raise ValueError(f'Invalid alpha value: {alpha}')
+        if differentiable or capturable:
+            raise NotImplementedError('differentiable / capturable optimizers are not supported')
+        defaults = dict(lr=lr, momentum=momentum, alpha=alpha, eps=eps, centered=centered, weight_decay=weight_decay,
+                        maximize=maximize)
+        super().__init__(params, defaults)
+
+    _KEYS = ('square_avg', 'momentum_buffer', 'grad_avg')
+
+    def _restore_state(self, old_state):
+        for a in self._arenas:
+            if a is None:
+                continue
+            for i, p in enumerate(a.params):
+                s = old_state.get(id(p))
+                if s and 'square_avg' in s:
+                    for slot, key in enumerate(self._KEYS):
+                        if s.get(key) is not None:
+                            a.state_view(slot, i).copy_(s[key])
+                            self.state[p][key] = a.state_view(slot, i)
+                    self.state[p]['step'] = s.get('step', 0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._ensure_built()
+        lib, st = _C.lib(), stream_ptr()
+        for group, arena in zip(self.param_groups, self._arenas):
+            if arena is None:
+                continue
+            for a, b, _ in self._runs(arena, lambda i: 0):
+                off = arena.offsets[a]
+                count = arena.padded_end(b) - off
+                _C.check(lib.tok_rmsprop_step(ptr(arena.master) + 4 * off, ptr(arena.grad) + 4 * off,
+                                              ptr(arena.state[0]) + 4 * off, ptr(arena.state[1]) + 4 * off,
+                                              ptr(arena.state[2]) + 4 * off, count, float(group['lr']),
+                                              float(group['alpha']), float(group['eps']), float(group['weight_decay']),
+                                              float(group['momentum']), int(group['centered']), int(group['maximize']),
+                                              st), 'tok_rmsprop_step')
+                for i in range(a, b + 1):
+                    s = self.state[arena.params[i]]
+                    if 'square_avg' not in s:
+                        s['square_avg'] = arena.state_view(0, i)
+                        if group['momentum'] > 0:
+                            s['momentum_buffer'] = arena.state_view(1, i)
+                        if group['centered']:
+                            s['grad_avg'] = arena.state_view(2, i)
+                    s['step'] = int(s.get('step', 0)) + 1
+        self._repack()
+        return loss
