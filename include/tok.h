@@ -265,6 +265,14 @@ int tok_bce_logits_fwd(const void* logits, const float* target, int64_t rows, in
 int tok_bce_logits_bwd(const void* logits, const float* target, const float* loss, const float* gscale,
                        int64_t rows, int classes, int ld, float ignore_value, int mean, void* dlogits, void* stream);
 
+/* torch.nn.L1Loss / MSELoss / SmoothL1Loss / HuberLoss as registered by the reference (losses/__init__.py:13,19,23,24):
+ * x bf16 [n] (flat), target fp32 [n]; kind 0 L1, 1 MSE, 2 smooth-L1 (knee = beta), 3 Huber (knee = delta); 'mean' or 'sum'.
+ * loss: TOK_CE_LOSS_FLOATS floats, [0] = loss.  backward: dx bf16 [n] = d elem / d x * gscale[0] / (mean ? n : 1).        */
+int tok_regression_loss_fwd(const void* x, const float* target, int64_t n, int kind, float knee, int mean, float* loss,
+                            void* stream);
+int tok_regression_loss_bwd(const void* x, const float* target, const float* gscale, int64_t n, int kind, float knee,
+                            int mean, void* dx, void* stream);
+
 /* On-device classification statistics behind the Accuracy / F1Score metrics the reference configs log every step
  * (metrics/metrics_manager.py:147-158, classification_cifar10.yaml:134-150; torchmetrics itself is third-party):
  * counts int64 [3][classes] += {true positives, predicted, actual} per class.  Predictions are bf16 logits

@@ -764,6 +764,30 @@ class FakeTok:
         d[:, :classes] = _bf(dz * g)
         return 0
 
+    @staticmethod
+    def _reg(kind, x, t, k):
+        fn = {0: lambda: F.l1_loss(x, t, reduction='none'), 1: lambda: F.mse_loss(x, t, reduction='none'),
+              2: lambda: F.smooth_l1_loss(x, t, reduction='none', beta=k),
+              3: lambda: F.huber_loss(x, t, reduction='none', delta=k)}[kind]
+        return fn()
+
+    def tok_regression_loss_fwd(self, x, target, n, kind, knee, mean, loss, st):
+        xv, t = _t(x, (n,), BF16).float(), _t(target, (n,), torch.float32)
+        el = self._reg(kind, xv, t, knee).double()
+        o = _t(loss, (2,), torch.float32)
+        o[0] = float(el.mean() if mean else el.sum())
+        o[1] = float(n)
+        return 0
+
+    def tok_regression_loss_bwd(self, x, target, gscale, n, kind, knee, mean, dx, st):
+        t = _t(target, (n,), torch.float32)
+        with torch.enable_grad():
+            xv = _t(x, (n,), BF16).float().requires_grad_(True)
+            self._reg(kind, xv, t, knee).sum().backward()
+        g = float(_t(gscale, (1,), torch.float32)[0]) * (1.0 / n if mean else 1.0)
+        _t(dx, (n,), BF16).copy_(_bf(xv.grad * g))
+        return 0
+
     def tok_bce_logits_fwd(self, logits, target, rows, classes, ld, ignore_value, mean, loss, st):
         x = _t(logits, (rows, ld), BF16).float()[:, :classes]
         t = _t(target, (rows, classes), torch.float32)

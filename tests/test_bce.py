@@ -70,3 +70,24 @@ def test_ignore_value_empty_selection_and_errors(dev):
         T.LOSSES.get('BCEWithLogitsLoss')(reduction='none')
     with pytest.raises(ValueError):
         T.LOSSES.get('BCEWithLogitsLoss')()(x, t[:, :5])
+
+
+@pytest.mark.parametrize('name,kw', [('L1Loss', {}), ('MSELoss', dict(reduction='sum')), ('SmoothL1Loss', dict(beta=0.7)),
+                                     ('SmoothL1Loss', dict(beta=0.0)), ('HuberLoss', dict(delta=1.5)),
+                                     ('HuberLoss', dict(delta=0.4, reduction='sum'))])
+def test_regression_losses_vs_torch(dev, name, kw):
+    """L1 / MSE / SmoothL1 / Huber are torch's own classes in the reference registry (losses/__init__.py:13-25): the oracle
+    is torch.nn itself, evaluated on the bf16-exact prediction."""
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(6, 5, 9, generator=g) * 2).bfloat16()
+    t = torch.randn(6, 5, 9, generator=g)
+    xr = x.float().requires_grad_(True)
+    ref = getattr(torch.nn, name)(**kw)(xr, t)
+    ref.backward()
+    xd = x.to(dev).requires_grad_(True)
+    loss = T.LOSSES.get(name)(**kw)(xd, t.to(dev))
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-6 * abs(float(ref.detach()))
+    loss.backward()
+    assert xd.grad.shape == x.shape and rel_err(xd.grad.float(), xr.grad) < 4e-3        # bf16 gradient storage
+    with pytest.raises(ValueError):
+        T.LOSSES.get(name)(**kw)(xd, t[:, :2].to(dev))

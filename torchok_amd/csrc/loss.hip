@@ -491,6 +491,69 @@ extern "C" int tok_bce_logits_bwd(const void* logits, const float* target, const
 }
 
 namespace {
+// torch.nn.L1Loss / MSELoss / SmoothL1Loss(beta) / HuberLoss(delta) (registered at losses/__init__.py:13-25) on a flat bf16
+// prediction and fp32 target: kind 0 |d|, 1 d^2, 2 smooth-L1, 3 Huber; d = x - t.  Same two-stage fp64 fold as above.
+__device__ __forceinline__ float reg_elem(int kind, float d, float k) {
+  const float a = fabsf(d);
+  if (kind == 0) return a;
+  if (kind == 1) return d * d;
+  if (kind == 2) return a < k ? 0.5f * d * d / k : a - 0.5f * k;
+  return a <= k ? 0.5f * d * d : k * (a - 0.5f * k);
+}
+__device__ __forceinline__ float reg_grad(int kind, float d, float k) {
+  const float a = fabsf(d), sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+  if (kind == 0) return sg;
+  if (kind == 1) return 2.f * d;
+  if (kind == 2) return a < k ? d / k : sg;
+  return a <= k ? d : k * sg;
+}
+
+__global__ __launch_bounds__(256) void reg_partial_kernel(const bf16* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                                          int kind, float k, int64_t chunk, double* __restrict__ part) {
+  const int64_t e0 = (int64_t)blockIdx.x * chunk;
+  const int64_t e1 = e0 + chunk < n ? e0 + chunk : n;
+  double s = 0.0, cnt = 0.0;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) { s += (double)reg_elem(kind, bf2f(x[e]) - t[e], k); cnt += 1.0; }
+  block_reduce2(s, cnt);
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = cnt; }
+}
+
+__global__ __launch_bounds__(256) void reg_bwd_kernel(const bf16* __restrict__ x, const float* __restrict__ t,
+                                                      const float* __restrict__ gscale, int64_t n, int kind, float k,
+                                                      float scale, bf16* __restrict__ dx) {
+  const float g = gscale[0] * scale;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dx[i] = f2bf(reg_grad(kind, bf2f(x[i]) - t[i], k) * g);
+}
+}  // namespace
+
+extern "C" int tok_regression_loss_fwd(const void* x, const float* target, int64_t n, int kind, float knee, int mean,
+                                       float* loss, void* stream) {
+  TOK_CHECK_ARG(x && target && loss && n > 0 && kind >= 0 && kind <= 3, "tok_regression_loss_fwd: bad args");
+  TOK_CHECK_ARG(kind < 2 || knee > 0.f, "tok_regression_loss_fwd: beta / delta must be positive");
+  TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_regression_loss_fwd: loss must be 8-byte aligned");
+  hipStream_t st = tok_stream(stream);
+  double* part = reinterpret_cast<double*>(loss + 2);   // loss holds TOK_CE_LOSS_FLOATS floats
+  const int nparts = n < 8192 ? 1 : (int)(tok_cdiv(n, (int64_t)8192) < CE_PARTS ? tok_cdiv(n, (int64_t)8192) : CE_PARTS);
+  const int64_t chunk = (n + nparts - 1) / nparts;
+  hipLaunchKernelGGL(reg_partial_kernel, dim3(nparts), dim3(256), 0, st, (const bf16*)x, target, n, kind, knee, chunk, part);
+  TOK_CHECK_LAUNCH("tok_regression_loss_fwd(partial)");
+  hipLaunchKernelGGL(bce_final_kernel, dim3(1), dim3(256), 0, st, part, nparts, mean, loss);
+  TOK_CHECK_LAUNCH("tok_regression_loss_fwd(final)");
+  return TOK_OK;
+}
+
+extern "C" int tok_regression_loss_bwd(const void* x, const float* target, const float* gscale, int64_t n, int kind,
+                                       float knee, int mean, void* dx, void* stream) {
+  TOK_CHECK_ARG(x && target && gscale && dx && n > 0 && kind >= 0 && kind <= 3, "tok_regression_loss_bwd: bad args");
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(reg_bwd_kernel, dim3(blocks), dim3(256), 0, tok_stream(stream), (const bf16*)x, target, gscale, n,
+                     kind, knee, mean ? 1.f / (float)n : 1.f, (bf16*)dx);
+  TOK_CHECK_LAUNCH("tok_regression_loss_bwd");
+  return TOK_OK;
+}
+
+namespace {
 // classification statistics for the on-device metrics: per class c: counts[0][c] += [argmax == c == target],
 // counts[1][c] += [argmax == c], counts[2][c] += [target == c]  (int64 atomics: exact, order-independent)
 __global__ __launch_bounds__(256) void cls_stats_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
