@@ -62,6 +62,55 @@ def test_accuracy_and_f1_values(dev):
         T.METRICS.get('AUROC')
 
 
+def test_precision_recall_fbeta_specificity(dev):
+    """The StatScores family from the same on-device counts, against the torchmetrics multiclass definitions in numpy."""
+    g = torch.Generator().manual_seed(4)
+    c = 6
+    logits = torch.randn(400, c, generator=g)
+    tgt = torch.randint(0, c - 1, (400,), generator=g)             # class 5 never occurs as a target
+    logits[:, 4] -= 50.0                                            # and class 4 is never predicted
+    logits[torch.arange(0, 400, 2), tgt[::2]] += 3.0
+    pred = logits.to(torch.bfloat16).float().argmax(1).numpy()
+    t = tgt.numpy()
+    tp = np.array([((pred == k) & (t == k)).sum() for k in range(c)], dtype=np.float64)
+    pp = np.array([(pred == k).sum() for k in range(c)], dtype=np.float64)
+    ap = np.array([(t == k).sum() for k in range(c)], dtype=np.float64)
+    fp, fn = pp - tp, ap - tp
+    tn = len(t) - pp - ap + tp
+    seen = (pp + ap) > 0
+    div = lambda a, b: np.where(b > 0, a / np.maximum(b, 1e-300), 0.0)      # noqa: E731
+    per = dict(Precision=div(tp, tp + fp), Recall=div(tp, tp + fn), Specificity=div(tn, tn + fp),
+               FBetaScore=div(1.25 * tp, 1.25 * tp + 0.25 * fn + fp))
+    micro = dict(Precision=tp.sum() / (tp + fp).sum(), Recall=tp.sum() / (tp + fn).sum(), Specificity=tn.sum() / (tn + fp).sum(),
+                 FBetaScore=1.25 * tp.sum() / (1.25 * tp.sum() + 0.25 * fn.sum() + fp.sum()))
+    for name in per:
+        kw = dict(beta=0.5) if name == 'FBetaScore' else {}
+        for avg, want in (('micro', micro[name]), ('macro', per[name][seen].mean()), ('none', per[name]),
+                          ('weighted', (per[name] * ap / ap.sum()).sum())):
+            m = T.METRICS.get(name)(task='multiclass', num_classes=c, average=avg, **kw).to(dev)
+            m.update(preds=logits[:150].to(dev), target=tgt[:150].to(dev))
+            m.update(preds=logits[150:].to(dev), target=tgt[150:].to(dev))
+            assert np.allclose(m.compute().cpu().numpy(), want, rtol=1e-6), (name, avg)
+    assert abs(micro['Precision'] - (pred == t).mean()) < 1e-12        # single-label: micro precision = recall = accuracy
+
+
+def test_mean_absolute_and_squared_error(dev):
+    g = torch.Generator().manual_seed(9)
+    p = torch.randn(300, 4, generator=g).bfloat16()
+    t = torch.randn(300, 4, generator=g)
+    d = (p.float() - t).double()
+    for name, kw, want in (('MeanAbsoluteError', {}, d.abs().mean()), ('MeanSquaredError', {}, d.pow(2).mean()),
+                           ('MeanSquaredError', dict(squared=False), d.pow(2).mean().sqrt())):
+        m = T.METRICS.get(name)(**kw).to(dev)
+        m.update(preds=p[:100].to(dev), target=t[:100].to(dev))
+        m.update(preds=p[100:].to(dev), target=t[100:].to(dev))
+        assert abs(float(m.compute()) - float(want)) < 2e-6 * float(want), name
+        m.reset()
+        assert float(m.compute()) == 0.0
+    with pytest.raises(RuntimeError):
+        T.METRICS.get('MeanAbsoluteError')().to(dev).update(preds=p.to(dev), target=t[:, :2].to(dev))
+
+
 def test_manager_semantics(dev):
     params = [dict(name='Accuracy', params=dict(task='multiclass', num_classes=4), mapping=dict(preds='prediction', target='target')),
               dict(name='F1Score', params=dict(task='multiclass', num_classes=4, average='macro'), tag='f1',

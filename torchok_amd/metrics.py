@@ -99,6 +99,56 @@ class F1Score(_MulticlassStat):
         return self._reduce(2 * tp / (pp + ap).clamp_min(1), ap, (ap + pp) > 0)
 
 
+class _FromCounts(_MulticlassStat):
+    """Metrics of the torchmetrics StatScores family from the same {tp, predicted, actual} counts: fp = predicted - tp,
+    fn = actual - tp, tn = rows - predicted - actual + tp; micro = the ratio of the summed terms, macro = the mean over
+    the classes that occur in prediction or target, weighted = by support (torchmetrics 0.11 `_adjust_weights_safe_divide`)."""
+
+    def _ratio(self, tp, fp, fn, tn):
+        raise NotImplementedError
+
+    def compute(self) -> Tensor:
+        tp, pp, ap = self._stats()
+        fp, fn = pp - tp, ap - tp
+        tn = ap.sum() - pp - ap + tp
+        if self.average == 'micro':
+            num, den = self._ratio(tp.sum(), fp.sum(), fn.sum(), tn.sum())
+            return (num / den.clamp_min(1)).float() if den > 0 else num.float() * 0
+        num, den = self._ratio(tp, fp, fn, tn)
+        return self._reduce(torch.where(den > 0, num / den.clamp_min(1e-300), torch.zeros_like(num)), ap, (ap + pp) > 0)
+
+
+@METRICS.register_class
+class Precision(_FromCounts):
+    def _ratio(self, tp, fp, fn, tn):
+        return tp, tp + fp
+
+
+@METRICS.register_class
+class Recall(_FromCounts):
+    def _ratio(self, tp, fp, fn, tn):
+        return tp, tp + fn
+
+
+@METRICS.register_class
+class Specificity(_FromCounts):
+    def _ratio(self, tp, fp, fn, tn):
+        return tn, tn + fp
+
+
+@METRICS.register_class
+class FBetaScore(_FromCounts):
+    def __init__(self, task: str = None, beta: float = 1.0, **kwargs):
+        super().__init__(task=task, **kwargs)
+        if beta <= 0:
+            raise ValueError(f'Expected argument `beta` to be a float larger than 0, but got {beta}.')
+        self.beta = float(beta)
+
+    def _ratio(self, tp, fp, fn, tn):
+        b2 = self.beta ** 2
+        return (1 + b2) * tp, (1 + b2) * tp + b2 * fn + fp
+
+
 @METRICS.register_class
 class JaccardIndex(_MulticlassStat):
     """Intersection over union per class from the same {tp, predicted, actual} counts.  Legacy (task-less) form, as in
@@ -126,6 +176,54 @@ class JaccardIndex(_MulticlassStat):
                 iou = torch.cat([iou[:self.drop_class], iou[self.drop_class + 1:]])
             return iou.float() if self.reduction in ('none', None) else iou.mean().float()
         return self._reduce(iou, ap, union > 0)
+
+
+class _ErrorSum(nn.Module):
+    """MeanAbsoluteError / MeanSquaredError of the reference registry (metrics/__init__.py:76,78): running sum of the
+    element errors and element count kept on the device (`tok_regression_loss_fwd`, 'sum'), no host sync until compute()."""
+    kind = 0
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.register_buffer('total', torch.zeros(2, dtype=torch.float64), persistent=False)    # [sum, count]
+
+    def update(self, preds: Tensor, target: Tensor) -> None:
+        require_device(preds)
+        if tuple(preds.shape) != tuple(target.shape):
+            raise RuntimeError(f'Predictions and targets are expected to have the same shape, got {tuple(preds.shape)} and '
+                               f'{tuple(target.shape)}')
+        x = preds.detach().to(BF16).contiguous().view(-1)
+        t = target.detach().to(torch.float32).contiguous().view(-1)
+        buf = torch.empty(_C.TOK_CE_LOSS_FLOATS, dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().tok_regression_loss_fwd(ptr(x), ptr(t), x.numel(), self.kind, 1.0, 0, ptr(buf), stream_ptr()),
+                 'tok_regression_loss_fwd')
+        if self.total.device != x.device:
+            self.total = self.total.to(x.device)
+        self.total += buf[:2].double()
+
+    def reset(self) -> None:
+        self.total.zero_()
+
+    def compute(self) -> Tensor:
+        return (self.total[0] / self.total[1].clamp_min(1)).float()
+
+
+@METRICS.register_class
+class MeanAbsoluteError(_ErrorSum):
+    kind = 0
+
+
+@METRICS.register_class
+class MeanSquaredError(_ErrorSum):
+    kind = 1
+
+    def __init__(self, squared: bool = True, **kwargs):
+        super().__init__(**kwargs)
+        self.squared = squared
+
+    def compute(self) -> Tensor:
+        mse = super().compute()
+        return mse if self.squared else mse.sqrt()
 
 
 class MetricWithUtils(nn.Module):
