@@ -279,6 +279,9 @@ int tok_regression_loss_bwd(const void* x, const float* target, const float* gsc
  * [rows][ld] (first maximum, as torch.argmax) or int64 labels; rows whose target is ignore_index are skipped.   */
 int tok_cls_stats_update(const void* logits, const int64_t* labels, const int64_t* target, int64_t rows,
                          int classes, int ld, int64_t ignore_index, int64_t* counts, void* stream);
+/* ConfusionMatrix (metrics/__init__.py:53): confusion int64 [classes][classes], [target][prediction] += 1, same inputs */
+int tok_confusion_update(const void* logits, const int64_t* labels, const int64_t* target, int64_t rows,
+                         int classes, int ld, int64_t ignore_index, int64_t* confusion, void* stream);
 
 /* ---- metric-learning head and loss -----------------------------------------------------------
  * F.normalize (arcface_head.py:125-126, linear_head.py:33-34): y = x / max(||x||_2, eps) per row;

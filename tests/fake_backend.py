@@ -710,6 +710,14 @@ class FakeTok:
             cnt[2, c] += int(((t == c) & ok).sum())
         return 0
 
+    def tok_confusion_update(self, logits, labels, target, rows, classes, ld, ignore_index, confusion, st):
+        t = _t(target, (rows,), torch.int64)
+        pred = _t(labels, (rows,), torch.int64) if labels is not None else _t(logits, (rows, ld), BF16)[:, :classes].float().argmax(1)
+        ok = (t != ignore_index) & (t >= 0) & (t < classes) & (pred >= 0) & (pred < classes)
+        conf = _t(confusion, (classes, classes), torch.int64)
+        conf += torch.bincount(t[ok] * classes + pred[ok], minlength=classes * classes).view(classes, classes)
+        return 0
+
     # ---- Dice loss ----------------------------------------------------------------------------------------------
     def tok_dice_rows(self, rows):
         return 1

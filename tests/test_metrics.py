@@ -94,6 +94,31 @@ def test_precision_recall_fbeta_specificity(dev):
     assert abs(micro['Precision'] - (pred == t).mean()) < 1e-12        # single-label: micro precision = recall = accuracy
 
 
+def test_confusion_matrix(dev):
+    g = torch.Generator().manual_seed(6)
+    c = 5
+    logits = torch.randn(600, c, generator=g)
+    tgt = torch.randint(0, c - 1, (600,), generator=g)             # class 4 never occurs as a target: an empty row
+    pred = logits.to(torch.bfloat16).float().argmax(1)
+    want = torch.bincount(tgt * c + pred, minlength=c * c).view(c, c)
+    m = T.METRICS.get('ConfusionMatrix')(task='multiclass', num_classes=c).to(dev)
+    m.update(preds=logits[:250].to(dev), target=tgt[:250].to(dev))
+    m.update(preds=pred[250:].to(dev), target=tgt[250:].to(dev))    # label predictions accumulate into the same matrix
+    assert torch.equal(m.compute().cpu(), want)                     # exact
+    rows = T.METRICS.get('ConfusionMatrix')(task='multiclass', num_classes=c, normalize='true').to(dev)
+    rows.update(preds=logits.to(dev), target=tgt.to(dev))
+    got = rows.compute().cpu()
+    assert torch.allclose(got[:4].sum(1), torch.ones(4)) and float(got[4].abs().sum()) == 0.0
+    assert torch.allclose(got[:4], want[:4].float() / want[:4].sum(1, keepdim=True))
+    ig = T.METRICS.get('ConfusionMatrix')(task='multiclass', num_classes=c, ignore_index=1).to(dev)
+    ig.update(preds=logits.to(dev), target=tgt.to(dev))
+    assert int(ig.compute()[1].sum()) == 0 and int(ig.compute().sum()) == int((tgt != 1).sum())
+    m.reset()
+    assert int(m.compute().sum()) == 0
+    with pytest.raises(ValueError):
+        T.METRICS.get('ConfusionMatrix')(task='multiclass', num_classes=c, normalize='rows')
+
+
 def test_mean_absolute_and_squared_error(dev):
     g = torch.Generator().manual_seed(9)
     p = torch.randn(300, 4, generator=g).bfloat16()

@@ -38,8 +38,10 @@ def test_registry_semantics():
 
 def test_list_models_natural_order_and_filters():
     names = T.BACKBONES.list_models('resnet*')
-    assert names == ['resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152']  # natural, not lexical
-    assert T.BACKBONES.list_models('resnet*', exclude_filters='resnet1*') == ['resnet34', 'resnet50']
+    assert names == ['resnet18', 'resnet18d', 'resnet26', 'resnet26d', 'resnet26t', 'resnet34', 'resnet34d', 'resnet50',
+                     'resnet50d', 'resnet50t', 'resnet101', 'resnet101d', 'resnet152', 'resnet152d', 'resnet200',
+                     'resnet200d']                                               # natural, not lexical
+    assert T.BACKBONES.list_models('resnet*', exclude_filters=['resnet1*', 'resnet2*', '*d', '*t']) == ['resnet34', 'resnet50']
     assert reg_mod._natural_key('resnet101') == ['resnet', 101, '']
 
 

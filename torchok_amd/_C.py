@@ -95,6 +95,7 @@ PROTOTYPES = {
     'tok_embed_reg_bwd': (c_int, [_P, _P, _P, c_float, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_regression_loss_fwd': (c_int, [_P, _P, c_int64, c_int, c_float, c_int, _P, _P]),
     'tok_regression_loss_bwd': (c_int, [_P, _P, _P, c_int64, c_int, c_float, c_int, _P, _P]),
+    'tok_confusion_update': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P]),
     'tok_cls_stats_update': (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, _P, _P]),
     'tok_l2norm_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P]),
     'tok_l2norm_bwd': (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -558,7 +558,8 @@ namespace {
 // counts[1][c] += [argmax == c], counts[2][c] += [target == c]  (int64 atomics: exact, order-independent)
 __global__ __launch_bounds__(256) void cls_stats_kernel(const bf16* __restrict__ logits, const int64_t* __restrict__ labels,
                                                         const int64_t* __restrict__ target, int64_t rows, int classes,
-                                                        int ld, int64_t ignore_index, unsigned long long* counts) {
+                                                        int ld, int64_t ignore_index, unsigned long long* counts,
+                                                        unsigned long long* confusion) {
   const int lane = threadIdx.x & 63;
   for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (int64_t)gridDim.x * 4) {
     const int64_t t = target[row];
@@ -580,7 +581,9 @@ __global__ __launch_bounds__(256) void cls_stats_kernel(const bf16* __restrict__
       }
       pred = bi;
     }
-    if (lane == 0) {
+    if (lane == 0 && confusion != nullptr) {        // confusion[target][prediction] += 1
+      if (pred >= 0 && pred < classes) atomicAdd(&confusion[(size_t)t * classes + pred], 1ull);
+    } else if (lane == 0) {
       if (pred >= 0 && pred < classes) {
         atomicAdd(&counts[classes + pred], 1ull);
         if (pred == (int)t) atomicAdd(&counts[pred], 1ull);
@@ -597,7 +600,20 @@ extern "C" int tok_cls_stats_update(const void* logits, const int64_t* labels, c
   TOK_CHECK_ARG(target && counts && rows > 0 && classes > 0 && (labels || ld >= classes), "tok_cls_stats_update: bad args");
   const int64_t b = (rows + 3) / 4;
   hipLaunchKernelGGL(cls_stats_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, tok_stream(stream),
-                     (const bf16*)logits, labels, target, rows, classes, ld, ignore_index, (unsigned long long*)counts);
+                     (const bf16*)logits, labels, target, rows, classes, ld, ignore_index, (unsigned long long*)counts,
+                     (unsigned long long*)nullptr);
   TOK_CHECK_LAUNCH("tok_cls_stats_update");
+  return TOK_OK;
+}
+
+extern "C" int tok_confusion_update(const void* logits, const int64_t* labels, const int64_t* target, int64_t rows,
+                                    int classes, int ld, int64_t ignore_index, int64_t* confusion, void* stream) {
+  TOK_CHECK_ARG((logits != nullptr) != (labels != nullptr), "tok_confusion_update: give logits OR predicted labels");
+  TOK_CHECK_ARG(target && confusion && rows > 0 && classes > 0 && (labels || ld >= classes), "tok_confusion_update: bad args");
+  const int64_t b = (rows + 3) / 4;
+  hipLaunchKernelGGL(cls_stats_kernel, dim3((unsigned)(b > 2048 ? 2048 : b)), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)logits, labels, target, rows, classes, ld, ignore_index, (unsigned long long*)nullptr,
+                     (unsigned long long*)confusion);
+  TOK_CHECK_LAUNCH("tok_confusion_update");
   return TOK_OK;
 }

@@ -178,6 +178,60 @@ class JaccardIndex(_MulticlassStat):
         return self._reduce(iou, ap, union > 0)
 
 
+@METRICS.register_class
+class ConfusionMatrix(_MulticlassStat):
+    """Multiclass confusion matrix [target][prediction] (metrics/__init__.py:53), accumulated on the device with exact int64
+    atomics; `normalize` None / 'none' / 'true' (rows) / 'pred' (columns) / 'all' as in torchmetrics."""
+
+    def __init__(self, task: str = None, num_classes: Optional[int] = None, normalize: Optional[str] = None,
+                 ignore_index: Optional[int] = None, **kwargs):
+        if normalize not in (None, 'none', 'true', 'pred', 'all'):
+            raise ValueError(f'Argument `normalize` needs to be one of true / pred / all / none, got {normalize}')
+        if num_classes is None:
+            raise ValueError('ConfusionMatrix: `num_classes` is required')
+        super().__init__(task=task, num_classes=num_classes, ignore_index=ignore_index, **kwargs)
+        self.normalize = normalize
+        self.register_buffer('confmat', torch.zeros(self.num_classes, self.num_classes, dtype=torch.int64), persistent=False)
+
+    def update(self, preds: Tensor, target: Tensor) -> None:
+        require_device(preds)
+        c = self.num_classes
+        tgt = target.reshape(-1).to(torch.int64).contiguous()
+        if self.confmat.device != preds.device:
+            self.confmat = self.confmat.to(preds.device)
+        lib, st = _C.lib(), stream_ptr()
+        if preds.is_floating_point():
+            if preds.dim() > 2:
+                preds = preds.movedim(1, -1).reshape(-1, preds.shape[1])
+            if preds.shape[-1] != c:
+                raise ValueError(f'Expected {c} classes in `preds`, got shape {tuple(preds.shape)}')
+            p = preds.detach()
+            if p.dtype != BF16 or p.stride(-1) != 1:
+                p = p.to(BF16).contiguous()
+            _C.check(lib.tok_confusion_update(ptr(p), None, ptr(tgt), p.shape[0], c, p.stride(0), self.ignore_index,
+                                              ptr(self.confmat), st), 'tok_confusion_update')
+        else:
+            lab = preds.detach().reshape(-1).to(torch.int64).contiguous()
+            _C.check(lib.tok_confusion_update(None, ptr(lab), ptr(tgt), lab.shape[0], c, pad8(c), self.ignore_index,
+                                              ptr(self.confmat), st), 'tok_confusion_update')
+
+    def reset(self) -> None:
+        self.confmat.zero_()
+
+    def compute(self) -> Tensor:
+        cm = self.confmat
+        if self.normalize in (None, 'none'):
+            return cm
+        cm = cm.to(torch.float32)
+        if self.normalize == 'true':
+            cm = cm / cm.sum(1, keepdim=True)
+        elif self.normalize == 'pred':
+            cm = cm / cm.sum(0, keepdim=True)
+        else:
+            cm = cm / cm.sum()
+        return torch.nan_to_num(cm, nan=0.0)      # torchmetrics: empty rows / columns read 0
+
+
 class _ErrorSum(nn.Module):
     """MeanAbsoluteError / MeanSquaredError of the reference registry (metrics/__init__.py:76,78): running sum of the
     element errors and element count kept on the device (`tok_regression_loss_fwd`, 'sum'), no host sync until compute()."""
