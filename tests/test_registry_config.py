@@ -45,6 +45,13 @@ def test_list_models_natural_order_and_filters():
     assert reg_mod._natural_key('resnet101') == ['resnet', 101, '']
 
 
+def test_identity_loss_passes_a_precomputed_loss_through():
+    import torch
+    loss = T.LOSSES.get('Identity')()
+    x = torch.tensor(1.5)
+    assert loss(x) is x
+
+
 def test_hot_path_names_registered():
     for reg, names in ((T.BACKBONES, ['resnet18', 'resnet50']), (T.POOLINGS, ['Pooling', 'PoolingLinear']),
                        (T.HEADS, ['LinearHead', 'ClassificationHead']), (T.LOSSES, ['CrossEntropyLoss']),
