@@ -67,6 +67,9 @@ int tok_nchw_to_nhwc_bf16(const void* src, int src_dtype, int n, int c, int h, i
                           void* dst, int c_pad, void* stream);
 /* fp32 -> bf16 elementwise cast (refreshing the bf16 weight shadow of the fp32 masters). */
 int tok_cast_f32_bf16(const float* src, void* dst, size_t count, void* stream);
+/* dst[i] = float(src[i]) * scale: the widening half of a bf16 gradient exchange (dist/ddp.py: torch DDP's
+   bf16_compress_hook equivalent, scale = 1 / world for backends without an averaging all-reduce).  16-byte aligned buffers. */
+int tok_cast_bf16_f32(const void* src, float* dst, float scale, size_t count, void* stream);
 /* master fp32 [k][r][s][c] -> bf16 [k_pad][r][s_pad][c_pad] (zero padded)               */
 int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c,
                         void* dst, int k_pad, int s_pad, int c_pad, void* stream);
@@ -217,6 +220,13 @@ int tok_avgpool2x2_fwd(const void* x, void* y, int n, int h, int w, int c, void*
 int tok_avgpool2x2_bwd(const void* dy, void* dx, int accumulate, int n, int h, int w, int c, void* stream);
 int tok_gap_fwd(const void* x, void* y, int n, int hw, int c, void* stream);
 int tok_gap_bwd(const void* dy, void* dx, int accumulate, int n, int hw, int c, void* stream);
+/* SelectAdaptivePool2d(1, pool_type) beyond 'avg' ([timm] adaptive_avgmax_pool; reference
+ * poolings/classification/pooling.py:7-12): mode 1 'max', 2 'avgmax' = 0.5 * (avg + max), 3 'catavgmax' = cat(avg, max)
+ * (y row = [avg(c) | max(c)], needs ldy >= 2c).  argmax [n][c] int32 = first maximal pixel per (image, channel), the
+ * index-exact route of the max gradient (ATen adaptive_max_pool2d_backward).                                            */
+int tok_global_pool_fwd(const void* x, void* y, int* argmax, int n, int hw, int c, int ldy, int mode, void* stream);
+int tok_global_pool_bwd(const void* dy, const int* argmax, void* dx, int accumulate, int n, int hw, int c, int ldy,
+                        int mode, void* stream);
 
 /* column sums of a bf16 [m][n] matrix -> fp32 (bias gradients of Linear / biased conv)     */
 int tok_colsum(const void* dy, int64_t m, int n_pad, int n_real, float* out, int accumulate,

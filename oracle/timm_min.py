@@ -139,12 +139,42 @@ def downsample_avg(in_channels, out_channels, kernel_size, stride=1, dilation=1,
                          norm_layer(out_channels))
 
 
+class _AvgMax(nn.Module):
+    """[timm 0.6.13] layers/adaptive_avgmax_pool.py: adaptive_avgmax_pool2d / adaptive_catavgmax_pool2d."""
+
+    def __init__(self, output_size, cat):
+        super().__init__()
+        self.output_size, self.cat = output_size, cat
+
+    def forward(self, x):
+        x_avg = nn.functional.adaptive_avg_pool2d(x, self.output_size)
+        x_max = nn.functional.adaptive_max_pool2d(x, self.output_size)
+        return torch.cat((x_avg, x_max), 1) if self.cat else 0.5 * (x_avg + x_max)
+
+
 class SelectAdaptivePool2d(nn.Module):
+    """[timm 0.6.13] SelectAdaptivePool2d: '' identity, 'avg', 'max', 'avgmax' = 0.5 * (avg + max),
+    'catavgmax' = cat(avg, max, dim=1); then Flatten(1) when flatten=True."""
+
     def __init__(self, output_size=1, pool_type='fast', flatten=False):
         super().__init__()
-        assert pool_type == 'avg'
-        self.pool = nn.AdaptiveAvgPool2d(output_size)
+        self.pool_type = pool_type or ''
+        if pool_type == '':
+            self.pool = nn.Identity()
+        elif pool_type == 'avg':
+            self.pool = nn.AdaptiveAvgPool2d(output_size)
+        elif pool_type == 'max':
+            self.pool = nn.AdaptiveMaxPool2d(output_size)
+        elif pool_type == 'avgmax':
+            self.pool = _AvgMax(output_size, cat=False)
+        elif pool_type == 'catavgmax':
+            self.pool = _AvgMax(output_size, cat=True)
+        else:
+            assert False, 'Invalid pool type: %s' % pool_type
         self.flatten = nn.Flatten(1) if flatten else nn.Identity()
+
+    def feat_mult(self):
+        return 2 if self.pool_type == 'catavgmax' else 1
 
     def forward(self, x):
         return self.flatten(self.pool(x))

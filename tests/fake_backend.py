@@ -60,6 +60,10 @@ class FakeTok:
         _t(dst, (count,), BF16).copy_(_t(src, (count,), torch.float32))
         return 0
 
+    def tok_cast_bf16_f32(self, src, dst, scale, count, st):
+        _t(dst, (count,), torch.float32).copy_(_t(src, (count,), BF16).float() * scale)
+        return 0
+
     def tok_pack_weight_fwd(self, src, k, r, s, c, dst, k_pad, s_pad, c_pad, st):
         w = _t(src, (k, r, s, c), torch.float32)
         d = _t(dst, (k_pad, r, s_pad, c_pad), BF16)
@@ -411,6 +415,36 @@ class FakeTok:
         out.copy_(((g + out.float()) if accumulate else g).to(BF16))
         return 0
 
+    def tok_global_pool_fwd(self, x, y, argmax, n, hw, c, ldy, mode, st):
+        xv = _t(x, (n, hw, c), BF16).float()
+        avg = (xv.sum(1) * (1.0 / hw)).to(BF16)
+        mx, am = xv.max(1)
+        # first maximal pixel (ATen keeps the earlier one on ties)
+        first = (xv == mx[:, None, :]).float().argmax(1)
+        _t(argmax, (n, c), torch.int32).copy_(first.to(torch.int32))
+        out = _t(y, (n, ldy), BF16)
+        if mode == 1:
+            out[:, :c] = mx.to(BF16)
+        elif mode == 2:
+            out[:, :c] = (0.5 * (avg.float() + mx.to(BF16).float()).to(BF16).float()).to(BF16)
+        else:
+            out[:, :c] = avg
+            out[:, c:2 * c] = mx.to(BF16)
+        return 0
+
+    def tok_global_pool_bwd(self, dy, argmax, dx, accumulate, n, hw, c, ldy, mode, st):
+        g = _t(dy, (n, ldy), BF16).float()
+        am = _t(argmax, (n, c), torch.int32).long()
+        ga = g[:, :c]
+        gm = g[:, c:2 * c] if mode == 3 else ga
+        wa = 0.0 if mode == 1 else (0.5 / hw if mode == 2 else 1.0 / hw)
+        wm = 0.5 if mode == 2 else 1.0
+        grad = (ga * wa).unsqueeze(1).expand(n, hw, c).clone()
+        grad.scatter_add_(1, am.unsqueeze(1), (gm * wm).unsqueeze(1))
+        out = _t(dx, (n, hw, c), BF16)
+        out.copy_(((grad + out.float()) if accumulate else grad).to(BF16))
+        return 0
+
     def tok_colsum(self, dy, m, n_pad, n_real, out, accumulate, st):
         s = _t(dy, (m, n_pad), BF16).float().sum(0)[:n_real]
         o = _t(out, (n_real,), torch.float32)
@@ -428,7 +462,7 @@ class FakeTok:
         z = _t(logits, (rows, ld), BF16).float()[:, :classes]
         t = _t(target, (rows,), torch.int64)
         l = torch.logsumexp(z, 1)
-        valid = t != ignore_index
+        valid = (t != ignore_index) & (t >= 0) & (t < classes)
         tt = t.clamp(0, classes - 1)
         nll = l - z.gather(1, tt[:, None])[:, 0]
         if smooth:
@@ -453,7 +487,7 @@ class FakeTok:
         l = _t(lse, (rows,), torch.float32)
         nv = _t(loss, (2,), torch.float32)[1]
         gs = _t(gscale, (1,), torch.float32)[0] if gscale is not None else 1.0
-        valid = (t != ignore_index)
+        valid = (t != ignore_index) & (t >= 0) & (t < classes)
         p = torch.exp(z - l[:, None]) - smooth / classes
         p[torch.arange(rows)[valid], t[valid]] -= 1.0 - smooth
         p = p * (gs / nv) * valid[:, None]

@@ -748,12 +748,53 @@ def golden_retrieval(out_known, out_meters):
     print(f'wrote {out_meters}: {len(cases)} cases, restatement == reference files: OK')
 
 
+def golden_pooling(mods, out_path, seed=91):
+    """Pooling / PoolingLinear of the reference's OWN poolings/classification/{pooling,linear}.py for every pool type
+    ('avg', 'max', 'avgmax', 'catavgmax'; [timm] SelectAdaptivePool2d stubbed by oracle/timm_min.py): outputs, the input
+    gradient of a weighted-sum loss and, for PoolingLinear, the weight / bias gradients.  Inputs hold exact ties (bf16
+    grid, repeated maxima) so the first-maximum rule of the max gradient is pinned."""
+    _, pooling, _, _ = mods
+    linear = _load('torchok.models.poolings.classification.linear', f'{REF}/models/poolings/classification/linear.py')
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(5, 16, 7, 7, generator=g) * 2).bfloat16().float()
+    x[0, 3, 2, 2] = x[0, 3, 4, 5] = 9.0           # a tie: the earlier pixel takes the whole max gradient
+    x[1, :, 0, 0] = 8.0
+    x[1, :, 6, 6] = 8.0
+    out = {'x': x.numpy()}
+    for pt in ('avg', 'max', 'avgmax', 'catavgmax'):
+        m = pooling.Pooling(in_channels=16, pooling_type=pt)
+        xi = x.clone().requires_grad_(True)
+        y = m(xi)
+        w = torch.randn(y.shape, generator=g)
+        (y * w).sum().backward()
+        assert m.out_channels == y.shape[1]
+        out.update({f'{pt}_y': y.detach().numpy(), f'{pt}_w': w.numpy(), f'{pt}_dx': xi.grad.numpy()})
+        # the restated SelectAdaptivePool2d alone (what oracle/torchok_ref.py uses) gives the same bits
+        yo = timm_min.SelectAdaptivePool2d(1, pt, flatten=True)(x)
+        assert torch.equal(yo, y.detach())
+        pl = linear.PoolingLinear(in_channels=16, out_channels=24, pooling_type=pt)
+        with torch.no_grad():
+            pl.fc.weight.copy_(torch.randn(pl.fc.weight.shape, generator=g) * 0.2)
+            pl.fc.bias.copy_(torch.randn(24, generator=g) * 0.1)
+        xi = x.clone().requires_grad_(True)
+        z = pl(xi)
+        wz = torch.randn(z.shape, generator=g)
+        (z * wz).sum().backward()
+        out.update({f'{pt}_lin_weight': pl.fc.weight.detach().numpy(), f'{pt}_lin_bias': pl.fc.bias.detach().numpy(),
+                    f'{pt}_lin_z': z.detach().numpy(), f'{pt}_lin_wz': wz.numpy(), f'{pt}_lin_dx': xi.grad.numpy(),
+                    f'{pt}_lin_dweight': pl.fc.weight.grad.numpy(), f'{pt}_lin_dbias': pl.fc.bias.grad.numpy()})
+    np.savez_compressed(out_path, **out)
+    print(f'wrote {out_path}: reference Pooling / PoolingLinear, 4 pool types')
+
+
 def main():
     mods = install_shim()
     gd = os.path.join(ROOT, 'tests', 'golden')
     os.makedirs(gd, exist_ok=True)
     # batch/size chosen so that the deepest BatchNorm still sees >= 32 samples per channel (bf16 parity
     # of the HIP path is checked against these same vectors)
+    if '--pooling-only' in sys.argv:
+        return golden_pooling(mods, os.path.join(gd, 'pooling_modes.npz'))
     if '--retrieval-only' in sys.argv:
         return golden_retrieval(os.path.join(gd, 'retrieval_known_answers.npz'), os.path.join(gd, 'retrieval_meters.npz'))
     if '--metric-only' in sys.argv:
@@ -775,6 +816,7 @@ def main():
     golden_step(mods, 'resnet18', 10, 8, 96, 11, os.path.join(gd, 'resnet18_cls_step.npz'))
     golden_step(mods, 'resnet50', 16, 8, 128, 12, os.path.join(gd, 'resnet50_cls_step.npz'))
     golden_heads(mods, os.path.join(gd, 'classification_head.npz'))
+    golden_pooling(mods, os.path.join(gd, 'pooling_modes.npz'))
     golden_metric(os.path.join(gd, 'metric_heads.npz'))
     golden_hrnet(os.path.join(gd, 'hrnet_seg_step.npz'))
     golden_swin(os.path.join(gd, 'swinv2_cls_step.npz'))

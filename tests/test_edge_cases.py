@@ -92,3 +92,29 @@ def test_swin_rejects_a_wrong_image_size_and_hrnet_needs_multiples_of_32(dev):
         T.BACKBONES.get('resnet51')
     with pytest.raises(RuntimeError, match='pretrained'):
         T.BACKBONES.get('resnet18')(pretrained=True)
+
+
+@pytest.mark.parametrize('shape', [(6, 5), (2, 5, 4, 4), (20000, 16)])
+def test_cross_entropy_out_of_range_labels_are_dropped_consistently(dev, shape):
+    """A label that is neither a class index nor `ignore_index` (a 255 'void' pixel with the default ignore_index=-100):
+    torch raises; the kernels drop the row from the loss, from the mean denominator AND from the gradient — the value
+    equals torch's with those rows ignored (one predicate in forward / partial / backward, wave-per-row and thread-per-row
+    kernels)."""
+    g = torch.Generator().manual_seed(4)
+    logits = torch.randn(*shape, generator=g).to(torch.bfloat16)
+    tshape = (shape[0],) + tuple(shape[2:])
+    target = torch.randint(0, shape[1], tshape, generator=g)
+    target.view(-1)[::3] = 255
+    target.view(-1)[1] = -7
+    z = logits.to(dev).detach().clone().requires_grad_(True)
+    loss = T.LOSSES.get('CrossEntropyLoss')()(input=z, target=target.to(dev))
+    loss.backward()
+    zr = logits.float().detach().clone().requires_grad_(True)
+    clean = torch.where((target < 0) | (target >= shape[1]), torch.full_like(target, -100), target)
+    want = torch.nn.functional.cross_entropy(zr, clean, ignore_index=-100)
+    want.backward()
+    assert abs(float(loss.detach()) - float(want.detach())) < 2e-5 * max(1.0, abs(float(want.detach())))
+    assert rel_err(z.grad.float().cpu(), zr.grad) < 5e-3
+    dropped = ((target < 0) | (target >= shape[1]))
+    gd = z.grad.float().cpu().movedim(1, -1)[dropped] if len(shape) == 4 else z.grad.float().cpu()[dropped]
+    assert float(gd.abs().max()) == 0.0

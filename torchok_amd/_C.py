@@ -50,6 +50,7 @@ PROTOTYPES = {
     'tok_version': (c_int, []),
     'tok_nchw_to_nhwc_bf16': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_cast_f32_bf16': (c_int, [_P, _P, c_size_t, _P]),
+    'tok_cast_bf16_f32': (c_int, [_P, _P, c_float, c_size_t, _P]),
     'tok_pack_weight_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P]),
     'tok_pack_weight_dgrad': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     'tok_pack_weight_both': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
@@ -80,6 +81,8 @@ PROTOTYPES = {
     'tok_avgpool2x2_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_gap_fwd': (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     'tok_gap_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    'tok_global_pool_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tok_global_pool_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
     'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),

@@ -208,6 +208,30 @@ extern "C" int tok_cast_f32_bf16(const float* src, void* dst, size_t count, void
   return TOK_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void widen_kernel(const bf16* __restrict__ src, float* __restrict__ dst, float scale, size_t n) {
+  const size_t n8 = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 v = ldg16(src + i * 8);
+    f32x4 lo, hi;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo[e] = bf2f(v[e]) * scale; hi[e] = bf2f(v[4 + e]) * scale; }
+    reinterpret_cast<f32x4*>(dst)[2 * i] = lo;
+    reinterpret_cast<f32x4*>(dst)[2 * i + 1] = hi;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = bf2f(src[n8 * 8 + threadIdx.x]) * scale;
+}
+}  // namespace
+
+extern "C" int tok_cast_bf16_f32(const void* src, float* dst, float scale, size_t count, void* stream) {
+  TOK_CHECK_ARG(src && dst && count > 0, "tok_cast_bf16_f32: bad args");
+  TOK_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "tok_cast_bf16_f32: 16-byte aligned buffers");
+  hipLaunchKernelGGL(widen_kernel, dim3(grid_for(count / 8 + 1)), dim3(256), 0, tok_stream(stream), (const bf16*)src, dst,
+                     scale, count);
+  TOK_CHECK_LAUNCH("tok_cast_bf16_f32");
+  return TOK_OK;
+}
+
 extern "C" int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c, void* dst, int k_pad,
                                    int s_pad, int c_pad, void* stream) {
   TOK_CHECK_ARG(src && dst && k > 0 && r > 0 && s > 0 && c > 0, "tok_pack_weight_fwd: bad args");

@@ -5,6 +5,14 @@
 
 namespace {
 
+// ONE validity predicate for forward, mean denominator and backward: a row counts iff its label is a class index and is not
+// `ignore_index`.  (torch raises on labels outside [0, classes) that are not ignore_index; a device-side raise would need a
+// host sync per step, so such rows are dropped — consistently: zero loss, not counted in the mean, zero gradient.  The
+// Python wrapper validates the labels on the host under TOK_CHECK_TARGETS=1.)
+__device__ __forceinline__ bool ce_row_valid(int64_t t, int64_t ignore_index, int classes) {
+  return t != ignore_index && t >= 0 && t < (int64_t)classes;
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -31,7 +39,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const bf16* __restrict__ lo
     lse[row] = l;
     const int64_t t = target[row];
     float rl = 0.f;
-    if (!(t == ignore_index || t < 0 || t >= classes)) {
+    if (ce_row_valid(t, ignore_index, classes)) {
       rl = l - bf2f(z[t]);
       if (smooth != 0.f) rl = (1.f - smooth) * rl + smooth * (l - zs / (float)classes);
     }
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(256) void ce_fwd_small_kernel(const bf16* __restric
   lse[row] = l;
   const int64_t t = target[row];
   float rl = 0.f;
-  if (!(t == ignore_index || t < 0 || t >= classes)) {
+  if (ce_row_valid(t, ignore_index, classes)) {
     rl = l - bf2f(z[t]);
     if (smooth != 0.f) {
       float zs = 0.f;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(256) void ce_bwd_small_kernel(const bf16* __restric
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= rows) return;
   const int64_t t = target[row];
-  const bool valid = t != ignore_index;
+  const bool valid = ce_row_valid(t, ignore_index, classes);
   const float g = valid ? (gscale ? gscale[0] : 1.f) / loss[1] : 0.f;
   const float l = lse[row];
   const bf16* z = logits + (size_t)row * ld;
@@ -134,12 +142,13 @@ __device__ __forceinline__ void block_reduce2(double& s, double& c) {
 
 __global__ __launch_bounds__(256) void ce_partial_kernel(const float* __restrict__ row_loss,
                                                          const int64_t* __restrict__ target, int rows,
-                                                         int64_t ignore_index, int chunk, double* __restrict__ part) {
+                                                         int64_t ignore_index, int classes, int chunk,
+                                                         double* __restrict__ part) {
   const int r0 = blockIdx.x * chunk;
   const int r1 = min(rows, r0 + chunk);
   double s = 0.0, cnt = 0.0;
   for (int r = r0 + threadIdx.x; r < r1; r += 256) {
-    if (target[r] != ignore_index) { s += (double)row_loss[r]; cnt += 1.0; }
+    if (ce_row_valid(target[r], ignore_index, classes)) { s += (double)row_loss[r]; cnt += 1.0; }
   }
   block_reduce2(s, cnt);
   if (threadIdx.x == 0) { part[2 * blockIdx.x] = s; part[2 * blockIdx.x + 1] = cnt; }
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const bf16* __restrict__ lo
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int64_t t = target[row];
-  const bool valid = t != ignore_index;
+  const bool valid = ce_row_valid(t, ignore_index, classes);
   const float g = valid ? (gscale ? gscale[0] : 1.f) / loss[1] : 0.f;
   const float l = lse[row];
   const bf16* z = logits + (size_t)row * ld;
@@ -359,8 +368,8 @@ extern "C" int tok_softmax_ce_smooth_fwd(const void* logits, const int64_t* targ
   TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(loss) & 7) == 0, "tok_softmax_ce_fwd: loss must be 8-byte aligned");
   const int nparts = rows < 4096 ? 1 : (tok_cdiv(rows, 4096) < CE_PARTS ? tok_cdiv(rows, 4096) : CE_PARTS);
   const int chunk = tok_cdiv(rows, nparts);
-  hipLaunchKernelGGL(ce_partial_kernel, dim3(nparts), dim3(256), 0, st, row_loss, target, rows, ignore_index, chunk,
-                     part);
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(nparts), dim3(256), 0, st, row_loss, target, rows, ignore_index, classes,
+                     chunk, part);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd(partial)");
   hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, part, nparts, loss);
   TOK_CHECK_LAUNCH("tok_softmax_ce_fwd(mean)");

@@ -376,6 +376,103 @@ extern "C" int tok_gap_bwd(const void* dy, void* dx, int accumulate, int n, int 
   return TOK_OK;
 }
 
+namespace {
+// SelectAdaptivePool2d(output_size=1) beyond 'avg': max / avgmax / catavgmax ([timm] adaptive_avgmax_pool via the
+// reference's poolings/classification/pooling.py:7-12).  One thread owns 8 channels of one image and walks its pixels:
+// running fp32 sum, running max with the FIRST maximal pixel as argmax (ATen's adaptive_max_pool2d keeps the earlier
+// pixel on ties).  Values follow the bf16 autocast chain of the reference: avg and max are bf16 tensors, avgmax is
+// 0.5 * bf16(avg + max).
+__global__ __launch_bounds__(256) void global_pool_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y,
+                                                              int* __restrict__ argmax, int N, int HW, int C, int ldy,
+                                                              int mode, float inv) {
+  const int cg_total = C >> 3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * cg_total) return;
+  const int cg = i % cg_total, n = i / cg_total;
+  float acc[8], mx[8];
+  int am[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { acc[e] = 0.f; mx[e] = -INFINITY; am[e] = 0; }
+  const bf16* p = x + (size_t)n * HW * C + cg * 8;
+  for (int j = 0; j < HW; ++j) {
+    const bf16x8 v = ldg16(p + (size_t)j * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = bf2f(v[e]);
+      acc[e] += f;
+      if (f > mx[e] || f != f) { mx[e] = f; am[e] = j; }
+    }
+  }
+  bf16x8 oa, om;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { oa[e] = f2bf(acc[e] * inv); om[e] = f2bf(mx[e]); }
+  bf16* yo = y + (size_t)n * ldy + cg * 8;
+  if (mode == 1) {
+    stg16(yo, om);
+  } else if (mode == 2) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(0.5f * bf2f(f2bf(bf2f(oa[e]) + bf2f(om[e]))));
+    stg16(yo, o);
+  } else {
+    stg16(yo, oa);
+    stg16(yo + C, om);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) argmax[(size_t)n * C + cg * 8 + e] = am[e];
+}
+
+__global__ __launch_bounds__(256) void global_pool_bwd_kernel(const bf16* __restrict__ dy, const int* __restrict__ argmax,
+                                                              bf16* dx, int accumulate, int N, int HW, int C, int ldy,
+                                                              int mode, float inv) {
+  const int cg_total = C >> 3;
+  const size_t total = (size_t)N * HW * cg_total;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % cg_total);
+    const size_t pix = i / cg_total;
+    const int n = (int)(pix / HW), j = (int)(pix - (size_t)n * HW);
+    const bf16* g = dy + (size_t)n * ldy + cg * 8;
+    const bf16x8 ga = ldg16(g);                                // avg part (mode 2 / 3) or the max gradient (mode 1)
+    const bf16x8 gm = mode == 3 ? ldg16(g + C) : ga;
+    const int* am = argmax + (size_t)n * C + cg * 8;
+    const float wa = mode == 1 ? 0.f : (mode == 2 ? 0.5f * inv : inv);
+    const float wm = mode == 2 ? 0.5f : 1.f;
+    bf16* d = dx + pix * C + cg * 8;
+    bf16x8 o;
+    bf16x8 old = zero8();
+    if (accumulate) old = ldg16(d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float v = bf2f(ga[e]) * wa + (am[e] == j ? bf2f(gm[e]) * wm : 0.f);
+      if (accumulate) v += bf2f(old[e]);
+      o[e] = f2bf(v);
+    }
+    stg16(d, o);
+  }
+}
+}  // namespace
+
+extern "C" int tok_global_pool_fwd(const void* x, void* y, int* argmax, int n, int hw, int c, int ldy, int mode,
+                                   void* stream) {
+  TOK_CHECK_ARG(x && y && argmax && n > 0 && hw > 0 && c > 0 && c % 8 == 0, "tok_global_pool_fwd: bad args");
+  TOK_CHECK_ARG(mode >= 1 && mode <= 3 && ldy >= (mode == 3 ? 2 * c : c) && ldy % 8 == 0,
+                "tok_global_pool_fwd: mode 1 (max) / 2 (avgmax) / 3 (catavgmax), ldy >= channels written");
+  hipLaunchKernelGGL(global_pool_fwd_kernel, dim3((n * (c / 8) + 255) / 256), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)x, (bf16*)y, argmax, n, hw, c, ldy, mode, 1.0f / (float)hw);
+  TOK_CHECK_LAUNCH("tok_global_pool_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_global_pool_bwd(const void* dy, const int* argmax, void* dx, int accumulate, int n, int hw, int c,
+                                   int ldy, int mode, void* stream) {
+  TOK_CHECK_ARG(dy && argmax && dx && n > 0 && hw > 0 && c > 0 && c % 8 == 0, "tok_global_pool_bwd: bad args");
+  TOK_CHECK_ARG(mode >= 1 && mode <= 3 && ldy >= (mode == 3 ? 2 * c : c) && ldy % 8 == 0, "tok_global_pool_bwd: bad mode / ldy");
+  hipLaunchKernelGGL(global_pool_bwd_kernel, dim3(grid_for((size_t)n * hw * (c / 8))), dim3(256), 0, tok_stream(stream),
+                     (const bf16*)dy, argmax, (bf16*)dx, accumulate, n, hw, c, ldy, mode, 1.0f / (float)hw);
+  TOK_CHECK_LAUNCH("tok_global_pool_bwd");
+  return TOK_OK;
+}
+
 extern "C" int tok_colsum(const void* dy, int64_t m, int n_pad, int n_real, float* out, int accumulate,
                           void* stream) {
   TOK_CHECK_ARG(dy && out && m > 0 && n_pad > 0 && n_pad % 8 == 0 && n_real <= n_pad, "tok_colsum: bad args");

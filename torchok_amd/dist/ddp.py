@@ -2,23 +2,31 @@
 RCCL (xGMI) on a side HIP stream, overlapped with backward.
 
 What it replaces: Lightning's ``strategy: ddp`` = torch DistributedDataParallel's C++ reducer
-(25 MiB buckets, NCCL all-reduce overlapped with backward) that the reference
-enables through ``trainer.strategy`` (``torchok/constructor/runner.py:18``).
+(25 MiB buckets, NCCL all-reduce overlapped with backward, rank-0 buffer broadcast before every
+forward) that the reference enables through ``trainer.strategy``
+(``torchok/constructor/runner.py:18``, ``config_structure.py:138``).
 
 MI355X design: one process per GPU; gradients already live in ONE contiguous fp32 arena in
 registration order (engine/arena.py), so a bucket is simply an arena range — no copy-in /
 copy-out.  Gradients become ready from the END of the arena during backward; buckets are cut
 from the end, each is launched on the comm stream as soon as its last parameter gradient has been
-written (hipEvent dependency from the compute stream), and the optimizer waits on the comm
-stream.  xGMI is point-to-point (7 links x ~153 GB/s): few LARGE messages amortise the per-link
+written (hipEvent dependency from every stream that wrote into it), and the optimizer waits on the
+comm stream.  xGMI is point-to-point (7 links x ~153 GB/s): few LARGE messages amortise the per-link
 ring latency, hence arena-range buckets of >= 32 MiB instead of per-parameter messages.
+
+``grad_dtype='bf16'`` halves the payload (ResNet-50: 102 -> 51 MB): a bucket is narrowed to bf16 by
+``tok_cast_f32_bf16``, reduced, and widened back (``tok_cast_bf16_f32``) — torch DDP's
+``bf16_compress_hook``.  The default is fp32, the arithmetic of the reference's DDP.
 
 The path shards by images only (pure data parallelism): no activation exchange, BatchNorm
 statistics stay per-GPU (the reference default, config_structure.py:170 sync_batchnorm=False).
-Deviation: BN running-statistic buffers are NOT re-broadcast from rank 0 before every forward
-(DDP broadcast_buffers=True); each rank keeps the running stats of its own shard.
+Module buffers (BatchNorm running statistics / ``num_batches_tracked``, the task's example inputs)
+follow DDP's ``broadcast_buffers=True``: with ``module=`` given they are re-homed into one flat
+buffer per dtype and rank 0's copy is broadcast once per step — two small collectives on the
+comm stream instead of one per buffer; every rank's ``state_dict`` stays identical to rank 0's.
 """
-from typing import List, Optional
+import os
+from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -30,25 +38,89 @@ from ..engine.core import ptr, stream_ptr
 
 
 class _Bucket:
-    __slots__ = ('lo', 'hi', 'first', 'last', 'pending', 'work', 'streams')
+    __slots__ = ('lo', 'hi', 'first', 'last', 'pending', 'work', 'streams', 'narrow')
 
     def __init__(self, lo, hi, first, last):
         self.lo, self.hi, self.first, self.last = lo, hi, first, last
         self.pending = 0
         self.work = None
         self.streams = {}     # streams that produced gradients of this bucket in the current step
+        self.narrow = None    # bf16 staging buffer (grad_dtype='bf16')
+
+
+class _BufferArena:
+    """Module buffers of one dtype re-homed into ONE flat tensor (each buffer becomes a view), so that DDP's per-forward
+    buffer broadcast is a single collective."""
+
+    def __init__(self, bufs: List[torch.Tensor]):
+        self.bufs = bufs
+        align = 64
+        self.offsets, off = [], 0
+        for b in bufs:
+            self.offsets.append(off)
+            off += (b.numel() + align - 1) // align * align
+        self.flat = torch.zeros(max(off, 1), dtype=bufs[0].dtype, device=bufs[0].device)
+        self.rehome()
+
+    def rehome(self):
+        with torch.no_grad():
+            for b, o in zip(self.bufs, self.offsets):
+                want = self.flat.data_ptr() + o * self.flat.element_size()
+                if b.data_ptr() != want:
+                    view = self.flat[o:o + b.numel()].view(b.shape)
+                    view.copy_(b)
+                    b.data = view
 
 
 class GradientAllReducer:
-    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True):
+    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True,
+                 module: Optional[torch.nn.Module] = None, broadcast_buffers: bool = True,
+                 grad_dtype: Optional[str] = None):
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        optimizer._ensure_built()
-        self.arenas: List[ParamArena] = [a for a in optimizer._arenas if a is not None]
+        self.rank = dist.get_rank(process_group)
+        self.optimizer = optimizer
+        self.bucket_bytes = bucket_bytes
+        grad_dtype = grad_dtype or os.environ.get('TOK_DDP_GRAD_DTYPE', 'fp32')
+        if grad_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"grad_dtype must be 'fp32' or 'bf16', got {grad_dtype}")
+        self.bf16 = grad_dtype == 'bf16'
+        self._generation = None
+        self._cut_buckets()
+        if broadcast_params:
+            for arena in self.arenas:
+                dist.broadcast(arena.master, src=0, group=process_group)
         self.cuda = self.arenas[0].master.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self._avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else None
+        self._active = False
+        self._buffer_arenas: List[_BufferArena] = []
+        self._buffer_work = []
+        if module is not None and broadcast_buffers:
+            by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+            seen = set()
+            for b in module.buffers():
+                if b is None or b.numel() == 0 or id(b) in seen:
+                    continue
+                seen.add(id(b))
+                by_dtype.setdefault(b.dtype, []).append(b)
+            self._buffer_arenas = [_BufferArena(v) for v in by_dtype.values()]
+            self.sync_buffers()
+            for w in self._buffer_work:
+                w.wait()
+            self._buffer_work = []
+        core.param_grad_hooks.append(self._on_grad)
+
+    # ---- buckets ------------------------------------------------------------------------------
+    def _cut_buckets(self):
+        """Buckets = contiguous arena ranges cut from the END of every arena.  Re-cut whenever the optimizer re-homed its
+        parameters (`arena_generation`: add_param_group after the first step, module.to(), load_state_dict)."""
+        opt = self.optimizer
+        opt._ensure_built()
+        self._generation = opt.arena_generation
+        self.arenas: List[ParamArena] = [a for a in opt._arenas if a is not None]
         self.buckets: List[List[_Bucket]] = []
         self._owner = {}
         for ai, arena in enumerate(self.arenas):
@@ -58,7 +130,7 @@ class GradientAllReducer:
             i = hi_i
             while i >= 0:
                 lo = arena.offsets[i]
-                if (hi - lo) * 4 >= bucket_bytes or i == 0:
+                if (hi - lo) * 4 >= self.bucket_bytes or i == 0:
                     blist.append(_Bucket(lo, hi, i, hi_i))
                     hi, hi_i = lo, i - 1
                 i -= 1
@@ -66,15 +138,17 @@ class GradientAllReducer:
             for b in blist:
                 for pi in range(b.first, b.last + 1):
                     self._owner[id(arena.params[pi])] = (ai, b)
-            if broadcast_params:
-                dist.broadcast(arena.master, src=0, group=process_group)
-        self._avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else None
-        self._active = False
-        core.param_grad_hooks.append(self._on_grad)
+        # one float per parameter: 1 where this rank produced a gradient (see finish_step)
+        n = sum(len(a.params) for a in self.arenas)
+        self._used = torch.zeros(n, dtype=torch.float32, device=self.arenas[0].master.device)
+        self._flags_dev, self._flags_host = torch.zeros_like(self._used), None
 
     # ---- per step ---------------------------------------------------------------------------
     def begin_step(self):
         """Call before backward: arms the buckets."""
+        self.optimizer._ensure_built()
+        if self.optimizer.arena_generation != self._generation:
+            self._cut_buckets()
         for ai, blist in enumerate(self.buckets):
             arena = self.arenas[ai]
             for b in blist:
@@ -99,8 +173,20 @@ class GradientAllReducer:
         if b.pending == 0:
             self._launch(ai, b)
 
+    def _reduce(self, buf: torch.Tensor):
+        if self._avg is not None:
+            return dist.all_reduce(buf, op=self._avg, group=self.group, async_op=True)
+        return dist.all_reduce(buf, group=self.group, async_op=True)
+
     def _launch(self, ai: int, b: _Bucket):
-        view = self.arenas[ai].grad[b.lo:b.hi]
+        arena = self.arenas[ai]
+        # gradients that did not come out of the engine's kernels (a plain torch module under autograd) sit outside the
+        # arena: move them in; a parameter without a gradient on THIS rank contributes zeros, never stale slot contents
+        for pi in range(b.first, b.last + 1):
+            if not arena.adopt_grad(pi) and arena.params[pi].requires_grad:
+                arena.grad_view(pi).zero_()
+        view = arena.grad[b.lo:b.hi]
+        lib = _C.lib()
         if self.cuda:
             cur = torch.cuda.current_stream()
             b.streams[cur.cuda_stream] = cur
@@ -109,29 +195,101 @@ class GradientAllReducer:
                 ev.record(s_)
                 self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                if self._avg is not None:
-                    b.work = dist.all_reduce(view, op=self._avg, group=self.group, async_op=True)
+                if self.bf16:
+                    if b.narrow is None or b.narrow.numel() != view.numel():
+                        b.narrow = torch.empty(view.numel(), dtype=torch.bfloat16, device=view.device)
+                    _C.check(lib.tok_cast_f32_bf16(ptr(view), ptr(b.narrow), view.numel(), stream_ptr()), 'tok_cast_f32_bf16')
+                    b.work = self._reduce(b.narrow)
                 else:
-                    b.work = dist.all_reduce(view, group=self.group, async_op=True)
+                    b.work = self._reduce(view)
         else:
-            b.work = dist.all_reduce(view, group=self.group, async_op=True)
+            if self.bf16:
+                if b.narrow is None or b.narrow.numel() != view.numel():
+                    b.narrow = torch.empty(view.numel(), dtype=torch.bfloat16, device=view.device)
+                if _C.is_fake():
+                    _C.check(lib.tok_cast_f32_bf16(ptr(view), ptr(b.narrow), view.numel(), None), 'tok_cast_f32_bf16')
+                else:
+                    b.narrow.copy_(view)
+                b.work = self._reduce(b.narrow)
+            else:
+                b.work = self._reduce(view)
+
+    def sync_buffers(self):
+        """DDP `broadcast_buffers=True`: rank 0's module buffers replace every rank's (one collective per dtype)."""
+        for ba in self._buffer_arenas:
+            ba.rehome()      # a module.to() / load_state_dict may have detached buffers from the flat tensor
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm_stream.wait_event(ev)
+                with torch.cuda.stream(self.comm_stream):
+                    self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
+            else:
+                self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
 
     def finish_step(self):
-        """Call after backward, before optimizer.step(): flush stragglers, join the comm stream."""
+        """Call after backward, before optimizer.step(): flush stragglers, exchange the used-parameter map and the module
+        buffers, join the comm stream."""
+        # which parameters got a gradient on this rank (before the stragglers' slots are zero-filled)
+        flags, any_missing = [], False
+        for arena in self.arenas:
+            for p in arena.params:
+                has = p.grad is not None
+                flags.append(1.0 if has else 0.0)
+                any_missing |= (not has) and p.requires_grad
         for ai, blist in enumerate(self.buckets):
             for b in blist:
                 if b.work is None:
                     self._launch(ai, b)
+        used_work = None
+        if self.world > 1:
+            if flags != self._flags_host:      # uploaded only when the pattern changes (normally: once)
+                self._flags_dev.copy_(torch.tensor(flags, dtype=torch.float32))
+                self._flags_host = flags
+            self._used.copy_(self._flags_dev)
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm_stream.wait_event(ev)
+                with torch.cuda.stream(self.comm_stream):
+                    used_work = dist.all_reduce(self._used, group=self.group, async_op=True)
+            else:
+                used_work = dist.all_reduce(self._used, group=self.group, async_op=True)
+        if self._buffer_arenas:
+            self.sync_buffers()
+        lib = _C.lib()
         for ai, blist in enumerate(self.buckets):
             for b in blist:
                 b.work.wait()   # on CUDA: makes the CURRENT stream wait for the collective (no host sync)
-                if self._avg is None:
-                    view = self.arenas[ai].grad[b.lo:b.hi]
+                view = self.arenas[ai].grad[b.lo:b.hi]
+                scale = 1.0 if self._avg is not None else 1.0 / self.world
+                if self.bf16:
                     if self.cuda or _C.is_fake():
-                        _C.check(_C.lib().tok_scale_f32(ptr(view), 1.0 / self.world, view.numel(), stream_ptr()),
-                                 'tok_scale_f32')
+                        _C.check(lib.tok_cast_bf16_f32(ptr(b.narrow), ptr(view), scale, view.numel(), stream_ptr()),
+                                 'tok_cast_bf16_f32')
                     else:
-                        view.mul_(1.0 / self.world)
+                        view.copy_(b.narrow.float() * scale)
+                elif self._avg is None:
+                    if self.cuda or _C.is_fake():
+                        _C.check(lib.tok_scale_f32(ptr(view), scale, view.numel(), stream_ptr()), 'tok_scale_f32')
+                    else:
+                        view.mul_(scale)
+        for w in self._buffer_work:
+            w.wait()
+        self._buffer_work = []
+        if used_work is not None:
+            used_work.wait()
+            if any_missing:
+                # a parameter unused on this rank but used on another one: every rank must apply the same (averaged)
+                # update, so the reduced slot becomes this rank's gradient too.  (Host read only on ranks that are
+                # missing a gradient; a parameter unused on EVERY rank keeps grad None, as under torch DDP.)
+                used = self._used.cpu()
+                k = 0
+                for arena in self.arenas:
+                    for pi, p in enumerate(arena.params):
+                        if p.grad is None and p.requires_grad and used[k] > 0:
+                            p.grad = arena.grad_view(pi)
+                        k += 1
         self._active = False
 
     def close(self):

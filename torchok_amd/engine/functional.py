@@ -646,3 +646,50 @@ def global_avg_pool(region: Region, x: TTensor) -> TTensor:
         x.uses += 1
         region.add(node)
     return out
+
+
+# ---- global max / avgmax / catavgmax pool ------------------------------------------------------------------
+
+POOL_MODES = {'max': 1, 'avgmax': 2, 'catavgmax': 3}
+
+
+class _GlobalPoolNode(Node):
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        if g is None or not self.x.requires_grad:
+            return
+        n, h, w, c = self.x.shape
+        tgt, acc = grad_target(self.x)
+        _C.check(_C.lib().tok_global_pool_bwd(ptr(g), ptr(self.argmax), ptr(tgt), acc, n, h * w, c, g.shape[-1], self.mode,
+                                              stream_ptr()), 'tok_global_pool_bwd')
+        self.out.grad = None
+
+    def release(self):
+        self.x = self.out = self.argmax = None
+
+
+def global_pool(region: Region, x: TTensor, pool_type: str) -> TTensor:
+    """SelectAdaptivePool2d(1, pool_type, flatten=True) ([timm], reference pooling.py:7-12): 'avg', 'max',
+    'avgmax' = 0.5 * (avg + max), 'catavgmax' = cat(avg, max) along channels."""
+    if pool_type == 'avg':
+        return global_avg_pool(region, x)
+    mode = POOL_MODES[pool_type]
+    n, h, w, c = x.shape
+    if mode == 3 and x.c != c:
+        raise NotImplementedError("torchok_amd Pooling 'catavgmax': channel counts that are multiples of 8")
+    cout = 2 * c if mode == 3 else c
+    y = torch.empty((n, cout), dtype=BF16, device=x.data.device)
+    argmax = torch.empty((n, c), dtype=torch.int32, device=x.data.device)
+    _C.check(_C.lib().tok_global_pool_fwd(ptr(x.data), ptr(y), ptr(argmax), n, h * w, c, cout, mode, stream_ptr()),
+             'tok_global_pool_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, 2 * x.c if mode == 3 else x.c, requires_grad=req)
+    if req:
+        node = _GlobalPoolNode()
+        node.x, node.out, node.argmax, node.mode = x, out, argmax, mode
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out

@@ -10,6 +10,10 @@ from ..constructor import LOSSES
 from ..engine.core import BF16, mark_padded, pad8, ptr, require_device, stream_ptr
 
 
+import os
+_CHECK_TARGETS = os.environ.get('TOK_CHECK_TARGETS', '0') == '1'
+
+
 class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits: Tensor, target: Tensor, ignore_index: int, smooth: float = 0.0):
@@ -34,6 +38,12 @@ class _SoftmaxCE(torch.autograd.Function):
         rows, classes = z.shape
         if target.dtype != torch.int64 or not target.is_contiguous():
             target = target.to(torch.int64).contiguous()
+        if _CHECK_TARGETS:
+            # torch raises "Target t is out of bounds" (a device-side assert on GPUs); the kernels drop such rows
+            # consistently instead (no per-step host sync) — this opt-in check restores the raise for debugging
+            bad = (target != ignore_index) & ((target < 0) | (target >= classes))
+            if bool(bad.any()):
+                raise IndexError(f'Target {int(target[bad][0])} is out of bounds.')
         dev = z.device
         lse = torch.empty(rows, dtype=torch.float32, device=dev)
         row_loss = torch.empty(rows, dtype=torch.float32, device=dev)

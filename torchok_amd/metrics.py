@@ -19,6 +19,17 @@ from .constructor.config import Phase
 from .engine.core import BF16, pad8, ptr, require_device, stream_ptr
 
 
+def _sum_over_ranks(t: Tensor) -> Tensor:
+    """torchmetrics `dist_reduce_fx='sum'`: the state every rank accumulated on its own shard is summed over the
+    data-parallel group once, at compute() (one all-reduce per metric and epoch; identity outside a process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 class _MulticlassStat(nn.Module):
     def __init__(self, task: str = None, num_classes: Optional[int] = None, average: Optional[str] = 'micro', top_k: int = 1,
                  ignore_index: Optional[int] = None, threshold: float = 0.5, multidim_average: str = 'global',
@@ -70,8 +81,8 @@ class _MulticlassStat(nn.Module):
         self.counts.zero_()
 
     def _stats(self):
-        tp, pp, ap = (self.counts[i].to('cpu', torch.float64) for i in range(3))     # the one host sync, at epoch end
-        return tp, pp, ap
+        counts = _sum_over_ranks(self.counts).to('cpu', torch.float64)     # the one host sync, at epoch end
+        return counts[0], counts[1], counts[2]
 
     def _reduce(self, per_class: Tensor, support: Tensor, seen: Tensor) -> Tensor:
         if self.average in ('none', None):
@@ -219,7 +230,7 @@ class ConfusionMatrix(_MulticlassStat):
         self.confmat.zero_()
 
     def compute(self) -> Tensor:
-        cm = self.confmat
+        cm = _sum_over_ranks(self.confmat)
         if self.normalize in (None, 'none'):
             return cm
         cm = cm.to(torch.float32)
@@ -259,7 +270,8 @@ class _ErrorSum(nn.Module):
         self.total.zero_()
 
     def compute(self) -> Tensor:
-        return (self.total[0] / self.total[1].clamp_min(1)).float()
+        total = _sum_over_ranks(self.total)
+        return (total[0] / total[1].clamp_min(1)).float()
 
 
 @METRICS.register_class

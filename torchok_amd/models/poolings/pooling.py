@@ -13,13 +13,15 @@ from ..base import BaseModel
 class Pooling(BaseModel):
     def __init__(self, in_channels: int, pooling_type: str = 'avg', output_size: int = 1):
         super().__init__(in_channels, in_channels if pooling_type != 'catavgmax' else 2 * in_channels)
-        if pooling_type != 'avg' or output_size != 1:
-            raise NotImplementedError("torchok_amd Pooling: pooling_type='avg', output_size=1 only")
+        if pooling_type not in ('avg', 'max', 'avgmax', 'catavgmax'):
+            raise ValueError(f'Invalid pool type: {pooling_type}')      # [timm] SelectAdaptivePool2d's assert
+        if output_size != 1:
+            raise NotImplementedError('torchok_amd Pooling: output_size=1 (global pooling) only')
         self.pool_type = pooling_type
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         with engine.region() as r:
-            return r.output(EF.global_avg_pool(r, r.input(x)))
+            return r.output(EF.global_pool(r, r.input(x), self.pool_type))
 
 
 @POOLINGS.register_class
@@ -32,7 +34,7 @@ class PoolingLinear(Pooling):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         with engine.region() as r:
-            t = EF.global_avg_pool(r, r.input(x))
+            t = EF.global_pool(r, r.input(x), self.pool_type)
             return r.output(EF.linear(r, t, self.fc))
 
     def init_weights(self):

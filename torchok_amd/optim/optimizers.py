@@ -21,17 +21,22 @@ from ..engine.core import ptr, require_device, stream_ptr
 class _ArenaOptimizer(Optimizer):
     _n_state = 0
 
+    def _new_arena(self, group):
+        params = [p for p in group['params']]
+        if not params:
+            return None
+        for p in params:
+            require_device(p)
+        return ParamArena(params, self._n_state)
+
     def _build(self):
-        self._arenas: List[ParamArena] = []
-        for group in self.param_groups:
-            params = [p for p in group['params']]
-            if not params:
-                self._arenas.append(None)
-                continue
-            for p in params:
-                require_device(p)
-            self._arenas.append(ParamArena(params, self._n_state))
+        """(Re)home every group in an arena; optimizer state that already exists (a resumed checkpoint, a rebuild after
+        `module.to()`) is copied into the arena's state slots and `self.state` is re-pointed at them."""
+        old_state = {id(p): dict(s) for p, s in self.state.items()}
+        self._arenas: List[ParamArena] = [self._new_arena(g) for g in self.param_groups]
         self._built = True
+        self.arena_generation = getattr(self, 'arena_generation', 0) + 1   # dist/ddp.py re-cuts its buckets on a change
+        self._restore_state(old_state)
 
     def _ensure_built(self):
         if not getattr(self, '_built', False):
@@ -41,16 +46,28 @@ class _ArenaOptimizer(Optimizer):
         for g, a in zip(self.param_groups, self._arenas):
             if a is not None and (len(a.params) != len(g['params']) or
                                   any(not a.owns_data(i) for i in range(len(a.params)))):
-                self._rebuild()
+                self._build()
                 return
-
-    def _rebuild(self):
-        old_state = {id(p): dict(s) for p, s in self.state.items()}
-        self._build()
-        self._restore_state(old_state)
+        if len(self._arenas) < len(self.param_groups):
+            # add_param_group() after the first step (the reference's FreezeUnfreeze callback does it): the new groups get
+            # arenas of their own, the existing ones keep theirs (and their state)
+            for g in self.param_groups[len(self._arenas):]:
+                self._arenas.append(self._new_arena(g))
+            self.arena_generation += 1
 
     def _restore_state(self, old_state):
         pass
+
+    def load_state_dict(self, state_dict):
+        """torch's loader leaves stand-alone copies of the state tensors in `self.state`; the step kernels read the
+        arena slots, so the loaded moments are copied there and `self.state` is re-pointed at the slots."""
+        super().load_state_dict(state_dict)
+        self._built = False
+        self._ensure_built()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._built = False     # an unpickled optimizer re-homes its parameters at the next step
 
     def _repack(self):
         """The step kernels moved the fp32 masters: refresh every bf16 MFMA operand pack in one launch."""
@@ -171,7 +188,7 @@ class _AdamBase(_ArenaOptimizer):
                 if s and 'exp_avg' in s:
                     a.state_view(0, i).copy_(s['exp_avg'])
                     a.state_view(1, i).copy_(s['exp_avg_sq'])
-                    self.state[p].update(step=s['step'], exp_avg=a.state_view(0, i),
+                    self.state[p].update(step=int(s['step']), exp_avg=a.state_view(0, i),
                                          exp_avg_sq=a.state_view(1, i))
 
     @torch.no_grad()
@@ -258,7 +275,7 @@ class RMSprop(_ArenaOptimizer):
                         if s.get(key) is not None:
                             a.state_view(slot, i).copy_(s[key])
                             self.state[p][key] = a.state_view(slot, i)
-                    self.state[p]['step'] = s.get('step', 0)
+                    self.state[p]['step'] = int(s.get('step', 0))
 
     @torch.no_grad()
     def step(self, closure=None):
