@@ -29,16 +29,25 @@ import torch  # noqa: E402
 ALG_BYTES_PER_IMG = {'resnet50': 309.7e6, 'resnet18': 70.6e6}   # SURVEY.md App. C (Model F + weights @B=256)
 ALG_BYTES_SEG = {('hrnet_w48', 512, 1024): 8.08e9}               # HRNet-W48 seg 512x1024
 HBM_PEAK = 8.0e12
-# PMC-measured HBM bytes of ONE step of the default workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes of this same command, summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r01_resnet50_bs256_pmc_traffic.json')
+# PMC-measured HBM bytes of ONE step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command,
+# summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md).  One file per workload, newest round first.
+PMC_FILES = {
+    ('resnet50', 224, 224, 256): ['r02_resnet50_bs256_pmc_traffic.json', 'r01_resnet50_bs256_pmc_traffic.json'],
+    ('swinv2_custom', 224, 224, 256): ['r02_swinv2t_224_bs256_pmc_traffic.json'],
+    ('davit_t', 224, 224, 256): ['r02_davit_t_224_bs256_pmc_traffic.json'],
+    ('hrnet_w48', 512, 1024, 24): ['r02_hrnet_w48_512x1024_bs24_pmc_traffic.json'],
+    ('hrnet_w48', 512, 1024, 8): ['r02_hrnet_w48_512x1024_bs8_pmc_traffic.json'],
+}
 
 
-def measured_traffic(backbone: str, res: int, batch: int):
-    if (backbone, res, batch) != ('resnet50', 224, 256) or not os.path.exists(PMC_TRAFFIC):
-        return None
-    with open(PMC_TRAFFIC) as f:
-        return round(json.load(f)['hbm_bytes_per_step'] / 1e9, 2)
+def measured_traffic(backbone: str, res: int, width: int, batch: int):
+    """(GB per step, file) of the committed PMC measurement of this exact workload, or (None, None)."""
+    for name in PMC_FILES.get((backbone, res, width, batch), []):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return round(json.load(f)['hbm_bytes_per_step'] / 1e9, 2), 'profiles/' + name
+    return None, None
 
 
 def build_seg_task(backbone: str, num_classes: int, h: int, w: int):
@@ -120,35 +129,88 @@ def _usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(backbone: str, num_classes: int, res: int, batch: int = 16, steps: int = 2):
-    """The oracle's training step on the host cores (reported baseline, not the target)."""
-    import oracle.torchok_ref as R
+def _cpu_model() -> str:
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(backbone: str, num_classes: int, res: int, width: int = 0, batch: int = 0, steps: int = 5,
+                 warmup: int = 2, budget_s: float = 45.0):
+    """The oracle's training step (fp32, the reference's `trainer.accelerator='cpu'` arithmetic) on the host cores:
+    a bounded sample — `warmup` + `steps` steps at a batch that fits the host, cut short when a step is so slow
+    that the default run would not finish within minutes.  A reported baseline, not the target."""
     threads = _usable_cores()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    ref = R.ClassificationModel(backbone, num_classes, zero_init_last=False).train()
-    opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
-    x = torch.randn(batch, 3, res, res)
-    y = torch.randint(0, num_classes, (batch,))
-    t0 = time.perf_counter()
-    R.training_step(ref, {'image': x, 'target': y}, opt)  # warm-up
-    warm = time.perf_counter() - t0
-    if warm > 15.0:   # keep the default run within minutes on a slow host
-        steps = 1
+    width = width or res
+    if backbone.startswith('hrnet'):
+        import oracle.hrnet_ref as H
+        batch = batch or 1
+        ref = H.SegmentationModel(backbone, num_classes).train()
+        opt = torch.optim.SGD(ref.parameters(), lr=0.01, momentum=0.9, weight_decay=5e-4)
+        x, y = torch.randn(batch, 3, res, width), torch.randint(0, num_classes, (batch, res, width))
+        ce = torch.nn.CrossEntropyLoss(ignore_index=255)
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            ce(ref.forward_with_gt({'image': x, 'target': y})['prediction'], y).backward()
+            opt.step()
+    elif backbone in ('swinv2_custom', 'davit_t'):
+        batch = batch or 16
+        if backbone == 'swinv2_custom':
+            import oracle.swin_ref as S
+            bb = S.SwinV2(img_size=res, window_size=7, drop_path_rate=0.1)
+        else:
+            import oracle.davit_ref as D
+            bb = D.davit_t(drop_path_rate=0.1)
+        ref = torch.nn.Sequential(bb, torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(1),
+                                  torch.nn.Linear(bb.out_channels, num_classes)).train()
+        opt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.05)
+        x, y = torch.randn(batch, 3, res, res), torch.randint(0, num_classes, (batch,))
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(ref(x), y).backward()
+            opt.step()
+    else:
+        import oracle.torchok_ref as R
+        batch = batch or 16
+        ref = R.ClassificationModel(backbone, num_classes, zero_init_last=False).train()
+        opt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+        x, y = torch.randn(batch, 3, res, res), torch.randint(0, num_classes, (batch,))
+
+        def one():
+            R.training_step(ref, {'image': x, 'target': y}, opt)
+    t_all = time.perf_counter()
+    done_w = 0
+    for _ in range(warmup):
+        one()
+        done_w += 1
+        if time.perf_counter() - t_all > budget_s * 0.3:
+            break
+    per = (time.perf_counter() - t_all) / done_w
+    steps = max(1, min(steps, int((budget_s - (time.perf_counter() - t_all)) / max(per, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
-        R.training_step(ref, {'image': x, 'target': y}, opt)
+        one()
     dt = time.perf_counter() - t0
-    return {'value': batch * steps / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
-            'sample': f'{steps} fp32 steps of the same {backbone} {res}x{res} training step at batch {batch} '
-                      f'(1 warm-up), torch {torch.__version__} CPU'}
+    return {'value': batch * steps / dt, 'unit': 'images/sec', 'cores': threads, 'cpu_model': _cpu_model(), 'kind': 'port',
+            'sample': f'{steps} fp32 steps ({done_w} warm-up) of the same {backbone} {res}x{width} training step at batch '
+                      f'{batch}, oracle/ on torch {torch.__version__} CPU, {threads} threads'}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
     ap.add_argument('--backbone', default='resnet50')
     ap.add_argument('--res', type=int, default=224)
@@ -199,7 +261,7 @@ def main():
     reducer = None
     if dist_on:
         from torchok_amd.dist import GradientAllReducer
-        reducer = GradientAllReducer(opt)
+        reducer = GradientAllReducer(opt, module=task)     # + DDP's rank-0 buffer broadcast (one flat collective per dtype)
 
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
     image = torch.randn(args.batch, 3, args.res, width, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
@@ -256,18 +318,19 @@ def main():
             (ALG_BYTES_PER_IMG.get(args.backbone) if args.res == 224 else None)
         ev_ms = sum(step_ms) / len(step_ms)
         roofline = None
+        traffic, traffic_file = measured_traffic(args.backbone, args.res, width, args.batch)
         flops = ALG_FLOPS_PER_IMG.get((args.backbone, args.res)) if swin else None
         if flops is not None:
             ach = flops * args.batch / (ev_ms * 1e-3) / 1e12
             roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
-                        'frac': round(ach * 1e12 / MFMA_PEAK_BF16, 4), 'traffic': None,
+                        'frac': round(ach * 1e12 / MFMA_PEAK_BF16, 4), 'traffic': traffic,
+                        'traffic_unit': f'GB/step (PMC, {traffic_file})' if traffic_file else None,
                         'launch': f'one training step, HIP-event avg {ev_ms:.3f} ms'}
         elif alg is not None:
             achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                         'frac': round(achieved * 1e9 / HBM_PEAK, 4),
-                        'traffic': measured_traffic(args.backbone, args.res, args.batch), 'traffic_unit': 'GB/step '
-                        '(PMC, profiles/r01_resnet50_bs256_pmc_traffic.json)',
+                        'traffic': traffic, 'traffic_unit': f'GB/step (PMC, {traffic_file})' if traffic_file else None,
                         'algorithmic': round(alg * args.batch / 1e9, 2), 'algorithmic_unit': 'GB/step',
                         'launch': 'one training step (all kernels of fwd+bwd+optimizer on the step stream), '
                                   f'HIP-event avg {ev_ms:.3f} ms'}
@@ -291,8 +354,12 @@ def main():
                        'parallelism': f'dp{world}', 'launch_mode': 'hipGraph replay' if use_graph else 'eager'},
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline and not seg and not swin:
-            line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res)
+        if dist_on:
+            line['config']['rccl_ranks'] = dist.get_world_size()
+            line['config']['grad_exchange'] = f"bucketed all-reduce(AVG), {'bf16' if reducer.bf16 else 'fp32'} payload, " \
+                                              f"{sum(len(b) for b in reducer.buckets)} buckets + buffer broadcast"
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res, width)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist_on:

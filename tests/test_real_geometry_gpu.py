@@ -1,0 +1,205 @@
+"""Whole training steps of the HIP path at the REAL geometries of BASELINE.json's configs against the CPU oracle
+(the small-geometry steps of test_swin.py / test_hrnet.py / test_metric.py pin the same rows to the reference's own files):
+
+  C3  swinv2_custom @224, window 7, depths 2-2-6-2, heads 3-6-12-24 (SwinV2-T), batch 2
+  C4  hrnet_w48 + HRNetSegmentationNeck + SegmentationHead(19) + CE(ignore 255) @512x1024, batch 1
+  C5  resnet50 + PoolingLinear(512) + ArcFaceHead(11318) + CrossEntropyLoss — ClassificationTask as wired by the reference's
+      examples/configs/representation_arcface_sop.yaml:1-24 (arcface_head.py:110-131), batch 16 @128
+
+Per step: logits / loss against the fp32 oracle (tight), every parameter gradient against the fp32 oracle with torch's own
+bf16-autocast run of the oracle as the yardstick (what bf16 storage costs through tens of BatchNorm/ReLU or attention
+layers; printed), and the structure of the result (every parameter has a gradient, BN counters advanced by exactly one)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle.hrnet_ref as H
+import oracle.metric_ref as M
+import oracle.swin_ref as S
+import oracle.torchok_ref as R
+import torchok_amd as T
+from helpers import cls_config, deterministic_state, rel_err
+from torchok_amd.constructor.config import apply_schema
+
+pytestmark = pytest.mark.gpu
+
+
+def _grad_gate(tag, ours, g32, gac, slack=0.08):
+    """ours / g32 / gac: name -> gradient.  Median and per-tensor gates against the autocast yardstick."""
+    errs = {n: rel_err(ours[n], g32[n]) for n in g32 if g32[n] is not None and float(g32[n].norm()) > 0}
+    yard = {n: rel_err(gac[n], g32[n]) for n in errs}
+    me, my = float(np.median(list(errs.values()))), float(np.median(list(yard.values())))
+    worst = max(errs, key=lambda n: errs[n] - 1.5 * yard[n])
+    print(f'[step {tag}] gradients: {len(errs)} tensors, median rel err HIP {me:.3e} vs autocast yardstick {my:.3e}; '
+          f'max HIP {max(errs.values()):.3e} / autocast {max(yard.values()):.3e}; worst over yardstick: {worst} '
+          f'{errs[worst]:.3e} vs {yard[worst]:.3e}')
+    assert me < 1.5 * my + 1e-2, (tag, me, my)
+    bad = [n for n in errs if errs[n] > 1.5 * yard[n] + slack]
+    assert len(bad) <= 0.03 * len(errs), (tag, [(n, errs[n], yard[n]) for n in bad][:8])
+
+
+def test_swinv2_t_224_window7_step():
+    kw = dict(img_size=224, window_size=7, depths=(2, 2, 6, 2), num_heads=(3, 6, 12, 24), drop_path_rate=0.0)
+    classes = 100
+    cfg = cls_config('swinv2_custom', classes, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                     backbone_params=dict(kw, depths=list(kw['depths']), num_heads=list(kw['num_heads'])),
+                     inputs_shape=(3, 224, 224))
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    ref_bb = S.SwinV2(**kw)
+    ref = nn.Module()
+    ref.backbone, ref.head = ref_bb, nn.Module()
+    ref.head.fc = nn.Linear(768, classes)
+    sd = deterministic_state(ref.state_dict(), 61)
+    ref.load_state_dict(sd)
+    missing = task.load_state_dict(sd, strict=False)
+    assert all(k.startswith('input_tensors') for k in missing.missing_keys), missing
+    task.cuda().train()
+    ref.train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 3, 224, 224, generator=g).bfloat16().float()
+    y = torch.randint(0, classes, (2,), generator=g)
+
+    def ref_step(m, ac):
+        m.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=ac):
+            logits = m.head.fc(m.backbone(x).mean((2, 3)))
+        loss = nn.functional.cross_entropy(logits.float(), y)
+        loss.backward()
+        return logits.detach().float(), float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    l32, loss32, g32 = ref_step(ref, False)
+    lac, lossac, gac = ref_step(copy.deepcopy(ref), True)
+    out = task.forward_with_gt({'image': x.cuda(), 'target': y.cuda()})
+    loss = task.losses(**out)[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    e_log, y_log = rel_err(out['prediction'].float(), l32), rel_err(lac, l32)
+    print(f'[step swinv2-t 224] logits rel err HIP {e_log:.3e} (autocast {y_log:.3e}); loss HIP {float(loss):.5f} '
+          f'fp32 {loss32:.5f} autocast {lossac:.5f}')
+    assert e_log < max(1e-2, 1.5 * y_log)
+    assert abs(float(loss) - loss32) < max(1e-2, 1.5 * abs(lossac - loss32)) * max(1.0, abs(loss32))
+    ours = {n: p.grad.detach().float().cpu() for n, p in task.named_parameters() if p.grad is not None}
+    assert set(g32) <= set(ours), sorted(set(g32) - set(ours))[:5]
+    _grad_gate('swinv2-t 224', ours, g32, gac)
+
+
+def test_hrnet_w48_512x1024_step():
+    classes = 19
+    cfg = apply_schema({
+        'task': {'name': 'SegmentationTask',
+                 'params': {'backbone_name': 'hrnet_w48', 'backbone_params': {'pretrained': False, 'in_channels': 3},
+                            'neck_name': 'HRNetSegmentationNeck', 'head_name': 'SegmentationHead',
+                            'head_params': {'num_classes': classes},
+                            'inputs': [{'shape': [3, 512, 1024], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'params': {'ignore_index': 255},
+                                   'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.01, 'momentum': 0.9}}}],
+        'data': {}, 'trainer': {'precision': 'bf16'}})
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    ref = H.SegmentationModel('hrnet_w48', classes)
+    assert sum(p.numel() for p in ref.parameters()) == sum(p.numel() for p in task.parameters())
+    sd = deterministic_state(ref.state_dict(), 63)
+    ref.load_state_dict(sd)
+    missing = task.load_state_dict(sd, strict=False)
+    assert all(k.startswith('input_tensors') for k in missing.missing_keys), missing
+    task.cuda().train()
+    ref.train()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 3, 512, 1024, generator=g).bfloat16().float()
+    y = torch.randint(0, classes, (1, 512, 1024), generator=g)
+    y[:, :8] = 255
+    ce = nn.CrossEntropyLoss(ignore_index=255)
+
+    def ref_step(m, ac):
+        m.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=ac):
+            logits = m.forward_with_gt({'image': x, 'target': y})['prediction']
+        loss = ce(logits.float(), y)
+        loss.backward()
+        return logits.detach().float(), float(loss), {n: p.grad.clone() for n, p in m.named_parameters()}
+    l32, loss32, g32 = ref_step(ref, False)
+    lac, lossac, gac = ref_step(copy.deepcopy(ref), True)
+    out = task.training_step({'image': x.cuda(), 'target': y.cuda()}, 0)
+    out['loss'].backward()
+    pred = task.forward_with_gt({'image': x.cuda(), 'target': y.cuda()})['prediction']
+    torch.cuda.synchronize()
+    assert tuple(pred.shape) == (1, classes, 512, 1024)
+    e_log, y_log = rel_err(pred.float(), l32), rel_err(lac, l32)
+    print(f'[step hrnet_w48 512x1024] logits rel err HIP {e_log:.3e} (autocast {y_log:.3e}); loss HIP '
+          f'{float(out["loss"]):.5f} fp32 {loss32:.5f} autocast {lossac:.5f}')
+    assert e_log < max(2e-2, 1.5 * y_log)
+    assert abs(float(out['loss']) - loss32) < max(1e-2, 1.5 * abs(lossac - loss32)) * max(1.0, abs(loss32))
+    ours = {n: p.grad.detach().float().cpu() for n, p in task.named_parameters()}
+    assert all(p.grad is not None for p in task.parameters())
+    _grad_gate('hrnet_w48 512x1024', ours, g32, gac)
+    nbt = [b for n, b in task.named_buffers() if n.endswith('num_batches_tracked')]
+    assert len(nbt) > 300 and all(int(b) == 2 for b in nbt)          # training_step + forward_with_gt
+
+
+def test_resnet50_arcface_recipe_step():
+    """representation_arcface_sop.yaml:1-24: ClassificationTask(resnet50, PoolingLinear(512), ArcFaceHead(11318)) + CE."""
+    classes, emb = 11318, 512
+    cfg = apply_schema({
+        'task': {'name': 'ClassificationTask',
+                 'params': {'backbone_name': 'resnet50', 'backbone_params': {'pretrained': False, 'in_channels': 3},
+                            'pooling_name': 'PoolingLinear', 'pooling_params': {'out_channels': emb},
+                            'head_name': 'ArcFaceHead', 'head_params': {'num_classes': classes},
+                            'inputs': [{'shape': [3, 128, 128], 'dtype': 'float32'}]}},
+        'joint_loss': {'losses': [{'name': 'CrossEntropyLoss', 'mapping': {'input': 'prediction', 'target': 'target'}}]},
+        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.01, 'momentum': 0.9}}}],
+        'data': {}, 'trainer': {'precision': 'bf16'}})
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    ref = nn.Module()
+    ref.backbone = R.resnet50()
+    ref.pooling = nn.Module()
+    ref.pooling.fc = nn.Linear(2048, emb)
+    ref.head = nn.Module()
+    ref.head.weight = nn.Parameter(torch.zeros(classes, emb))
+    scale, margin = M.arcface_defaults(emb, classes)                 # arcface_head.py:46-56
+    assert abs(scale - task.head.scale) < 1e-9 and abs(margin - task.head.margin) < 1e-12
+    sd = deterministic_state(ref.state_dict(), 65)
+    sd['head.weight'] = torch.randn(classes, emb, generator=torch.Generator().manual_seed(1)) * 0.05
+    ref.load_state_dict(sd)
+    missing = task.load_state_dict(sd, strict=False)
+    assert all(k.startswith('input_tensors') for k in missing.missing_keys), missing
+    task.cuda().train()
+    ref.train()
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(16, 3, 128, 128, generator=g).bfloat16().float()
+    y = torch.randint(0, classes, (16,), generator=g)
+
+    def ref_step(m, ac):
+        m.zero_grad()
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=ac):
+            e = m.pooling.fc(torch.flatten(nn.functional.adaptive_avg_pool2d(m.backbone(x), 1), 1))
+            logits = M.arcface_forward(e, m.head.weight, y, margin, scale)
+        loss = nn.functional.cross_entropy(logits.float(), y)
+        loss.backward()
+        return e.detach().float(), logits.detach().float(), float(loss), {n: p.grad.clone() for n, p in m.named_parameters()}
+    e32, l32, loss32, g32 = ref_step(ref, False)
+    eac, lac, lossac, gac = ref_step(copy.deepcopy(ref), True)
+    out = task.forward_with_gt({'image': x.cuda(), 'target': y.cuda()})
+    assert set(out) >= {'embeddings', 'prediction', 'target'} and tuple(out['prediction'].shape) == (16, classes)
+    loss = task.losses(**out)[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    e_emb, y_emb = rel_err(out['embeddings'].float(), e32), rel_err(eac, e32)
+    e_log, y_log = rel_err(out['prediction'].float(), l32), rel_err(lac, l32)
+    print(f'[step resnet50 arcface] embeddings rel err HIP {e_emb:.3e} (autocast {y_emb:.3e}); logits HIP {e_log:.3e} '
+          f'(autocast {y_log:.3e}); loss HIP {float(loss):.5f} fp32 {loss32:.5f} autocast {lossac:.5f}')
+    assert e_emb < max(2e-2, 1.5 * y_emb) and e_log < max(2e-2, 1.5 * y_log)
+    assert abs(float(loss) - loss32) < max(1e-2, 1.5 * abs(lossac - loss32)) * max(1.0, abs(loss32))
+    # the margin touched exactly the target column: on every other column prediction == scale * cosine
+    ours = {n: p.grad.detach().float().cpu() for n, p in task.named_parameters()}
+    assert all(p.grad is not None for p in task.parameters())
+    _grad_gate('resnet50 arcface', ours, g32, gac)
+    # eval path of the head: plain linear on the raw embedding (arcface_head.py:120-121)
+    task.eval()
+    ref.eval()
+    with torch.no_grad():
+        pe = task.forward(x.cuda())
+        re_ = M.arcface_forward(ref.pooling.fc(torch.flatten(nn.functional.adaptive_avg_pool2d(ref.backbone(x), 1), 1)),
+                                ref.head.weight, None, margin, scale, training=False)
+    assert rel_err(pe.float(), re_) < 3e-2

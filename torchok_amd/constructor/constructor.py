@@ -15,6 +15,48 @@ from ..losses.base import JointLoss
 from ..metrics import MetricsManager
 
 
+class _ParamwiseRules:
+    """Per-parameter learning-rate / weight-decay overrides.
+
+    Precedence, as in the reference: the first `custom_keys` entry (longest key first, ties alphabetical) that is a
+    substring of '<module path>.<parameter name>' decides alone; otherwise the bias learning-rate multiplier applies to
+    non-norm biases and exactly one weight-decay multiplier applies: norm layer > depth-wise conv > bias."""
+    NORMS = (_BatchNorm, _InstanceNorm, GroupNorm, LayerNorm)
+
+    def __init__(self, optimizer_cfg: Dict, cfg: Dict):
+        self.lr, self.wd = optimizer_cfg.get('lr', None), optimizer_cfg.get('weight_decay', None)
+        custom = cfg.get('custom_keys', {})
+        self.custom = [(k, custom[k]) for k in sorted(sorted(custom), key=len, reverse=True)]
+        self.bias_lr = cfg.get('bias_lr_mult', 1.)
+        self.decay = {'norm': cfg.get('norm_decay_mult', 1.), 'dwconv': cfg.get('dwconv_decay_mult', 1.),
+                      'bias': cfg.get('bias_decay_mult', 1.)}
+
+    def module_kind(self, module: nn.Module) -> str:
+        if isinstance(module, self.NORMS):
+            return 'norm'
+        if isinstance(module, torch.nn.Conv2d) and module.in_channels == module.groups:
+            return 'dwconv'
+        return 'plain'
+
+    def options(self, kind: str, path: str, name: str) -> Dict[str, float]:
+        full = f'{path}.{name}'
+        for key, mult in self.custom:
+            if key in full:
+                opts = {'lr': self.lr * mult.get('lr_mult', 1.)}
+                if self.wd is not None:
+                    opts['weight_decay'] = self.wd * mult.get('decay_mult', 1.)
+                return opts
+        opts = {}
+        is_bias = name == 'bias'
+        if is_bias and kind != 'norm':
+            opts['lr'] = self.lr * self.bias_lr
+        if self.wd is not None:
+            which = kind if kind in ('norm', 'dwconv') else ('bias' if is_bias else None)
+            if which is not None:
+                opts['weight_decay'] = self.wd * self.decay[which]
+        return opts
+
+
 class Constructor:
     def __init__(self, hparams):
         self._hparams = hparams
@@ -53,49 +95,23 @@ class Constructor:
     @staticmethod
     def add_params(parameters: List[Dict], module: nn.Module, optimizer_cfg: Dict,
                    paramwise_cfg: Optional[Dict] = None, prefix: str = '', is_dcn_module=None) -> None:
-        """mmcv-style per-parameter groups (reference :163-251)."""
-        paramwise_cfg = paramwise_cfg or {}
-        base_lr = optimizer_cfg.get('lr', None)
-        base_wd = optimizer_cfg.get('weight_decay', None)
-        custom_keys = paramwise_cfg.get('custom_keys', {})
-        sorted_keys = sorted(sorted(custom_keys.keys()), key=len, reverse=True)
-        bias_lr_mult = paramwise_cfg.get('bias_lr_mult', 1.)
-        bias_decay_mult = paramwise_cfg.get('bias_decay_mult', 1.)
-        norm_decay_mult = paramwise_cfg.get('norm_decay_mult', 1.)
-        dwconv_decay_mult = paramwise_cfg.get('dwconv_decay_mult', 1.)
-        dcn_offset_lr_mult = paramwise_cfg.get('dcn_offset_lr_mult', 1.)
-        is_norm = isinstance(module, (_BatchNorm, _InstanceNorm, GroupNorm, LayerNorm))
-        is_dwconv = isinstance(module, torch.nn.Conv2d) and module.in_channels == module.groups
-        for name, param in module.named_parameters(recurse=False):
-            param_group = {'params': [param]}
-            if not param.requires_grad:
-                parameters.append(param_group)
-                continue
-            is_custom = False
-            for key in sorted_keys:
-                if key in f'{prefix}.{name}':
-                    is_custom = True
-                    param_group['lr'] = base_lr * custom_keys[key].get('lr_mult', 1.)
-                    if base_wd is not None:
-                        param_group['weight_decay'] = base_wd * custom_keys[key].get('decay_mult', 1.)
-                    break
-            if not is_custom:
-                if name == 'bias' and not (is_norm or is_dcn_module):
-                    param_group['lr'] = base_lr * bias_lr_mult
-                if prefix.find('conv_offset') != -1 and is_dcn_module and isinstance(module, torch.nn.Conv2d):
-                    param_group['lr'] = base_lr * dcn_offset_lr_mult
-                if base_wd is not None:
-                    if is_norm:
-                        param_group['weight_decay'] = base_wd * norm_decay_mult
-                    elif is_dwconv:
-                        param_group['weight_decay'] = base_wd * dwconv_decay_mult
-                    elif name == 'bias' and not is_dcn_module:
-                        param_group['weight_decay'] = base_wd * bias_decay_mult
-            parameters.append(param_group)
-        for child_name, child_mod in module.named_children():
-            child_prefix = f'{prefix}.{child_name}' if prefix else child_name
-            Constructor.add_params(parameters, child_mod, optimizer_cfg, paramwise_cfg, prefix=child_prefix,
-                                   is_dcn_module=False)
+        """One param group per parameter, options from the mmcv-style `paramwise_cfg` (behaviour of reference :163-251).
+
+        Walk order = the reference's recursion: a module's own parameters, then its children in registration order.
+        `is_dcn_module` is accepted for signature compatibility; the reference only ever passes a falsy value down, so
+        its `dcn_offset_lr_mult` rule can never fire and is not evaluated here."""
+        rules = _ParamwiseRules(optimizer_cfg, paramwise_cfg or {})
+        stack = [(prefix, module)]
+        while stack:
+            path, mod = stack.pop()
+            kind = rules.module_kind(mod)
+            for name, param in mod.named_parameters(recurse=False):
+                group = {'params': [param]}
+                if param.requires_grad:
+                    group.update(rules.options(kind, path, name))
+                parameters.append(group)
+            children = [(f'{path}.{cn}' if path else cn, cm) for cn, cm in mod.named_children()]
+            stack.extend(reversed(children))
 
     @staticmethod
     def _create_scheduler(optimizer: Optimizer, scheduler_params) -> Dict[str, Any]:
