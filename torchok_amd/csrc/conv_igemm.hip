@@ -446,19 +446,22 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
                 const size_t eoff = opix * a.K + nb + half * 32;
                 const bf16x8 yv = ldg16(a.bn_y + eoff);
                 const unsigned bits = a.bn_mask != nullptr ? a.bn_mask[eoff >> 3] : 0xffu;
-                // (sums are taken over the fp32 values: the bf16 rounding of dx is zero-mean noise of
-                //  relative size 2^-9 / sqrt(M) in a sum over M pixels)
+                // (sums over the STORED bf16 values: the statistics of the tensor the next kernels read — and the rounding
+                //  point of the reference's bf16 autocast, where BatchNorm's backward reduces a bf16 gradient tensor)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  const float dz = ((bits >> e) & 1u) ? v[e] : 0.f;
+                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
                   s1[half * 8 + e] += dz;
                   s2[half * 8 + e] = fmaf(dz, bf2f(yv[e]), s2[half * 8 + e]);
                 }
               } else {
+                // batch statistics of the bf16 conv output as stored (torch autocast: batch_norm reduces the bf16 output
+                // of the convolution in fp32): mean / variance describe exactly the tensor bn_act_fwd normalises
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                  s1[half * 8 + e] += v[e];
-                  s2[half * 8 + e] = fmaf(v[e], v[e], s2[half * 8 + e]);
+                  const float r = bf2f(o[e]);
+                  s1[half * 8 + e] += r;
+                  s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
                 }
               }
             }

@@ -15,6 +15,7 @@
 // kernel sums the partials in a fixed order (deterministic — no atomics) and un-pads into the
 // fp32 master-gradient layout [k][r][s][c].
 #include "tok_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -29,6 +30,12 @@ struct WgradArgs {
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ u32x2 tr_read_asm(uint32_t lds_addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  return v;
+}
 
 __device__ __forceinline__ bf16x4 tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
@@ -239,6 +246,190 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   }
 }
 
+
+// ---- ring variant ------------------------------------------------------------------------------------------
+// Same tiles and fragment reads as conv_wgrad_kernel (DMA layout), but the staging is a THREE-deep ring of LDS stages filled by
+// global -> LDS DMA with counted waits: stage st+2 is issued while stage st is consumed, so two stages (2 x 16-20 KB per
+// workgroup) are in flight across every barrier.  The long-M layers of a ResNet (56x56 / 28x28 maps at batch 256) are
+// HBM-latency problems for this kernel shape — 98 dependent "load a stage, barrier, 16 MFMAs" rounds per workgroup with 2
+// workgroups per CU gave 0.9-1.3 TB/s —, and __syncthreads() drains vmcnt(0) while a DMA is in flight, so the ring needs the
+// raw barrier + `s_waitcnt vmcnt(L)` form (L = DMA instructions per stage and thread: the NEXT stage may stay in flight).
+//   iteration st:  wait vmcnt(L) -> stage st has landed (this wave's share); lgkmcnt(0) -> this wave's reads of stage st-1 retired
+//                  s_barrier     -> every wave's share of stage st landed, nobody reads stage st-1 any more
+//                  issue stage st+2 into the buffer of stage st-1;  fragment reads + MFMAs of stage st
+// Tiles 64/128/256 x 64/128/256 (2 x 2 waves): a 64-channel layer takes a 64 x 256 (or 256 x 64) tile so that every barrier
+// still covers 16 MFMAs per wave.
+template <int TN, int TK, bool PWK>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
+  constexpr int MS = 32, NST = 3;
+  constexpr int CN = TN / 8, CK = TK / 8;
+  constexpr int RPY = 256 / CN, RPX = 256 / CK;
+  constexpr int YP = MS / RPY, XP = MS / RPX;
+  static_assert(YP >= 1 && XP >= 1, "tile too narrow for 256 threads");
+  constexpr int LOADS = YP + XP;                 // DMA instructions per thread and stage
+  constexpr int YS = TN * 2, XS = TK * 2;
+  constexpr int YBYTES = MS * YS, XBYTES = MS * XS, STAGE = YBYTES + XBYTES;
+  // swizzle masks: row bits that do not change from one staging pass to the next (a thread keeps ONE logical chunk)
+  constexpr int SWY = (CN / 2 - 1) < (RPY - 1) ? (CN / 2 - 1) : (RPY - 1);
+  constexpr int SWX = (CK / 2 - 1) < (RPX - 1) ? (CK / 2 - 1) : (RPX - 1);
+  constexpr int NT = TN / 32, KTL = TK / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wn2 = wv & 1, wk2 = wv >> 1;
+
+  const int ntile = a.tilesN * a.tilesK;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / a.tilesK;
+  const int tk = t - tn * a.tilesK;
+
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + MS - 1) / MS;
+
+  const int ycol = tid % CN, yrow = tid / CN;
+  const int xcol = tid % CK, xrow = tid / CK;
+  const int ylog = ycol ^ ((yrow & SWY) << 1);
+  const int xlog = xcol ^ ((xrow & SWX) << 1);
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int yn = tn * TN + ylog * 8;
+  const bool yn_ok = yn < a.K;
+
+  const int k0 = tk * TK + xlog * 8;
+  const int tap = k0 / a.C;
+  const int kc0 = k0 - tap * a.C;
+  const int kr = tap / a.S;
+  const int ks = tap - kr * a.S;
+  const bool k_ok = kr < a.R;
+
+  int xm[XP], xq[XP], xp[XP], xpix[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int m = mstart + xrow + i * RPX;
+    xm[i] = m;
+    const int mm = min(m, a.M - 1);
+    const int b = mm / a.PQ;
+    const int rem = mm - b * a.PQ;
+    xp[i] = rem / a.Q;
+    xq[i] = rem - xp[i] * a.Q;
+    xpix[i] = b * a.HW;
+  }
+  int ym = mstart + yrow;
+
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  auto issue = [&](int dbuf) {
+    char* Ydst = smem + dbuf * STAGE + wave_u * 1024;
+    char* Xdst = smem + dbuf * STAGE + YBYTES + wave_u * 1024;
+#pragma unroll
+    for (int i = 0; i < YP; ++i) {
+      const int m = ym + i * RPY;
+      uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));      // one unconditional DMA per row (hipcc otherwise splits it into exec-masked halves)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(Ydst + i * RPY * YS), 16, off, 0, 0, 0);
+    }
+    ym += MS;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      uint32_t off;
+      if (PWK) {
+        off = (k_ok && xm[i] < mend) ? (uint32_t)(xm[i] * a.C + kc0) * 2u : 0xFFFFFFF0u;
+      } else {
+        const int hh = xp[i] * a.stride - a.pad + kr;
+        const int ww = xq[i] * a.stride - a.pad + ks;
+        const bool ok = k_ok && xm[i] < mend && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
+        off = ok ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
+      }
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
+      xm[i] += MS;
+      if (!PWK) {
+        xq[i] += MS;
+        while (xq[i] >= a.Q) {
+          xq[i] -= a.Q;
+          if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
+        }
+      }
+    }
+  };
+
+  const int g = lane >> 4, li = lane & 15;
+  const int rrow = 4 * g + (li >> 2);
+  const int yswz = ((rrow & SWY) << 1) << 4, xswz = ((rrow & SWX) << 1) << 4;
+  auto ycolb = [&](int i) { return ((wn2 * (TN / 2) + i * 16 + (li & 3) * 4) * 2) ^ yswz; };
+  auto xcolb = [&](int j) { return ((wk2 * (TK / 2) + j * 16 + (li & 3) * 4) * 2) ^ xswz; };
+
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
+  issue(0);
+  issue(1);
+  int cur = 0, nxt = 2;     // ring slots of stage st and of stage st + 2
+  for (int st = 0; st < steps; ++st) {
+    // stage st has landed once at most one stage's worth of this wave's DMAs is still outstanding
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);
+    // fragment reads as inline asm: for hipcc a `ds_read` behind an LDS-DMA in flight means "wait vmcnt(0)" (it cannot
+    // prove the stages disjoint), which would drain the ring; the counted wait + barrier above is the real dependency
+    const uint32_t Yb = lds_base + cur * STAGE;
+    const uint32_t Xb = Yb + YBYTES;
+    u32x2 ya[NT][2], xb[KTL][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      ya[i][0] = tr_read_asm(Yb + rrow * YS + ycolb(i));
+      ya[i][1] = tr_read_asm(Yb + (rrow + 16) * YS + ycolb(i));
+    }
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      xb[j][0] = tr_read_asm(Xb + rrow * XS + xcolb(j));
+      xb[j][1] = tr_read_asm(Xb + (rrow + 16) * XS + xcolb(j));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);     // keeps the MFMAs below the wait (they only depend on registers)
+    bf16x8 af[NT], bfr[KTL];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < KTL; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
+  }
+  // the two stages issued past the end (zeros) must have landed before this workgroup's LDS can be handed to another one
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      const int kcol = tk * TK + wk2 * (TK / 2) + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
+        if (n < a.K && kcol < a.Ktot) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+    }
+  }
+}
+
 // dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splitM,
                                     int k_real, int R, int S, int c_real, int K, int S_pad,
@@ -309,12 +500,50 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 
 struct Plan {
   int TN, TK, tilesN, tilesK, splitM, mchunk, MS;
+  bool ring;
 };
+
+static int ring_enabled() {   // TOK_WGRAD_RING=0: the two-buffer kernels of round 1 (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_WGRAD_RING"); v = e ? atoi(e) : 1; }   // 2: every layer
+  return v;
+}
+static int ring_target() {    // TOK_WGRAD_WGS=<n>: workgroups the split aims at (default: what is resident at once)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_WGRAD_WGS"); v = e ? atoi(e) : 0; }
+  return v;
+}
 
 Plan make_plan(const tok_conv_desc* d) {
   Plan p;
   const int Ktot = d->r * d->s_pad * d->c;
   const long long M = (long long)d->n * d->p * d->q;
+  // the ring pays on the streaming (pointwise) layers; 3x3 / strided layers are LDS-read bound and keep the 64-row
+  // two-buffer kernel (measured per layer, tools/bench_conv.py: ring 3x3 0.9-2x slower)
+  p.ring = d->c != 4 && ring_enabled() && ((d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0) || ring_enabled() == 2);
+  if (p.ring) {
+    // ring kernel: 32 reduction rows per stage, three stages.  Narrow layers take a 64 x 256 / 256 x 64 tile.
+    p.MS = 32;
+    if (d->k <= 64) { p.TN = 64; p.TK = Ktot >= 256 ? 256 : (Ktot >= 128 ? 128 : 64); }
+    else if (Ktot <= 64) { p.TK = 64; p.TN = d->k >= 256 ? 256 : 128; }
+    else { p.TN = 128; p.TK = 128; }
+    p.tilesN = tok_cdiv(d->k, p.TN);
+    p.tilesK = tok_cdiv(Ktot, p.TK);
+    const int tiles = p.tilesN * p.tilesK;
+    const int stage = 32 * (p.TN + p.TK) * 2;
+    const int per_cu = (160 * 1024) / (3 * stage);                 // LDS-resident workgroups per CU
+    const int target = ring_target() > 0 ? ring_target() : 256 * (per_cu > 4 ? 4 : per_cu);
+    long long split = (target + tiles - 1) / tiles;
+    const long long max_split = (M + 8 * 32 - 1) / (8 * 32);        // at least 8 stages per workgroup
+    if (split > max_split) split = max_split;
+    if (split > 512) split = 512;
+    if (split < 1) split = 1;
+    long long chunk = (M + split - 1) / split;
+    chunk = ((chunk + 31) / 32) * 32;
+    p.mchunk = (int)chunk;
+    p.splitM = (int)((M + chunk - 1) / chunk);
+    return p;
+  }
   p.TN = d->k >= 128 ? 128 : 64;
   p.TK = Ktot >= 128 ? 128 : 64;
   // (a 128 x 256 tile for deep filters was measured: no gain — the loop is LDS-write bound, not barrier bound)
@@ -337,6 +566,24 @@ Plan make_plan(const tok_conv_desc* d) {
   p.mchunk = (int)chunk;
   p.splitM = (int)((M + chunk - 1) / chunk);
   return p;
+}
+
+template <int TN, int TK, bool PWK>
+void launch_ring_pw(const WgradArgs& a, hipStream_t st) {
+  constexpr int smem = 3 * 32 * (TN + TK) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TN, TK, PWK>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<TN, TK, PWK>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
+}
+
+template <int TN, int TK>
+void launch_ring(const WgradArgs& a, hipStream_t st) {
+  if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) launch_ring_pw<TN, TK, true>(a, st);
+  else launch_ring_pw<TN, TK, false>(a, st);
 }
 
 template <int TN, int TK, bool C4, int MS, bool DMA_T, bool PWK>
@@ -413,7 +660,14 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (p.TN == 128 && p.TK == 128) {
+  if (p.ring) {
+    if (p.TN == 64 && p.TK == 64) launch_ring<64, 64>(a, st);
+    else if (p.TN == 64 && p.TK == 128) launch_ring<64, 128>(a, st);
+    else if (p.TN == 64 && p.TK == 256) launch_ring<64, 256>(a, st);
+    else if (p.TN == 128 && p.TK == 64) launch_ring<128, 64>(a, st);
+    else if (p.TN == 256 && p.TK == 64) launch_ring<256, 64>(a, st);
+    else launch_ring<128, 128>(a, st);
+  } else if (p.TN == 128 && p.TK == 128) {
     if (c4) launch_wgrad<128, 128, true>(a, st, p.MS); else launch_wgrad<128, 128, false>(a, st, p.MS);
   } else if (p.TN == 128) {
     if (c4) launch_wgrad<128, 64, true>(a, st, p.MS); else launch_wgrad<128, 64, false>(a, st, p.MS);
