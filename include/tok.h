@@ -150,6 +150,42 @@ int tok_conv_fwd_bn(const tok_conv_desc* d, const void* x, const void* w_fwd, vo
 int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                       const void* bn_y, const uint8_t* bn_mask, float* partial, const tok_bn_fused* bn,
                       void* stream);
+/* ---- "unit 3" of a bottleneck without its pre-normalisation tensor ------------------------------------------------
+ * [timm] Bottleneck: x = conv3(x); x = bn3(x); x += shortcut; x = act3(x)  (via torchok/models/backbones/resnet.py:12-14).
+ * The 4P-channel tensor between conv3 and bn3 is the largest of the block; because conv3 is a 1x1 convolution its batch
+ * statistics follow from the P x P second moments of conv3's INPUT, so the normalisation can run in the GEMM epilogue and the
+ * backward pass can be written on tensors that exist anyway (csrc/unit3.hip has the algebra).
+ *
+ * tok_bn_gram_finalize: Z = z^T z (P x P, e.g. from tok_conv_wgrad on (z, z)), zsum = column sums of z, w = fp32 master
+ *   filter [k][p] (rounded to bf16 inside, the operand the GEMM uses) -> mean / rstd / scale / shift [k] and the running
+ *   statistics update of F.batch_norm (momentum, unbiased variance, num_batches_tracked += 1); count = rows of z.
+ * tok_conv_fwd_bn_apply: out = relu(conv1x1(x) * scale + shift + shortcut) as bf16, mask bit = (out > 0)  (the bits
+ *   tok_bn_act_fwd writes); replaces tok_conv_fwd + tok_bn_finalize + tok_bn_act_fwd for such a unit.
+ * tok_conv_dgrad_maskstore: tok_conv_dgrad whose epilogue stores dz = mask ? dx : 0 and reduces sum(dz) into
+ *   partial[2][tok_conv_dgrad_stat_rows][c] (second half zero) — for the launch that COMPLETES the gradient of the unit's
+ *   output; tok_relu_mask_reduce is the stand-alone form (partial[2][tok_bn_bwd_rows(m, c)][c], in place allowed).
+ * tok_bn3_bwd_prepare: G = dz^T z [k][p], w, wz (from tok_bn_gram_finalize), zsum, the sum(dz) partial rows -> dgamma / dbeta (+= if param_accumulate),
+ *   coef [3][k], dw [k][p] (+= if dw_accumulate), wa = bf16 diag(c1) W in dgrad-pack layout [p][k], wb = bf16
+ *   W^T diag(c2) W [p][p], cvec = c3^T W [p]:   d(input) = dz wa + z wb + cvec  (tok_conv_dgrad + tok_conv_dgrad_bias).
+ * tok_conv_dgrad_bias: tok_conv_dgrad / tok_conv_dgrad_bnstats with a per-channel fp32 bias added to the result.          */
+int tok_bn_gram_finalize(const float* Z, const float* zsum, const float* w, int64_t count, int p, int k,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float momentum, float eps, float* mean, float* rstd,
+                         float* scale, float* shift, float* wz /* out [k][p] = W_bf16 Z, input of tok_bn3_bwd_prepare */,
+                         void* stream);
+int tok_conv_fwd_bn_apply(const tok_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
+                          const void* shortcut, void* out, uint8_t* mask, void* stream);
+int tok_conv_dgrad_maskstore(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                             const uint8_t* mask, float* partial, void* stream);
+int tok_relu_mask_reduce(const void* dout, const uint8_t* mask, int64_t m, int c, void* dz, float* partial, void* stream);
+int tok_bn3_bwd_prepare(const float* G, const float* w, const float* wz, const float* zsum, const float* partial, int rows,
+                        int64_t count, int p, int k, const float* gamma, const float* mean, const float* rstd,
+                        float* dgamma, float* dbeta, int param_accumulate, float* coef, float* dw, int dw_accumulate,
+                        void* wa, void* wb, float* cvec, float* ws /* scratch, tok_bn3_bwd_prepare_ws_floats(p, k) */,
+                        void* stream);
+size_t tok_bn3_bwd_prepare_ws_floats(int p, int k);
+int tok_conv_dgrad_bias(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const float* bias, void* dx,
+                        int accumulate, const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream);
 size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 /* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
  * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */

@@ -187,6 +187,123 @@ class FakeTok:
         return rc or self.tok_bn_bwd_finalize(partial, self.tok_conv_dgrad_stat_rows(d), b.count, dd.c, b.c_real, b.gamma, b.mean, b.rstd, b.dgamma,
                                               b.dbeta, b.coef, b.param_accumulate, 1, st)
 
+    # ---- "unit 3" (1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor) -----------------------
+    def tok_bn_gram_finalize(self, Z, zsum, w, count, p, k, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd, scale, shift,
+                             wz, st):
+        self.calls.append('bn_gram_finalize')
+        Zm = _t(Z, (p, p), torch.float32).double()
+        mu_z = _t(zsum, (p,), torch.float32).double() / count
+        wb = _t(w, (k, p), torch.float32).to(BF16).double()
+        cov = Zm / count - torch.outer(mu_z, mu_z)
+        _t(wz, (k, p), torch.float32).copy_((wb @ Zm).float())
+        mu = wb @ mu_z
+        var = ((wb @ cov) * wb).sum(1).clamp_min(0)
+        g, b = _t(gamma, (k,), torch.float32), _t(beta, (k,), torch.float32)
+        muf, rs = mu.float(), (1.0 / torch.sqrt(var + eps)).float()
+        sc = g * rs
+        for dst, val in ((mean, muf), (rstd, rs), (scale, sc), (shift, b - muf * sc)):
+            _t(dst, (k,), torch.float32).copy_(val)
+        if rm is not None:
+            unb = count / (count - 1) if count > 1 else 1.0
+            _t(rm, (k,), torch.float32).mul_(1 - momentum).add_(momentum * muf)
+            _t(rv, (k,), torch.float32).mul_(1 - momentum).add_(momentum * (var * unb).float())
+        if nbt is not None:
+            _t(nbt, (1,), torch.int64).add_(1)
+        return 0
+
+    def tok_conv_fwd_bn_apply(self, d, x, w, scale, shift, shortcut, out, mask, st):
+        d = _desc(d)
+        self.calls.append('conv_fwd_bn_apply')
+        m = d.n * d.p * d.q
+        xin = _t(x, (m, d.c), BF16).float()
+        wt = _t(w, (d.k, d.c), BF16).float()
+        z = (xin @ wt.t()) * _t(scale, (d.k,), torch.float32) + _t(shift, (d.k,), torch.float32) + \
+            _t(shortcut, (m, d.k), BF16).float()
+        o = z.clamp_min(0).to(BF16)
+        _t(out, (m, d.k), BF16).copy_(o)
+        if mask is not None:
+            bits = (o.float() > 0).long().reshape(m, d.k // 8, 8)
+            _t(mask, (m, d.k // 8), torch.uint8).copy_((bits << torch.arange(8)).sum(-1).to(torch.uint8))
+        return 0
+
+    def tok_conv_dgrad_maskstore(self, d, dy, wd, dx, accumulate, mask, partial, st):
+        rc = self.tok_conv_dgrad(d, dy, wd, dx, accumulate, st)
+        d = _desc(d)
+        self.calls.append('dgrad_maskstore')
+        m = d.n * d.h * d.w
+        g = _t(dx, (m, d.c), BF16)
+        dz = (g.float() * self._bits(mask, m, d.c)).to(BF16)
+        g.copy_(dz)
+        p = _t(partial, (2, 2, d.c), torch.float32)
+        p.zero_()
+        p[0, 1] = dz.float().sum(0)
+        return rc
+
+    def tok_relu_mask_reduce(self, dout, mask, m, c, dz, partial, st):
+        self.calls.append('relu_mask_reduce')
+        g = (_t(dout, (m, c), BF16).float() * self._bits(mask, m, c)).to(BF16)
+        _t(dz, (m, c), BF16).copy_(g)
+        p = _t(partial, (2, 1, c), torch.float32)
+        p.zero_()
+        p[0, 0] = g.float().sum(0)
+        return 0
+
+    def tok_bn3_bwd_prepare_ws_floats(self, p, k):
+        return k * (p + 1)
+
+    def tok_bn3_bwd_prepare(self, G, w, wz, zsum, partial, rows, count, p, k, gamma, mean, rstd, dgamma, dbeta, pacc, coef, dw,
+                            dw_acc, wa, wb, cvec, ws, st):
+        self.calls.append('bn3_bwd_prepare')
+        Gm = _t(G, (k, p), torch.float32).double()
+        wq = _t(w, (k, p), torch.float32).to(BF16).double()
+        WZ, zs = _t(wz, (k, p), torch.float32).double(), _t(zsum, (p,), torch.float32).double()
+        s1 = _t(partial, (2, rows, k), torch.float32)[0].double().sum(0)
+        s2 = (Gm * wq).sum(1)
+        mu, rs = _t(mean, (k,), torch.float32).double(), _t(rstd, (k,), torch.float32).double()
+        sx = rs * (s2 - mu * s1)
+        for ptr_, val in ((dgamma, sx.float()), (dbeta, s1.float())):
+            if ptr_ is not None:
+                t = _t(ptr_, (k,), torch.float32)
+                t.copy_(t + val if pacc else val)
+        g = _t(gamma, (k,), torch.float32)
+        m1, m2 = (s1 / count).float(), (sx / count).float()
+        c1 = g * rs.float()
+        c2 = -c1 * rs.float() * m2
+        c3 = -c1 * m1 - c2 * mu.float()
+        co = _t(coef, (3, k), torch.float32)
+        co[0], co[1], co[2] = c1, c2, c3
+        dwv = (c1.double()[:, None] * Gm + c2.double()[:, None] * WZ + torch.outer(c3.double(), zs)).float()
+        t = _t(dw, (k, p), torch.float32)
+        t.copy_(t + dwv if dw_acc else dwv)
+        _t(wa, (p, k), BF16).copy_((c1.double()[:, None] * wq).t().to(BF16))
+        _t(wb, (p, p), BF16).copy_((wq.t() @ (c2.double()[:, None] * wq)).to(BF16))
+        _t(cvec, (p,), torch.float32).copy_((c3.double() @ wq).float())
+        return 0
+
+    def tok_conv_dgrad_bias(self, d, dy, wd, bias, dx, accumulate, bn_y, bn_mask, partial, st):
+        dd = _desc(d)
+        m = dd.n * dd.h * dd.w
+        self.calls.append('conv_dgrad')
+        g = _t(dy, (dd.n, dd.p, dd.q, dd.k), BF16).float().permute(0, 3, 1, 2)
+        pack = _t(wd, (dd.c, dd.r, dd.s, dd.k), BF16).float()
+        wt = pack.flip(1, 2).permute(3, 0, 1, 2).contiguous()
+        gi = torch.nn.grad.conv2d_input((dd.n, dd.c, dd.h, dd.w), wt, g.contiguous(), stride=dd.stride, padding=dd.pad)
+        gi = gi.permute(0, 2, 3, 1)
+        if bias is not None:
+            gi = gi + _t(bias, (dd.c,), torch.float32)
+        out = _t(dx, (dd.n, dd.h, dd.w, dd.c), BF16)
+        out.copy_((gi + out.float()).to(BF16) if accumulate else gi.to(BF16))
+        if bn_y is not None:
+            self.calls.append('dgrad_bnstats')
+            gv = _t(dx, (m, dd.c), BF16).float()
+            yv = _t(bn_y, (m, dd.c), BF16).float()
+            dz = gv * self._bits(bn_mask, m, dd.c) if bn_mask is not None else gv
+            pt = _t(partial, (2, 2, dd.c), torch.float32)
+            pt.zero_()
+            pt[0, 1] = dz.sum(0)
+            pt[1, 1] = (dz * yv).sum(0)
+        return 0
+
     @staticmethod
     def _bits(mask, m, c):
         b = _t(mask, (m, c // 8), torch.uint8).long()

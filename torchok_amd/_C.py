@@ -84,6 +84,14 @@ PROTOTYPES = {
     'tok_global_pool_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_global_pool_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
+    'tok_bn_gram_finalize': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
+    'tok_conv_fwd_bn_apply': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'tok_conv_dgrad_maskstore': (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P]),
+    'tok_relu_mask_reduce': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P]),
+    'tok_bn3_bwd_prepare': (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int,
+                                    _P, _P, _P, _P, _P]),
+    'tok_bn3_bwd_prepare_ws_floats': (c_size_t, [c_int, c_int]),
+    'tok_conv_dgrad_bias': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
     'tok_softmax_ce_smooth_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, _P, _P]),

@@ -57,6 +57,15 @@ struct ConvArgs {
   int act;                 // 0 ReLU, 1 GELU (erf)
   const bf16* bn_y;        // dgrad + BatchNorm-backward statistics: raw conv output of the unit that
   const uint8_t* bn_mask;  // produced the tensor whose gradient this launch completes, and its ReLU bits
+  // PWM 4 forward ("unit 3": 1x1 conv whose BatchNorm scale / shift are known BEFORE the GEMM): the epilogue applies
+  // out = relu(acc * scale + shift + shortcut) and emits the ReLU bits; the pre-normalisation tensor is never stored
+  const float* ep_scale;
+  const float* ep_shift;
+  const bf16* ep_short;
+  uint8_t* ep_mask;
+  // dgrad completing the gradient of such a unit's output: the epilogue stores dz = relu_mask ? dx : 0 (what the unit's
+  // backward and its shortcut both want) and reduces sum(dz) into the statistics rows; bn_y is not needed
+  int mask_store;
   int H, W, C;   // gathered tensor
   int K;         // output channels (padded count of y)
   int R, S;      // S = stored filter width (s_pad)
@@ -98,6 +107,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   constexpr bool PW = PWM != 0;    // PWM 1: pointwise; 2: pointwise with streaming (non-temporal) stores
   constexpr bool NTS = PWM == 2;
   constexpr bool ACT = PWM == 3;   // pointwise with a fused activation epilogue (forward: second output; dgrad: * act')
+  constexpr bool BNEP = PWM == 4;  // pointwise forward with the BatchNorm + shortcut + ReLU epilogue
   // DMA: global -> LDS directly (buffer_load ... lds), no staging registers and no ds_write pass
   // (LDS stores run at ~80 B/clk/CU: the register-staged loop was LDS-write bound on deep-K layers).
   // The LDS image of a wave instruction is lane-linear, so the XOR swizzle is applied to the SOURCE:
@@ -438,9 +448,32 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
                 stg16(a.y2 + eoff, o2);
               }
             }
+            if (BNEP) {
+              // v = acc * scale + shift + shortcut, ReLU, bf16; mask bit e = (out[e] > 0) as tok_bn_act_fwd writes it
+              const int n0 = nb + half * 32;
+              const size_t eoff = opix * a.K + n0;
+              const bf16x8 sv = ldg16(a.ep_short + eoff);
+              unsigned bits = 0;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = fmaxf(fmaf(v[e], a.ep_scale[n0 + e], a.ep_shift[n0 + e]) + bf2f(sv[e]), 0.f);
+                o[e] = f2bf(z);
+                bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
+              }
+              if (a.ep_mask != nullptr) a.ep_mask[eoff >> 3] = (uint8_t)bits;
+            }
+            if (a.mask_store) {
+              const size_t eoff = opix * a.K + nb + half * 32;
+              const unsigned bits = a.bn_mask[eoff >> 3];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
+                s1[half * 8 + e] += bf2f(o[e]);
+              }
+            }
             if (NTS) __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(yp + half * 32));
             else stg16(yp + half * 32, o);
-            if (a.stats != nullptr) {
+            if (a.stats != nullptr && !a.mask_store) {
               if (a.bn_y != nullptr) {
                 // backward statistics of the producing BatchNorm: dz = dx * relu_mask, sum dz, sum dz*y
                 const size_t eoff = opix * a.K + nb + half * 32;
@@ -736,11 +769,12 @@ int launch(ConvArgs& a, hipStream_t st) {
       //  isolation, but the consumer BatchNorm pass then misses the 256 MB Infinity Cache and the
       //  whole step loses 2 % — measured, so it stays off)
       if (a.y2 != nullptr || a.act_x != nullptr) return launch_pw<BM, BN, 1, false, 3>(a, st);
+      if (a.ep_scale != nullptr) return launch_pw<BM, BN, 1, false, 4>(a, st);
       return launch_pw<BM, BN, 1, false, 1>(a, st);
     }
   }
-  if (a.y2 != nullptr || a.act_x != nullptr) {
-    tok_set_error("fused activation epilogue: 1x1 / stride 1 / no padding layers only");
+  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr) {
+    tok_set_error("fused activation / BatchNorm epilogue: 1x1 / stride 1 / no padding layers only");
     return TOK_ERR_INVALID;
   }
   return launch_pw<BM, BN, IN_DIV, C4, 0>(a, st);
@@ -815,8 +849,9 @@ int check_fused(const tok_bn_fused* bn, int k, bool fwd, const char* who) {
   else TOK_CHECK_ARG(bn->coef, "%s: bad tok_bn_fused (coef)", who);
   return 0;
 }
+struct BnEpilogue { const float* scale; const float* shift; const void* shortcut; uint8_t* mask; };
 int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
-                  const tok_bn_fused* bn, void* stream, void* y_act = nullptr, int act = 0);
+                  const tok_bn_fused* bn, void* stream, void* y_act = nullptr, int act = 0, const BnEpilogue* ep = nullptr);
 }  // namespace
 
 extern "C" int tok_conv_fwd(const tok_conv_desc* d, const void* x, const void* w,
@@ -832,7 +867,7 @@ extern "C" int tok_conv_fwd_bn(const tok_conv_desc* d, const void* x, const void
 
 namespace {
 int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
-                  const tok_bn_fused* bn, void* stream, void* y_act, int act) {
+                  const tok_bn_fused* bn, void* stream, void* y_act, int act, const BnEpilogue* ep) {
   if (int e = check_desc(d, "tok_conv_fwd")) return e;
   TOK_CHECK_ARG(x && w && y, "tok_conv_fwd: null pointer");
   ConvArgs a = {};
@@ -844,6 +879,7 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   }
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.bias = bias; a.stats = stats;
   a.y2 = (bf16*)y_act; a.act = act;
+  if (ep != nullptr) { a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_short = (const bf16*)ep->shortcut; a.ep_mask = ep->mask; }
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad;
   a.P = d->p; a.Q = d->q; a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q;
@@ -913,14 +949,15 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
 
 int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who,
-               const tok_bn_fused* bn = nullptr, const void* act_x = nullptr, int act = 0) {
+               const tok_bn_fused* bn = nullptr, const void* act_x = nullptr, int act = 0, const float* bias = nullptr,
+               int mask_store = 0) {
   if (int e = check_desc(d, who)) return e;
   TOK_CHECK_ARG(dy && w_dgrad && dx, "%s: null pointer", who);
   ConvArgs a = {};
   DgradPlan pl;
   if (int e = dgrad_fill(d, a, pl)) return e;
-  a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = nullptr;
-  a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask;
+  a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = bias;
+  a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask; a.mask_store = mask_store;
   a.accumulate = accumulate;
   a.act_x = (const bf16*)act_x; a.act = act;
   if (bn != nullptr) {
@@ -977,4 +1014,30 @@ extern "C" int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const v
                                  void* stream) {
   TOK_CHECK_ARG(bn_y && partial && bn, "tok_conv_dgrad_bn: bn_y / partial / bn must not be null");
   return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bn", bn);
+}
+
+
+// ---- "unit 3" of a bottleneck: 1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor -----------
+
+extern "C" int tok_conv_fwd_bn_apply(const tok_conv_desc* d, const void* x, const void* w, const float* scale,
+                                     const float* shift, const void* shortcut, void* out, uint8_t* mask, void* stream) {
+  TOK_CHECK_ARG(d && scale && shift && shortcut && out, "tok_conv_fwd_bn_apply: null pointer");
+  TOK_CHECK_ARG(d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c % 8 == 0,
+                "tok_conv_fwd_bn_apply: 1x1 / stride 1 / no padding layers only");
+  const BnEpilogue ep = {scale, shift, shortcut, mask};
+  return conv_fwd_impl(d, x, w, nullptr, out, nullptr, nullptr, stream, nullptr, 0, &ep);
+}
+
+extern "C" int tok_conv_dgrad_maskstore(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                        int accumulate, const uint8_t* mask, float* partial, void* stream) {
+  TOK_CHECK_ARG(mask && partial, "tok_conv_dgrad_maskstore: mask / partial must not be null");
+  return dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, mask, partial, stream, "tok_conv_dgrad_maskstore", nullptr,
+                    nullptr, 0, nullptr, 1);
+}
+
+extern "C" int tok_conv_dgrad_bias(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const float* bias, void* dx,
+                                   int accumulate, const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream) {
+  TOK_CHECK_ARG((bn_y == nullptr) == (partial == nullptr), "tok_conv_dgrad_bias: bn_y and partial go together");
+  return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bias", nullptr, nullptr, 0,
+                    bias);
 }

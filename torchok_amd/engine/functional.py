@@ -386,8 +386,17 @@ class _ConvBnActNode(Node):
             prod = x.node
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
                     and prod.fused_partial is None and prod.fused_coef is None)
+            mask_fuse = isinstance(prod, _Unit3Node) and is_last_contribution(x) and prod.masked_partial is None
             tgt, acc = grad_target(x)
-            if fuse:
+            if mask_fuse:
+                # this dgrad completes the gradient of a fused unit-3 output: its epilogue stores dz = relu_mask * d(out)
+                # (what that unit's backward and its shortcut both consume) and reduces sum(dz)
+                rows = lib.tok_conv_dgrad_stat_rows(d)
+                partial = torch.empty((2, rows, x.cp), dtype=F32, device=g.device)
+                _C.check(lib.tok_conv_dgrad_maskstore(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, ptr(prod.mask),
+                                                      ptr(partial), st), 'tok_conv_dgrad_maskstore')
+                prod.masked_partial = (partial, rows)
+            elif fuse:
                 # this dgrad completes d(x): its epilogue also reduces the BatchNorm-backward sums of the
                 # unit that produced x (saves that unit a full pass over d(x) and y)
                 rows = lib.tok_conv_dgrad_stat_rows(d)
@@ -422,6 +431,182 @@ class _ConvBnActNode(Node):
                 _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
 
 
+
+# ---- unit 3 of a bottleneck: 1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor ----------
+
+FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
+# the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
+# it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
+UNIT3_MIN_ROWS = int(os.environ.get('TOK_UNIT3_MIN_ROWS', '100000'))   # measured: 0 -> 22.4, 40000 -> 22.0, 100000 -> 21.8, plain 23.2 ms/step
+
+
+def _pointwise_desc(x: TTensor, k: int) -> _C.ConvDesc:
+    n, h, w, cp = x.shape
+    return _C.ConvDesc(n, h, w, cp, k, 1, 1, h, w, 1, 0, 1)
+
+
+def _colsum_f32(lib, st, t: torch.Tensor, m: int, c: int) -> torch.Tensor:
+    out = torch.empty(c, dtype=F32, device=t.device)
+    if m > 4096:
+        nrows = lib.tok_colsum_partial_rows(m, c)
+        part = torch.empty((nrows, c), dtype=F32, device=t.device)
+        _C.check(lib.tok_colsum_partial(ptr(t), m, c, ptr(part), st), 'tok_colsum_partial')
+        _C.check(lib.tok_colsum_f32(ptr(part), nrows, c, ptr(out), 0, st), 'tok_colsum_f32')
+    else:
+        _C.check(lib.tok_colsum(ptr(t), m, c, c, ptr(out), 0, st), 'tok_colsum')
+    return out
+
+
+def _wgrad_f32(lib, st, d: _C.ConvDesc, x: torch.Tensor, dy: torch.Tensor, k: int, c: int, out: torch.Tensor = None,
+               accumulate: int = 0) -> torch.Tensor:
+    """out[k][c] (fp32) = dy^T x through the weight-gradient kernels (also used for the Gram matrix z^T z)."""
+    if out is None:
+        out = torch.empty((k, c), dtype=F32, device=x.device)
+    ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
+    ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=x.device)
+    _C.check(lib.tok_conv_wgrad(d, ptr(x), ptr(dy), ptr(out), k, c, ptr(ws), ws_bytes, accumulate, st), 'tok_conv_wgrad')
+    return out
+
+
+class _Unit3Node(Node):
+    """out = relu(bn(conv1x1(x)) + shortcut) with the BatchNorm statistics taken from the second moments of x and the whole
+    backward written on x, dz = relu_mask * d(out) and small P x P / K x P matrices (csrc/unit3.hip).  The K-channel tensor
+    between conv and BatchNorm (and its gradient) never exists."""
+    needs_backward = True
+
+    def __init__(self):
+        self.x = self.out = self.shortcut = self.mask = None
+        self.masked_partial = None      # (partial, rows): the launch that completed d(out) already stored dz and sum(dz)
+
+    def release(self):
+        self.x = self.out = self.shortcut = self.mask = self.masked_partial = None
+        self.mean = self.rstd = self.wz = self.zsum = self.pk = None
+
+    def backward(self):
+        lib, st = _C.lib(), stream_ptr()
+        out: TTensor = self.out
+        g = out.grad
+        if g is None:
+            return
+        conv, bn, d, x, sc = self.conv, self.bn, self.desc, self.x, self.shortcut
+        kp, p = d.k, d.c
+        m = d.n * d.p * d.q
+        dev = g.device
+        # 1. dz = relu_mask * d(out) and the partial sums of dz
+        if self.masked_partial is not None:
+            partial, rows = self.masked_partial
+            dz = g
+        else:
+            rows = lib.tok_bn_bwd_rows(m, kp)
+            partial = torch.empty((2, rows, kp), dtype=F32, device=dev)
+            dz = g if out.grad_owned else torch.empty_like(g)
+            _C.check(lib.tok_relu_mask_reduce(ptr(g), ptr(self.mask), m, kp, ptr(dz), ptr(partial), st), 'tok_relu_mask_reduce')
+        out.grad = None
+        # 2. the shortcut receives dz itself
+        if sc is not None and sc.requires_grad:
+            if not donate_grad(sc, dz):
+                tgt, _ = grad_target(sc)
+                tgt.add_(dz)
+        w_need = conv.weight.requires_grad
+        x_need = x.requires_grad
+        g_need, b_need = bn.weight.requires_grad, bn.bias.requires_grad
+        if not (w_need or x_need or g_need or b_need):
+            return
+        # 3. G = dz^T x   (the weight-gradient launch, on dz)
+        G = _wgrad_f32(lib, st, d, x.data, dz, kp, p)
+        # 4. dgamma / dbeta / dW, coefficients and the two operands of the data gradient
+        gs, gm = param_grad_target(bn.weight) if g_need else (None, 0)
+        bs, bm = param_grad_target(bn.bias) if b_need else (None, 0)
+        ws_, wm = param_grad_target(conv.weight) if w_need else (torch.empty((kp, p), dtype=F32, device=dev), 0)
+        mixed = g_need and b_need and (gm == 1) != (bm == 1)
+        if mixed:     # one accumulates in its slot, the other does not: take both through temporaries
+            gbuf, bbuf = torch.empty_like(gs), torch.empty_like(bs)
+        else:
+            gbuf, bbuf = gs, bs
+        pacc = 1 if (not mixed and (gm == 1 or bm == 1)) else 0
+        coef = torch.empty((3, kp), dtype=F32, device=dev)
+        wa = torch.empty((p, kp), dtype=BF16, device=dev)
+        wb = torch.empty((p, p), dtype=BF16, device=dev)
+        cvec = torch.empty(p, dtype=F32, device=dev)
+        scratch = torch.empty(lib.tok_bn3_bwd_prepare_ws_floats(p, kp), dtype=F32, device=dev)
+        _C.check(lib.tok_bn3_bwd_prepare(ptr(G), ptr(conv.weight), ptr(self.wz), ptr(self.zsum), ptr(partial), rows, m, p,
+                                         kp, ptr(bn.weight), ptr(self.mean), ptr(self.rstd), ptr(gbuf), ptr(bbuf), pacc,
+                                         ptr(coef), ptr(ws_), 1 if wm == 1 else 0, ptr(wa), ptr(wb), ptr(cvec), ptr(scratch),
+                                         st), 'tok_bn3_bwd_prepare')
+        for need, prm, slot, mode, buf in ((g_need, bn.weight, gs, gm, gbuf), (b_need, bn.bias, bs, bm, bbuf)):
+            if not need:
+                continue
+            if mixed:
+                if mode == 1:
+                    slot.add_(buf)
+                else:
+                    slot.copy_(buf)
+            commit_param_grad(prm, slot, mode)
+        if w_need:
+            commit_param_grad(conv.weight, ws_, wm)
+        if not x_need:
+            return
+        # 5. d(x) = dz wa + x wb + cvec  (+ the BatchNorm-backward sums of the unit that produced x)
+        prod = x.node
+        fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
+                and prod.fused_partial is None and prod.fused_coef is None)
+        tgt, acc = grad_target(x)
+        _C.check(lib.tok_conv_dgrad(d, ptr(dz), ptr(wa), ptr(tgt), acc, st), 'tok_conv_dgrad')
+        dpp = _pointwise_desc(x, p)
+        if fuse:
+            rows2 = lib.tok_conv_dgrad_stat_rows(dpp)
+            part2 = torch.empty((2, rows2, p), dtype=F32, device=dev)
+            _C.check(lib.tok_conv_dgrad_bias(dpp, ptr(x.data), ptr(wb), ptr(cvec), ptr(tgt), 1, ptr(prod.y),
+                                             ptr(prod.mask) if prod.relu else None, ptr(part2), st), 'tok_conv_dgrad_bias')
+            prod.fused_partial = (part2, rows2)
+        else:
+            _C.check(lib.tok_conv_dgrad_bias(dpp, ptr(x.data), ptr(wb), ptr(cvec), ptr(tgt), 1, None, None, None, st),
+                     'tok_conv_dgrad_bias')
+        if self.region is not None:
+            self.region.keep_until_join(dz, wa, wb, cvec, G, scratch)
+
+
+def _unit3_forward(region: Region, x: TTensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, shortcut: TTensor, kp: int) -> TTensor:
+    lib, st = _C.lib(), stream_ptr()
+    dev = x.data.device
+    if bn.momentum is None:
+        raise NotImplementedError('BatchNorm momentum=None (cumulative average)')
+    d = _pointwise_desc(x, kp)
+    p = x.cp
+    m = d.n * d.p * d.q
+    pk = get_packs(conv.weight, None, kp, 1, p, want_dgrad=False, refresh=True)
+    # batch statistics of conv(x) from the second moments of x:  Z = x^T x  and  colsum(x)
+    dz_ = _pointwise_desc(x, p)
+    zz = _wgrad_f32(lib, st, dz_, x.data, x.data, p, p)
+    zsum = _colsum_f32(lib, st, x.data, m, p)
+    mean, rstd, scale, shift = (torch.empty(kp, dtype=F32, device=dev) for _ in range(4))
+    wz = torch.empty((kp, p), dtype=F32, device=dev)       # W Z: the statistics now, the weight gradient later
+    track = bn.training and bn.track_running_stats and bn.running_mean is not None
+    _C.check(lib.tok_bn_gram_finalize(ptr(zz), ptr(zsum), ptr(conv.weight), m, p, kp, ptr(bn.weight), ptr(bn.bias),
+                                      ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                                      ptr(bn.num_batches_tracked) if track else None, float(bn.momentum), float(bn.eps),
+                                      ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(wz), st), 'tok_bn_gram_finalize')
+    out_data = torch.empty((d.n, d.p, d.q, kp), dtype=BF16, device=dev)
+    training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or bn.weight.requires_grad
+                                     or shortcut.requires_grad)
+    mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev) if training else None
+    _C.check(lib.tok_conv_fwd_bn_apply(d, ptr(x.data), ptr(pk.fwd), ptr(scale), ptr(shift), ptr(shortcut.data),
+                                       ptr(out_data), ptr(mask), st), 'tok_conv_fwd_bn_apply')
+    out = TTensor(out_data, kp, requires_grad=bool(training))
+    if training:
+        node = _Unit3Node()
+        node.x, node.out, node.shortcut, node.mask = x, out, shortcut, mask
+        node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
+        node.mean, node.rstd, node.wz, node.zsum = mean, rstd, wz, zsum
+        out.node = node
+        if x.requires_grad:
+            x.uses += 1
+        if shortcut.requires_grad:
+            shortcut.uses += 1
+        region.add(node)
+    return out
+
+
 FUSE_STEM_POOL = os.environ.get('TOK_FUSE_STEM_POOL', '1') != '0'
 STEM_POOLED_STATS = os.environ.get('TOK_STEM_POOLED_STATS', '1') != '0'   # BatchNorm-backward sums of the fused stem in the pooled domain
 
@@ -449,6 +634,12 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
     kp = pad8(k_real)
     if bn is not None and bn.num_features != k_real:
         raise ValueError(f'BatchNorm num_features {bn.num_features} != conv output channels {k_real}')
+    if (FUSE_UNIT3 and bn is not None and relu and shortcut is not None and not pool and isinstance(conv, nn.Conv2d)
+            and r == 1 and s == 1 and stride == 1 and pad == 0 and conv.bias is None and x.data.dim() == 4
+            and x.c == x.cp and kp == k_real and x.cp <= 1024 and shortcut.cp == kp and x.rows() >= UNIT3_MIN_ROWS
+            and (bn.training or bn.running_mean is None) and conv.weight.permute(0, 2, 3, 1).is_contiguous()):
+        # the residual unit of a bottleneck: normalise, add and activate in the GEMM epilogue (no 4P-channel pre-BN tensor)
+        return _unit3_forward(region, x, conv, bn, shortcut, kp)
     d = _conv_desc(x4, kp, r, s, stride, pad)
     training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or
                                      (bn is not None and bn.weight.requires_grad))
