@@ -159,11 +159,13 @@ int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const void* w_dgra
  * tok_bn_gram_finalize: Z = z^T z (P x P, e.g. from tok_conv_wgrad on (z, z)), zsum = column sums of z, w = fp32 master
  *   filter [k][p] (rounded to bf16 inside, the operand the GEMM uses) -> mean / rstd / scale / shift [k] and the running
  *   statistics update of F.batch_norm (momentum, unbiased variance, num_batches_tracked += 1); count = rows of z.
- * tok_conv_fwd_bn_apply: out = relu(conv1x1(x) * scale + shift + shortcut) as bf16, mask bit = (out > 0)  (the bits
- *   tok_bn_act_fwd writes); replaces tok_conv_fwd + tok_bn_finalize + tok_bn_act_fwd for such a unit.
+ * tok_conv_fwd_bn_apply: out = act(conv1x1(x) * scale + shift (+ shortcut)) as bf16, act = ReLU or identity (the projection
+ *   shortcut conv + BatchNorm of [timm] downsample_conv), mask bit = (out > 0)  (the bits tok_bn_act_fwd writes); replaces
+ *   tok_conv_fwd + tok_bn_finalize + tok_bn_act_fwd for such a unit.
  * tok_conv_dgrad_maskstore: tok_conv_dgrad whose epilogue stores dz = mask ? dx : 0 and reduces sum(dz) into
  *   partial[2][tok_conv_dgrad_stat_rows][c] (second half zero) — for the launch that COMPLETES the gradient of the unit's
- *   output; tok_relu_mask_reduce is the stand-alone form (partial[2][tok_bn_bwd_rows(m, c)][c], in place allowed).
+ *   output; tok_relu_mask_reduce is the stand-alone form (partial[2][tok_bn_bwd_rows(m, c)][c], in place allowed;
+ *   mask NULL: plain column sums of dout).
  * tok_bn3_bwd_prepare: G = dz^T z [k][p], w, wz (from tok_bn_gram_finalize), zsum, the sum(dz) partial rows -> dgamma / dbeta (+= if param_accumulate),
  *   coef [3][k], dw [k][p] (+= if dw_accumulate), wa = bf16 diag(c1) W in dgrad-pack layout [p][k], wb = bf16
  *   W^T diag(c2) W [p][p], cvec = c3^T W [p]:   d(input) = dz wa + z wb + cvec  (tok_conv_dgrad + tok_conv_dgrad_bias).
@@ -174,7 +176,8 @@ int tok_bn_gram_finalize(const float* Z, const float* zsum, const float* w, int6
                          float* scale, float* shift, float* wz /* out [k][p] = W_bf16 Z, input of tok_bn3_bwd_prepare */,
                          void* stream);
 int tok_conv_fwd_bn_apply(const tok_conv_desc* d, const void* x, const void* w, const float* scale, const float* shift,
-                          const void* shortcut, void* out, uint8_t* mask, void* stream);
+                          const void* shortcut /* may be NULL */, int relu, void* out, uint8_t* mask /* may be NULL */,
+                          void* stream);
 int tok_conv_dgrad_maskstore(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                              const uint8_t* mask, float* partial, void* stream);
 int tok_relu_mask_reduce(const void* dout, const uint8_t* mask, int64_t m, int c, void* dz, float* partial, void* stream);

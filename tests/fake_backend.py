@@ -211,15 +211,16 @@ class FakeTok:
             _t(nbt, (1,), torch.int64).add_(1)
         return 0
 
-    def tok_conv_fwd_bn_apply(self, d, x, w, scale, shift, shortcut, out, mask, st):
+    def tok_conv_fwd_bn_apply(self, d, x, w, scale, shift, shortcut, relu, out, mask, st):
         d = _desc(d)
         self.calls.append('conv_fwd_bn_apply')
         m = d.n * d.p * d.q
         xin = _t(x, (m, d.c), BF16).float()
         wt = _t(w, (d.k, d.c), BF16).float()
-        z = (xin @ wt.t()) * _t(scale, (d.k,), torch.float32) + _t(shift, (d.k,), torch.float32) + \
-            _t(shortcut, (m, d.k), BF16).float()
-        o = z.clamp_min(0).to(BF16)
+        z = (xin @ wt.t()) * _t(scale, (d.k,), torch.float32) + _t(shift, (d.k,), torch.float32)
+        if shortcut is not None:
+            z = z + _t(shortcut, (m, d.k), BF16).float()
+        o = (z.clamp_min(0) if relu else z).to(BF16)
         _t(out, (m, d.k), BF16).copy_(o)
         if mask is not None:
             bits = (o.float() > 0).long().reshape(m, d.k // 8, 8)
@@ -241,7 +242,8 @@ class FakeTok:
 
     def tok_relu_mask_reduce(self, dout, mask, m, c, dz, partial, st):
         self.calls.append('relu_mask_reduce')
-        g = (_t(dout, (m, c), BF16).float() * self._bits(mask, m, c)).to(BF16)
+        g = _t(dout, (m, c), BF16).float()
+        g = (g * self._bits(mask, m, c) if mask is not None else g).to(BF16)
         _t(dz, (m, c), BF16).copy_(g)
         p = _t(partial, (2, 1, c), torch.float32)
         p.zero_()

@@ -211,11 +211,15 @@ def test_conv_bn_relu_unit(dev, resnet50_capture, conv, bn, relu):
     assert int(ours_unit.bn.num_batches_tracked) == int(chk.bn.num_batches_tracked)
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused-unit3', 'plain'])
 @pytest.mark.parametrize('name', ['layer1.0', 'layer1.1', 'layer2.0', 'layer2.1', 'layer3.0', 'layer3.2', 'layer4.0',
                                   'layer4.2'])
-def test_bottleneck_unit(dev, resnet50_capture, name):
+def test_bottleneck_unit(dev, resnet50_capture, name, fused, monkeypatch):
     """[timm] Bottleneck (with / without the projection shortcut, stride 1 / 2) on the oracle's own block input and output
-    gradient."""
+    gradient — through both execution plans of its residual unit: 'fused-unit3' (engine.functional._Unit3Node: conv3 / bn3 /
+    add / ReLU and the stride-1 projection shortcut without their pre-BatchNorm tensors, the plan of the large maps) and
+    'plain' (conv, BatchNorm statistics, apply as three launches)."""
+    monkeypatch.setattr(EF, 'UNIT3_MIN_ROWS', 0 if fused else 1 << 40)
     ref, cap = resnet50_capture
     blk = dict(ref.backbone.named_modules())[name]
     x, gout = _bf(cap['backbone.' + name][0]), _bf(cap['backbone.' + name][1])

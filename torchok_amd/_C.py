@@ -85,7 +85,7 @@ PROTOTYPES = {
     'tok_global_pool_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_colsum': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
     'tok_bn_gram_finalize': (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P]),
-    'tok_conv_fwd_bn_apply': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'tok_conv_fwd_bn_apply': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     'tok_conv_dgrad_maskstore': (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P]),
     'tok_relu_mask_reduce': (c_int, [_P, _P, c_int64, c_int, _P, _P, _P]),
     'tok_bn3_bwd_prepare': (c_int, [_P, _P, _P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, c_int,

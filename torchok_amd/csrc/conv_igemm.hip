@@ -61,8 +61,9 @@ struct ConvArgs {
   // out = relu(acc * scale + shift + shortcut) and emits the ReLU bits; the pre-normalisation tensor is never stored
   const float* ep_scale;
   const float* ep_shift;
-  const bf16* ep_short;
+  const bf16* ep_short;    // may be null: no residual term
   uint8_t* ep_mask;
+  int ep_relu;
   // dgrad completing the gradient of such a unit's output: the epilogue stores dz = relu_mask ? dx : 0 (what the unit's
   // backward and its shortcut both want) and reduces sum(dz) into the statistics rows; bn_y is not needed
   int mask_store;
@@ -75,6 +76,7 @@ struct ConvArgs {
   int gridM, gridN;
   int accumulate, uniform_taps;
   uint32_t x_bytes, w_bytes;   // extents of x / w for the buffer descriptors (< 4 GiB)
+  uint32_t s_bytes;            // BNEP: extent of the shortcut tensor
   FastDiv fd_pq, fd_q;
   unsigned long long* timing;   // TOK_TIMING builds only: per-phase cycle totals of wave 0
   int stat_rows;   // workgroups per channel tile = rows of the partial-statistics buffer
@@ -103,7 +105,7 @@ __device__ __forceinline__ int fw_swz(int n) {
 }
 
 template <int BM, int BN, int IN_DIV, bool C4, int PWM>
-__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr bool PW = PWM != 0;    // PWM 1: pointwise; 2: pointwise with streaming (non-temporal) stores
   constexpr bool NTS = PWM == 2;
   constexpr bool ACT = PWM == 3;   // pointwise with a fused activation epilogue (forward: second output; dgrad: * act')
@@ -131,6 +133,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);  // [2][WGM][BN]
+  // BNEP: the shortcut tile (BM pixels x BN channels, the layout and swizzle of the activation tile) is staged by DMA
+  // together with the FIRST K step of its output tile — one whole tile ahead of the epilogue that adds it; two buffers
+  constexpr int S_BYTES = BM * BN * 2;
+  char* sbase = smem + 2 * TILE_BYTES + 2 * 4 * BN * 4;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -149,6 +155,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
 
   // ---- loader state (belongs to the tile whose loads are being issued) ----------------------
   int h0[AROWS], w0[AROWS], pix[AROWS];   // pix: pixel base (C4 / IN_DIV 2) or ELEMENT base of tap (0,0)
+  int spix[AROWS];                        // BNEP: element base of the row in the shortcut tensor (m * K)
+  int s_ld = 0, s_rd = 0;                 // BNEP: shortcut buffer being filled / being consumed
   int kr, ks, kc0, kt;
   size_t wk;
   int par_h = 0, par_w = 0;  // (ph - pad), (pw - pad) of the loader's tile (IN_DIV == 2)
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
           h0[i] = m < a.M ? 0 : -1;
           w0[i] = 0;
           pix[i] = m * a.C;
+          if (BNEP) spix[i] = m * a.K;
         } else if (m < a.M) {
           const uint32_t b = fdiv(m, a.fd_pq);
           const uint32_t rem = m - b * a.PQ;
@@ -311,6 +320,19 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
         else ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
     }
+    if (BNEP) {
+      if (kt == 0 && a.ep_short != nullptr) {     // wave-uniform: first K step of an output tile
+        char* Sdst = sbase + s_ld * S_BYTES + wave_u * 1024;
+        const __amdgpu_buffer_rsrc_t ssrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.ep_short, 0, a.s_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < AROWS; ++i) {
+          const int n = bn_fixed * BN + kcA * 8;
+          uint32_t off = (ld_on && h0[i] == 0 && n < a.K) ? (uint32_t)(spix[i] + n) * 2u : 0xFFFFFFF0u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ssrd, (lds_void*)(Sdst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
+        }
+        s_ld ^= 1;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       const int n = bn_fixed * BN + lrow + RSTEP * j;
@@ -349,6 +371,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
   float s1[16], s2[16];   // per-lane BatchNorm partial sums of this workgroup's channel tile
 #pragma unroll
   for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+  float esc[16], esh[16];   // BNEP: scale / shift of this lane's 16 channels (the channel tile never changes)
+  if (BNEP) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int n = bn_fixed * BN + wn * 64 + sl * 8 + (c >> 3) * 32 + (c & 7);
+      esc[c] = n < a.K ? a.ep_scale[n] : 0.f;
+      esh[c] = n < a.K ? a.ep_shift[n] : 0.f;
+    }
+  }
 
   f32x4 acc[4][MT];
   auto zero_acc = [&]() {
@@ -452,11 +483,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
               // v = acc * scale + shift + shortcut, ReLU, bf16; mask bit e = (out[e] > 0) as tok_bn_act_fwd writes it
               const int n0 = nb + half * 32;
               const size_t eoff = opix * a.K + n0;
-              const bf16x8 sv = ldg16(a.ep_short + eoff);
+              bf16x8 sv = zero8();
+              if (a.ep_short != nullptr)
+                sv = *reinterpret_cast<const bf16x8*>(sbase + s_rd * S_BYTES + (arow0 + mt * 16) * 128 +
+                                                      (((sl + 4 * half) ^ aswz) << 4));
               unsigned bits = 0;
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                const float z = fmaxf(fmaf(v[e], a.ep_scale[n0 + e], a.ep_shift[n0 + e]) + bf2f(sv[e]), 0.f);
+                float z = fmaf(v[e], esc[half * 8 + e], esh[half * 8 + e]) + bf2f(sv[e]);
+                if (a.ep_relu) z = fmaxf(z, 0.f);
                 o[e] = f2bf(z);
                 bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
               }
@@ -565,6 +600,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
     if (tile_done) {
       epilogue(cur);
       zero_acc();
+      if (BNEP) s_rd ^= 1;
     }
 #ifdef TOK_TIMING
     __builtin_amdgcn_sched_barrier(0);
@@ -717,9 +753,9 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(ConvA
 
 // Persistent grid: 2 (128x128 tile) or 3 (128x64) workgroups per CU, rounded to a multiple of
 // 8 * gridN so every XCD holds whole (channel tile, m-slot) groups; never more than the tiles need.
-int plan_grid(int bn_tile, int gridM, int gridN) {
+int plan_grid(int bn_tile, int gridM, int gridN, int per_cu = 0) {
   const int unit = 8 * gridN;
-  int G = 256 * (bn_tile == 64 ? 3 : 2);
+  int G = 256 * (per_cu > 0 ? per_cu : (bn_tile == 64 ? 3 : 2));
   const long long need = (long long)gridM * gridN;
   if (need < G) G = (int)((need + unit - 1) / unit) * unit;
   G = G / unit * unit;
@@ -729,14 +765,14 @@ int plan_grid(int bn_tile, int gridM, int gridN) {
 
 template <int BM, int BN, int IN_DIV, bool C4, int PW>
 int launch_pw(ConvArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * (BM + BN) * BK * 2 + 2 * 4 * BN * 4;
+  constexpr int smem = 2 * (BM + BN) * BK * 2 + 2 * 4 * BN * 4 + (PW == 4 ? 2 * BM * BN * 2 : 0);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, IN_DIV, C4, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  const int grid = plan_grid(BN, a.gridM, a.gridN);
+  const int grid = plan_grid(BN, a.gridM, a.gridN, PW == 4 ? 2 : 0);   // (PW 4: two shortcut tiles in LDS -> 2 per CU)
   a.stat_rows = grid / a.gridN;
 
 #ifdef TOK_TIMING
@@ -849,7 +885,7 @@ int check_fused(const tok_bn_fused* bn, int k, bool fwd, const char* who) {
   else TOK_CHECK_ARG(bn->coef, "%s: bad tok_bn_fused (coef)", who);
   return 0;
 }
-struct BnEpilogue { const float* scale; const float* shift; const void* shortcut; uint8_t* mask; };
+struct BnEpilogue { const float* scale; const float* shift; const void* shortcut; uint8_t* mask; int relu; };
 int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const float* bias, void* y, float* stats,
                   const tok_bn_fused* bn, void* stream, void* y_act = nullptr, int act = 0, const BnEpilogue* ep = nullptr);
 }  // namespace
@@ -879,7 +915,13 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   }
   a.x = (const bf16*)x; a.w = (const bf16*)w; a.y = (bf16*)y; a.bias = bias; a.stats = stats;
   a.y2 = (bf16*)y_act; a.act = act;
-  if (ep != nullptr) { a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_short = (const bf16*)ep->shortcut; a.ep_mask = ep->mask; }
+  if (ep != nullptr) {
+    a.ep_scale = ep->scale; a.ep_shift = ep->shift; a.ep_short = (const bf16*)ep->shortcut; a.ep_mask = ep->mask;
+    a.ep_relu = ep->relu;
+    const unsigned long long sb = (unsigned long long)d->n * d->p * d->q * d->k * 2;
+    TOK_CHECK_ARG(sb < 0xFFFFFFF0ull, "tok_conv_fwd_bn_apply: tensors of 4 GiB or more are not supported");
+    a.s_bytes = (uint32_t)sb;
+  }
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad;
   a.P = d->p; a.Q = d->q; a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q;
@@ -892,7 +934,7 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
   int rc;
-  if (pick_bn(d->k, a.Ktot, a.gridM, d->h == 1 && d->w == 1) == 64) {
+  if (ep != nullptr || pick_bn(d->k, a.Ktot, a.gridM, d->h == 1 && d->w == 1) == 64) {   // (BN epilogue: 64-wide tiles)
     a.gridN = tok_cdiv(d->k, 64);
     rc = c4 ? launch<128, 64, 1, true>(a, st) : launch<128, 64, 1, false>(a, st);
   } else {
@@ -1020,11 +1062,12 @@ extern "C" int tok_conv_dgrad_bn(const tok_conv_desc* d, const void* dy, const v
 // ---- "unit 3" of a bottleneck: 1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor -----------
 
 extern "C" int tok_conv_fwd_bn_apply(const tok_conv_desc* d, const void* x, const void* w, const float* scale,
-                                     const float* shift, const void* shortcut, void* out, uint8_t* mask, void* stream) {
-  TOK_CHECK_ARG(d && scale && shift && shortcut && out, "tok_conv_fwd_bn_apply: null pointer");
+                                     const float* shift, const void* shortcut, int relu, void* out, uint8_t* mask,
+                                     void* stream) {
+  TOK_CHECK_ARG(d && scale && shift && out, "tok_conv_fwd_bn_apply: null pointer");
   TOK_CHECK_ARG(d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c % 8 == 0,
                 "tok_conv_fwd_bn_apply: 1x1 / stride 1 / no padding layers only");
-  const BnEpilogue ep = {scale, shift, shortcut, mask};
+  const BnEpilogue ep = {scale, shift, shortcut, mask, relu};
   return conv_fwd_impl(d, x, w, nullptr, out, nullptr, nullptr, stream, nullptr, 0, &ep);
 }
 

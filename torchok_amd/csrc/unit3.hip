@@ -167,13 +167,13 @@ __global__ __launch_bounds__(256) void relu_mask_reduce_kernel(const bf16* dout,
       for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
         const size_t off = (size_t)m * C + cg * 8;
         bf16x8 g = ldg16(dout + off);
-        const unsigned bits = mask[(size_t)m * cg_total + cg];
+        const unsigned bits = mask != nullptr ? mask[(size_t)m * cg_total + cg] : 0xffu;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           if (!((bits >> e) & 1u)) g[e] = (bf16)0.f;
           s1[e] += bf2f(g[e]);
         }
-        stg16(dz + off, g);
+        if (mask != nullptr || dz != dout) stg16(dz + off, g);
       }
     }
 #pragma unroll
@@ -313,7 +313,7 @@ extern "C" int tok_bn_gram_finalize(const float* Z, const float* zsum, const flo
 
 extern "C" int tok_relu_mask_reduce(const void* dout, const uint8_t* mask, int64_t m, int c, void* dz, float* partial,
                                     void* stream) {
-  TOK_CHECK_ARG(dout && mask && dz && partial && m > 0 && c > 0 && c % 8 == 0, "tok_relu_mask_reduce: bad args");
+  TOK_CHECK_ARG(dout && dz && partial && m > 0 && c > 0 && c % 8 == 0, "tok_relu_mask_reduce: bad args");
   int cge, rpb;
   mr_geo(c, cge, rpb);
   const int rows = tok_bn_bwd_rows(m, c);

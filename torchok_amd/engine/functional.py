@@ -124,6 +124,9 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
 
 
 WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
+# which weight gradients go to the side stream: 'all', or only the LDS/MFMA-bound ones ('3x3': filters larger than 1x1),
+# whose resource profile complements the HBM-bound main chain
+WGRAD_SIDE_WHICH = os.environ.get('TOK_WGRAD_SIDE_WHICH', '3x3')   # measured (ResNet-50, unit-3 fusion on): all 21.58, 3x3 21.45 ms/step
 FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
 
@@ -375,7 +378,9 @@ class _ConvBnActNode(Node):
                                             1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(conv.weight, slot, mode)
                 return ws
-            if WGRAD_SIDE_STREAM and g.is_cuda and self.region is not None and not torch.cuda.is_current_stream_capturing():
+            side_ok = WGRAD_SIDE_WHICH == 'all' or r * s > 1
+            if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
+                    and not torch.cuda.is_current_stream_capturing():
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
                 with self.region.fork_side((x.data, dy)):
@@ -476,6 +481,7 @@ class _Unit3Node(Node):
 
     def __init__(self):
         self.x = self.out = self.shortcut = self.mask = None
+        self.relu = True
         self.masked_partial = None      # (partial, rows): the launch that completed d(out) already stored dz and sum(dz)
 
     def release(self):
@@ -492,19 +498,25 @@ class _Unit3Node(Node):
         kp, p = d.k, d.c
         m = d.n * d.p * d.q
         dev = g.device
-        # 1. dz = relu_mask * d(out) and the partial sums of dz
+        # 1. dz = relu_mask * d(out) (d(out) itself for a unit without activation) and the partial sums of dz
         if self.masked_partial is not None:
             partial, rows = self.masked_partial
             dz = g
         else:
             rows = lib.tok_bn_bwd_rows(m, kp)
             partial = torch.empty((2, rows, kp), dtype=F32, device=dev)
-            dz = g if out.grad_owned else torch.empty_like(g)
-            _C.check(lib.tok_relu_mask_reduce(ptr(g), ptr(self.mask), m, kp, ptr(dz), ptr(partial), st), 'tok_relu_mask_reduce')
+            dz = g if (out.grad_owned or not self.relu) else torch.empty_like(g)
+            _C.check(lib.tok_relu_mask_reduce(ptr(g), ptr(self.mask) if self.relu else None, m, kp, ptr(dz), ptr(partial), st),
+                     'tok_relu_mask_reduce')
         out.grad = None
-        # 2. the shortcut receives dz itself
+        # 2. the shortcut receives dz itself; a projection shortcut of the same kind (conv1x1 + BatchNorm, no activation,
+        #    nobody else reads its output) inherits the partial sums of dz as well
         if sc is not None and sc.requires_grad:
-            if not donate_grad(sc, dz):
+            if donate_grad(sc, dz):
+                scn = sc.node
+                if isinstance(scn, _Unit3Node) and not scn.relu and sc.uses == 1 and scn.masked_partial is None:
+                    scn.masked_partial = (partial, rows)
+            else:
                 tgt, _ = grad_target(sc)
                 tgt.add_(dz)
         w_need = conv.weight.requires_grad
@@ -566,7 +578,8 @@ class _Unit3Node(Node):
             self.region.keep_until_join(dz, wa, wb, cvec, G, scratch)
 
 
-def _unit3_forward(region: Region, x: TTensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, shortcut: TTensor, kp: int) -> TTensor:
+def _unit3_forward(region: Region, x: TTensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, shortcut: Optional[TTensor], kp: int,
+                   relu: bool) -> TTensor:
     lib, st = _C.lib(), stream_ptr()
     dev = x.data.device
     if bn.momentum is None:
@@ -588,20 +601,21 @@ def _unit3_forward(region: Region, x: TTensor, conv: nn.Conv2d, bn: nn.BatchNorm
                                       ptr(mean), ptr(rstd), ptr(scale), ptr(shift), ptr(wz), st), 'tok_bn_gram_finalize')
     out_data = torch.empty((d.n, d.p, d.q, kp), dtype=BF16, device=dev)
     training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or bn.weight.requires_grad
-                                     or shortcut.requires_grad)
-    mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev) if training else None
-    _C.check(lib.tok_conv_fwd_bn_apply(d, ptr(x.data), ptr(pk.fwd), ptr(scale), ptr(shift), ptr(shortcut.data),
-                                       ptr(out_data), ptr(mask), st), 'tok_conv_fwd_bn_apply')
+                                     or (shortcut is not None and shortcut.requires_grad))
+    mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev) if (training and relu) else None
+    _C.check(lib.tok_conv_fwd_bn_apply(d, ptr(x.data), ptr(pk.fwd), ptr(scale), ptr(shift),
+                                       ptr(shortcut.data) if shortcut is not None else None, int(relu), ptr(out_data),
+                                       ptr(mask), st), 'tok_conv_fwd_bn_apply')
     out = TTensor(out_data, kp, requires_grad=bool(training))
     if training:
         node = _Unit3Node()
-        node.x, node.out, node.shortcut, node.mask = x, out, shortcut, mask
+        node.x, node.out, node.shortcut, node.mask, node.relu = x, out, shortcut, mask, relu
         node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
         node.mean, node.rstd, node.wz, node.zsum = mean, rstd, wz, zsum
         out.node = node
         if x.requires_grad:
             x.uses += 1
-        if shortcut.requires_grad:
+        if shortcut is not None and shortcut.requires_grad:
             shortcut.uses += 1
         region.add(node)
     return out
@@ -634,12 +648,14 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
     kp = pad8(k_real)
     if bn is not None and bn.num_features != k_real:
         raise ValueError(f'BatchNorm num_features {bn.num_features} != conv output channels {k_real}')
-    if (FUSE_UNIT3 and bn is not None and relu and shortcut is not None and not pool and isinstance(conv, nn.Conv2d)
+    if (FUSE_UNIT3 and bn is not None and (relu == (shortcut is not None)) and not pool and isinstance(conv, nn.Conv2d)
             and r == 1 and s == 1 and stride == 1 and pad == 0 and conv.bias is None and x.data.dim() == 4
-            and x.c == x.cp and kp == k_real and x.cp <= 1024 and shortcut.cp == kp and x.rows() >= UNIT3_MIN_ROWS
+            and x.c == x.cp and kp == k_real and x.cp <= 1024 and (shortcut is None or shortcut.cp == kp)
+            and x.rows() >= UNIT3_MIN_ROWS and kp >= 2 * x.cp
             and (bn.training or bn.running_mean is None) and conv.weight.permute(0, 2, 3, 1).is_contiguous()):
-        # the residual unit of a bottleneck: normalise, add and activate in the GEMM epilogue (no 4P-channel pre-BN tensor)
-        return _unit3_forward(region, x, conv, bn, shortcut, kp)
+        # the residual unit of a bottleneck (conv3 + bn3 + shortcut + ReLU) and its stride-1 projection shortcut (conv + bn):
+        # normalise (add, activate) in the GEMM epilogue — the wide pre-BatchNorm tensor is never stored
+        return _unit3_forward(region, x, conv, bn, shortcut, kp, relu)
     d = _conv_desc(x4, kp, r, s, stride, pad)
     training = region.grad_mode and (conv.weight.requires_grad or x.requires_grad or
                                      (bn is not None and bn.weight.requires_grad))
