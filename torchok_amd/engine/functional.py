@@ -126,6 +126,7 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
 WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
 # which weight gradients go to the side stream: 'all', or only the LDS/MFMA-bound ones ('3x3': filters larger than 1x1),
 # whose resource profile complements the HBM-bound main chain
+WGRAD_SIDE_MAX_ROWS = int(os.environ.get('TOK_WGRAD_SIDE_MAX_ROWS', '100000'))
 WGRAD_SIDE_WHICH = os.environ.get('TOK_WGRAD_SIDE_WHICH', '3x3')   # measured (ResNet-50, unit-3 fusion on): all 21.58, 3x3 21.45 ms/step
 FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
@@ -378,7 +379,9 @@ class _ConvBnActNode(Node):
                                             1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(conv.weight, slot, mode)
                 return ws
-            side_ok = WGRAD_SIDE_WHICH == 'all' or r * s > 1
+            # LDS/MFMA-bound (3x3) and short-M weight gradients complement the HBM-bound main chain; the long-M pointwise ones
+            # are HBM-bound themselves and only fight it for bandwidth
+            side_ok = WGRAD_SIDE_WHICH == 'all' or r * s > 1 or m < WGRAD_SIDE_MAX_ROWS
             if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
                     and not torch.cuda.is_current_stream_capturing():
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
