@@ -96,7 +96,8 @@ def _report(tag, what, e_hip, e_yard, e_pair):
 def _check(tag, ours, ref32, ref_ac, composite=False):
     """ours / ref32 / ref_ac: (outs, dxs, param grads).  Two gates per tensor (relative L2):
       (1) HIP vs the bf16-autocast oracle  <= 1e-2  — the reference's own arithmetic under `precision: bf16`, same rounding
-          points (conv / linear outputs and normalised activations are bf16 tensors), teacher-forced inputs;
+          points (conv / linear outputs and normalised activations are bf16 tensors), teacher-forced inputs — or HIP vs the
+          fp32 oracle <= 1e-2 outright;
       (2) HIP vs the fp32 oracle <= max(1e-2, 1.25 x autocast-vs-fp32) — no further from exact arithmetic than bf16 storage
           itself costs (a ReLU behind a bf16-rounded pre-activation flips ~1e-3 of the elements: 2-3 % of a gradient's norm
           for ANY bf16 pipeline, the reference's included; the yardstick is printed).
@@ -109,7 +110,9 @@ def _check(tag, ours, ref32, ref_ac, composite=False):
         e, y, pair = rel_err(o, r32), rel_err(rac, r32), rel_err(o, rac)
         _report(tag, what, e, y, pair)
         if not (composite and grad):
-            assert pair < TOL, (tag, what, 'vs autocast oracle', pair)
+            # (within 1e-2 of the fp32 oracle is better still: where the autocast run is itself ~1e-2 from fp32 — bf16
+            #  LayerNorm statistics — its distance to an fp32-accurate result says nothing about that result)
+            assert pair < TOL or e < TOL, (tag, what, 'vs autocast oracle', pair, 'vs fp32 oracle', e)
         assert e < max(TOL, (1.5 if composite else 1.25) * y), (tag, what, 'vs fp32 oracle', e, y)
     for i, (o, r32, rac) in enumerate(zip(ours[0], ref32[0], ref_ac[0])):
         gate(f'out[{i}]', o, r32, rac.float(), grad=False)
