@@ -126,6 +126,7 @@ def get_packs(weight: nn.Parameter, bias: Optional[nn.Parameter], kp: int, sp: i
 WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
 # which weight gradients go to the side stream: 'all', or only the LDS/MFMA-bound ones ('3x3': filters larger than 1x1),
 # whose resource profile complements the HBM-bound main chain
+WGRAD_AFTER_DGRAD = os.environ.get('TOK_WGRAD_AFTER_DGRAD', '0') == '1'   # measured: 22.0 vs 21.1 ms/step — the later start costs more
 WGRAD_SIDE_MAX_ROWS = int(os.environ.get('TOK_WGRAD_SIDE_MAX_ROWS', '100000'))
 WGRAD_SIDE_WHICH = os.environ.get('TOK_WGRAD_SIDE_WHICH', '3x3')   # measured (ResNet-50, unit-3 fusion on): all 21.58, 3x3 21.45 ms/step
 FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
@@ -368,7 +369,7 @@ class _ConvBnActNode(Node):
                 _C.check(lib.tok_colsum(ptr(dy), m, kp, conv.bias.shape[0], ptr(bs), 1 if bm == 1 else 0, st),
                          'tok_colsum')
             commit_param_grad(conv.bias, bs, bm)
-        if w_need:
+        def launch_wgrad():
             k, r, s, c = _krsc(conv.weight)
             ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
 
@@ -390,6 +391,10 @@ class _ConvBnActNode(Node):
                     self.region.keep_until_join(run_wgrad())
             else:
                 run_wgrad()
+        # a 3x3 weight gradient started BEFORE its unit's 3x3 data gradient runs beside it — two LDS/MFMA-bound kernels
+        # sharing the LDS pipes; started AFTER it, it runs beside the HBM-bound BatchNorm / pointwise kernels that follow
+        if w_need and not WGRAD_AFTER_DGRAD:
+            launch_wgrad()
         if x_need:
             prod = x.node
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
@@ -437,6 +442,8 @@ class _ConvBnActNode(Node):
                     prod.fused_partial = (partial, rows)
             else:
                 _C.check(lib.tok_conv_dgrad(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+        if w_need and WGRAD_AFTER_DGRAD:
+            launch_wgrad()
 
 
 

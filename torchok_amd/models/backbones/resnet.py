@@ -102,7 +102,8 @@ class Bottleneck(nn.Module):
 
 # measured on ResNet-50 (B=256): no gain (23.8 vs 23.7 ms/step) — the main-stream kernels already fill the GPU; the
 # mechanism pays off where the main chain is under-filled (HRNet's parallel branches)
-SHORTCUT_BRANCH = False
+import os as _os
+SHORTCUT_BRANCH = _os.environ.get('TOK_SHORTCUT_BRANCH', '0') == '1'
 
 
 def _shortcut_branch(r, x, downsample):
