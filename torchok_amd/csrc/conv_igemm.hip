@@ -26,6 +26,7 @@
 // Staging: global -> registers -> LDS (two buffers, one barrier per K step), 16-byte
 // XOR-swizzled slots so every ds_read_b128 of a fragment is bank-conflict free.
 #include "tok_common.h"
+#include "pw_gemm.h"
 #include <stdlib.h>
 
 namespace {
@@ -67,6 +68,7 @@ struct ConvArgs {
   // dgrad completing the gradient of such a unit's output: the epilogue stores dz = relu_mask ? dx : 0 (what the unit's
   // backward and its shortcut both want) and reduces sum(dz) into the statistics rows; bn_y is not needed
   int mask_store;
+  int force_grid;          // > 0: persistent grid size decided by the caller (statistics rows sized for the ring kernel)
   int H, W, C;   // gathered tensor
   int K;         // output channels (padded count of y)
   int R, S;      // S = stored filter width (s_pad)
@@ -772,7 +774,8 @@ int launch_pw(ConvArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  const int grid = plan_grid(BN, a.gridM, a.gridN, PW == 4 ? 2 : 0);   // (PW 4: two shortcut tiles in LDS -> 2 per CU)
+  const int grid = a.force_grid > 0 ? a.force_grid
+                                    : plan_grid(BN, a.gridM, a.gridN, PW == 4 ? 2 : 0);   // (PW 4: two shortcut tiles in LDS -> 2 per CU)
   a.stat_rows = grid / a.gridN;
 
 #ifdef TOK_TIMING
@@ -797,10 +800,41 @@ int launch_pw(ConvArgs& a, hipStream_t st) {
   return 0;
 }
 
+// pointwise layers whose reduction and output widths fit the ring kernel's access pattern (decided from the geometry alone,
+// so that tok_conv_*_stat_rows can size the statistics rows before any launch)
+// (the ring pays on the long-M streaming layers; short-M / deep-K ones are MFMA/LDS-bound and keep the two-buffer kernel's
+//  3 workgroups per CU — measured per layer with tools/bench_conv.py)
+static long long pw_min_rows() {
+  static long long v = -1;
+  if (v < 0) { const char* e = getenv("TOK_PW_RING_MIN_ROWS"); v = e ? atoll(e) : 100000; }
+  return v;
+}
+static bool pw_serves(int bn_tile, long long rows, int c_red, int n_out) {
+  // (the 128-wide tile would run 1 workgroup per CU on the ring: SwinV2-T 26.0 -> 30.3 ms/step; 64-wide tiles only)
+  return pw_ring_enabled() && bn_tile == 64 && rows >= pw_min_rows() && c_red % 8 == 0 && n_out % 64 == 0;
+}
+
 template <int BM, int BN, int IN_DIV, bool C4>
 int launch(ConvArgs& a, hipStream_t st) {
   if constexpr (IN_DIV == 1 && !C4) {
     if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0) {
+      if (pw_serves(BN, a.M, a.C, a.K)) {
+        // pointwise layers run on the three-stage DMA ring (pw_gemm.hip); modes it does not carry (fused activation, "last
+        // workgroup finalizes") stay here, on the ring's grid so that the statistics rows agree
+        if (a.y2 == nullptr && a.act_x == nullptr && a.fin_mode == 0) {
+          PwArgs p = {};
+          p.x = a.x; p.w = a.w; p.y = a.y; p.bias = a.bias; p.stats = a.stats;
+          p.stat_rows = pw_ring_grid(BN, a.gridM, a.gridN) / a.gridN;
+          p.e1 = a.accumulate ? a.y : a.ep_short;
+          p.e2 = a.bn_y; p.mask_in = a.bn_mask; p.mask_out = a.ep_mask;
+          p.ep_scale = a.ep_scale; p.ep_shift = a.ep_shift; p.ep_relu = a.ep_relu;
+          p.accumulate = a.accumulate; p.mask_store = a.mask_store;
+          p.M = a.M; p.C = a.C; p.N = a.K; p.gridM = a.gridM; p.gridN = a.gridN;
+          const int rc = pw_ring_launch(p, BN, st);
+          if (rc <= 0) return rc;
+        }
+        a.force_grid = pw_ring_grid(BN, a.gridM, a.gridN);
+      }
       // (PWM 2 = streaming / non-temporal output stores: +5..25 % on the write-heavy layers in
       //  isolation, but the consumer BatchNorm pass then misses the 256 MB Infinity Cache and the
       //  whole step loses 2 % — measured, so it stays off)
@@ -873,6 +907,8 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   const int gridM = tok_cdiv((long long)d->n * d->p * d->q, 128);
   const int bn_tile = pick_bn(d->k, d->r * d->s_pad * d->c, gridM, d->h == 1 && d->w == 1);
   const int gridN = tok_cdiv(d->k, bn_tile);
+  if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c != 4 && pw_serves(bn_tile, (long long)d->n * d->p * d->q, d->c, d->k))
+    return pw_ring_grid(bn_tile, gridM, gridN) / gridN;
   return plan_grid(bn_tile, gridM, gridN) / gridN;
 }
 
@@ -1041,6 +1077,8 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
   ConvArgs a = {};
   DgradPlan pl;
   if (dgrad_fill(d, a, pl)) return TOK_ERR_INVALID;
+  if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c))
+    return pw_ring_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;
   return plan_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;
 }
 
