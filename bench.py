@@ -50,6 +50,17 @@ def measured_traffic(backbone: str, res: int, width: int, batch: int):
     return None, None
 
 
+def measured_mfma_util(backbone: str, res: int, width: int, batch: int):
+    """Counter-based MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x 1024 SIMDs, tools/pmc_mfma.py) of the
+    committed PMC pass of this exact workload, or None."""
+    for name in PMC_FILES.get((backbone, res, width, batch), []):
+        path = os.path.join(ROOT, 'profiles', name.replace('pmc_traffic', 'pmc_mfma'))
+        if os.path.exists(path):
+            with open(path) as f:
+                return round(json.load(f)['mfma_util_busy_over_active'], 4)
+    return None
+
+
 def build_seg_task(backbone: str, num_classes: int, h: int, w: int):
     """HRNet + HRNetSegmentationNeck + SegmentationHead + CrossEntropyLoss (secondary workload,
     `--backbone hrnet_w48 --res 512 --width 1024 --classes 19 --batch 8`; never the default line)."""
@@ -354,6 +365,8 @@ def main():
                        'parallelism': f'dp{world}', 'launch_mode': 'hipGraph replay' if use_graph else 'eager'},
             'roofline': roofline,
         }
+        if roofline is not None:
+            roofline['mfma_util_pmc'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
         if dist_on:
             line['config']['rccl_ranks'] = dist.get_world_size()
             line['config']['grad_exchange'] = f"bucketed all-reduce(AVG), {'bf16' if reducer.bf16 else 'fp32'} payload, " \

@@ -31,6 +31,7 @@ class Spy(TorchDispatchMode):
                          if 'torchok_amd' in f.filename or f.filename.endswith('bench.py')), '?')
             cnt[(name, site[:150])] += 1
         return func(*args, **(kwargs or {}))
+torch.autograd.set_multithreading_enabled(False)
 with Spy():
     step(3)
 torch.cuda.synchronize()

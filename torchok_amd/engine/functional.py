@@ -382,7 +382,8 @@ class _ConvBnActNode(Node):
                 return ws
             # LDS/MFMA-bound (3x3) and short-M weight gradients complement the HBM-bound main chain; the long-M pointwise ones
             # are HBM-bound themselves and only fight it for bandwidth
-            side_ok = WGRAD_SIDE_WHICH == 'all' or r * s > 1 or m < WGRAD_SIDE_MAX_ROWS
+            side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
+                       (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')))
             if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
                     and not torch.cuda.is_current_stream_capturing():
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
