@@ -270,6 +270,14 @@ _padded_rows = {}
 
 
 def mark_padded(buf: torch.Tensor):
+    """Remember that `buf` is one of OUR zero-padded channel-last buffers (its logical view may re-enter a region without a
+    copy; one buffer may enter several regions, so entries are not consumed on the forward path).  The table is bounded
+    (oldest half dropped at 4096 entries: a dropped entry only costs a copy), and an address recycled for another tensor is
+    additionally caught by the stride test at the point of use."""
+    if len(_padded_rows) >= 4096:
+        for k in list(_padded_rows)[:2048]:      # oldest first (insertion order)
+            _padded_rows.pop(k, None)
+    _padded_rows.pop(buf.data_ptr(), None)
     _padded_rows[buf.data_ptr()] = buf.shape[-1]
 
 
