@@ -189,6 +189,19 @@ int tok_bn3_bwd_prepare(const float* G, const float* w, const float* wz, const f
 size_t tok_bn3_bwd_prepare_ws_floats(int p, int k);
 int tok_conv_dgrad_bias(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const float* bias, void* dx,
                         int accumulate, const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream);
+/* Stride-2 projection shortcuts ([timm] downsample_conv with stride 2, resnet.py) as pointwise layers:
+ * tok_subsample2_fwd: out[b][p][q][:] = x[b][2p][2q][:], p < ceil(h/2), q < ceil(w/2) — conv1x1/stride2(x) == conv1x1(out).
+ * tok_subsample2_bwd: dx[b][hh][ww][:] (+= if accumulate) = (hh, ww even) ? dsub[b][hh/2][ww/2][:] : 0 (stand-alone form).
+ * tok_conv_dgrad_subacc: dx = dgrad_1x1(dy) + that scatter of dsub, in the epilogue of the pointwise data gradient that
+ *   shares the input tensor (conv1 of a strided bottleneck); optional BatchNorm-backward sums (bn_y, mask, partial: as
+ *   tok_conv_dgrad_bnstats) or, with mask_store, the ReLU-masked store of tok_conv_dgrad_maskstore.  Served for the layers
+ *   tok_conv_dgrad_subacc_ok(d) returns 1 for; TOK_ERR_INVALID otherwise. */
+int tok_subsample2_fwd(const void* x, int n, int h, int w, int c, void* out, void* stream);
+int tok_subsample2_bwd(const void* dsub, int n, int h, int w, int c, void* dx, int accumulate, void* stream);
+int tok_conv_dgrad_subacc_ok(const tok_conv_desc* d);
+int tok_conv_dgrad_subacc(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* dsub,
+                          const void* bn_y /* may be NULL */, const uint8_t* mask /* may be NULL */,
+                          float* partial /* may be NULL */, int mask_store, void* stream);
 size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 /* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
  * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */

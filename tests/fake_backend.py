@@ -240,6 +240,42 @@ class FakeTok:
         p[0, 1] = dz.float().sum(0)
         return rc
 
+    # ---- stride-2 projection shortcut as a pointwise layer ---------------------------------------------------------------
+    def tok_subsample2_fwd(self, x, n, h, w, c, out, st):
+        self.calls.append('subsample2_fwd')
+        p, q = (h + 1) // 2, (w + 1) // 2
+        _t(out, (n, p, q, c), BF16).copy_(_t(x, (n, h, w, c), BF16)[:, ::2, ::2])
+        return 0
+
+    def tok_subsample2_bwd(self, dsub, n, h, w, c, dx, accumulate, st):
+        self.calls.append('subsample2_bwd')
+        p, q = (h + 1) // 2, (w + 1) // 2
+        g = _t(dx, (n, h, w, c), BF16)
+        s = _t(dsub, (n, p, q, c), BF16)
+        if accumulate:
+            g[:, ::2, ::2] = (g[:, ::2, ::2].float() + s.float()).to(BF16)
+        else:
+            g.zero_()
+            g[:, ::2, ::2] = s
+        return 0
+
+    def tok_conv_dgrad_subacc_ok(self, d):
+        d = _desc(d)
+        return 1 if (d.r == 1 and d.s == 1 and d.stride == 1 and d.pad == 0 and d.c % 64 == 0) else 0
+
+    def tok_conv_dgrad_subacc(self, d, dy, wd, dx, dsub, bn_y, mask, partial, mask_store, st):
+        dd = _desc(d)
+        self.calls.append('dgrad_subacc')
+        p, q = (dd.h + 1) // 2, (dd.w + 1) // 2
+        g = _t(dx, (dd.n, dd.h, dd.w, dd.c), BF16)
+        g.zero_()
+        g[:, ::2, ::2] = _t(dsub, (dd.n, p, q, dd.c), BF16)
+        if mask_store:
+            return self.tok_conv_dgrad_maskstore(d, dy, wd, dx, 1, mask, partial, st)
+        if bn_y is not None:
+            return self.tok_conv_dgrad_bnstats(d, dy, wd, dx, 1, bn_y, mask, partial, st)
+        return self.tok_conv_dgrad(d, dy, wd, dx, 1, st)
+
     def tok_relu_mask_reduce(self, dout, mask, m, c, dz, partial, st):
         self.calls.append('relu_mask_reduce')
         g = _t(dout, (m, c), BF16).float()

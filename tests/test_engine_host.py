@@ -258,3 +258,38 @@ def test_fused_bn_finalize_path(fake_backend, monkeypatch):
     for n, p in task.named_parameters():
         assert rel_err(p.grad, rp[n].grad) < 1.5 * rel_err(ac[n], rp[n].grad) + 1e-2, n
     assert task.backbone.bn1.num_batches_tracked.item() == 1
+
+
+def test_strided_projection_runs_pointwise_and_parks_its_gradient(fake_backend, monkeypatch):
+    """[timm] downsample_conv with stride 2 (resnet.py): conv1x1/s2(x) == conv1x1(x[:, ::2, ::2]).  The half-resolution
+    gradient is absorbed by conv1's data gradient (tok_conv_dgrad_subacc) where that layer qualifies and expanded by
+    tok_subsample2_bwd where it does not; gradients agree with the oracle either way."""
+    import torchok_amd.engine.functional as EF
+    monkeypatch.setattr(EF, 'SUBSAMPLE_MIN_ROWS', 0)
+    torch.manual_seed(3)
+    task, ref = _pair('resnet50', 10, seed=9)
+    x, y = torch.randn(4, 3, 64, 64), torch.randint(0, 10, (4,))
+    out = task.training_step({'image': x, 'target': y}, 0)
+    out['loss'].backward()
+    ref_loss, _ = R.training_step(ref, {'image': x, 'target': y}, None)
+    assert abs(float(out['loss']) - float(ref_loss)) < 2e-2 * max(1, abs(float(ref_loss)))
+    ac = _autocast_grads(ref, x, y)
+    rp = dict(ref.named_parameters())
+    for n, p in task.named_parameters():
+        assert p.grad is not None, n
+        assert rel_err(p.grad, rp[n].grad) < 1.5 * rel_err(ac[n], rp[n].grad) + 1e-2, n
+    calls = fake_backend.calls
+    assert calls.count('subsample2_fwd') == 3                       # layers 2.0, 3.0, 4.0
+    # the fake backend's closers are the layers with c % 64 == 0: all three conv1's absorb the parked gradient
+    assert calls.count('dgrad_subacc') == 3 and calls.count('subsample2_bwd') == 0
+
+    # a consumer that cannot absorb it: the stand-alone scatter takes over (same gradients)
+    monkeypatch.setattr(type(fake_backend), 'tok_conv_dgrad_subacc_ok', lambda self, d: 0)
+    task2, _ = _pair('resnet50', 10, seed=9)
+    fake_backend.calls.clear()
+    out2 = task2.training_step({'image': x, 'target': y}, 0)
+    out2['loss'].backward()
+    assert fake_backend.calls.count('subsample2_bwd') == 3 and fake_backend.calls.count('dgrad_subacc') == 0
+    g1 = dict(task.named_parameters())
+    for n, p in task2.named_parameters():
+        assert rel_err(p.grad, g1[n].grad) < 1e-6, n

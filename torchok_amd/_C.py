@@ -92,6 +92,10 @@ PROTOTYPES = {
                                     _P, _P, _P, _P, _P]),
     'tok_bn3_bwd_prepare_ws_floats': (c_size_t, [c_int, c_int]),
     'tok_conv_dgrad_bias': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'tok_subsample2_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    'tok_subsample2_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    'tok_conv_dgrad_subacc_ok': (c_int, [POINTER(ConvDesc)]),
+    'tok_conv_dgrad_subacc': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P]),
     'tok_softmax_ce_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, _P, _P, _P, _P]),
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
     'tok_softmax_ce_smooth_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, _P, _P]),

@@ -69,6 +69,9 @@ struct ConvArgs {
   // backward and its shortcut both want) and reduces sum(dz) into the statistics rows; bn_y is not needed
   int mask_store;
   int force_grid;          // > 0: persistent grid size decided by the caller (statistics rows sized for the ring kernel)
+  // pointwise dgrad on the ring whose result also takes the gradient of the stride-2 pixel subsample of the same tensor
+  // (tok_conv_dgrad_subacc): dx[b][h][w] = acc + (h, w even ? sub[b][h/2][w/2] : 0)
+  const bf16* sub;
   int H, W, C;   // gathered tensor
   int K;         // output channels (padded count of y)
   int R, S;      // S = stored filter width (s_pad)
@@ -93,6 +96,11 @@ struct ConvArgs {
 };
 
 constexpr int BK = 64;
+#ifdef TOK_NO_FRAG_ASM
+constexpr bool FRAG_ASM = false;
+#else
+constexpr bool FRAG_ASM = true;
+#endif
 #ifdef TOK_NO_DMA
 constexpr bool DMA_ENABLED = false;
 #else
@@ -318,8 +326,13 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
           ok = ok && ((unsigned)ww < (unsigned)a.W);
           off = ok ? (uint32_t)(pix[i] + tap_delta) * 2u : 0xFFFFFFF0u;
         }
-        if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
-        else ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
+        if (DMA) {
+          // (value barrier: without it hipcc turns the select above into a branch around the load — eight branches per K step)
+          asm volatile("" : "+v"(off));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
+        } else {
+          ra[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
+        }
       }
     }
     if (BNEP) {
@@ -330,6 +343,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
         for (int i = 0; i < AROWS; ++i) {
           const int n = bn_fixed * BN + kcA * 8;
           uint32_t off = (ld_on && h0[i] == 0 && n < a.K) ? (uint32_t)(spix[i] + n) * 2u : 0xFFFFFFF0u;
+          asm volatile("" : "+v"(off));
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ssrd, (lds_void*)(Sdst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
         }
         s_ld ^= 1;
@@ -339,8 +353,13 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
     for (int j = 0; j < WROWS; ++j) {
       const int n = bn_fixed * BN + lrow + RSTEP * j;
       const bool wvalid = DMA ? (ld_on && (int)wk < a.Ktot) : kvalid;
-      const uint32_t off = (wvalid && n < a.K) ? (uint32_t)(n * a.Ktot + (int)wk) * 2u : 0xFFFFFFF0u;
-      if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
+      uint32_t woff = (uint32_t)(n * a.Ktot + (int)wk) * 2u;
+      if (DMA) asm volatile("" : "+v"(woff));     // offset computed unconditionally: the select stays a v_cndmask
+      uint32_t off = (wvalid && n < a.K) ? woff : 0xFFFFFFF0u;
+      if (DMA) {
+        asm volatile("" : "+v"(off));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
+      }
       else rw[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0));
     }
   };
@@ -391,7 +410,47 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
 
+  typedef __attribute__((address_space(3))) char lds_char_t;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char_t*)smem;
+  auto lds_read16 = [](uint32_t addr) -> u32x4 {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+  };
   auto compute = [&](int buf) {
+    if constexpr (DMA && FRAG_ASM) {
+      // all 2 x (4 + MT) fragment reads of the K step go out first (inline asm: hipcc interleaves its own ds_reads with the
+      // MFMAs one wait at a time, and fences them with vmcnt(0) while the next stage's DMA is in flight); the first half's
+      // MFMAs start when ITS fragments have landed, the second half's reads complete underneath
+      const uint32_t Ab = lds_base + buf * TILE_BYTES, Wb = Ab + BM * BK * 2;
+      u32x4 wf[2][4], af[2][MT];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int s = sl + 4 * kk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[kk][t] = lds_read16(Wb + (wrow0 + (t >> 1) * 32 + (t & 1) * 4) * 128 + ((s ^ wswz) << 4));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[kk][mt] = lds_read16(Ab + (arow0 + mt * 16) * 128 + ((s ^ aswz) << 4));
+      }
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(4 + MT) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][t]),
+                                                               __builtin_bit_cast(bf16x8, af[0][mt]), acc[t][mt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // (the wait must not float above the first half's MFMAs)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[1][t]),
+                                                               __builtin_bit_cast(bf16x8, af[1][mt]), acc[t][mt], 0, 0, 0);
+      return;
+    }
     const char* Ab = smem + buf * TILE_BYTES;
     const char* Wb = Ab + BM * BK * 2;
 #pragma unroll
@@ -558,6 +617,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
     cur_has = kt < a.KT;
     if (cur_has) { load_tile(0); store_tile(0); }
   }
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   zero_acc();
   int buf = 0;
@@ -614,6 +674,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
 #endif
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next stage has landed in LDS
     __syncthreads();
 #ifdef TOK_TIMING
     const unsigned long long t5 = __builtin_amdgcn_s_memtime();
@@ -829,11 +890,17 @@ int launch(ConvArgs& a, hipStream_t st) {
           p.e2 = a.bn_y; p.mask_in = a.bn_mask; p.mask_out = a.ep_mask;
           p.ep_scale = a.ep_scale; p.ep_shift = a.ep_shift; p.ep_relu = a.ep_relu;
           p.accumulate = a.accumulate; p.mask_store = a.mask_store;
+          if (a.sub != nullptr) { p.e1 = a.sub; p.accumulate = 1; p.e1_sub = 1; p.sub_H = a.P; p.sub_W = a.Q; }
           p.M = a.M; p.C = a.C; p.N = a.K; p.gridM = a.gridM; p.gridN = a.gridN;
           const int rc = pw_ring_launch(p, BN, st);
-          if (rc <= 0) return rc;
+          if (rc == 0) return 0;
+          if (rc < 0) { tok_set_error("pointwise ring kernel: inconsistent arguments"); return TOK_ERR_INVALID; }
         }
         a.force_grid = pw_ring_grid(BN, a.gridM, a.gridN);
+      }
+      if (a.sub != nullptr) {
+        tok_set_error("tok_conv_dgrad_subacc: layer not served by the pointwise ring kernel (ask tok_conv_dgrad_subacc_ok)");
+        return TOK_ERR_INVALID;
       }
       // (PWM 2 = streaming / non-temporal output stores: +5..25 % on the write-heavy layers in
       //  isolation, but the consumer BatchNorm pass then misses the 256 MB Infinity Cache and the
@@ -843,8 +910,8 @@ int launch(ConvArgs& a, hipStream_t st) {
       return launch_pw<BM, BN, 1, false, 1>(a, st);
     }
   }
-  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr) {
-    tok_set_error("fused activation / BatchNorm epilogue: 1x1 / stride 1 / no padding layers only");
+  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.sub != nullptr) {
+    tok_set_error("fused activation / BatchNorm epilogue / subsample accumulate: 1x1 / stride 1 / no padding layers only");
     return TOK_ERR_INVALID;
   }
   return launch_pw<BM, BN, IN_DIV, C4, 0>(a, st);
@@ -1028,7 +1095,7 @@ int dgrad_fill(const tok_conv_desc* d, ConvArgs& a, DgradPlan& pl) {
 int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
                const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream, const char* who,
                const tok_bn_fused* bn = nullptr, const void* act_x = nullptr, int act = 0, const float* bias = nullptr,
-               int mask_store = 0) {
+               int mask_store = 0, const void* sub = nullptr) {
   if (int e = check_desc(d, who)) return e;
   TOK_CHECK_ARG(dy && w_dgrad && dx, "%s: null pointer", who);
   ConvArgs a = {};
@@ -1037,6 +1104,7 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
   a.x = (const bf16*)dy; a.w = (const bf16*)w_dgrad; a.y = (bf16*)dx; a.bias = bias;
   a.stats = partial; a.bn_y = (const bf16*)bn_y; a.bn_mask = bn_mask; a.mask_store = mask_store;
   a.accumulate = accumulate;
+  a.sub = (const bf16*)sub;
   a.act_x = (const bf16*)act_x; a.act = act;
   if (bn != nullptr) {
     if (int e = check_fused(bn, d->c, false, who)) return e;
@@ -1121,4 +1189,27 @@ extern "C" int tok_conv_dgrad_bias(const tok_conv_desc* d, const void* dy, const
   TOK_CHECK_ARG((bn_y == nullptr) == (partial == nullptr), "tok_conv_dgrad_bias: bn_y and partial go together");
   return dgrad_impl(d, dy, w_dgrad, dx, accumulate, bn_y, bn_mask, partial, stream, "tok_conv_dgrad_bias", nullptr, nullptr, 0,
                     bias);
+}
+
+// ---- pointwise dgrad + the gradient of the stride-2 pixel subsample of the same tensor ----------------------------------------
+// The block input x of a strided bottleneck feeds conv1 (1x1 / stride 1) and, through tok_subsample2_fwd, the projection
+// shortcut.  d(x) = dgrad(conv1) + scatter(d(subsample)): the scatter rides the ring kernel's accumulate stage (rows with an
+// odd coordinate fetch nothing), so d(x) is written once and the half-resolution gradient is never expanded in HBM.
+
+extern "C" int tok_conv_dgrad_subacc_ok(const tok_conv_desc* d) {
+  if (check_desc(d, "tok_conv_dgrad_subacc_ok")) return 0;
+  if (!(d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c % 8 == 0)) return 0;
+  ConvArgs a = {};
+  DgradPlan pl;
+  if (dgrad_fill(d, a, pl)) return 0;
+  return pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c) ? 1 : 0;
+}
+
+extern "C" int tok_conv_dgrad_subacc(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* dsub,
+                                     const void* bn_y, const uint8_t* mask, float* partial, int mask_store, void* stream) {
+  TOK_CHECK_ARG(dsub != nullptr, "tok_conv_dgrad_subacc: dsub must not be null");
+  TOK_CHECK_ARG(!mask_store || (mask && partial && !bn_y), "tok_conv_dgrad_subacc: mask_store needs mask + partial, no bn_y");
+  TOK_CHECK_ARG(mask_store || ((bn_y == nullptr) == (partial == nullptr)), "tok_conv_dgrad_subacc: bn_y and partial go together");
+  return dgrad_impl(d, dy, w_dgrad, dx, 0, bn_y, mask, partial, stream, "tok_conv_dgrad_subacc", nullptr, nullptr, 0, nullptr,
+                    mask_store, dsub);
 }

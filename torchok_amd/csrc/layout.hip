@@ -232,6 +232,68 @@ extern "C" int tok_cast_bf16_f32(const void* src, float* dst, float scale, size_
   return TOK_OK;
 }
 
+// ---- stride-2 pixel subsample (the input of a 1x1 / stride-2 projection as a dense tensor) ---------------------------------
+// out[b][p][q][:] = x[b][2p][2q][:],  P = ceil(H/2), Q = ceil(W/2): the projection then runs as a plain pointwise GEMM in
+// forward, weight- and data-gradient (conv_igemm's parity-class path streams at 1.2-2.4 TB/s on these layers).
+namespace {
+__global__ __launch_bounds__(256) void subsample2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int h, int w,
+                                                            int p, int q, int c8, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    size_t pix = i / c8;
+    const int qq = (int)(pix % q);
+    pix /= q;
+    const int pp = (int)(pix % p);
+    const size_t b = pix / p;
+    stg16(out + i * 8, ldg16(x + (((b * h + 2 * pp) * w + 2 * qq) * (size_t)c8 + cc) * 8));
+  }
+}
+// dx[b][hh][ww][:] (+)= (hh, ww both even) ? dsub[b][hh/2][ww/2][:] : 0
+__global__ __launch_bounds__(256) void subsample2_bwd_kernel(const bf16* __restrict__ dsub, bf16* __restrict__ dx, int h, int w,
+                                                            int p, int q, int c8, int accumulate, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    size_t pix = i / c8;
+    const int ww = (int)(pix % w);
+    pix /= w;
+    const int hh = (int)(pix % h);
+    const size_t b = pix / h;
+    const bool hit = ((hh | ww) & 1) == 0;
+    if (!hit) {
+      if (!accumulate) stg16(dx + i * 8, zero8());
+      continue;
+    }
+    bf16x8 v = ldg16(dsub + (((b * p + (hh >> 1)) * q + (ww >> 1)) * (size_t)c8 + cc) * 8);
+    if (accumulate) {
+      const bf16x8 old = ldg16(dx + i * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(old[e]) + bf2f(v[e]));
+    }
+    stg16(dx + i * 8, v);
+  }
+}
+}  // namespace
+
+extern "C" int tok_subsample2_fwd(const void* x, int n, int h, int w, int c, void* out, void* stream) {
+  TOK_CHECK_ARG(x && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_subsample2_fwd: bad args (c %% 8 == 0)");
+  const int p = (h + 1) / 2, q = (w + 1) / 2;
+  const size_t total = (size_t)n * p * q * (c / 8);
+  hipLaunchKernelGGL(subsample2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, tok_stream(stream), (const bf16*)x, (bf16*)out, h,
+                     w, p, q, c / 8, total);
+  TOK_CHECK_LAUNCH("tok_subsample2_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_subsample2_bwd(const void* dsub, int n, int h, int w, int c, void* dx, int accumulate, void* stream) {
+  TOK_CHECK_ARG(dsub && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_subsample2_bwd: bad args (c %% 8 == 0)");
+  const int p = (h + 1) / 2, q = (w + 1) / 2;
+  const size_t total = (size_t)n * h * w * (c / 8);
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, tok_stream(stream), (const bf16*)dsub, (bf16*)dx,
+                     h, w, p, q, c / 8, accumulate, total);
+  TOK_CHECK_LAUNCH("tok_subsample2_bwd");
+  return TOK_OK;
+}
+
 extern "C" int tok_pack_weight_fwd(const float* src, int k, int r, int s, int c, void* dst, int k_pad,
                                    int s_pad, int c_pad, void* stream) {
   TOK_CHECK_ARG(src && dst && k > 0 && r > 0 && s > 0 && c > 0, "tok_pack_weight_fwd: bad args");

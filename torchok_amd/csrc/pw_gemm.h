@@ -18,6 +18,9 @@ struct PwArgs {
   const float* ep_shift;
   int ep_relu;
   int accumulate;       // y = e1 + acc  (e1 == y's previous contents)
+  // e1_sub: e1 is the gradient of the stride-2 pixel subsample of y's tensor ([B][ceil(H/2)][ceil(W/2)][N], tok_subsample2_fwd):
+  // row m = (b, h, w) of y receives e1[b][h/2][w/2] when h and w are even and nothing otherwise (accumulate must be set)
+  int e1_sub, sub_H, sub_W;
   int mask_store;       // store relu_mask * y, sum it into stats row 0
   int M, C, N;
   int gridM, gridN;

@@ -33,6 +33,18 @@ __device__ __forceinline__ int fw_swz(int n) {
   return ((0x78 >> (((n >> 3) & 3) << 1)) & 3) | (((n >> 1) & 1) << 2);
 }
 
+struct PwDiv { uint32_t mul, shift; };
+PwDiv make_pwdiv(uint32_t d) {
+  PwDiv f = {0, 0};
+  if (d <= 1) return f;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ uint32_t pwdiv(uint32_t n, PwDiv f) { return (uint32_t)(((uint64_t)__umulhi(n, f.mul) + n) >> f.shift); }
+
 __device__ __forceinline__ u32x4 lds_read16(uint32_t addr) {
   u32x4 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
@@ -47,7 +59,7 @@ __device__ __forceinline__ uint32_t lds_read_u8(uint32_t addr) {
 template <int BN, bool BNEP>
 __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwArgs a, uint32_t x_bytes, uint32_t w_bytes,
                                                                              uint32_t y_bytes, uint32_t m_bytes, int KT,
-                                                                             int SPT) {
+                                                                             int SPT, uint32_t e1_bytes, PwDiv fd_hw, PwDiv fd_w) {
   constexpr int NT = 256;
   constexpr int WGN = BN / 64;
   constexpr int WGM = (NT / 64) / WGN;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
 
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t e1srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e1 ? a.e1 : a.x), 0, a.e1 ? y_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t e1srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e1 ? a.e1 : a.x), 0, a.e1 ? e1_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t e2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e2 ? a.e2 : a.x), 0, a.e2 ? y_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t msrd =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_in ? (const void*)a.mask_in : (const void*)a.x), 0, a.mask_in ? m_bytes : 0, 0x00020000);
@@ -128,11 +140,26 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
       // epilogue operand tile: channels n0 .. n0+63 in the A region, n0+64 .. n0+127 (BN = 128) in the W region
       const bool first_e = (ksL - KT) == 0 && nE1;
       const __amdgpu_buffer_rsrc_t esrd = first_e ? e1srd : e2srd;
+      const bool sub = first_e && a.e1_sub;      // wave-uniform
+      // element offset of row m / channel n in the operand tensor; e1_sub: the row of the half-resolution tensor, even pixels only
+      auto erow = [&](int m, int n, bool ok) -> uint32_t {
+        if (!ok) return 0xFFFFFFF0u;
+        if (sub) {
+          const uint32_t b = pwdiv((uint32_t)m, fd_hw);
+          const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.sub_H * a.sub_W);
+          const uint32_t h = pwdiv(rem, fd_w);
+          const uint32_t w = rem - h * (uint32_t)a.sub_W;
+          if ((h | w) & 1u) return 0xFFFFFFF0u;
+          const uint32_t ph = (uint32_t)(a.sub_H + 1) >> 1, pw = (uint32_t)(a.sub_W + 1) >> 1;
+          return (((b * ph + (h >> 1)) * pw + (w >> 1)) * (uint32_t)a.N + (uint32_t)n) * 2u;
+        }
+        return (uint32_t)(m * a.N + n) * 2u;
+      };
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const int m = m0 + lrow + RSTEP * i;
         const int n = n0 + kcA * 8;
-        uint32_t off = (live && m < a.M && n < a.N) ? (uint32_t)(m * a.N + n) * 2u : 0xFFFFFFF0u;
+        uint32_t off = erow(m, n, live && m < a.M && n < a.N);
         asm volatile("" : "+v"(off));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(esrd, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
       }
@@ -140,7 +167,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
       for (int j = 0; j < WROWS; ++j) {
         const int m = m0 + lrow + RSTEP * j;
         const int n = n0 + 64 + kcA * 8;
-        uint32_t off = (BN == 128 && live && m < a.M && n < a.N) ? (uint32_t)(m * a.N + n) * 2u : 0xFFFFFFF0u;
+        uint32_t off = erow(m, n, BN == 128 && live && m < a.M && n < a.N);
         asm volatile("" : "+v"(off));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(esrd, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
       }
@@ -216,6 +243,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
       for (int mt = 0; mt < MT; ++mt)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[0][t]), __builtin_bit_cast(bf16x8, af[0][mt]),
                                                              acc[t][mt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // (the wait must not float above the first half's MFMAs)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -414,9 +442,17 @@ int launch_ring(const PwArgs& a, hipStream_t st) {
   const unsigned long long xb = (unsigned long long)a.M * a.C * 2, wb = (unsigned long long)a.N * a.C * 2,
                            yb = (unsigned long long)a.M * a.N * 2, mb = (unsigned long long)a.M * (a.N / 8);
   if (xb >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull || yb >= 0xFFFFFFF0ull) return 1;
+  unsigned long long e1b = yb;
+  PwDiv fd_hw = {0, 0}, fd_w = {0, 0};
+  if (a.e1_sub) {
+    const unsigned long long hw = (unsigned long long)a.sub_H * a.sub_W;
+    e1b = (unsigned long long)(a.M / hw) * ((a.sub_H + 1) / 2) * ((a.sub_W + 1) / 2) * a.N * 2;
+    fd_hw = make_pwdiv((uint32_t)hw);
+    fd_w = make_pwdiv((uint32_t)a.sub_W);
+  }
   const int grid = pw_ring_grid(BN, a.gridM, a.gridN);
   hipLaunchKernelGGL((pw_gemm_ring_kernel<BN, BNEP>), dim3(grid), dim3(256), smem, st, a, (uint32_t)xb, (uint32_t)wb, (uint32_t)yb,
-                     (uint32_t)mb, KT, SPT);
+                     (uint32_t)mb, KT, SPT, (uint32_t)e1b, fd_hw, fd_w);
   return 0;
 }
 
@@ -439,6 +475,8 @@ int pw_ring_launch(const PwArgs& a, int bn_tile, hipStream_t st) {
   if (a.C % 8 != 0 || a.N % 8 != 0) return 1;
   if (a.mask_in != nullptr && a.N % 64 != 0) return 1;       // mask rows are fetched as aligned 4 / 16-byte pieces
   if (a.accumulate && a.e1 == nullptr) return 1;
+  if (a.e1_sub && (!a.accumulate || a.ep_scale != nullptr || a.sub_H <= 0 || a.sub_W <= 0 ||
+                   a.M % (a.sub_H * a.sub_W) != 0)) return -1;
   const bool bnep = a.ep_scale != nullptr;
   if (bn_tile == 64) return bnep ? launch_ring<64, true>(a, st) : launch_ring<64, false>(a, st);
   if (bnep) return 1;

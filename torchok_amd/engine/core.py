@@ -51,7 +51,7 @@ class TTensor:
 
     data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
     __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', 'ready', 'gevents',
-                 '__weakref__')
+                 'sub_closers', 'grad_sub', '__weakref__')
 
     def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
         self.data = data
@@ -64,6 +64,8 @@ class TTensor:
         self.arrived = 0    # gradient contributions received so far (backward)
         self.ready = None   # (event, stream): produced on a branch stream (forward), see Region.branch
         self.gevents = None  # [(event, stream)]: gradient contributions written on other streams (backward)
+        self.sub_closers = 0  # consumers whose data gradient can absorb a pending half-resolution contribution (forward)
+        self.grad_sub = None  # pending contribution: gradient of the stride-2 pixel subsample of this tensor (backward)
 
     @property
     def cp(self) -> int:
@@ -114,13 +116,36 @@ def _touch(x: 'TTensor'):
         _ms.touched.append(x)
 
 
-def grad_target(x: TTensor):
+def flush_sub(x: TTensor):
+    """Expand a pending half-resolution contribution (see functional.subsample2) into the full gradient buffer: the
+    stand-alone scatter, for arrivals that cannot absorb it in their own epilogue."""
+    if x.grad_sub is None:
+        return
+    sub, x.grad_sub = x.grad_sub, None
+    n, h, w, c = x.data.shape
+    if x.grad is None:
+        x.grad = torch.empty_like(x.data)
+        x.grad_owned = True
+        acc = 0
+    else:
+        if not x.grad_owned:
+            x.grad = x.grad.clone()
+            x.grad_owned = True
+        acc = 1
+    _C.check(_C.lib().tok_subsample2_bwd(ptr(sub), n, h, w, c, ptr(x.grad), acc, stream_ptr()), 'tok_subsample2_bwd')
+
+
+def grad_target(x: TTensor, sub_ok: bool = False):
     """Buffer to write a gradient contribution of `x` into, and whether to accumulate.
 
     First arrival allocates (accumulate=0); later arrivals add in the producer's epilogue.
     A gradient tensor that came from outside the region (autograd grad_output) is never
-    written in place: it is cloned first."""
+    written in place: it is cloned first.
+    sub_ok: the caller takes `x.grad_sub` (a pending half-resolution contribution) into its own kernel; everybody else
+    gets it expanded first."""
     _touch(x)
+    if x.grad_sub is not None and not sub_ok:
+        flush_sub(x)
     x.arrived += 1
     if x.grad is None:
         x.grad = torch.empty_like(x.data)
@@ -395,6 +420,9 @@ class Region:
             return self._run_backward_multi()
         for node in reversed(self.nodes):
             if node.needs_backward:
+                out = getattr(node, 'out', None)
+                if out is not None and out.grad_sub is not None:
+                    flush_sub(out)         # the consumer that would have absorbed it never reported (dead branch)
                 node.backward()
             node.release()
         self.nodes = []
@@ -422,6 +450,8 @@ class Region:
                             if out.grad is not None:
                                 out.grad.record_stream(s)
                         _ms.touched = []
+                        if out is not None and out.grad_sub is not None:
+                            flush_sub(out)
                         node.backward()
                         if _ms.touched:
                             ev = torch.cuda.Event()
@@ -524,6 +554,7 @@ class _RegionFn(torch.autograd.Function):
         region.run_backward()
         gins = []
         for t, x in region.inputs:
+            flush_sub(t)
             if t.grad is None:
                 gins.append(None)
             else:

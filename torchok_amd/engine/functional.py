@@ -18,6 +18,7 @@ import torch
 from torch import nn
 
 from .. import _C
+from .core import _ms as _core_ms
 from .core import (BF16, Node, Region, TTensor, await_ready, commit_param_grad, donate_grad, grad_target,
                    is_last_contribution, pad8, param_grad_target, ptr, stream_ptr)
 
@@ -401,8 +402,29 @@ class _ConvBnActNode(Node):
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
                     and prod.fused_partial is None and prod.fused_coef is None)
             mask_fuse = isinstance(prod, _Unit3Node) and is_last_contribution(x) and prod.masked_partial is None
-            tgt, acc = grad_target(x)
-            if mask_fuse:
+            sub = x.grad_sub if getattr(self, 'sub_capable', False) else None
+            tgt, acc = grad_target(x, sub_ok=sub is not None)
+            if sub is not None:
+                # d(x) = this data gradient + the parked gradient of x[:, ::2, ::2] (a strided projection shortcut): one
+                # launch, d(x) written once; the epilogue variants of the plain call sites below
+                x.grad_sub = None
+                assert acc == 0
+                rows = lib.tok_conv_dgrad_stat_rows(d)
+                if mask_fuse:
+                    partial = torch.empty((2, rows, x.cp), dtype=F32, device=g.device)
+                    _C.check(lib.tok_conv_dgrad_subacc(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), ptr(sub), None, ptr(prod.mask),
+                                                       ptr(partial), 1, st), 'tok_conv_dgrad_subacc')
+                    prod.masked_partial = (partial, rows)
+                elif fuse:
+                    partial = torch.empty((2, rows, x.cp), dtype=F32, device=g.device)
+                    _C.check(lib.tok_conv_dgrad_subacc(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), ptr(sub), ptr(prod.y),
+                                                       ptr(prod.mask) if prod.relu else None, ptr(partial), 0, st),
+                             'tok_conv_dgrad_subacc')
+                    prod.fused_partial = (partial, rows)
+                else:
+                    _C.check(lib.tok_conv_dgrad_subacc(d, ptr(dy), ptr(self.pk.dgrad), ptr(tgt), ptr(sub), None, None, None, 0,
+                                                       st), 'tok_conv_dgrad_subacc')
+            elif mask_fuse:
                 # this dgrad completes the gradient of a fused unit-3 output: its epilogue stores dz = relu_mask * d(out)
                 # (what that unit's backward and its shortcut both consume) and reduces sum(dz)
                 rows = lib.tok_conv_dgrad_stat_rows(d)
@@ -655,6 +677,11 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
         r, s = conv.kernel_size
         stride, pad = conv.stride[0], conv.padding[0]
         k_real = conv.out_channels
+    if (SUBSAMPLE_S2 and r == 1 and s == 1 and stride == 2 and pad == 0 and x.data.dim() == 4 and not pool
+            and x.rows() >= SUBSAMPLE_MIN_ROWS):
+        # conv1x1/stride2(x) == conv1x1(x[:, ::2, ::2]): one strided copy, then a pointwise layer in all three passes
+        x = subsample2(region, x)
+        stride = 1
     x4 = x
     kp = pad8(k_real)
     if bn is not None and bn.num_features != k_real:
@@ -749,8 +776,13 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
         node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
         node.relu, node.batch_stats = relu, batch_stats
         out.node = node
+        node.sub_capable = False
         if x.requires_grad:
             x.uses += 1
+            if (r == 1 and s == 1 and stride == 1 and pad == 0 and x.data.dim() == 4
+                    and lib.tok_conv_dgrad_subacc_ok(d)):
+                node.sub_capable = True      # this unit's data gradient can absorb a half-resolution contribution to d(x)
+                x.sub_closers += 1
         if shortcut is not None and shortcut.requires_grad:
             shortcut.uses += 1
         region.add(node)
@@ -800,6 +832,53 @@ def max_pool_3x3_s2(region: Region, x: TTensor) -> TTensor:
 
 
 # ---- 2x2 average pool (avg_down shortcuts) ---------------------------------------------------------------------
+
+class _Subsample2Node(Node):
+    """x -> x[:, ::2, ::2]: the input of a 1x1 / stride-2 projection as a dense tensor.  Its backward does not touch d(x)
+    when exactly one more contribution is due and that consumer's data gradient can absorb the half-resolution gradient
+    in its epilogue (tok_conv_dgrad_subacc): the buffer is parked on `x.grad_sub`."""
+    needs_backward = True
+
+    def backward(self):
+        g = self.out.grad
+        x = self.x
+        if g is None or not x.requires_grad:
+            return
+        self.out.grad = None
+        if (x.grad is None and x.grad_sub is None and x.uses == 2 and x.arrived == 0 and x.sub_closers == 1
+                and not getattr(_core_ms, 'active', False)):
+            x.grad_sub = g
+            x.arrived += 1
+            return
+        n, h, w, c = x.shape
+        tgt, acc = grad_target(x)
+        _C.check(_C.lib().tok_subsample2_bwd(ptr(g), n, h, w, c, ptr(tgt), acc, stream_ptr()), 'tok_subsample2_bwd')
+
+    def release(self):
+        self.x = self.out = None
+
+
+# 1x1 / stride-2 / no-padding convolutions run as pointwise layers on the subsampled input (forward, weight gradient, data
+# gradient on the streaming kernels; the unit-3 fusion applies to the projection + BatchNorm).  Measured on ResNet-50 B=256:
+# see DESIGN.md section 8.
+SUBSAMPLE_S2 = os.environ.get('TOK_SUBSAMPLE_S2', '1') != '0'
+SUBSAMPLE_MIN_ROWS = int(os.environ.get('TOK_SUBSAMPLE_MIN_ROWS', '100000'))   # rows of the full-resolution input
+
+
+def subsample2(region: Region, x: TTensor) -> TTensor:
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 1) // 2, (w + 1) // 2, c), dtype=BF16, device=x.data.device)
+    _C.check(_C.lib().tok_subsample2_fwd(ptr(x.data), n, h, w, c, ptr(y), stream_ptr()), 'tok_subsample2_fwd')
+    req = region.grad_mode and x.requires_grad
+    out = TTensor(y, x.c, requires_grad=req)
+    if req:
+        node = _Subsample2Node()
+        node.x, node.out = x, out
+        out.node = node
+        x.uses += 1
+        region.add(node)
+    return out
+
 
 class _AvgPool2Node(Node):
     needs_backward = True

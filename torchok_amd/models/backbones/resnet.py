@@ -94,9 +94,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         r = engine.current_region()
-        shortcut = _shortcut_branch(r, x, self.downsample)
+        late = SHORTCUT_LATE and self.downsample is not None and not SHORTCUT_BRANCH
+        shortcut = None if late else _shortcut_branch(r, x, self.downsample)
         y = EF.conv_bn_act(r, x, self.conv1, self.bn1, relu=True)
         y = EF.conv_bn_act(r, y, self.conv2, self.bn2, relu=True)
+        if late:
+            shortcut = _shortcut_branch(r, x, self.downsample)
         return EF.conv_bn_act(r, y, self.conv3, self.bn3, relu=True, shortcut=shortcut)
 
 
@@ -104,6 +107,10 @@ class Bottleneck(nn.Module):
 # mechanism pays off where the main chain is under-filled (HRNet's parallel branches)
 import os as _os
 SHORTCUT_BRANCH = _os.environ.get('TOK_SHORTCUT_BRANCH', '0') == '1'
+# The projection recorded LAST before the unit that adds it: in backward its (strided) data gradient then opens the
+# gradient of the block input and conv1's dense 1x1 data gradient closes it — the accumulate + ReLU-mask pass over the whole
+# tensor runs in the ring kernel's staged epilogue instead of the parity-class kernel's read-modify-write of untouched pixels
+SHORTCUT_LATE = _os.environ.get('TOK_SHORTCUT_LATE', '1') == '1'
 
 
 def _shortcut_branch(r, x, downsample):
