@@ -674,7 +674,10 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
 #endif
-    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next stage has landed in LDS
+    if (DMA) {
+      __builtin_amdgcn_sched_barrier(0);                         // (MFMAs / epilogue stay in front of the wait)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this thread's share of the next stage has landed in LDS
+    }
     __syncthreads();
 #ifdef TOK_TIMING
     const unsigned long long t5 = __builtin_amdgcn_s_memtime();

@@ -27,7 +27,21 @@ struct WgradArgs {
   int M, PQ, HW, Ktot;
   int tilesN, tilesK, splitM, mchunk;
   uint32_t x_bytes, dy_bytes;
+  uint32_t pq_mul, pq_shift, q_mul, q_shift;   // magic-number division by PQ and Q (row cursor of the 3x3 gather)
 };
+
+// n / d for n < 2^31 with (mul, shift) from make_magic(d)
+__device__ __forceinline__ uint32_t magic_div(uint32_t n, uint32_t mul, uint32_t shift) {
+  return (uint32_t)(((uint64_t)__umulhi(n, mul) + n) >> shift);
+}
+void make_magic(uint32_t d, uint32_t& mul, uint32_t& shift) {
+  mul = 0; shift = 0;
+  if (d <= 1) return;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  shift = l;
+}
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
@@ -96,16 +110,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   // PWK: 1x1, stride 1, no padding (every Linear and most ResNet convs): input pixel == output pixel, no row cursor
   constexpr bool pointwise = PWK;
 
-  int xm[XP], xq[XP], xp[XP], xpix[XP];
+  // row cursor: output pixel of this thread's X rows as (image base, pixel inside the image); (p, q) by one magic-number
+  // division per step — straight-line code (the incremental "while (q >= Q)" cursor was a divergent loop per row and step)
+  int xm[XP], xrem[XP], xpix[XP];
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
-    const int m = mstart + xrow + i * RPX;
-    xm[i] = m;
-    const int mm = min(m, a.M - 1);
+    xm[i] = mstart + xrow + i * RPX;
+    const int mm = min(xm[i], a.M - 1);
     const int b = mm / a.PQ;
-    const int rem = mm - b * a.PQ;
-    xp[i] = rem / a.Q;
-    xq[i] = rem - xp[i] * a.Q;
+    xrem[i] = mm - b * a.PQ;
     xpix[i] = b * a.HW;
   }
   int ym = mstart + yrow;
@@ -123,20 +136,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
 #pragma unroll
     for (int i = 0; i < YP; ++i) {
       const int m = ym + i * RPY;
-      const uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
-      if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(Ydst + i * RPY * YS), 16, off, 0, 0, 0);
+      uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
+      if (DMA) {
+        asm volatile("" : "+v"(off));      // one unconditional DMA per row (no branch around the load)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(Ydst + i * RPY * YS), 16, off, 0, 0, 0);
+      }
       else ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ysrd, off, 0, 0));
     }
     ym += MS;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-      const int hh = xp[i] * a.stride - a.pad + kr;
-      const int ww = xq[i] * a.stride - a.pad + ks;
+      int hh = 0, ww = 0, xpix_i = 0;
+      if (!pointwise) {
+        const uint32_t pp = magic_div((uint32_t)xrem[i], a.q_mul, a.q_shift);
+        hh = (int)pp * a.stride - a.pad + kr;
+        ww = (int)((uint32_t)xrem[i] - pp * (uint32_t)a.Q) * a.stride - a.pad + ks;
+        xpix_i = xpix[i];
+      }
       const bool ok = k_ok && xm[i] < mend && (unsigned)hh < (unsigned)a.H;
       bf16x8 v = zero8();
       if (C4) {
         if (ok) {
-          const bf16* ptr = a.x + ((size_t)(xpix[i] + hh * a.W + ww)) * 4;
+          const bf16* ptr = a.x + ((size_t)(xpix_i + hh * a.W + ww)) * 4;
           bf16x4 lo = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f}, hi = lo;
           if ((unsigned)ww < (unsigned)a.W) lo = *reinterpret_cast<const bf16x4*>(ptr);
           if ((unsigned)(ww + 1) < (unsigned)a.W) hi = *reinterpret_cast<const bf16x4*>(ptr + 4);
@@ -145,20 +166,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
         }
       } else {
         // pointwise (1x1, stride 1, no padding: every Linear and most ResNet convs): input pixel == output pixel
-        const uint32_t off = pointwise ? ((k_ok && xm[i] < mend) ? (uint32_t)(xm[i] * a.C + kc0) * 2u : 0xFFFFFFF0u)
-                             : (ok && (unsigned)ww < (unsigned)a.W)
-                                 ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
-        if (DMA) __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
+        uint32_t goff = pointwise ? (uint32_t)(xm[i] * a.C + kc0) * 2u : (uint32_t)((xpix_i + hh * a.W + ww) * a.C + kc0) * 2u;
+        if (DMA) asm volatile("" : "+v"(goff));
+        uint32_t off = (pointwise ? (k_ok && xm[i] < mend) : (ok && (unsigned)ww < (unsigned)a.W)) ? goff : 0xFFFFFFF0u;
+        if (DMA) {
+          asm volatile("" : "+v"(off));
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
+        }
         else v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0));
       }
       rx[i] = v;
       // advance this row cursor by MS output pixels
       xm[i] += MS;
       if (!pointwise) {
-        xq[i] += MS;
-        while (xq[i] >= a.Q) {
-          xq[i] -= a.Q;
-          if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
+        // pixel index inside the image advances by MS; MS <= 64 < 2 * PQ is not guaranteed (7x7 maps): up to two wraps
+        xrem[i] += MS;
+#pragma unroll
+        for (int w_ = 0; w_ < (MS + 48) / 49; ++w_) {
+          const bool wrap = xrem[i] >= a.PQ;
+          xrem[i] -= wrap ? a.PQ : 0;
+          xpix[i] += wrap ? a.HW : 0;
         }
       }
     }
@@ -196,13 +223,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
     load_tile(0);
     store_tile(0);
   }
+  if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
 
   for (int st = 0; st < steps; ++st) {
     // past the last step the cursors point beyond `mend`: the loads return zeros without traffic
     load_tile((st + 1) & 1);
     const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
     const char* Xb = Yb + YBYTES;
+    if constexpr (DMA) {
+      // every transpose read of the stage first (inline asm: no vmcnt(0) fence against the DMA of the next stage, no
+      // one-wait-per-MFMA interleaving), then the MFMAs of each 32-row half as its fragments land
+      constexpr int HALVES = MS / 32;
+      const uint32_t Yl = lds_base + (st & 1) * (YBYTES + XBYTES), Xl = Yl + YBYTES;
+      u32x2 ya[HALVES][NT][2], xb[HALVES][KTL][2];
+#pragma unroll
+      for (int ks = 0; ks < HALVES; ++ks) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          ya[ks][i][0] = tr_read_asm(Yl + (rrow + ks * 32) * YS + ycolb(i));
+          ya[ks][i][1] = tr_read_asm(Yl + (rrow + ks * 32 + 16) * YS + ycolb(i));
+        }
+#pragma unroll
+        for (int j = 0; j < KTL; ++j) {
+          xb[ks][j][0] = tr_read_asm(Xl + (rrow + ks * 32) * XS + xcolb(j));
+          xb[ks][j][1] = tr_read_asm(Xl + (rrow + ks * 32 + 16) * XS + xcolb(j));
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < HALVES; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < HALVES) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (NT + KTL) > 15 ? 15 : 2 * (NT + KTL)) : "memory");   // (4-bit counter)
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          const bf16x8 af = __builtin_bit_cast(bf16x8, (u32x4){ya[ks][i][0][0], ya[ks][i][0][1], ya[ks][i][1][0], ya[ks][i][1][1]});
+#pragma unroll
+          for (int j = 0; j < KTL; ++j) {
+            const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[ks][j][0][0], xb[ks][j][0][1], xb[ks][j][1][0], xb[ks][j][1][1]});
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);                 // (the MFMAs stay in front of the wait: they cover the DMA's latency)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next stage has landed
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int ks = 0; ks < MS / 32; ++ks) {
       bf16x8 af[NT], bfr[KTL];
@@ -307,18 +377,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
   const int ks = tap - kr * a.S;
   const bool k_ok = kr < a.R;
 
-  int xm[XP], xq[XP], xp[XP], xpix[XP];
+  // row cursor: output pixel of this thread's X rows; (image, p, q) are re-derived per step by magic-number division —
+  // uniform straight-line code (the incremental "while (q >= Q)" cursor was a divergent loop per row and step)
+  int xm[XP];
 #pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    const int m = mstart + xrow + i * RPX;
-    xm[i] = m;
-    const int mm = min(m, a.M - 1);
-    const int b = mm / a.PQ;
-    const int rem = mm - b * a.PQ;
-    xp[i] = rem / a.Q;
-    xq[i] = rem - xp[i] * a.Q;
-    xpix[i] = b * a.HW;
-  }
+  for (int i = 0; i < XP; ++i) xm[i] = mstart + xrow + i * RPX;
   int ym = mstart + yrow;
 
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
@@ -342,21 +405,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
       if (PWK) {
         off = (k_ok && xm[i] < mend) ? (uint32_t)(xm[i] * a.C + kc0) * 2u : 0xFFFFFFF0u;
       } else {
-        const int hh = xp[i] * a.stride - a.pad + kr;
-        const int ww = xq[i] * a.stride - a.pad + ks;
+        const uint32_t mm = (uint32_t)min(xm[i], a.M - 1);
+        const uint32_t b = magic_div(mm, a.pq_mul, a.pq_shift);
+        const uint32_t rem = mm - b * (uint32_t)a.PQ;
+        const uint32_t pp = magic_div(rem, a.q_mul, a.q_shift);
+        const int hh = (int)pp * a.stride - a.pad + kr;
+        const int ww = (int)(rem - pp * (uint32_t)a.Q) * a.stride - a.pad + ks;
         const bool ok = k_ok && xm[i] < mend && (unsigned)hh < (unsigned)a.H && (unsigned)ww < (unsigned)a.W;
-        off = ok ? (uint32_t)((xpix[i] + hh * a.W + ww) * a.C + kc0) * 2u : 0xFFFFFFF0u;
+        uint32_t goff = (uint32_t)(((int)b * a.HW + hh * a.W + ww) * a.C + kc0) * 2u;
+        asm volatile("" : "+v"(goff));
+        off = ok ? goff : 0xFFFFFFF0u;
       }
       asm volatile("" : "+v"(off));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
       xm[i] += MS;
-      if (!PWK) {
-        xq[i] += MS;
-        while (xq[i] >= a.Q) {
-          xq[i] -= a.Q;
-          if (++xp[i] == a.P) { xp[i] = 0; xpix[i] += a.HW; }
-        }
-      }
     }
   };
 
@@ -553,7 +615,9 @@ Plan make_plan(const tok_conv_desc* d) {
   long long split = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
   // reduction rows per barrier: 64 on the long-M layers (twice the MFMAs per barrier), 32 where M is
   // short and occupancy (4 workgroups per CU instead of 2) matters more
-  p.MS = (M >= 100000 && p.TN == 128 && p.TK == 128) ? 64 : 32;
+  static int ms64_any = -1;     // TOK_WGRAD_MS64_ANY=1: 64 rows per barrier on every long-M tile shape (experiment)
+  if (ms64_any < 0) { const char* e = getenv("TOK_WGRAD_MS64_ANY"); ms64_any = e ? atoi(e) : 0; }
+  p.MS = (M >= 100000 && ((p.TN == 128 && p.TK == 128) || ms64_any)) ? 64 : 32;
   const long long max_split = (M + 8 * p.MS - 1) / (8 * p.MS);   // at least 8 steps per workgroup
   if (split > max_split) split = max_split;
   // (512 only for the stem — 2 tiles over 3.2 M pixels at B = 256: 512 workgroups left every CU with 2 and the launch
@@ -609,8 +673,10 @@ void launch_wgrad_dma(const WgradArgs& a, hipStream_t st) {
 
 template <int TN, int TK, bool C4, int MS>
 void launch_wgrad_ms(const WgradArgs& a, hipStream_t st) {
-  if constexpr (!C4 && MS == 32) {
-    if (a.M < 100000) { launch_wgrad_dma<TN, TK, C4, MS, true>(a, st); return; }
+  if constexpr (!C4) {
+    static long long dma_rows = -1;      // TOK_WGRAD_DMA_ROWS=<n>: layers with fewer output pixels stage by DMA
+    if (dma_rows < 0) { const char* e = getenv("TOK_WGRAD_DMA_ROWS"); dma_rows = e ? atoll(e) : (1ll << 40); }
+    if (a.M < dma_rows) { launch_wgrad_dma<TN, TK, C4, MS, true>(a, st); return; }
   }
   launch_wgrad_dma<TN, TK, C4, MS, false>(a, st);
 }
@@ -650,6 +716,8 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   a.H = d->h; a.W = d->w; a.C = d->c; a.K = d->k; a.R = d->r; a.S = d->s_pad; a.P = d->p; a.Q = d->q;
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q; a.HW = d->h * d->w;
+  make_magic((uint32_t)a.PQ, a.pq_mul, a.pq_shift);
+  make_magic((uint32_t)d->q, a.q_mul, a.q_shift);
   a.Ktot = d->r * d->s_pad * d->c;
   a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
   {
