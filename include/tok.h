@@ -208,6 +208,15 @@ size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
                    int k_real, int c_real, void* ws, size_t ws_bytes, int accumulate,
                    void* stream);
+/* tok_conv_wgrad that also produces the bias gradient dbias[k_real] (+= if bias_accumulate) = column sums of dy, from the dy
+ * fragments the kernel already holds (one extra MFMA against an all-ones operand per fragment) — replaces the separate
+ * tok_colsum_partial + tok_colsum_f32 pass of nn.Linear / conv biases ([timm] Mlp, WindowAttention qkv/proj; swin_v2.py).
+ * Served for the layers tok_conv_wgrad_bias_ok(d) returns 1 for (the pointwise layers); ws of at least
+ * tok_conv_wgrad_bias_ws_bytes(d) bytes. */
+int tok_conv_wgrad_bias_ok(const tok_conv_desc* d);
+size_t tok_conv_wgrad_bias_ws_bytes(const tok_conv_desc* d);
+int tok_conv_wgrad_bias(const tok_conv_desc* d, const void* x, const void* dy, float* dw, int k_real, int c_real,
+                        void* ws, size_t ws_bytes, int accumulate, float* dbias, int bias_accumulate, void* stream);
 
 /* ---- batch norm (training mode, batch statistics) -------------------------------------
  * Replace aten::batch_norm fwd/bwd + relu_ + residual add_ reached from resnet.py:489-490,

@@ -364,6 +364,25 @@ class FakeTok:
             out.copy_(gw)
         return 0
 
+    def tok_conv_wgrad_bias_ok(self, d):
+        d = _desc(d)
+        return 1 if (d.r == 1 and d.s == 1 and d.stride == 1 and d.pad == 0 and d.c != 4) else 0
+
+    def tok_conv_wgrad_bias_ws_bytes(self, d):
+        return self.tok_conv_wgrad_ws_bytes(d) + 4 * _desc(d).k
+
+    def tok_conv_wgrad_bias(self, d, x, dy, dw, k_real, c_real, ws, ws_bytes, accumulate, dbias, bias_accumulate, st):
+        rc = self.tok_conv_wgrad(d, x, dy, dw, k_real, c_real, ws, ws_bytes, accumulate, st)
+        dd = _desc(d)
+        self.calls.append('wgrad_bias')
+        g = _t(dy, (dd.n * dd.p * dd.q, dd.k), BF16).float().sum(0)[:k_real]
+        out = _t(dbias, (k_real,), torch.float32)
+        if bias_accumulate:
+            out.add_(g)
+        else:
+            out.copy_(g)
+        return rc
+
     # ---- batch norm -------------------------------------------------------------------------------
     def tok_bn_finalize(self, stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd,
                         scale, shift, st):

@@ -153,6 +153,48 @@ def test_conv_wgrad(libs, case):
     assert torch.equal(first, dv2[id(dw)])
 
 
+# token matrices with a bias ([timm] Mlp fc1/fc2, WindowAttention qkv/proj of swin_v2.py; k_real < k_pad: the 1000-class head)
+WGRAD_BIAS_CASES = [(64, 56, 56, 96, 288, 288), (4, 7, 7, 768, 3072, 3072), (3, 1, 1, 2048, 1000, 1000),
+                    (2, 28, 28, 192, 192, 192), (1, 5, 3, 64, 64, 64), (2, 14, 14, 384, 1536, 1530)]
+
+
+@pytest.mark.parametrize('case', WGRAD_BIAS_CASES)
+@pytest.mark.parametrize('acc', [0, 1])
+def test_conv_wgrad_bias(libs, case, acc):
+    """dW and the bias gradient (column sums of dy) from one launch: equal to tok_conv_wgrad bit for bit on dW, and to the
+    fp32 column sums of the bf16 dy within fp32 summation noise."""
+    lib, _ = libs
+    n, h, w, c, kpad, k = case
+    kpad = (kpad + 7) // 8 * 8
+    d = _desc(n, h, w, c, kpad, 1, 1, 0)
+    assert lib.tok_conv_wgrad_bias_ok(ctypes.byref(d)) == 1
+    x = rnd(n, h, w, c).to(BF16)
+    dy = rnd(n, h, w, kpad).to(BF16)
+    dw = rnd(k, 1, 1, c, seed=3)
+    db = rnd(k, seed=4)
+    wsb = lib.tok_conv_wgrad_bias_ws_bytes(ctypes.byref(d))
+    assert wsb >= lib.tok_conv_wgrad_ws_bytes(ctypes.byref(d)) + 4 * k
+    ws = torch.zeros(max(wsb // 4, 16))
+    dv = both(libs, 'tok_conv_wgrad_bias', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                      f(x), f(dy), f(dw), k, c, f(ws), wsb, acc, f(db), acc, None])
+    assert relerr(dv[id(dw)], dw) < 2e-3
+    assert relerr(dv[id(db)], db) < 1e-4
+    dw2 = rnd(k, 1, 1, c, seed=3)
+    dv2 = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                  f(x), f(dy), f(dw2), k, c, f(ws), wsb, acc, None])
+    assert torch.equal(dv[id(dw)], dv2[id(dw2)])
+
+
+def test_conv_wgrad_bias_refuses_layers_off_the_ring(libs):
+    lib, _ = libs
+    d = _desc(2, 16, 16, 64, 64, 3, 1, 1)
+    assert lib.tok_conv_wgrad_bias_ok(ctypes.byref(d)) == 0
+    t = torch.zeros(16, device=DEV)
+    rc = lib.tok_conv_wgrad_bias(ctypes.byref(d), t.data_ptr(), t.data_ptr(), t.data_ptr(), 64, 64, t.data_ptr(), 64, 0,
+                                 t.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b'wgrad_bias' in lib.tok_last_error()
+
+
 def test_conv_wgrad_stem_c4(libs):
     n, h, w, k = 2, 33, 35, 64
     d = _desc(n, h, w, 4, k, 7, 2, 3, s_pad=8)

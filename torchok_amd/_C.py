@@ -65,6 +65,9 @@ PROTOTYPES = {
     'tok_conv_dgrad_bn': (c_int, [_PD, _P, _P, _P, c_int, _P, _P, _P, POINTER(BnFused), _P]),
     'tok_conv_wgrad_ws_bytes': (c_size_t, [_PD]),
     'tok_conv_wgrad': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P]),
+    'tok_conv_wgrad_bias_ok': (c_int, [_PD]),
+    'tok_conv_wgrad_bias_ws_bytes': (c_size_t, [_PD]),
+    'tok_conv_wgrad_bias': (c_int, [_PD, _P, _P, _P, c_int, c_int, _P, c_size_t, c_int, _P, c_int, _P]),
     'tok_bn_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float,
                                 _P, _P, _P, _P, _P]),
     'tok_bn_eval_coeffs': (c_int, [_P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),

@@ -28,6 +28,8 @@ struct WgradArgs {
   int tilesN, tilesK, splitM, mchunk;
   uint32_t x_bytes, dy_bytes;
   uint32_t pq_mul, pq_shift, q_mul, q_shift;   // magic-number division by PQ and Q (row cursor of the 3x3 gather)
+  float* cs;     // ring kernel, may be null: [splitM][cs_cols] column sums of dy over this split's rows (bias-gradient partials)
+  int cs_cols;   // unpadded output channel count
 };
 
 // n / d for n < 2^31 with (mul, shift) from make_magic(d)
@@ -434,6 +436,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient = dy^T 1: the waves that own the first k-tile multiply their dy fragments with an all-ones operand as well
+  // (NT extra MFMAs per stage; every column of the result tile holds the column sums) — no separate pass over dy
+  const bool do_cs = a.cs != nullptr && tk == 0 && wk2 == 0;     // wave-uniform
+  f32x4 csacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) csacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16 one_b = (bf16)1.0f;
+  const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+
   typedef __attribute__((address_space(3))) char lds_char;
   const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
   issue(0);
@@ -471,11 +482,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < KTL; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) csacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, csacc[i], 0, 0, 0);
+    }
     cur = cur == NST - 1 ? 0 : cur + 1;
     nxt = nxt == NST - 1 ? 0 : nxt + 1;
   }
   // the two stages issued past the end (zeros) must have landed before this workgroup's LDS can be handed to another one
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (do_cs && li == 0) {      // column 0 of the ones-product: rows g*4 + r
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
+        if (n < a.cs_cols) a.cs[(size_t)split * a.cs_cols + n] = csacc[i][r];
+      }
+  }
 
   float* out = a.ws + (size_t)split * a.K * a.Ktot;
 #pragma unroll
@@ -695,15 +720,44 @@ extern "C" size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d) {
   return (size_t)p.splitM * d->k * d->r * d->s_pad * d->c * sizeof(float);
 }
 
+extern "C" int tok_conv_wgrad_bias_ok(const tok_conv_desc* d) {
+  if (d == nullptr || d->c == 4) return 0;
+  return make_plan(d).ring ? 1 : 0;
+}
+
+extern "C" size_t tok_conv_wgrad_bias_ws_bytes(const tok_conv_desc* d) {
+  if (d == nullptr) return 0;
+  const Plan p = make_plan(d);
+  return tok_conv_wgrad_ws_bytes(d) + (size_t)p.splitM * d->k * sizeof(float);
+}
+
+namespace {
+int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw, int k_real, int c_real, void* ws, size_t ws_bytes,
+               int accumulate, float* dbias, int bias_accumulate, void* stream);
+}
+
 extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
                               int k_real, int c_real, void* ws, size_t ws_bytes, int accumulate,
                               void* stream) {
+  return wgrad_impl(d, x, dy, dw, k_real, c_real, ws, ws_bytes, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int tok_conv_wgrad_bias(const tok_conv_desc* d, const void* x, const void* dy, float* dw, int k_real, int c_real,
+                                   void* ws, size_t ws_bytes, int accumulate, float* dbias, int bias_accumulate, void* stream) {
+  TOK_CHECK_ARG(dbias != nullptr, "tok_conv_wgrad_bias: dbias must not be null");
+  TOK_CHECK_ARG(tok_conv_wgrad_bias_ok(d), "tok_conv_wgrad_bias: layer not served (ask tok_conv_wgrad_bias_ok)");
+  return wgrad_impl(d, x, dy, dw, k_real, c_real, ws, ws_bytes, accumulate, dbias, bias_accumulate, stream);
+}
+
+namespace {
+int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw, int k_real, int c_real, void* ws, size_t ws_bytes,
+               int accumulate, float* dbias, int bias_accumulate, void* stream) {
   TOK_CHECK_ARG(d && x && dy && dw && ws, "tok_conv_wgrad: null pointer");
   TOK_CHECK_ARG(d->k % 8 == 0 && (d->c % 8 == 0 || d->c == 4), "tok_conv_wgrad: bad channel padding");
   TOK_CHECK_ARG(k_real <= d->k && c_real <= d->c, "tok_conv_wgrad: real dims exceed padded dims");
   TOK_CHECK_ARG(d->c == 4 ? d->s_pad == 8 : d->s_pad == d->s, "tok_conv_wgrad: bad s_pad");
   const Plan p = make_plan(d);
-  const size_t need = tok_conv_wgrad_ws_bytes(d);
+  const size_t need = dbias ? tok_conv_wgrad_bias_ws_bytes(d) : tok_conv_wgrad_ws_bytes(d);
   if (ws_bytes < need) {
     tok_set_error("tok_conv_wgrad: workspace %zu < %zu bytes", ws_bytes, need);
     return TOK_ERR_WORKSPACE;
@@ -720,6 +774,8 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   make_magic((uint32_t)d->q, a.q_mul, a.q_shift);
   a.Ktot = d->r * d->s_pad * d->c;
   a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
+  a.cs = dbias ? (float*)((char*)ws + tok_conv_wgrad_ws_bytes(d)) : nullptr;   // behind the dW partials
+  a.cs_cols = k_real;
   {
     const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->c * 2;
     const unsigned long long yb = (unsigned long long)a.M * d->k * 2;
@@ -745,6 +801,10 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
     if (c4) launch_wgrad<64, 64, true>(a, st, p.MS); else launch_wgrad<64, 64, false>(a, st, p.MS);
   }
   TOK_CHECK_LAUNCH("tok_conv_wgrad");
+  if (dbias != nullptr) {
+    // fold the per-split column sums (fixed order) into the bias gradient; padded channels (>= k_real) are not written
+    if (int e = tok_colsum_f32(a.cs, p.splitM, k_real, dbias, bias_accumulate, stream)) return e;
+  }
   if (direct) return TOK_OK;
   if (flat) {
     const size_t slab = (size_t)d->k * d->r * d->s * d->c;
@@ -761,3 +821,4 @@ extern "C" int tok_conv_wgrad(const tok_conv_desc* d, const void* x, const void*
   TOK_CHECK_LAUNCH("tok_conv_wgrad(reduce)");
   return TOK_OK;
 }
+}  // namespace

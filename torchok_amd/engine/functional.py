@@ -358,7 +358,9 @@ class _ConvBnActNode(Node):
         out.grad = None
         if dy is None:
             return
-        if bias_need:
+        # the bias gradient (column sums of dy) rides the weight-gradient kernel where that serves the layer
+        bias_in_wgrad = bool(bias_need and w_need and BIAS_IN_WGRAD and lib.tok_conv_wgrad_bias_ok(d))
+        if bias_need and not bias_in_wgrad:
             bs, bm = param_grad_target(conv.bias)
             if m > 4096 and kp == conv.bias.shape[0]:
                 # tall dy (a conv / token GEMM bias): coalesced row-chunk partials, then a fixed-order fold
@@ -372,13 +374,24 @@ class _ConvBnActNode(Node):
             commit_param_grad(conv.bias, bs, bm)
         def launch_wgrad():
             k, r, s, c = _krsc(conv.weight)
-            ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
+            ws_bytes = lib.tok_conv_wgrad_bias_ws_bytes(d) if bias_in_wgrad else lib.tok_conv_wgrad_ws_bytes(d)
 
             def run_wgrad():
                 ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
                 slot, mode = param_grad_target(conv.weight)
-                _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
-                                            1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
+                if bias_in_wgrad:
+                    bslot, bmode = param_grad_target(conv.bias)
+                    if bmode == 2:     # foreign .grad tensor on the bias: compute into the slot, commit adds it
+                        bacc = 0
+                    else:
+                        bacc = 1 if bmode == 1 else 0
+                    _C.check(lib.tok_conv_wgrad_bias(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                                     1 if mode == 1 else 0, ptr(bslot), bacc, stream_ptr()),
+                             'tok_conv_wgrad_bias')
+                    commit_param_grad(conv.bias, bslot, bmode)
+                else:
+                    _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(dy), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                                1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(conv.weight, slot, mode)
                 return ws
             # LDS/MFMA-bound (3x3) and short-M weight gradients complement the HBM-bound main chain; the long-M pointwise ones
@@ -473,6 +486,7 @@ class _ConvBnActNode(Node):
 # ---- unit 3 of a bottleneck: 1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor ----------
 
 FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
+BIAS_IN_WGRAD = os.environ.get('TOK_BIAS_IN_WGRAD', '1') != '0'
 # the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
 # it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
 UNIT3_MIN_ROWS = int(os.environ.get('TOK_UNIT3_MIN_ROWS', '100000'))   # measured: 0 -> 22.4, 40000 -> 22.0, 100000 -> 21.8, plain 23.2 ms/step

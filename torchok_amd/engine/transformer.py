@@ -21,7 +21,7 @@ from torch import nn
 from .. import _C
 from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target, pad8, param_grad_target,
                    ptr, stream_ptr)
-from .functional import _krsc, get_packs
+from .functional import BIAS_IN_WGRAD, _krsc, get_packs
 
 F32 = torch.float32
 
@@ -77,7 +77,21 @@ class _LinearNode(Node):
         x, w, d = self.x, self.weight, self.desc
         m, kp = g.shape
         side = _use_side(self, g)
-        if self.bias_sinks:
+
+        def scatter_bias(tmp):
+            for p, start in self.bias_sinks:
+                if not p.requires_grad:
+                    continue
+                slot, mode = param_grad_target(p)
+                seg = tmp[start:start + p.numel()]
+                if mode == 1:
+                    slot.add_(seg)
+                else:
+                    slot.copy_(seg)
+                commit_param_grad(p, slot, mode)
+        # the column sums of g (bias gradients) come out of the weight-gradient kernel where it serves the layer
+        bias_in_wgrad = bool(self.bias_sinks and w.requires_grad and BIAS_IN_WGRAD and lib.tok_conv_wgrad_bias_ok(d))
+        if self.bias_sinks and not bias_in_wgrad:
             def run_bias():
                 tmp = torch.empty(kp, dtype=F32, device=g.device)
                 nrows = lib.tok_colsum_partial_rows(m, kp)
@@ -85,16 +99,7 @@ class _LinearNode(Node):
                 st_ = stream_ptr()
                 _C.check(lib.tok_colsum_partial(ptr(g), m, kp, ptr(part), st_), 'tok_colsum_partial')
                 _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(tmp), 0, st_), 'tok_colsum_f32')
-                for p, start in self.bias_sinks:
-                    if not p.requires_grad:
-                        continue
-                    slot, mode = param_grad_target(p)
-                    seg = tmp[start:start + p.numel()]
-                    if mode == 1:
-                        slot.add_(seg)
-                    else:
-                        slot.copy_(seg)
-                    commit_param_grad(p, slot, mode)
+                scatter_bias(tmp)
                 return tmp, part
             if side:       # parameter gradients only: off the main chain, beside it (see functional.py)
                 with self.region.fork_side((g,)):
@@ -103,13 +108,19 @@ class _LinearNode(Node):
                 run_bias()
         if w.requires_grad:
             k, r, s, c = _krsc(w)
-            ws_bytes = lib.tok_conv_wgrad_ws_bytes(d)
+            ws_bytes = lib.tok_conv_wgrad_bias_ws_bytes(d) if bias_in_wgrad else lib.tok_conv_wgrad_ws_bytes(d)
 
             def run_wgrad():
                 ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
                 slot, mode = param_grad_target(w)
-                _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
-                                            1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
+                if bias_in_wgrad:
+                    tmp = torch.empty(kp, dtype=F32, device=g.device)
+                    _C.check(lib.tok_conv_wgrad_bias(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                                     1 if mode == 1 else 0, ptr(tmp), 0, stream_ptr()), 'tok_conv_wgrad_bias')
+                    scatter_bias(tmp)
+                else:
+                    _C.check(lib.tok_conv_wgrad(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                                1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(w, slot, mode)
                 return ws
             if side:
