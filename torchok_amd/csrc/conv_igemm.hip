@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
     return v;
   };
   auto compute = [&](int buf) {
-    if constexpr (DMA && FRAG_ASM) {
+    if constexpr (DMA && FRAG_ASM) {   // (the register-staged stem keeps hipcc's own schedule: measured 294 -> 494 us with this form)
       // all 2 x (4 + MT) fragment reads of the K step go out first (inline asm: hipcc interleaves its own ds_reads with the
       // MFMAs one wait at a time, and fences them with vmcnt(0) while the next stage's DMA is in flight); the first half's
       // MFMAs start when ITS fragments have landed, the second half's reads complete underneath
@@ -930,9 +930,9 @@ static int force_bn64() {
 // Channel-tile width.  Short-K layers are HBM-streaming problems: the 128x64 tile (4 waves, 3
 // workgroups per CU) keeps more loads/stores in flight; deep-K layers are MFMA-bound and want the
 // 128x128 tile's operand reuse.  (Measured on the ResNet-50 shapes, tools/bench_conv.py.)
-static int short_k() {   // TOK_SHORT_K=<k>: reduction depths up to k take the 128x64 tile (default 768, tuned on ResNet-50)
+static int short_k() {   // TOK_SHORT_K=<k>: reduction depths up to k take the 128x64 tile (default 400: ResNet-50 B=256 sweep 100 / 260 / 400 / 520 / 768 -> 20.4 / 19.8 / 19.9 / 20.1 / 20.0 ms)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_SHORT_K"); v = e ? atoi(e) : 768; }
+  if (v < 0) { const char* e = getenv("TOK_SHORT_K"); v = e ? atoi(e) : 400; }
   return v;
 }
 

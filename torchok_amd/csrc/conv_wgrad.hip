@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
     load_tile((st + 1) & 1);
     const char* Yb = smem + (st & 1) * (YBYTES + XBYTES);
     const char* Xb = Yb + YBYTES;
-    if constexpr (DMA) {
+    if constexpr (true) {
       // every transpose read of the stage first (inline asm: no vmcnt(0) fence against the DMA of the next stage, no
       // one-wait-per-MFMA interleaving), then the MFMAs of each 32-row half as its fragments land
       constexpr int HALVES = MS / 32;
@@ -270,8 +270,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);                 // (the MFMAs stay in front of the wait: they cover the DMA's latency)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next stage has landed
+      __builtin_amdgcn_sched_barrier(0);                 // (the MFMAs stay in front of the wait: they cover the loads' latency)
+      if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's share of the next stage has landed
+      else store_tile((st + 1) & 1);                     // register-staged stem: park the landed rows (ds_write)
       __syncthreads();
       continue;
     }

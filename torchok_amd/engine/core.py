@@ -24,6 +24,11 @@ from .. import _C
 BF16 = torch.bfloat16
 
 
+# main-stream weight gradients run this many units late (Region.defer_wgrad); 0: in place.  Measured on ResNet-50 B=256: see
+# DESIGN.md section 8
+WGRAD_DEFER = int(os.environ.get('TOK_WGRAD_DEFER', '0'))   # measured: 0 -> 19.62, 3 -> 19.66, 5 -> 19.74, 8 -> 19.73 ms/step: off
+
+
 def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -329,6 +334,7 @@ class Region:
         self.device = None
         self._side = None
         self._deferred = []
+        self._wq = []          # main-stream weight-gradient launches held back (defer_wgrad)
         self._tag = 0            # branch stream index of the units being recorded (0 = main)
         self._streams = {}       # branch index -> stream, for the branches this region used
         self._branch_done = []   # forward: (event, stream) of every closed branch, joined in output()
@@ -490,7 +496,25 @@ class Region:
     def keep_until_join(self, *tensors):
         self._deferred.extend(tensors)
 
+    # -- held-back weight gradients ------------------------------------------------------------------
+    def defer_wgrad(self, fn):
+        """Run `fn` (a main-stream weight-gradient launch; nothing downstream waits for its result) WGRAD_DEFER units later
+        than its place in the tape.  The last ones are therefore still pending when the backward walk reaches the region
+        input, and run beside the side stream's final launches (the stem's issue-bound weight gradient in a ResNet) instead
+        of leaving the main stream idle until the join."""
+        if WGRAD_DEFER <= 0 or torch.cuda.is_current_stream_capturing():
+            fn()
+            return
+        self._wq.append(fn)
+        if len(self._wq) > WGRAD_DEFER:
+            self._wq.pop(0)()
+
+    def flush_wgrads(self):
+        while self._wq:
+            self._wq.pop(0)()
+
     def join_side(self):
+        self.flush_wgrads()
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side[1])
             self._side = None

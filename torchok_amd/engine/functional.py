@@ -404,6 +404,8 @@ class _ConvBnActNode(Node):
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
                 with self.region.fork_side((x.data, dy)):
                     self.region.keep_until_join(run_wgrad())
+            elif self.region is not None and g.is_cuda:
+                self.region.defer_wgrad(run_wgrad)     # (the closure keeps x and dy alive)
             else:
                 run_wgrad()
         # a 3x3 weight gradient started BEFORE its unit's 3x3 data gradient runs beside it — two LDS/MFMA-bound kernels
