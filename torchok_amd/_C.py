@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtok_gfx950.so')
+LIB_PATH = os.environ.get('TOK_LIB') or os.path.join(_HERE, 'lib', 'libtok_gfx950.so')   # TOK_LIB: A/B runs against another build
 
 TOK_F32, TOK_F16, TOK_BF16 = 0, 1, 2
 TOK_CE_LOSS_FLOATS = 2050

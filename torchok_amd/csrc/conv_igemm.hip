@@ -484,23 +484,49 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
         for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
       }
     }
+    // output pixel of each of this lane's MT rows, then EVERY global operand of the epilogue (previous value, producer's raw
+    // output, ReLU bits) requested before the first one is consumed: one exposed memory latency per tile instead of one per
+    // 16-byte piece (hipcc keeps the load -> use -> store chains in program order)
+    size_t opix_[MT];
+    bool rowok_[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int ml = ctx.m0 + arow0 + mt * 16;
-      size_t opix;
-      bool rowok;
       if (IN_DIV == 2) {
-        rowok = ml < a.cls_M[ctx.cls];
-        const uint32_t mm = rowok ? ml : 0;
+        rowok_[mt] = ml < a.cls_M[ctx.cls];
+        const uint32_t mm = rowok_[mt] ? ml : 0;
         const uint32_t b = fdiv(mm, a.cls_fd_hw[ctx.cls]);
         const uint32_t rem = mm - b * a.cls_hw[ctx.cls];
         const uint32_t h2 = fdiv(rem, a.cls_fd_w[ctx.cls]);
         const uint32_t w2 = rem - h2 * a.cls_nw[ctx.cls];
-        opix = ((size_t)b * a.P + (2 * h2 + (ctx.cls >> 1))) * a.Q + (2 * w2 + (ctx.cls & 1));
+        opix_[mt] = ((size_t)b * a.P + (2 * h2 + (ctx.cls >> 1))) * a.Q + (2 * w2 + (ctx.cls & 1));
       } else {
-        rowok = ml < a.M;
-        opix = (size_t)ml;
+        rowok_[mt] = ml < a.M;
+        opix_[mt] = (size_t)ml;
       }
+    }
+    bf16x8 pre_old[MT][2], pre_y[MT][2];
+    unsigned pre_bits[MT][2];
+    const bool want_old = a.accumulate != 0;
+    const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
+    const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
+    constexpr bool PRE = !BNEP && !ACT && !C4;     // (the stem kernel is forward-only: no epilogue operands)
+    if (PRE) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const bool ok = rowok_[mt] && nb + half * 32 + 8 <= a.K;
+          const size_t eoff = opix_[mt] * a.K + nb + half * 32;
+          pre_old[mt][half] = (ok && want_old) ? ldg16(a.y + eoff) : zero8();
+          pre_y[mt][half] = (ok && want_y) ? ldg16(a.bn_y + eoff) : zero8();
+          pre_bits[mt][half] = (ok && want_bits) ? (unsigned)a.bn_mask[eoff >> 3] : 0xffu;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t opix = opix_[mt];
+      const bool rowok = rowok_[mt];
       if (rowok) {
         bf16* yp = a.y + opix * a.K + nb;
 #pragma unroll
@@ -511,7 +537,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[half * 2 + (e >> 2)][mt][e & 3];
             if (a.accumulate) {
-              const bf16x8 old = ldg16(yp + half * 32);
+              const bf16x8 old = PRE ? pre_old[mt][half] : ldg16(yp + half * 32);
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] += bf2f(old[e]);
             }
@@ -559,8 +585,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
               if (a.ep_mask != nullptr) a.ep_mask[eoff >> 3] = (uint8_t)bits;
             }
             if (a.mask_store) {
-              const size_t eoff = opix * a.K + nb + half * 32;
-              const unsigned bits = a.bn_mask[eoff >> 3];
+              const unsigned bits = PRE ? pre_bits[mt][half] : (unsigned)a.bn_mask[(opix * a.K + nb + half * 32) >> 3];
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
@@ -573,8 +598,8 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
               if (a.bn_y != nullptr) {
                 // backward statistics of the producing BatchNorm: dz = dx * relu_mask, sum dz, sum dz*y
                 const size_t eoff = opix * a.K + nb + half * 32;
-                const bf16x8 yv = ldg16(a.bn_y + eoff);
-                const unsigned bits = a.bn_mask != nullptr ? a.bn_mask[eoff >> 3] : 0xffu;
+                const bf16x8 yv = PRE ? pre_y[mt][half] : ldg16(a.bn_y + eoff);
+                const unsigned bits = PRE ? pre_bits[mt][half] : (a.bn_mask != nullptr ? (unsigned)a.bn_mask[eoff >> 3] : 0xffu);
                 // (sums over the STORED bf16 values: the statistics of the tensor the next kernels read — and the rounding
                 //  point of the reference's bf16 autocast, where BatchNorm's backward reduces a bf16 gradient tensor)
 #pragma unroll
