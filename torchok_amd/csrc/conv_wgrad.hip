@@ -15,6 +15,7 @@
 // kernel sums the partials in a fixed order (deterministic — no atomics) and un-pads into the
 // fp32 master-gradient layout [k][r][s][c].
 #include "tok_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -518,6 +519,382 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
   }
 }
 
+
+// ---- tap-stationary 3x3 variant --------------------------------------------------------------------------------------------
+// The two kernels above treat the nine taps as independent column tiles: every (tap, channel) tile stages the SAME dy rows
+// again, decomposes the SAME output pixels into (image, p, q) again, and a barrier round covers 16 MFMAs per wave — on the 3x3
+// layers they sit at ~20 % MFMA utilisation whatever the shape (ResNet-50 56x56 ... 7x7: 100 us each), bounded by address
+// arithmetic and load latency, not by LDS or the matrix pipe.  Here one workgroup owns 64 output channels x 64 input channels
+// x ALL NINE taps:
+//   * a stage = 32 output pixels: dy[32][64] once + the nine shifted x[32][64] tiles (40 KB), three stages in a DMA ring
+//     (two in flight across every barrier: 80 KB of loads per CU, enough to cover HBM latency with ONE resident workgroup);
+//   * thread t owns pixel t/8 and 16-byte chunk t%8 of every tile: one (image, p, q) decomposition per stage, the nine x
+//     offsets are base + tap displacement (uniform) under 3 + 3 precomputed bounds flags;
+//   * the four waves split the 36 sixteen-column tiles (9 each); every wave reads all four dy fragments (8 transpose reads)
+//     + its 18 x half-fragments and issues 36 MFMAs per stage: 2.25x the MFMAs per barrier and per fragment byte.
+// Output layout, split-M partials and the reduce kernels are those of the other variants.
+template <int DUMMY>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_taps_kernel(WgradArgs a) {
+  constexpr int MS = 32, NST = 3, TN = 64, TC = 64, TAPS = 9;
+  constexpr int TILE = MS * 128;                 // one 32 x 64 bf16 tile: 4 KB, one DMA instruction per thread
+  constexpr int STAGE = (1 + TAPS) * TILE;       // 40 KB
+  constexpr int LOADS = 1 + TAPS;
+  constexpr int NT = 4, KTL = 9;                 // per wave: 64 output channels x 144 (tap, channel) columns
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tilesC = a.tilesK;                   // input-channel tiles (all taps inside)
+  const int ntile = a.tilesN * tilesC;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / tilesC;
+  const int ct = t - tn * tilesC;
+
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + MS - 1) / MS;
+
+  const int row = tid >> 3, cc = tid & 7;
+  const int clog = cc ^ ((row & 3) << 1);        // logical chunk fetched into slot cc (source-side swizzle)
+  const int yn = tn * TN + clog * 8;
+  const bool yn_ok = yn < a.K;
+  const int cx = ct * TC + clog * 8;
+  const bool cx_ok = cx < a.C;
+
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  int mcur = mstart + row;
+  auto issue = [&](int slot) {
+    char* base = smem + slot * STAGE + wv * 1024;
+    const int m = mcur;
+    const bool mok = m < mend;
+    {
+      uint32_t off = (uint32_t)(m * a.K + yn) * 2u;
+      asm volatile("" : "+v"(off));
+      off = (mok && yn_ok) ? off : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)base, 16, off, 0, 0, 0);
+    }
+    const uint32_t mm = (uint32_t)min(m, a.M - 1);
+    const uint32_t b = magic_div(mm, a.pq_mul, a.pq_shift);
+    const uint32_t rem = mm - b * (uint32_t)a.PQ;
+    const uint32_t pp = magic_div(rem, a.q_mul, a.q_shift);
+    const int h0 = (int)pp * a.stride - a.pad;
+    const int w0 = (int)(rem - pp * (uint32_t)a.Q) * a.stride - a.pad;
+    const int xbase = (((int)b * a.H + h0) * a.W + w0) * a.C + cx;
+    const bool live = mok && cx_ok;
+    bool hok[3], wok[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      hok[k] = live && (unsigned)(h0 + k) < (unsigned)a.H;
+      wok[k] = (unsigned)(w0 + k) < (unsigned)a.W;
+    }
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int kr = tap / 3, ks = tap - kr * 3;
+      uint32_t off = (uint32_t)(xbase + (kr * a.W + ks) * a.C) * 2u;
+      asm volatile("" : "+v"(off));
+      off = (hok[kr] && wok[ks]) ? off : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(base + (1 + tap) * TILE), 16, off, 0, 0, 0);
+    }
+    mcur += MS;
+  };
+
+  const int g = lane >> 4, li = lane & 15;
+  const int rrow = 4 * g + (li >> 2);
+  const int swz = ((rrow & 3) << 1) << 4;
+  const uint32_t rbase = (uint32_t)(rrow * 128);
+  auto colb = [&](int tile16) { return (uint32_t)(((tile16 * 16 + (li & 3) * 4) * 2) ^ swz); };
+
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
+  issue(0);
+  issue(1);
+  int cur = 0, nxt = 2;
+  for (int st = 0; st < steps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);
+    const uint32_t Yb = lds_base + cur * STAGE + rbase;
+    const uint32_t Xb = Yb + TILE;
+    u32x2 ya[NT][2], xb[KTL][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      ya[i][0] = tr_read_asm(Yb + colb(i));
+      ya[i][1] = tr_read_asm(Yb + 16 * 128 + colb(i));
+    }
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      const int J = wv * KTL + j;                 // global 16-column tile: tap J / 4, channels (J % 4) * 16 ...
+      const uint32_t ad = Xb + (uint32_t)((J >> 2) * TILE) + colb(J & 3);
+      xb[j][0] = tr_read_asm(ad);
+      xb[j][1] = tr_read_asm(ad + 16 * 128);
+    }
+    bf16x8 af[NT];
+    // first five column tiles as soon as their fragments are in (2 * (KTL - 5) reads still in flight), the rest behind them
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KTL - 5)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 5; j < KTL; ++j) {
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+    }
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+#pragma unroll
+  for (int j = 0; j < KTL; ++j) {
+    const int J = wv * KTL + j;
+    const int cin = ct * TC + (J & 3) * 16 + li;
+    const int kcol = (J >> 2) * a.C + cin;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + i * 16 + g * 4 + r;
+        if (n < a.K && cin < a.C) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+  }
+}
+
+
+// ---- shared-window form of the tap-stationary kernel (3x3, stride 1, padding 1) ---------------------------------------------
+// Measured on the kernel above: 36 MFMAs per barrier did not move the 3x3 layers (113-124 us, ~500 TF/s) — the nine shifted
+// x tiles of a stage are 36 of its 40 KB, and 25 k workgroup-stages x 40 KB in 113 us is 9 TB/s of L2 -> LDS traffic for 51 MB
+// of distinct data: the layer is bound by re-staging the same pixels nine times.  With stride 1 / padding 1 the input pixel of
+// output pixel m and tap (kr, ks) is m + (kr - 1) W + (ks - 1) in the flat [B H W] pixel index, image borders aside: the
+// three taps of a filter row read ONE window of 34 consecutive pixels at row offsets 0, 1, 2.  A stage therefore holds
+// dy[32][64] + three 34-pixel windows (102 rows, 13 KB instead of 36) and the nine taps are nine row offsets of the transpose
+// reads.  Border taps (p + kr - 1 or q + ks - 1 outside the image) are dropped on the READ side: a lane's transpose read
+// covers one reduction row, so a lane whose row is invalid for the tap reads a zeroed LDS line instead.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
+  constexpr int MS = 32, NST = 3, TN = 64, TC = 64, TAPS = 9;
+  constexpr int WIN = MS + 2;                    // pixels per filter-row window
+  constexpr int YT = MS * 128;                   // dy tile: 4 KB
+  constexpr int XT = 128 * 128;                  // x region: room for 4 DMA instructions (128 rows), 3 * 34 = 102 used
+  constexpr int STAGE = YT + XT;                 // 20 KB
+  constexpr int LOADS = 1 + 4;
+  constexpr int NT = 4, KTL = 9;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tilesC = a.tilesK;
+  const int ntile = a.tilesN * tilesC;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / tilesC;
+  const int ct = t - tn * tilesC;
+
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + MS - 1) / MS;
+
+  const int row = tid >> 3, cc = tid & 7;
+  const int clog = cc ^ ((row & 3) << 1);        // (row + 32 j) & 3 == row & 3: one logical chunk per thread
+  const int yn = tn * TN + clog * 8;
+  const bool yn_ok = yn < a.K;
+  const int cx = ct * TC + clog * 8;
+  const bool cx_ok = cx < a.C;
+  // LDS row R = row + 32 j of the x region -> window R / 34, pixel R % 34 of it
+  int xdelta[4];
+  bool xlive[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int R = row + 32 * j;
+    const int win = R / WIN;
+    xlive[j] = cx_ok && R < 3 * WIN;
+    xdelta[j] = (win - 1) * a.W - 1 + (R - win * WIN);
+  }
+  const int total_pix = a.M;                     // stride 1, "same" padding: input pixels == output pixels
+
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  int m0 = mstart;                               // first output pixel of the stage being issued (uniform)
+  auto issue = [&](int slot) {
+    char* base = smem + slot * STAGE + wv * 1024;
+    {
+      const int m = m0 + row;
+      uint32_t off = (uint32_t)(m * a.K + yn) * 2u;
+      asm volatile("" : "+v"(off));
+      off = (m < mend && yn_ok) ? off : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)base, 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pix = m0 + xdelta[j];
+      uint32_t off = (uint32_t)(pix * a.C + cx) * 2u;
+      asm volatile("" : "+v"(off));
+      off = (xlive[j] && m0 < mend && (unsigned)pix < (unsigned)total_pix) ? off : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(base + YT + j * 4096), 16, off, 0, 0, 0);
+    }
+    m0 += MS;
+  };
+
+  const int g = lane >> 4, li = lane & 15;
+  const int rrow = 4 * g + (li >> 2);
+  const uint32_t ysw = (uint32_t)(((rrow & 3) << 1) << 4);
+  const uint32_t cq = (uint32_t)((li & 3) * 8);          // byte offset of this lane's 4 columns inside a 16-column tile
+  // zero line behind the ring (128 bytes): target of the transpose reads of invalid (pixel, tap) pairs
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
+  const uint32_t zero_line = lds_base + NST * STAGE;
+  if (tid < 8) *reinterpret_cast<u32x4*>(smem + NST * STAGE + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
+  // per tap: byte offset of LDS row (kr * 34 + ks + rrow) and the swizzle of that row (rows + 16 share it)
+  uint32_t trow[TAPS], tsw[TAPS];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int kr = tap / 3, ks = tap - kr * 3;
+    const int R = kr * WIN + ks + rrow;
+    trow[tap] = (uint32_t)(R * 128);
+    tsw[tap] = (uint32_t)(((R & 3) << 1) << 4);
+  }
+
+  // the whole stage loop is instantiated once per wave index (tap / tile numbers become literals); every copy executes the
+  // same barriers, so the four waves of a workgroup may sit in different copies
+  auto run = [&](auto WVC) {
+  constexpr int W0 = decltype(WVC)::value;
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  issue(1);
+  int cur = 0, nxt = 2;
+  int mrd = mstart + rrow;                        // output pixel of this lane's first reduction row in the stage being read
+  for (int st = 0; st < steps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);
+    // validity of (row, tap) for this lane's two reduction rows: bit tap of va / vb
+    uint32_t va = 0, vb = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = mrd + 16 * h;
+      const uint32_t mm = (uint32_t)min(m, a.M - 1);
+      const uint32_t b = magic_div(mm, a.pq_mul, a.pq_shift);
+      const uint32_t rem = mm - b * (uint32_t)a.PQ;
+      const uint32_t pp = magic_div(rem, a.q_mul, a.q_shift);
+      const uint32_t qq = rem - pp * (uint32_t)a.Q;
+      const uint32_t rowm = (pp >= 1u ? 0x007u : 0u) | 0x038u | ((int)pp <= a.H - 2 ? 0x1C0u : 0u);
+      const uint32_t colm = (qq >= 1u ? 0x049u : 0u) | 0x092u | ((int)qq <= a.W - 2 ? 0x124u : 0u);
+      const uint32_t v = (m < mend) ? (rowm & colm) : 0u;
+      if (h == 0) va = v; else vb = v;
+    }
+    mrd += MS;
+    const uint32_t Yb = lds_base + cur * STAGE + (uint32_t)(rrow * 128);
+    const uint32_t Xb = lds_base + cur * STAGE + YT;
+    u32x2 ya[NT][2], xb[KTL][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const uint32_t cb = ((uint32_t)(i * 32) + cq) ^ ysw;
+      ya[i][0] = tr_read_asm(Yb + cb);
+      ya[i][1] = tr_read_asm(Yb + 16 * 128 + cb);
+    }
+    // the wave's nine column tiles cover three taps (2 W0 .. 2 W0 + 2): one base per (tap, half) — the stage's row of that
+    // tap, or the zero line where this lane's reduction row is outside the image for it — and one add per read
+    {
+      uint32_t tb[3][2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int tap = 2 * W0 + k;
+        tb[k][0] = (va & (1u << tap)) ? Xb + trow[tap] : zero_line;
+        tb[k][1] = (vb & (1u << tap)) ? Xb + trow[tap] + 16 * 128 : zero_line;
+      }
+#pragma unroll
+      for (int j = 0; j < KTL; ++j) {
+        const int J = W0 * KTL + j;
+        const int tap = J >> 2, k = tap - 2 * W0;
+        const uint32_t cb = ((uint32_t)((J & 3) * 32) + cq) ^ tsw[tap];      // stays inside 128 bytes: fine for the zero line too
+        xb[j][0] = tr_read_asm(tb[k][0] + cb);
+        xb[j][1] = tr_read_asm(tb[k][1] + cb);
+      }
+    }
+    bf16x8 af[NT];
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KTL - 5)) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 5; j < KTL; ++j) {
+      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+    }
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+#pragma unroll
+  for (int j = 0; j < KTL; ++j) {
+    const int J = W0 * KTL + j;
+    const int cin = ct * TC + (J & 3) * 16 + li;
+    const int kcol = (J >> 2) * a.C + cin;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + i * 16 + g * 4 + r;
+        if (n < a.K && cin < a.C) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+  }
+  };   // run
+  if (wv == 0) run(std::integral_constant<int, 0>{});
+  else if (wv == 1) run(std::integral_constant<int, 1>{});
+  else if (wv == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+}
+
 // dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splitM,
                                     int k_real, int R, int S, int c_real, int K, int S_pad,
@@ -589,7 +966,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 struct Plan {
   int TN, TK, tilesN, tilesK, splitM, mchunk, MS;
   bool ring;
+  bool taps;     // tap-stationary 3x3 kernel: tilesK counts 64-wide INPUT-CHANNEL tiles
 };
+
+static int taps_enabled() {   // TOK_WGRAD_TAPS=0: 3x3 layers stay on the two-buffer kernel (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS"); v = e ? atoi(e) : 1; }
+  return v;
+}
+static int taps_target() {    // TOK_WGRAD_TAPS_WGS=<n>: workgroups the split aims at (default 512: two resident per CU on the window kernel)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS_WGS"); v = e ? atoi(e) : 512; }
+  return v;
+}
 
 static int ring_enabled() {   // TOK_WGRAD_RING=0: the two-buffer kernels of round 1 (A/B switch)
   static int v = -1;
@@ -608,6 +997,24 @@ Plan make_plan(const tok_conv_desc* d) {
   const long long M = (long long)d->n * d->p * d->q;
   // the ring pays on the streaming (pointwise) layers; 3x3 / strided layers are LDS-read bound and keep the 64-row
   // two-buffer kernel (measured per layer, tools/bench_conv.py: ring 3x3 0.9-2x slower)
+  p.taps = false;
+  if (d->c != 4 && d->c % 8 == 0 && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
+    p.taps = true; p.ring = false;
+    p.TN = 64; p.TK = 64; p.MS = 32;
+    p.tilesN = tok_cdiv(d->k, 64);
+    p.tilesK = tok_cdiv(d->c, 64);
+    const int tiles = p.tilesN * p.tilesK;
+    long long split = (taps_target() + tiles - 1) / tiles;
+    const long long max_split = (M + 8 * 32 - 1) / (8 * 32);        // at least 8 stages per workgroup
+    if (split > max_split) split = max_split;
+    if (split > 512) split = 512;
+    if (split < 1) split = 1;
+    long long chunk = (M + split - 1) / split;
+    chunk = ((chunk + 31) / 32) * 32;
+    p.mchunk = (int)chunk;
+    p.splitM = (int)((M + chunk - 1) / chunk);
+    return p;
+  }
   p.ring = d->c != 4 && ring_enabled() && ((d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0) || ring_enabled() == 2);
   if (p.ring) {
     // ring kernel: 32 reduction rows per stage, three stages.  Narrow layers take a 64 x 256 / 256 x 64 tile.
@@ -785,7 +1192,29 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
-  if (p.ring) {
+  if (p.taps) {
+    constexpr int smem = 3 * 10 * 32 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      attr_set = true;
+    }
+    const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W &&
+                      (unsigned long long)a.M * a.C * 2 < 0xFFFFFFF0ull && taps_enabled() != 2;
+    if (same) {
+      constexpr int smem_w = 3 * (32 * 128 + 128 * 128) + 128;
+      static bool attr_w = false;
+      if (!attr_w) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  smem_w);
+        attr_w = true;
+      }
+      hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
+    } else {
+      hipLaunchKernelGGL((conv_wgrad_taps_kernel<0>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
+    }
+  } else if (p.ring) {
     if (p.TN == 64 && p.TK == 64) launch_ring<64, 64>(a, st);
     else if (p.TN == 64 && p.TK == 128) launch_ring<64, 128>(a, st);
     else if (p.TN == 64 && p.TK == 256) launch_ring<64, 256>(a, st);

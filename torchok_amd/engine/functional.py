@@ -130,7 +130,7 @@ WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
 WGRAD_AFTER_DGRAD = os.environ.get('TOK_WGRAD_AFTER_DGRAD', '0') == '1'   # measured: 22.0 vs 21.1 ms/step — the later start costs more
 WGRAD_SIDE_MAX_ROWS = int(os.environ.get('TOK_WGRAD_SIDE_MAX_ROWS', '100000'))
 WGRAD_SIDE_WHICH = os.environ.get('TOK_WGRAD_SIDE_WHICH', '3x3')   # measured (ResNet-50, unit-3 fusion on): all 21.58, 3x3 21.45 ms/step
-FUSE_BN_FINALIZE = False    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
+FUSE_BN_FINALIZE = os.environ.get('TOK_FUSE_BN_FINALIZE', '0') == '1'    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
 
 
