@@ -74,6 +74,9 @@ CONV_CASES = [
     (1, 20, 20, 48, 96, 3, 1, 1),      # HRNet-like widths (taps straddle BK)
     (2, 16, 16, 96, 192, 2, 2, 0),     # DaViT patch embed 2x2 s2 (davit.py:62-64)
     (3, 14, 14, 384, 768, 2, 2, 0),
+    (32, 8, 8, 128, 256, 1, 2, 0),     # maps smaller than a staging step (ResNet-18 at 64 px: 4x4 outputs, 16 pixels per image)
+    (40, 4, 4, 64, 64, 3, 1, 1),
+    (70, 2, 2, 64, 128, 3, 2, 1),      # 1x1 outputs: every staged row is another image
 ]
 
 

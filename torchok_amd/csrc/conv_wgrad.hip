@@ -113,17 +113,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
   // PWK: 1x1, stride 1, no padding (every Linear and most ResNet convs): input pixel == output pixel, no row cursor
   constexpr bool pointwise = PWK;
 
-  // row cursor: output pixel of this thread's X rows as (image base, pixel inside the image); (p, q) by one magic-number
-  // division per step — straight-line code (the incremental "while (q >= Q)" cursor was a divergent loop per row and step)
-  int xm[XP], xrem[XP], xpix[XP];
+  // row cursor: output pixel of this thread's X rows; (image, p, q) are re-derived per step by magic-number division —
+  // straight-line code for any map size (the incremental "while (q >= Q)" cursor was a divergent loop per row and step)
+  int xm[XP];
 #pragma unroll
-  for (int i = 0; i < XP; ++i) {
-    xm[i] = mstart + xrow + i * RPX;
-    const int mm = min(xm[i], a.M - 1);
-    const int b = mm / a.PQ;
-    xrem[i] = mm - b * a.PQ;
-    xpix[i] = b * a.HW;
-  }
+  for (int i = 0; i < XP; ++i) xm[i] = mstart + xrow + i * RPX;
   int ym = mstart + yrow;
 
   bf16x8 ry[YP], rx[XP];
@@ -151,10 +145,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
     for (int i = 0; i < XP; ++i) {
       int hh = 0, ww = 0, xpix_i = 0;
       if (!pointwise) {
-        const uint32_t pp = magic_div((uint32_t)xrem[i], a.q_mul, a.q_shift);
+        const uint32_t mm = (uint32_t)min(xm[i], a.M - 1);
+        const uint32_t b = magic_div(mm, a.pq_mul, a.pq_shift);
+        const uint32_t rem = mm - b * (uint32_t)a.PQ;
+        const uint32_t pp = magic_div(rem, a.q_mul, a.q_shift);
         hh = (int)pp * a.stride - a.pad + kr;
-        ww = (int)((uint32_t)xrem[i] - pp * (uint32_t)a.Q) * a.stride - a.pad + ks;
-        xpix_i = xpix[i];
+        ww = (int)(rem - pp * (uint32_t)a.Q) * a.stride - a.pad + ks;
+        xpix_i = (int)b * a.HW;
       }
       const bool ok = k_ok && xm[i] < mend && (unsigned)hh < (unsigned)a.H;
       bf16x8 v = zero8();
@@ -181,16 +178,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {         
       rx[i] = v;
       // advance this row cursor by MS output pixels
       xm[i] += MS;
-      if (!pointwise) {
-        // pixel index inside the image advances by MS; MS <= 64 < 2 * PQ is not guaranteed (7x7 maps): up to two wraps
-        xrem[i] += MS;
-#pragma unroll
-        for (int w_ = 0; w_ < (MS + 48) / 49; ++w_) {
-          const bool wrap = xrem[i] >= a.PQ;
-          xrem[i] -= wrap ? a.PQ : 0;
-          xpix[i] += wrap ? a.HW : 0;
-        }
-      }
     }
   };
 
