@@ -1265,3 +1265,26 @@ def test_depthwise_3x3(libs, n, h, w, c, ld):
     dw, db = torch.empty(c, 9), torch.empty(c)
     dv = both(libs, 'tok_dwconv3x3_wgrad', lambda d: [d(x), d(g), n, h, w, c, ld, d(part), d(dw), d(db), 0, None])
     assert relerr(dv[id(dw)], dw) < 1e-4 and relerr(dv[id(db)], db) < 1e-4
+
+
+@pytest.mark.parametrize('p,k', [(64, 256), (128, 512), (256, 512), (72, 40), (320, 640)])
+def test_bn_gram_finalize(libs, p, k):
+    """BatchNorm statistics of y = z W^T from the Gram matrix of z (the fused residual unit): mean / rstd / scale / shift /
+    running statistics and the kept product W Z, for the in-kernel product (p <= 256) and the tiled GEMM path."""
+    m = 5000
+    z = rnd(m, p).to(BF16).float() + 0.3
+    Z = (z.double().t() @ z.double()).float()
+    zsum = z.double().sum(0).float()
+    w = rnd(k, p, scale=p ** -0.5, seed=2)
+    gamma, beta = rnd(k, seed=3) + 1, rnd(k, seed=4)
+    rm, rv = rnd(k, seed=5), rnd(k, seed=6).abs() + 0.5
+    nbt = torch.zeros(1, dtype=torch.int64)
+    mean, rstd, scale, shift = (torch.zeros(k) for _ in range(4))
+    wz = torch.zeros(k, p)
+    dv = both(libs, 'tok_bn_gram_finalize',
+              lambda f: [f(Z), f(zsum), f(w), m, p, k, f(gamma), f(beta), f(rm), f(rv), f(nbt), 0.1, 1e-5, f(mean), f(rstd),
+                         f(scale), f(shift), f(wz), None])
+    for t in (mean, rstd, scale, shift, rm, rv):
+        assert relerr(dv[id(t)], t) < 1e-4
+    assert relerr(dv[id(wz)], wz) < 1e-5
+    assert int(dv[id(nbt)].item()) == 1 and int(nbt.item()) == 1

@@ -898,8 +898,15 @@ static long long pw_min_rows() {
   if (v < 0) { const char* e = getenv("TOK_PW_RING_MIN_ROWS"); v = e ? atoll(e) : 100000; }
   return v;
 }
+static int pw_ring128() {   // TOK_PW_RING_BN128=<k>: 128-wide tiles with a reduction depth >= k also ride the ring (experiment; 0 = off)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_PW_RING_BN128"); v = e ? atoi(e) : 0; }
+  return v;
+}
 static bool pw_serves(int bn_tile, long long rows, int c_red, int n_out) {
   // (the 128-wide tile would run 1 workgroup per CU on the ring: SwinV2-T 26.0 -> 30.3 ms/step; 64-wide tiles only)
+  if (bn_tile == 128 && pw_ring128() > 0 && c_red >= pw_ring128())
+    return pw_ring_enabled() && rows >= pw_min_rows() && c_red % 8 == 0 && n_out % 64 == 0;
   return pw_ring_enabled() && bn_tile == 64 && rows >= pw_min_rows() && c_red % 8 == 0 && n_out % 64 == 0;
 }
 

@@ -399,7 +399,7 @@ class _ConvBnActNode(Node):
             side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                        (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')))
             if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
-                    and not torch.cuda.is_current_stream_capturing():
+                    and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
                 with self.region.fork_side((x.data, dy)):
@@ -488,6 +488,8 @@ class _ConvBnActNode(Node):
 # ---- unit 3 of a bottleneck: 1x1 conv -> BatchNorm -> + shortcut -> ReLU without the pre-normalisation tensor ----------
 
 FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
+# the side-stream fork / join of the weight gradients inside a hipGraph capture (cross-stream capture): experiment switch
+SIDE_IN_GRAPH = os.environ.get('TOK_SIDE_IN_GRAPH', '0') == '1'
 BIAS_IN_WGRAD = os.environ.get('TOK_BIAS_IN_WGRAD', '1') != '0'
 # the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
 # it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
