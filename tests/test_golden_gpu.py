@@ -1,6 +1,8 @@
-"""HIP path vs the committed golden vectors (generated from the reference's own files by
-tests/golden/gen_golden.py).  bf16 tolerances: logits/loss tight-ish, gradient norms loose (ReLU-mask /
-argmax flips under bf16 rounding; see test_resnet_gpu.py for the autocast yardstick)."""
+"""HIP path vs the committed golden vectors (generated from the reference's own files in fp32 by
+tests/golden/gen_golden.py).  Tolerances are set at 1.5-3x the deviations measured on MI355X (tools/ubench/gold_probe.py,
+round 2): feature energy 3e-4, logits 0.7 % (ResNet-18) / 1.4 % (ResNet-50, 53 bf16 layers), loss 0.2 %, gradient norms
+median 0.8 % / 90th percentile 4.3 % / worst tensor 13 % (ReLU-mask flips behind bf16 conv outputs at batch 8; the per-tensor
+gate against the bf16-autocast yardstick is tests/test_resnet_gpu.py and tests/test_units_gpu.py), fc bias gradient 0.5 %."""
 import os
 
 import numpy as np
@@ -27,16 +29,17 @@ def test_hip_path_vs_reference_golden(name):
     feats = task.backbone.forward_features(x)
     assert [list(f.shape) for f in feats] == g['feat_shapes'].tolist()
     for f, ss in zip(feats[1:], g['feat_sumsq'][1:]):
-        assert abs(float((f.detach().double() ** 2).sum().item()) / float(ss) - 1) < 3e-2
+        assert abs(float((f.detach().double() ** 2).sum().item()) / float(ss) - 1) < 2e-3
     out = task.training_step({'image': x, 'target': y}, 0)
     fw = task.forward_with_gt({'image': x, 'target': y})
     pred = fw['prediction'].detach().float().cpu().numpy()
-    assert np.linalg.norm(pred - g['prediction']) < 0.05 * np.linalg.norm(g['prediction'])
-    assert abs(float(out['loss'].detach().item()) - float(g['loss'])) < 0.05 * abs(float(g['loss']))
+    assert np.linalg.norm(pred - g['prediction']) < 0.025 * np.linalg.norm(g['prediction'])
+    assert abs(float(out['loss'].detach().item()) - float(g['loss'])) < 5e-3 * abs(float(g['loss']))
     out['loss'].backward()
     names = [str(n) for n in g['param_names']]
     assert names == [n for n, _ in task.named_parameters()]
     gn = np.array([float(p.grad.detach().double().norm().item()) for _, p in task.named_parameters()])
-    assert np.median(np.abs(gn / g['grad_norm'] - 1)) < 0.1
+    dev = np.abs(gn / g['grad_norm'] - 1)
+    assert np.median(dev) < 0.02 and np.percentile(dev, 90) < 0.08 and dev.max() < 0.25
     fcb = task.head.fc.bias.grad.detach().float().cpu().numpy()
-    assert np.abs(fcb - g['grad__head.fc.bias']).max() < 0.05 * np.abs(g['grad__head.fc.bias']).max() + 1e-3
+    assert np.abs(fcb - g['grad__head.fc.bias']).max() < 0.015 * np.abs(g['grad__head.fc.bias']).max() + 1e-4
