@@ -985,7 +985,9 @@ Plan make_plan(const tok_conv_desc* d) {
   // the ring pays on the streaming (pointwise) layers; 3x3 / strided layers are LDS-read bound and keep the 64-row
   // two-buffer kernel (measured per layer, tools/bench_conv.py: ring 3x3 0.9-2x slower)
   p.taps = false;
-  if (d->c != 4 && d->c % 8 == 0 && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
+  // (64-wide channel tiles: layers whose widths are not multiples of 64 — HRNet's 48 / 96 — would waste a quarter of every
+  //  tile and of the split-M partials; they stay on the two-buffer kernel: measured neutral in time, +8 % HBM traffic)
+  if (d->c != 4 && d->c % 64 == 0 && d->k % 64 == 0 && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
     p.taps = true; p.ring = false;
     p.TN = 64; p.TK = 64; p.MS = 32;
     p.tilesN = tok_cdiv(d->k, 64);
