@@ -480,14 +480,24 @@ class Region:
             node.release()
 
     # -- side stream (weight gradients run beside the main chain) --------------------------------
-    def fork_side(self, keep_alive):
+    def mark_side(self):
+        """An event on the main stream NOW, for a later fork_side(..., event=...): the side kernels are then ordered after
+        the main stream's work up to this point only, although the host enqueues them after further main-stream launches."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def fork_side(self, keep_alive, event=None):
         """Context manager: kernels enqueued inside run on this device's side stream, ordered after everything the
-        main stream has been given so far.  `keep_alive` (tensors the side kernels read or use as scratch) stay
-        referenced until the join, so the allocator cannot hand their memory to later main-stream work."""
+        main stream has been given so far (or up to `event`, see mark_side).  `keep_alive` (tensors the side kernels read
+        or use as scratch) stay referenced until the join, so the allocator cannot hand their memory to later main-stream
+        work."""
         main = torch.cuda.current_stream()
         side = _side_stream(main.device)
-        ev = torch.cuda.Event()
-        ev.record(main)
+        ev = event
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(main)
         side.wait_event(ev)
         self._side = (main, side)
         self._deferred.extend(keep_alive)

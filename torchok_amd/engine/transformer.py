@@ -101,11 +101,10 @@ class _LinearNode(Node):
                 _C.check(lib.tok_colsum_f32(ptr(part), nrows, kp, ptr(tmp), 0, st_), 'tok_colsum_f32')
                 scatter_bias(tmp)
                 return tmp, part
-            if side:       # parameter gradients only: off the main chain, beside it (see functional.py)
-                with self.region.fork_side((g,)):
-                    self.region.keep_until_join(*run_bias())
-            else:
-                run_bias()
+            bias_fn = run_bias
+        else:
+            bias_fn = None
+        wgrad_fn = None
         if w.requires_grad:
             k, r, s, c = _krsc(w)
             ws_bytes = lib.tok_conv_wgrad_bias_ws_bytes(d) if bias_in_wgrad else lib.tok_conv_wgrad_ws_bytes(d)
@@ -123,11 +122,28 @@ class _LinearNode(Node):
                                                 1 if mode == 1 else 0, stream_ptr()), 'tok_conv_wgrad')
                 commit_param_grad(w, slot, mode)
                 return ws
-            if side:
-                with self.region.fork_side((x.data, g)):       # dW beside the main chain (see functional.py)
-                    self.region.keep_until_join(run_wgrad())
-            else:
-                run_wgrad()
+            wgrad_fn = run_wgrad
+
+        def param_grads(event=None):
+            if bias_fn is not None:
+                if side:       # parameter gradients only: off the main chain, beside it (see functional.py)
+                    with self.region.fork_side((g,), event=event):
+                        self.region.keep_until_join(*bias_fn())
+                else:
+                    bias_fn()
+            if wgrad_fn is not None:
+                if side:
+                    with self.region.fork_side((x.data, g), event=event):       # dW beside the main chain (see functional.py)
+                        self.region.keep_until_join(wgrad_fn())
+                else:
+                    wgrad_fn()
+        # the data gradient is the main chain: with DGRAD_FIRST the host enqueues it before the side-stream work (fork, scratch
+        # allocation, weight-gradient + bias launches, hooks) — the side kernels still start where they used to (the fork event
+        # is recorded up front).  Measured on SwinV2-T B=256: the main queue idled 100-190 us per block behind that host work.
+        early = DGRAD_FIRST and side and x.requires_grad
+        ev = self.region.mark_side() if early else None
+        if not early:
+            param_grads()
         if x.requires_grad:
             an = x.node
             if (FUSE_ACT and isinstance(an, _ActNode) and an.out is x and an.kind in (RELU, GELU) and x.uses == 1 and
@@ -140,6 +156,8 @@ class _LinearNode(Node):
             else:
                 tgt, acc = grad_target(x)
                 _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
+        if early:
+            param_grads(ev)
         self.out.grad = None
 
     def release(self):
@@ -151,6 +169,7 @@ class _LinearNode(Node):
 # arithmetic of 128 values per lane stretches the GEMM epilogue by what the deleted passes cost (their reads were served by
 # the 256 MB Infinity Cache).  Off by default; TOK_FUSE_ACT=1 turns it on.
 FUSE_ACT = os.environ.get('TOK_FUSE_ACT', '0') == '1'
+DGRAD_FIRST = os.environ.get('TOK_DGRAD_FIRST', '0') == '1'   # measured neutral (SwinV2-T 24.98 vs 24.97, DaViT-T 24.33 vs 24.20 ms): off
 
 
 def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Optional[torch.Tensor] = None,
