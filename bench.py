@@ -284,6 +284,9 @@ def main():
     graphed = None
     if use_graph:
         from torchok_amd.engine.graph import GraphedTrainingStep
+        for g_ in opt.param_groups:          # Adam / AdamW: device-side step count (torch's capturable=True)
+            if 'capturable' in g_:
+                g_['capturable'] = True
         graphed = GraphedTrainingStep(task, opt, batch)
 
     def step(i):

@@ -595,6 +595,13 @@ int tok_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   void* shadow_bf16, size_t count, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int decoupled /*AdamW*/, int64_t step,
                   int maximize, void* stream);
+/* torch.optim.Adam / AdamW with capturable=True: the step count is a device scalar (*step_dev = steps already taken), the bias
+ * corrections are formed in the kernel; tok_step_advance increments it after the arenas of a step have been updated.  No
+ * launch argument changes between steps: the optimizer step can be recorded into a hipGraph (engine/graph.py). */
+int tok_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                             size_t count, float lr, float beta1, float beta2, float eps, float weight_decay,
+                             int decoupled /*AdamW*/, const int64_t* step_dev, int maximize, void* stream);
+int tok_step_advance(int64_t* step_dev, void* stream);
 /* torch.optim.RMSprop (registered at optim/optimizers/__init__.py:16): square_avg / momentum_buf / grad_avg start at 0 */
 int tok_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
                      size_t count, float lr, float alpha, float eps, float weight_decay, float momentum,

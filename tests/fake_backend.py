@@ -1474,6 +1474,16 @@ class FakeTok:
             _t(shadow, (count,), BF16).copy_(p)
         return 0
 
+    def tok_adam_step_capturable(self, param, grad, m, v, shadow, count, lr, b1, b2, eps, wd, decoupled, step_dev, maximize, st):
+        step = int(_t(step_dev, (1,), torch.int64).item()) + 1
+        rc = self.tok_adam_step(param, grad, m, v, shadow, count, lr, b1, b2, eps, wd, decoupled, step, maximize, st)
+        self.calls[-1] = 'adam_step_capturable'
+        return rc
+
+    def tok_step_advance(self, step_dev, st):
+        _t(step_dev, (1,), torch.int64).add_(1)
+        return 0
+
     def tok_fill_f32(self, dst, value, count, st):
         _t(dst, (count,), torch.float32).fill_(value)
         return 0

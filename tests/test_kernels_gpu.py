@@ -1288,3 +1288,27 @@ def test_bn_gram_finalize(libs, p, k):
         assert relerr(dv[id(t)], t) < 1e-4
     assert relerr(dv[id(wz)], wz) < 1e-5
     assert int(dv[id(nbt)].item()) == 1 and int(nbt.item()) == 1
+
+
+@pytest.mark.parametrize('decoupled', [0, 1])
+def test_adam_capturable(libs, decoupled):
+    """Device-side step count: three successive launches + tok_step_advance equal the host-step kernel (and torch's update
+    restated in tests/fake_backend.py) step for step."""
+    lib, fake = libs
+    n = 5000
+    p0, m0, v0 = rnd(n), torch.zeros(n), torch.zeros(n)
+    st = torch.cuda.current_stream().cuda_stream
+    pd, md, vd = p0.to(DEV), m0.to(DEV), v0.to(DEV)
+    ph, mh, vh = p0.clone(), m0.clone(), v0.clone()
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for it in range(3):
+        g = rnd(n, seed=10 + it)
+        gd = g.to(DEV)
+        assert lib.tok_adam_step_capturable(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), None, n, 1e-2, 0.9, 0.999,
+                                            1e-8, 0.05, decoupled, step.data_ptr(), 0, st) == 0, lib.tok_last_error()
+        assert lib.tok_step_advance(step.data_ptr(), st) == 0
+        assert fake.tok_adam_step(ph.data_ptr(), g.data_ptr(), mh.data_ptr(), vh.data_ptr(), None, n, 1e-2, 0.9, 0.999, 1e-8,
+                                  0.05, decoupled, it + 1, 0, None) == 0
+    torch.cuda.synchronize()
+    assert int(step.item()) == 3
+    assert relerr(pd, ph) < 1e-6 and relerr(md, mh) < 1e-6 and relerr(vd, vh) < 5e-5     # (v: fma vs mul + addcmul rounding)

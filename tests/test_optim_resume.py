@@ -104,3 +104,38 @@ def test_add_param_group_after_first_step(fake_backend, name, tcls, kw):
     for a, b in zip(ours_p, ref_p):
         assert rel_err(a, b) < 2e-5
     assert len(ours._arenas) == 2 and ours.arena_generation == gen0 + 1      # the first group kept its arena and state
+
+
+def test_adam_capturable_matches_plain_adam(fake_backend):
+    """torch.optim.Adam(capturable=True): device-side step count (tok_adam_step_capturable + tok_step_advance) — the same
+    trajectory as the host-step form, step for step, and as torch's own AdamW."""
+    import torch
+    import torchok_amd as T
+    torch.manual_seed(0)
+    ws = [torch.randn(5, 3), torch.randn(7)]
+    gs = [[torch.randn_like(w) for w in ws] for _ in range(4)]
+
+    def run(make):
+        ps = [torch.nn.Parameter(w.clone()) for w in ws]
+        opt = make(ps)
+        for it in range(4):
+            for p, g in zip(ps, gs[it]):
+                p.grad = g.clone()
+            opt.step()
+        return [p.detach().clone() for p in ps], opt
+    ref, _ = run(lambda ps: torch.optim.AdamW(ps, lr=1e-2, weight_decay=0.05))
+    plain, _ = run(lambda ps: T.OPTIMIZERS.get('AdamW')(ps, lr=1e-2, weight_decay=0.05))
+    capt, opt = run(lambda ps: T.OPTIMIZERS.get('AdamW')(ps, lr=1e-2, weight_decay=0.05, capturable=True))
+    for a, b, c in zip(ref, plain, capt):
+        assert torch.allclose(a, b, atol=1e-6) and torch.allclose(b, c, atol=1e-7)
+    assert fake_backend.calls.count('adam_step_capturable') == 4
+    steps = {int(s['step']) for s in opt.state.values()}
+    assert steps == {4}
+    # the recorded step survives a state_dict round trip into a plain (host-step) optimizer
+    ps2 = [torch.nn.Parameter(w.clone()) for w in ws]
+    opt2 = T.OPTIMIZERS.get('AdamW')(ps2, lr=1e-2, weight_decay=0.05)
+    opt2.load_state_dict(opt.state_dict())
+    for p, g in zip(ps2, gs[0]):
+        p.grad = g.clone()
+    opt2.step()
+    assert {int(s['step']) for s in opt2.state.values()} == {5}

@@ -175,6 +175,9 @@ PROTOTYPES = {
                              c_int, c_int, c_int, _P]),
     'tok_adam_step': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float,
                               c_float, c_int, c_int64, c_int, _P]),
+    'tok_adam_step_capturable': (c_int, [_P, _P, _P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_float, c_int, _P,
+                                         c_int, _P]),
+    'tok_step_advance': (c_int, [_P, _P]),
     'tok_fill_f32': (c_int, [_P, c_float, c_size_t, _P]),
     'tok_scale_f32': (c_int, [_P, c_float, c_size_t, _P]),
 }

@@ -126,6 +126,59 @@ extern "C" int tok_adam_step(float* param, const float* grad, float* exp_avg, fl
   return TOK_OK;
 }
 
+// ---- capturable Adam: the step count lives on the device (torch.optim.Adam(capturable=True)) ----------------------------------
+// Same update as adam_kernel with the bias corrections derived in the kernel from *step (the number of steps ALREADY taken:
+// this launch is step *step + 1), in double like the host path; tok_step_advance increments the counter afterwards.  Nothing
+// in the launch arguments changes from step to step, so a hipGraph recording of the optimizer step replays correctly.
+namespace {
+__global__ __launch_bounds__(256) void adam_capturable_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              bf16* __restrict__ shadow, size_t n, float lr, float beta1,
+                                                              float beta2, float eps, float wd, int decoupled,
+                                                              const int64_t* __restrict__ step, int maximize) {
+  const double t = (double)(*step + 1);
+  const double bc1 = 1.0 - pow((double)beta1, t);
+  const double bc2 = 1.0 - pow((double)beta2, t);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float w = p[i];
+    float d = maximize ? -g[i] : g[i];
+    if (wd != 0.f) {
+      if (decoupled) w = w * (1.f - lr * wd);
+      else d = d + wd * w;
+    }
+    float mi = m[i], vi = v[i];
+    mi = mi + (d - mi) * (1.f - beta1);
+    vi = beta2 * vi + (1.f - beta2) * d * d;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w = w - step_size * (mi / denom);
+    p[i] = w;
+    if (shadow != nullptr) shadow[i] = f2bf(w);
+  }
+}
+__global__ void step_advance_kernel(int64_t* step) { *step += 1; }
+}  // namespace
+
+extern "C" int tok_adam_step_capturable(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                        size_t count, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                        int decoupled, const int64_t* step_dev, int maximize, void* stream) {
+  TOK_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && count > 0, "tok_adam_step_capturable: bad args");
+  hipLaunchKernelGGL(adam_capturable_kernel, dim3(grid_for(count)), dim3(256), 0, tok_stream(stream), param, grad, exp_avg,
+                     exp_avg_sq, (bf16*)shadow_bf16, count, lr, beta1, beta2, eps, weight_decay, decoupled, step_dev, maximize);
+  TOK_CHECK_LAUNCH("tok_adam_step_capturable");
+  return TOK_OK;
+}
+
+extern "C" int tok_step_advance(int64_t* step_dev, void* stream) {
+  TOK_CHECK_ARG(step_dev != nullptr, "tok_step_advance: null pointer");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, tok_stream(stream), step_dev);
+  TOK_CHECK_LAUNCH("tok_step_advance");
+  return TOK_OK;
+}
+
 extern "C" int tok_rmsprop_step(float* param, const float* grad, float* square_avg, float* momentum_buf, float* grad_avg,
                                 size_t count, float lr, float alpha, float eps, float weight_decay, float momentum,
                                 int centered, int maximize, void* stream) {

@@ -7,8 +7,8 @@ back to back on the device.  (This replaces nothing in the reference, which reli
 MI355X-native answer to its per-op launch overhead — streams and graphs instead of a tracing compiler.)
 
 Constraints (checked where possible): static shapes; no host synchronisation inside `training_step`; scalar
-hyper-parameters are baked into the recording, so call `recapture()` after changing the learning rate, and use
-SGD (Adam's bias correction takes the step count as a host scalar: refused here)."""
+hyper-parameters are baked into the recording, so call `recapture()` after changing the learning rate; SGD, or
+Adam / AdamW built with capturable=True (device-side step count, tok_adam_step_capturable)."""
 from typing import Dict, Optional
 
 import torch
@@ -16,9 +16,11 @@ import torch
 
 class GraphedTrainingStep:
     def __init__(self, task, optimizer, example_batch: Dict[str, torch.Tensor], reducer=None, warmup: int = 3):
-        from ..optim.optimizers import SGD
-        if not isinstance(optimizer, SGD):
-            raise NotImplementedError('GraphedTrainingStep: fused SGD only (Adam bakes its step count into the graph)')
+        from ..optim.optimizers import SGD, _AdamBase
+        capt = isinstance(optimizer, _AdamBase) and all(g.get('capturable', False) for g in optimizer.param_groups)
+        if not isinstance(optimizer, SGD) and not capt:
+            raise NotImplementedError('GraphedTrainingStep: fused SGD, or Adam / AdamW with capturable=True (the plain Adam step '
+                                      'takes its step count as a host scalar, which a recording would freeze)')
         self.task, self.optimizer, self.reducer = task, optimizer, reducer
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         self.graph: Optional[torch.cuda.CUDAGraph] = None

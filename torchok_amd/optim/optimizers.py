@@ -174,10 +174,23 @@ class _AdamBase(_ArenaOptimizer):
             raise ValueError(f'Invalid beta parameters: {betas}')
         if weight_decay < 0.0:
             raise ValueError(f'Invalid weight_decay value: {weight_decay}')
-        if amsgrad or differentiable or capturable:
-            raise NotImplementedError('amsgrad / differentiable / capturable are not supported')
-        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize)
+        if amsgrad or differentiable:
+            raise NotImplementedError('amsgrad / differentiable are not supported')
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize,
+                        capturable=bool(capturable))
         super().__init__(params, defaults)
+        self._step_dev = {}      # id(arena) -> int64 device scalar: steps already taken (capturable groups)
+
+    def _arena_step(self, arena, step_of):
+        """Device step counter of a capturable group's arena, created from the (uniform) host-side step of its parameters."""
+        t = self._step_dev.get(id(arena))
+        if t is None or t.device != arena.master.device:
+            steps = {step_of(i) for i in range(len(arena.params))}
+            if len(steps) > 1:
+                raise NotImplementedError('capturable Adam: the parameters of a group must share one step count')
+            t = torch.full((1,), steps.pop() if steps else 0, dtype=torch.int64, device=arena.master.device)
+            self._step_dev[id(arena)] = t
+        return t
 
     def _restore_state(self, old_state):
         for a in self._arenas:
@@ -206,6 +219,27 @@ class _AdamBase(_ArenaOptimizer):
 
             def step_of(i, arena=arena):
                 return int(self.state[arena.params[i]].get('step', 0))
+            if group.get('capturable', False):
+                # torch.optim.Adam(capturable=True): bias corrections from a device-side step count — nothing the host passes
+                # changes from step to step, so the launch sequence can be recorded once (engine/graph.py) and replayed
+                tdev = self._arena_step(arena, step_of)
+                for a, b, _ in self._runs(arena, lambda i: 0):
+                    off = arena.offsets[a]
+                    count = arena.padded_end(b) - off
+                    _C.check(lib.tok_adam_step_capturable(ptr(arena.master) + 4 * off, ptr(arena.grad) + 4 * off,
+                                                          ptr(arena.state[0]) + 4 * off, ptr(arena.state[1]) + 4 * off,
+                                                          None, count, float(group['lr']), float(b1), float(b2),
+                                                          float(group['eps']), float(group['weight_decay']),
+                                                          int(self._decoupled), ptr(tdev), int(group['maximize']), st),
+                             'tok_adam_step_capturable')
+                    for i in range(a, b + 1):
+                        s = self.state[arena.params[i]]
+                        if 'exp_avg' not in s:
+                            s['exp_avg'] = arena.state_view(0, i)
+                            s['exp_avg_sq'] = arena.state_view(1, i)
+                        s['step'] = tdev       # (as torch: a device tensor; shared by the parameters of the group)
+                _C.check(lib.tok_step_advance(ptr(tdev), st), 'tok_step_advance')
+                continue
             for a, b, t in self._runs(arena, step_of):
                 off = arena.offsets[a]
                 count = arena.padded_end(b) - off
