@@ -961,9 +961,9 @@ static int taps_enabled() {   // TOK_WGRAD_TAPS=0: 3x3 layers stay on the two-bu
   if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS"); v = e ? atoi(e) : 1; }
   return v;
 }
-static int taps_target() {    // TOK_WGRAD_TAPS_WGS=<n>: workgroups the split aims at (default 512: two resident per CU on the window kernel)
+static int taps_target() {    // TOK_WGRAD_TAPS_WGS=<n>: workgroups the split aims at (default 256; 512 is faster in isolation, 256 on the step)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS_WGS"); v = e ? atoi(e) : 512; }
+  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS_WGS"); v = e ? atoi(e) : 256; }
   return v;
 }
 
@@ -1016,7 +1016,10 @@ Plan make_plan(const tok_conv_desc* d) {
     const int tiles = p.tilesN * p.tilesK;
     const int stage = 32 * (p.TN + p.TK) * 2;
     const int per_cu = (160 * 1024) / (3 * stage);                 // LDS-resident workgroups per CU
-    const int target = ring_target() > 0 ? ring_target() : 256 * (per_cu > 4 ? 4 : per_cu);
+    // (split target: what is resident at once was 768 workgroups on the 128 x 128 tile; 512 measured better on the step — the
+    //  partial-sum slabs are a third smaller and the side stream leaves more of every CU to the main chain:
+    //  ResNet-50 19.93 -> 19.38 ms/step together with the tap kernels' 256, tools/ubench/sweep_r02.sh)
+    const int target = ring_target() > 0 ? ring_target() : 256 * (per_cu > 2 ? 2 : per_cu);
     long long split = (target + tiles - 1) / tiles;
     const long long max_split = (M + 8 * 32 - 1) / (8 * 32);        // at least 8 stages per workgroup
     if (split > max_split) split = max_split;
@@ -1034,7 +1037,9 @@ Plan make_plan(const tok_conv_desc* d) {
   p.tilesN = tok_cdiv(d->k, p.TN);
   p.tilesK = tok_cdiv(Ktot, p.TK);
   const int tiles = p.tilesN * p.tilesK;
-  long long split = (1024 + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
+  static int tb_target = -1;     // TOK_WGRAD_2BUF_WGS=<n>: workgroups the split of the two-buffer kernel aims at
+  if (tb_target < 0) { const char* e = getenv("TOK_WGRAD_2BUF_WGS"); tb_target = e ? atoi(e) : 1024; }
+  long long split = (tb_target + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
   // reduction rows per barrier: 64 on the long-M layers (twice the MFMAs per barrier), 32 where M is
   // short and occupancy (4 workgroups per CU instead of 2) matters more
   static int ms64_any = -1;     // TOK_WGRAD_MS64_ANY=1: 64 rows per barrier on every long-M tile shape (experiment)
