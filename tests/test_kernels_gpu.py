@@ -77,6 +77,8 @@ CONV_CASES = [
     (32, 8, 8, 128, 256, 1, 2, 0),     # maps smaller than a staging step (ResNet-18 at 64 px: 4x4 outputs, 16 pixels per image)
     (40, 4, 4, 64, 64, 3, 1, 1),
     (70, 2, 2, 64, 128, 3, 2, 1),      # 1x1 outputs: every staged row is another image
+    (2, 30, 26, 96, 48, 3, 1, 1),      # 48-wide tiles of the window weight-gradient kernel (HRNet-W48 branches), ragged rows
+    (3, 9, 33, 48, 48, 3, 1, 1),
 ]
 
 

@@ -1,9 +1,6 @@
 # A/B sweeps of kernel-plan switches on the headline workload (ResNet-50, B=256); one line per setting
 run() { env "$@" python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'])"; }
 run A=0
-run TOK_BN_BLOCKS=2048
-run TOK_BN_BLOCKS=1536
-run TOK_BN_BLOCKS=768
-run TOK_PW_RING_MIN_ROWS=150000
-run TOK_SHORT_K=300
+run TOK_WGRAD_MS64_ANY=1
+run TOK_WGRAD_SIDE_WHICH=none
 run A=1

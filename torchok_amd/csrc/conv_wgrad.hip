@@ -683,14 +683,18 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_taps_kernel(WgradArgs a) {
 // dy[32][64] + three 34-pixel windows (102 rows, 13 KB instead of 36) and the nine taps are nine row offsets of the transpose
 // reads.  Border taps (p + kr - 1 or q + ks - 1 outside the image) are dropped on the READ side: a lane's transpose read
 // covers one reduction row, so a lane whose row is invalid for the tap reads a zeroed LDS line instead.
+// CT = 16-channel tiles per side of the workgroup tile: 4 -> 64 x 64 channels (four compute waves, nine column tiles each, taps
+// straddle waves), 3 -> 48 x 48 (HRNet's 48 / 96-wide branches: three compute waves, one filter row each; the fourth wave only
+// stages).  Rows keep the 128-byte pitch; the 48-wide form leaves the last two 16-byte slots of a row unfetched.
+template <int CT>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
-  constexpr int MS = 32, NST = 3, TN = 64, TC = 64, TAPS = 9;
+  constexpr int MS = 32, NST = 3, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
   constexpr int WIN = MS + 2;                    // pixels per filter-row window
   constexpr int YT = MS * 128;                   // dy tile: 4 KB
   constexpr int XT = 128 * 128;                  // x region: room for 4 DMA instructions (128 rows), 3 * 34 = 102 used
   constexpr int STAGE = YT + XT;                 // 20 KB
   constexpr int LOADS = 1 + 4;
-  constexpr int NT = 4, KTL = 9;
+  constexpr int NT = CT, KTL = 9;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -713,9 +717,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   const int row = tid >> 3, cc = tid & 7;
   const int clog = cc ^ ((row & 3) << 1);        // (row + 32 j) & 3 == row & 3: one logical chunk per thread
   const int yn = tn * TN + clog * 8;
-  const bool yn_ok = yn < a.K;
+  const bool yn_ok = yn < a.K && clog * 8 < TN;
   const int cx = ct * TC + clog * 8;
-  const bool cx_ok = cx < a.C;
+  const bool cx_ok = cx < a.C && clog * 8 < TC;
   // LDS row R = row + 32 j of the x region -> window R / 34, pixel R % 34 of it
   int xdelta[4];
   bool xlive[4];
@@ -764,20 +768,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
   const uint32_t zero_line = lds_base + NST * STAGE;
   if (tid < 8) *reinterpret_cast<u32x4*>(smem + NST * STAGE + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
-  // per tap: byte offset of LDS row (kr * 34 + ks + rrow) and the swizzle of that row (rows + 16 share it)
-  uint32_t trow[TAPS], tsw[TAPS];
-#pragma unroll
-  for (int tap = 0; tap < TAPS; ++tap) {
-    const int kr = tap / 3, ks = tap - kr * 3;
-    const int R = kr * WIN + ks + rrow;
-    trow[tap] = (uint32_t)(R * 128);
-    tsw[tap] = (uint32_t)(((R & 3) << 1) << 4);
-  }
 
   // the whole stage loop is instantiated once per wave index (tap / tile numbers become literals); every copy executes the
   // same barriers, so the four waves of a workgroup may sit in different copies
   auto run = [&](auto WVC) {
   constexpr int W0 = decltype(WVC)::value;
+  constexpr int T0 = W0 >= 0 ? (W0 * KTL) / CT : 0;       // first tap of this wave's nine column tiles (three taps at most)
+  // per tap: byte offset of LDS row (kr * 34 + ks + rrow) and the swizzle of that row (rows + 16 share it)
+  uint32_t trow[3], tsw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int tap = T0 + k < TAPS ? T0 + k : TAPS - 1;
+    const int kr = tap / 3, ks = tap - kr * 3;
+    const int R = kr * WIN + ks + rrow;
+    trow[k] = (uint32_t)(R * 128);
+    tsw[k] = (uint32_t)(((R & 3) << 1) << 4);
+  }
   f32x4 acc[NT][KTL];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
@@ -792,6 +798,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
     __builtin_amdgcn_s_barrier();
     issue(nxt);
+    if constexpr (W0 < 0) {      // staging-only wave: its DMA share is issued, nothing to multiply
+      cur = cur == NST - 1 ? 0 : cur + 1;
+      nxt = nxt == NST - 1 ? 0 : nxt + 1;
+      continue;
+    } else {
     // validity of (row, tap) for this lane's two reduction rows: bit tap of va / vb
     uint32_t va = 0, vb = 0;
 #pragma unroll
@@ -823,15 +834,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
       uint32_t tb[3][2];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const int tap = 2 * W0 + k;
-        tb[k][0] = (va & (1u << tap)) ? Xb + trow[tap] : zero_line;
-        tb[k][1] = (vb & (1u << tap)) ? Xb + trow[tap] + 16 * 128 : zero_line;
+        const int tap = T0 + k;                         // (taps past 8 are never read)
+        tb[k][0] = (tap < TAPS && (va & (1u << tap))) ? Xb + trow[k] : zero_line;
+        tb[k][1] = (tap < TAPS && (vb & (1u << tap))) ? Xb + trow[k] + 16 * 128 : zero_line;
       }
 #pragma unroll
       for (int j = 0; j < KTL; ++j) {
         const int J = W0 * KTL + j;
-        const int tap = J >> 2, k = tap - 2 * W0;
-        const uint32_t cb = ((uint32_t)((J & 3) * 32) + cq) ^ tsw[tap];      // stays inside 128 bytes: fine for the zero line too
+        const int k = J / CT - T0;
+        const uint32_t cb = ((uint32_t)((J % CT) * 32) + cq) ^ tsw[k];       // stays inside 128 bytes: fine for the zero line too
         xb[j][0] = tr_read_asm(tb[k][0] + cb);
         xb[j][1] = tr_read_asm(tb[k][1] + cb);
       }
@@ -858,15 +869,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
     }
     cur = cur == NST - 1 ? 0 : cur + 1;
     nxt = nxt == NST - 1 ? 0 : nxt + 1;
+    }   // compute waves
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   float* out = a.ws + (size_t)split * a.K * a.Ktot;
+  if constexpr (W0 >= 0) {
 #pragma unroll
   for (int j = 0; j < KTL; ++j) {
     const int J = W0 * KTL + j;
-    const int cin = ct * TC + (J & 3) * 16 + li;
-    const int kcol = (J >> 2) * a.C + cin;
+    const int cin = ct * TC + (J % CT) * 16 + li;
+    const int kcol = (J / CT) * a.C + cin;
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -875,11 +888,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
         if (n < a.K && cin < a.C) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
       }
   }
+  }   // compute waves
+  (void)out;
   };   // run
   if (wv == 0) run(std::integral_constant<int, 0>{});
   else if (wv == 1) run(std::integral_constant<int, 1>{});
   else if (wv == 2) run(std::integral_constant<int, 2>{});
-  else run(std::integral_constant<int, 3>{});
+  else if (CT == 4) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, -1>{});       // staging-only wave (48-wide tiles)
 }
 
 // dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
@@ -985,13 +1001,17 @@ Plan make_plan(const tok_conv_desc* d) {
   // the ring pays on the streaming (pointwise) layers; 3x3 / strided layers are LDS-read bound and keep the 64-row
   // two-buffer kernel (measured per layer, tools/bench_conv.py: ring 3x3 0.9-2x slower)
   p.taps = false;
-  // (64-wide channel tiles: layers whose widths are not multiples of 64 — HRNet's 48 / 96 — would waste a quarter of every
-  //  tile and of the split-M partials; they stay on the two-buffer kernel: measured neutral in time, +8 % HBM traffic)
-  if (d->c != 4 && d->c % 64 == 0 && d->k % 64 == 0 && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
+  // (64-wide channel tiles; widths that are multiples of 48 but not of 64 — HRNet's 48 / 96 — take the 48-wide form of the
+  //  window kernel on stride-1 layers and stay on the two-buffer kernel otherwise)
+  const bool same3 = d->r == 3 && d->s == 3 && d->s_pad == 3 && d->stride == 1 && d->pad == 1 && taps_enabled() != 2 &&
+                     (unsigned long long)d->n * d->h * d->w * d->c * 2 < 0xFFFFFFF0ull;
+  const bool w64 = d->c % 64 == 0 && d->k % 64 == 0;
+  const bool w48 = !w64 && d->c % 48 == 0 && d->k % 48 == 0 && same3 && taps_enabled() != 3;   // window kernel only
+  if (d->c != 4 && (w64 || w48) && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
     p.taps = true; p.ring = false;
-    p.TN = 64; p.TK = 64; p.MS = 32;
-    p.tilesN = tok_cdiv(d->k, 64);
-    p.tilesK = tok_cdiv(d->c, 64);
+    p.TN = w64 ? 64 : 48; p.TK = p.TN; p.MS = 32;
+    p.tilesN = tok_cdiv(d->k, p.TN);
+    p.tilesK = tok_cdiv(d->c, p.TN);
     const int tiles = p.tilesN * p.tilesK;
     long long split = (taps_target() + tiles - 1) / tiles;
     const long long max_split = (M + 8 * 32 - 1) / (8 * 32);        // at least 8 stages per workgroup
@@ -1200,11 +1220,14 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
       constexpr int smem_w = 3 * (32 * 128 + 128 * 128) + 128;
       static bool attr_w = false;
       if (!attr_w) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   smem_w);
         attr_w = true;
       }
-      hipLaunchKernelGGL(conv_wgrad_win_kernel, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
+      if (p.TN == 48) hipLaunchKernelGGL(conv_wgrad_win_kernel<3>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
+      else hipLaunchKernelGGL(conv_wgrad_win_kernel<4>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
     } else {
       hipLaunchKernelGGL((conv_wgrad_taps_kernel<0>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
     }
