@@ -29,8 +29,10 @@ struct WgradArgs {
   int tilesN, tilesK, splitM, mchunk;
   uint32_t x_bytes, dy_bytes;
   uint32_t pq_mul, pq_shift, q_mul, q_shift;   // magic-number division by PQ and Q (row cursor of the 3x3 gather)
-  float* cs;     // ring kernel, may be null: [splitM][cs_cols] column sums of dy over this split's rows (bias-gradient partials)
+  float* cs;     // ring kernel, may be null: column sums of dy over this split's rows (bias-gradient partials); split s at
+                 // cs + s * cs_stride — with the flat reduce the row sits right behind the split's dW slab (one reduce launch)
   int cs_cols;   // unpadded output channel count
+  size_t cs_stride, ws_stride;   // floats between consecutive splits of cs / of the dW partial slabs
 };
 
 // n / d for n < 2^31 with (mul, shift) from make_magic(d)
@@ -487,11 +489,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
-        if (n < a.cs_cols) a.cs[(size_t)split * a.cs_cols + n] = csacc[i][r];
+        if (n < a.cs_cols) a.cs[(size_t)split * a.cs_stride + n] = csacc[i][r];
       }
   }
 
-  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+  float* out = a.ws + (size_t)split * a.ws_stride;
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
 #pragma unroll
@@ -928,18 +930,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // no padding anywhere: dw and the partial slabs share one flat index space.  A block owns 64
 // consecutive floats (16 float4 columns); its 16 thread-rows stride the split dimension so the
 // partial slabs are read with independent, coalesced 256-byte segments; fixed-order LDS tree.
+// `extra` (may be null): the floats [slab, slab + extra_pad) of every split are a second, short vector (the bias-gradient
+// partials of tok_conv_wgrad_bias) reduced by the same launch into extra[0 .. extra_n) (+= if extra_acc); stride = floats
+// between splits (slab + extra_pad, or slab).
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                int splitM, size_t slab, int accumulate) {
+                                                                int splitM, size_t slab, int accumulate, size_t stride,
+                                                                float* __restrict__ extra, int extra_n, int extra_pad,
+                                                                int extra_acc) {
   __shared__ float4 red[16][16];
   const int col = threadIdx.x & 15, row = threadIdx.x >> 4;
-  const size_t n4 = slab >> 2;
+  const size_t m4 = slab >> 2;
+  const size_t n4 = m4 + (extra != nullptr ? (size_t)(extra_pad >> 2) : 0);
   for (size_t base = (size_t)blockIdx.x * 16; base < n4; base += (size_t)gridDim.x * 16) {
     const size_t i = base + col;
     float4 t = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
 #pragma unroll 4
       for (int sp = row; sp < splitM; sp += 16) {
-        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)sp * slab)[i];
+        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)sp * stride)[i];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
       }
     }
@@ -954,13 +962,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
       }
       __syncthreads();
     }
-    if (row == 0 && i < n4) {
+    if (row == 0 && i < m4) {
       float4 r = red[0][col];
       if (accumulate) {
         const float4 o = reinterpret_cast<const float4*>(dw)[i];
         r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
       }
       reinterpret_cast<float4*>(dw)[i] = r;
+    } else if (row == 0 && i < n4) {
+      const float4 r = red[0][col];
+      const float rv[4] = {r.x, r.y, r.z, r.w};
+      const int e0 = (int)(i - m4) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e0 + e < extra_n) extra[e0 + e] = extra_acc ? extra[e0 + e] + rv[e] : rv[e];
     }
     __syncthreads();
   }
@@ -1196,7 +1211,14 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   make_magic((uint32_t)d->q, a.q_mul, a.q_shift);
   a.Ktot = d->r * d->s_pad * d->c;
   a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
-  a.cs = dbias ? (float*)((char*)ws + tok_conv_wgrad_ws_bytes(d)) : nullptr;   // behind the dW partials
+  // bias partials: with the flat reduce each split's row sits behind its dW slab (padded to 4 floats) and the one reduce
+  // launch folds both; otherwise (direct write / strided masters) a separate block behind all slabs + tok_colsum_f32
+  const size_t slab_f = (size_t)d->k * d->r * d->s_pad * d->c;
+  const int cs_pad = (k_real + 3) / 4 * 4;
+  const bool cs_inline = dbias != nullptr && flat && !direct;
+  a.ws_stride = cs_inline ? slab_f + cs_pad : slab_f;
+  a.cs = dbias ? (cs_inline ? (float*)ws + slab_f : (float*)((char*)ws + tok_conv_wgrad_ws_bytes(d))) : nullptr;
+  a.cs_stride = cs_inline ? a.ws_stride : (size_t)k_real;
   a.cs_cols = k_real;
   {
     const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->c * 2;
@@ -1248,7 +1270,7 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
     if (c4) launch_wgrad<64, 64, true>(a, st, p.MS); else launch_wgrad<64, 64, false>(a, st, p.MS);
   }
   TOK_CHECK_LAUNCH("tok_conv_wgrad");
-  if (dbias != nullptr) {
+  if (dbias != nullptr && !cs_inline) {
     // fold the per-split column sums (fixed order) into the bias gradient; padded channels (>= k_real) are not written
     if (int e = tok_colsum_f32(a.cs, p.splitM, k_real, dbias, bias_accumulate, stream)) return e;
   }
@@ -1257,7 +1279,8 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
     const size_t slab = (size_t)d->k * d->r * d->s * d->c;
     const size_t nb = (slab / 4 + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, st,
-                       (const float*)ws, dw, p.splitM, slab, accumulate);
+                       (const float*)ws, dw, p.splitM, slab, accumulate, cs_inline ? a.ws_stride : slab,
+                       cs_inline ? dbias : (float*)nullptr, k_real, cs_inline ? cs_pad : 0, bias_accumulate);
     TOK_CHECK_LAUNCH("tok_conv_wgrad(reduce)");
     return TOK_OK;
   }
