@@ -29,6 +29,15 @@ BF16 = torch.bfloat16
 WGRAD_DEFER = int(os.environ.get('TOK_WGRAD_DEFER', '0'))   # measured: 0 -> 19.62, 3 -> 19.66, 5 -> 19.74, 8 -> 19.73 ms/step: off
 
 
+# TOK_HOST_PROF=1: host seconds spent enqueuing each node class's backward (tools: where the launch thread goes)
+HOST_PROF = os.environ.get('TOK_HOST_PROF', '0') == '1'
+_host_prof = {}
+
+
+def host_prof_report():
+    return sorted(((k, n, t) for k, (n, t) in _host_prof.items()), key=lambda r: -r[2])
+
+
 def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -429,7 +438,15 @@ class Region:
                 out = getattr(node, 'out', None)
                 if out is not None and out.grad_sub is not None:
                     flush_sub(out)         # the consumer that would have absorbed it never reported (dead branch)
-                node.backward()
+                if HOST_PROF:
+                    import time
+                    t0 = time.perf_counter()
+                    node.backward()
+                    e = _host_prof.setdefault(type(node).__name__, [0, 0.0])
+                    e[0] += 1
+                    e[1] += time.perf_counter() - t0
+                else:
+                    node.backward()
             node.release()
         self.nodes = []
         self.join_side()

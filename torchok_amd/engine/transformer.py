@@ -66,6 +66,19 @@ def reshape(region: Region, x: TTensor, shape: Sequence[int]) -> TTensor:
 
 
 # ---- linear --------------------------------------------------------------------------------------------------
+_LIN_PLANS = {}
+
+
+def _linear_plan(lib, d):
+    """(bias gradient rides the weight-gradient kernel?, workspace bytes with / without it) of a token-matrix geometry."""
+    key = (d.n, d.c, d.k, _C.is_fake())
+    p = _LIN_PLANS.get(key)
+    if p is None:
+        p = (bool(lib.tok_conv_wgrad_bias_ok(d)), int(lib.tok_conv_wgrad_bias_ws_bytes(d)), int(lib.tok_conv_wgrad_ws_bytes(d)))
+        _LIN_PLANS[key] = p
+    return p
+
+
 class _LinearNode(Node):
     needs_backward = True
 
@@ -90,7 +103,9 @@ class _LinearNode(Node):
                     slot.copy_(seg)
                 commit_param_grad(p, slot, mode)
         # the column sums of g (bias gradients) come out of the weight-gradient kernel where it serves the layer
-        bias_in_wgrad = bool(self.bias_sinks and w.requires_grad and BIAS_IN_WGRAD and lib.tok_conv_wgrad_bias_ok(d))
+        # (plan facts of the geometry are cached: two library calls less per layer and step on the launch thread)
+        plan = _linear_plan(lib, d)
+        bias_in_wgrad = bool(self.bias_sinks and w.requires_grad and BIAS_IN_WGRAD and plan[0])
         if self.bias_sinks and not bias_in_wgrad:
             def run_bias():
                 tmp = torch.empty(kp, dtype=F32, device=g.device)
@@ -107,12 +122,24 @@ class _LinearNode(Node):
         wgrad_fn = None
         if w.requires_grad:
             k, r, s, c = _krsc(w)
-            ws_bytes = lib.tok_conv_wgrad_bias_ws_bytes(d) if bias_in_wgrad else lib.tok_conv_wgrad_ws_bytes(d)
+            ws_bytes = plan[1] if bias_in_wgrad else plan[2]
+            # one bias parameter spanning all output features (fc1 / fc2 / proj): the kernel writes its gradient slot itself
+            sole = None
+            if bias_in_wgrad and len(self.bias_sinks) == 1:
+                bp, bstart = self.bias_sinks[0]
+                if bstart == 0 and bp.numel() == k and bp.requires_grad:
+                    sole = bp
 
             def run_wgrad():
                 ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
                 slot, mode = param_grad_target(w)
-                if bias_in_wgrad:
+                if bias_in_wgrad and sole is not None:
+                    bslot, bmode = param_grad_target(sole)
+                    _C.check(lib.tok_conv_wgrad_bias(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
+                                                     1 if mode == 1 else 0, ptr(bslot), 1 if bmode == 1 else 0, stream_ptr()),
+                             'tok_conv_wgrad_bias')
+                    commit_param_grad(sole, bslot, bmode)
+                elif bias_in_wgrad:
                     tmp = torch.empty(kp, dtype=F32, device=g.device)
                     _C.check(lib.tok_conv_wgrad_bias(d, ptr(x.data), ptr(g), ptr(slot), k, c, ptr(ws), ws_bytes,
                                                      1 if mode == 1 else 0, ptr(tmp), 0, stream_ptr()), 'tok_conv_wgrad_bias')
