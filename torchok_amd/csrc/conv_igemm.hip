@@ -845,6 +845,9 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
 // Persistent grid: 2 (128x128 tile) or 3 (128x64) workgroups per CU, rounded to a multiple of
 // 8 * gridN so every XCD holds whole (channel tile, m-slot) groups; never more than the tiles need.
 int plan_grid(int bn_tile, int gridM, int gridN, int per_cu = 0) {
+  static int pc64 = -1;      // TOK_IGEMM_PER_CU_64=<n>: persistent workgroups per CU of the 128 x 64 tile (experiment; default 3)
+  if (pc64 < 0) { const char* e = getenv("TOK_IGEMM_PER_CU_64"); pc64 = e ? atoi(e) : 0; }
+  if (per_cu == 0 && bn_tile == 64 && pc64 > 0) per_cu = pc64;
   const int unit = 8 * gridN;
   int G = 256 * (per_cu > 0 ? per_cu : (bn_tile == 64 ? 3 : 2));
   const long long need = (long long)gridM * gridN;
