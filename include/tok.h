@@ -247,6 +247,11 @@ int tok_bn_stats(const void* y, int64_t m, int c, float* stats, void* stream);
 int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
                    const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m, int c,
                    void* stream);
+/* tok_bn_act_fwd that also leaves per-block column sums of `out` (the fused residual unit's colsum(z) without a pass over z):
+ * partial fp32 [tok_bn_act_fwd_colsum_rows(m, c)][c], folded by tok_colsum_f32 */
+int tok_bn_act_fwd_colsum_rows(int64_t m, int c);
+int tok_bn_act_fwd_colsum(const void* y, const float* scale, const float* shift, const void* shortcut, int relu, void* out,
+                          uint8_t* mask, int64_t m, int c, float* partial, void* stream);
 int tok_bn_bwd_rows(int64_t m, int c);
 /* partial[2][rows][c]: sum(dz), sum(dz * xhat), dz = dout * relu_mask.
  * mask = the bit mask tok_bn_act_fwd wrote (may be NULL when no shortcut was added: the mask

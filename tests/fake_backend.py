@@ -440,6 +440,17 @@ class FakeTok:
             _t(mask, (m, c // 8), torch.uint8).copy_((bits << torch.arange(8)).sum(-1).to(torch.uint8))
         return 0
 
+    def tok_bn_act_fwd_colsum_rows(self, m, c):
+        return 3
+
+    def tok_bn_act_fwd_colsum(self, y, scale, shift, shortcut, relu, out, mask, m, c, partial, st):
+        rc = self.tok_bn_act_fwd(y, scale, shift, shortcut, relu, out, mask, m, c, st)
+        self.calls[-1] = 'bn_act_fwd_colsum'
+        p = _t(partial, (3, c), torch.float32)
+        p.zero_()
+        p[1] = _t(out, (m, c), BF16).float().sum(0)
+        return rc
+
     def tok_bn_bwd_rows(self, m, c):
         return 1
 

@@ -1314,3 +1314,27 @@ def test_adam_capturable(libs, decoupled):
     torch.cuda.synchronize()
     assert int(step.item()) == 3
     assert relerr(pd, ph) < 1e-6 and relerr(md, mh) < 1e-6 and relerr(vd, vh) < 5e-5     # (v: fma vs mul + addcmul rounding)
+
+
+@pytest.mark.parametrize('m,c,relu', [(5000, 64, 1), (777, 256, 1), (130, 1024, 0), (64, 8, 1)])
+def test_bn_act_fwd_colsum(libs, m, c, relu):
+    """The activation pass that also leaves per-block column sums of its output: same `out` / mask as tok_bn_act_fwd, and
+    the folded partials equal the column sums of the STORED bf16 values."""
+    lib, _ = libs
+    st = torch.cuda.current_stream().cuda_stream
+    y = rnd(m, c).to(BF16).to(DEV)
+    scale, shift = (rnd(c, seed=1) * 0.5 + 1).to(DEV), rnd(c, seed=2).to(DEV)
+    out1, out2 = torch.empty_like(y), torch.empty_like(y)
+    mk1 = torch.zeros(m, c // 8, dtype=torch.uint8, device=DEV)
+    mk2 = torch.zeros_like(mk1)
+    rows = lib.tok_bn_act_fwd_colsum_rows(m, c)
+    assert rows > 0
+    part = torch.full((rows, c), float('nan'), device=DEV)
+    assert lib.tok_bn_act_fwd(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, relu, out1.data_ptr(), mk1.data_ptr(), m, c,
+                              st) == 0
+    assert lib.tok_bn_act_fwd_colsum(y.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, relu, out2.data_ptr(), mk2.data_ptr(),
+                                     m, c, part.data_ptr(), st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2) and torch.equal(mk1, mk2)
+    assert not torch.isnan(part).any()
+    assert relerr(part.sum(0), out2.float().sum(0)) < 1e-5

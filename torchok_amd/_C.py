@@ -74,6 +74,8 @@ PROTOTYPES = {
     'tok_bn_stats_rows': (c_int, [c_int64, c_int]),
     'tok_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P]),
     'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P]),
+    'tok_bn_act_fwd_colsum_rows': (c_int, [c_int64, c_int]),
+    'tok_bn_act_fwd_colsum': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P, _P]),
     'tok_bn_bwd_rows': (c_int, [c_int64, c_int]),
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
     'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -42,15 +42,20 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* __restrict_
                                                          const float* __restrict__ shift,
                                                          const bf16* __restrict__ shortcut, int relu,
                                                          bf16* __restrict__ out, uint8_t* __restrict__ mask,
-                                                         int64_t M, int C, int cge, int rpb) {
+                                                         int64_t M, int C, int cge, int rpb,
+                                                         float* __restrict__ csum /* may be null: [gridDim.x][C] */) {
+  __shared__ float cred[256][8];
   const int tid = threadIdx.x;
   const int cgl = tid % cge, rl = tid / cge;
-  if (rl >= rpb) return;
+  if (rl >= rpb && csum == nullptr) return;
   const int cg_total = C >> 3;
   for (int cg = cgl; cg < cg_total; cg += cge) {
-    float sc[8], sh[8];
+    float sc[8], sh[8], cs[8];
     load8f(scale + cg * 8, sc);
     load8f(shift + cg * 8, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    if (rl < rpb)
     for (int64_t m = (int64_t)blockIdx.x * rpb + rl; m < M; m += (int64_t)gridDim.x * rpb) {
       const size_t off = (size_t)m * C + cg * 8;
       const bf16x8 v = ldg16(y + off);
@@ -72,12 +77,31 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const bf16* __restrict_
         }
       }
       stg16(out + off, o);
+      if (csum != nullptr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += bf2f(o[e]);
+      }
       if (mask != nullptr) {   // bit e = (out[e] > 0): the ReLU mask the backward kernels read (1/16 of `out`)
         unsigned bits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
         mask[(size_t)m * cg_total + cg] = (uint8_t)bits;
       }
+    }
+    if (csum != nullptr) {
+      // column sums of the STORED values over this block's rows: one row of partials per block (the fused residual unit
+      // wants colsum(z) of its input; producing it here saves the stand-alone pass over z)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cred[tid][e] = cs[e];
+      __syncthreads();
+      if (rl == 0) {
+        for (int r = 1; r < rpb; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[e] += cred[r * cge + cgl][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum[(size_t)blockIdx.x * C + cg * 8 + e] = cs[e];
+      }
+      __syncthreads();
     }
   }
 }
@@ -667,8 +691,26 @@ extern "C" int tok_bn_act_fwd(const void* y, const float* scale, const float* sh
   const Geo g = make_geo(c);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
                      tok_stream(stream), (const bf16*)y, scale, shift, (const bf16*)shortcut, relu,
-                     (bf16*)out, mask, m, c, g.cge, g.rpb);
+                     (bf16*)out, mask, m, c, g.cge, g.rpb, (float*)nullptr);
   TOK_CHECK_LAUNCH("tok_bn_act_fwd");
+  return TOK_OK;
+}
+
+// tok_bn_act_fwd that also leaves per-block column sums of `out` (fp32 sums of the stored bf16 values):
+// partial[tok_bn_act_fwd_colsum_rows(m, c)][c], to be folded by tok_colsum_f32
+extern "C" int tok_bn_act_fwd_colsum_rows(int64_t m, int c) {
+  if (m <= 0 || c <= 0 || c % 8 != 0) return 0;
+  return stream_blocks(m, make_geo(c), kStreamCap);
+}
+
+extern "C" int tok_bn_act_fwd_colsum(const void* y, const float* scale, const float* shift, const void* shortcut, int relu,
+                                     void* out, uint8_t* mask, int64_t m, int c, float* partial, void* stream) {
+  TOK_CHECK_ARG(y && scale && shift && out && partial && m > 0 && c > 0 && c % 8 == 0, "tok_bn_act_fwd_colsum: bad args");
+  TOK_CHECK_ARG(c <= 2048, "tok_bn_act_fwd_colsum: c <= 2048 (one channel-group pass per thread: uniform barriers)");
+  const Geo g = make_geo(c);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0, tok_stream(stream), (const bf16*)y,
+                     scale, shift, (const bf16*)shortcut, relu, (bf16*)out, mask, m, c, g.cge, g.rpb, partial);
+  TOK_CHECK_LAUNCH("tok_bn_act_fwd_colsum");
   return TOK_OK;
 }
 

@@ -65,7 +65,7 @@ class TTensor:
 
     data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
     __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', 'ready', 'gevents',
-                 'sub_closers', 'grad_sub', '__weakref__')
+                 'sub_closers', 'grad_sub', 'colsum_part', '__weakref__')
 
     def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
         self.data = data
@@ -80,6 +80,7 @@ class TTensor:
         self.gevents = None  # [(event, stream)]: gradient contributions written on other streams (backward)
         self.sub_closers = 0  # consumers whose data gradient can absorb a pending half-resolution contribution (forward)
         self.grad_sub = None  # pending contribution: gradient of the stride-2 pixel subsample of this tensor (backward)
+        self.colsum_part = None  # (partial [rows][C] fp32, rows): per-block column sums left by the pass that produced `data`
 
     @property
     def cp(self) -> int:

@@ -491,6 +491,7 @@ FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
 # the side-stream fork / join of the weight gradients inside a hipGraph capture (cross-stream capture): experiment switch
 SIDE_IN_GRAPH = os.environ.get('TOK_SIDE_IN_GRAPH', '0') == '1'
 BIAS_IN_WGRAD = os.environ.get('TOK_BIAS_IN_WGRAD', '1') != '0'
+COLSUM_IN_ACT = os.environ.get('TOK_COLSUM_IN_ACT', '1') != '0'
 # the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
 # it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
 UNIT3_MIN_ROWS = int(os.environ.get('TOK_UNIT3_MIN_ROWS', '100000'))   # measured: 0 -> 22.4, 40000 -> 22.0, 100000 -> 21.8, plain 23.2 ms/step
@@ -642,7 +643,13 @@ def _unit3_forward(region: Region, x: TTensor, conv: nn.Conv2d, bn: nn.BatchNorm
     # batch statistics of conv(x) from the second moments of x:  Z = x^T x  and  colsum(x)
     dz_ = _pointwise_desc(x, p)
     zz = _wgrad_f32(lib, st, dz_, x.data, x.data, p, p)
-    zsum = _colsum_f32(lib, st, x.data, m, p)
+    if x.colsum_part is not None:
+        part, nrows = x.colsum_part        # left behind by the activation pass that produced x
+        zsum = torch.empty(p, dtype=F32, device=x.data.device)
+        _C.check(lib.tok_colsum_f32(ptr(part), nrows, p, ptr(zsum), 0, st), 'tok_colsum_f32')
+        x.colsum_part = None
+    else:
+        zsum = _colsum_f32(lib, st, x.data, m, p)
     mean, rstd, scale, shift = (torch.empty(kp, dtype=F32, device=dev) for _ in range(4))
     wz = torch.empty((kp, p), dtype=F32, device=dev)       # W Z: the statistics now, the weight gradient later
     track = bn.training and bn.track_running_stats and bn.running_mean is not None
@@ -775,8 +782,19 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             out_data = torch.empty_like(y)
             if relu and region.grad_mode and batch_stats:
                 mask = torch.empty((m, kp // 8), dtype=torch.uint8, device=dev)   # ReLU bits for the backward pass
-            _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
-                                        int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
+            # a 3x3 unit of a bottleneck feeds the fused residual unit, which wants colsum(z) of its input: the activation pass
+            # has z in registers (saves that unit a stand-alone pass over z)
+            want_cs = (FUSE_UNIT3 and COLSUM_IN_ACT and r == 3 and relu and shortcut is None and m >= UNIT3_MIN_ROWS
+                       and kp == k_real and kp <= 1024 and region.grad_mode and batch_stats)
+            if want_cs:
+                cs_rows = lib.tok_bn_act_fwd_colsum_rows(m, kp)
+                cs_part = torch.empty((cs_rows, kp), dtype=F32, device=dev)
+                _C.check(lib.tok_bn_act_fwd_colsum(ptr(y), ptr(scale), ptr(shift), None, int(relu), ptr(out_data), ptr(mask), m,
+                                                   kp, ptr(cs_part), st), 'tok_bn_act_fwd_colsum')
+            else:
+                cs_part = None
+                _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift), ptr(shortcut.data) if shortcut is not None else None,
+                                            int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
         node.mask = mask
         node.mean, node.rstd, node.scale, node.shift = mean, rstd, scale, shift
     else:
@@ -789,6 +807,8 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
 
     req = bool(training or (shortcut is not None and shortcut.requires_grad and region.grad_mode))
     out = TTensor(out_data, k_real, requires_grad=req)
+    if bn is not None and not pool and cs_part is not None:
+        out.colsum_part = (cs_part, cs_rows)
     if req:
         node.x, node.out, node.shortcut, node.y = x, out, shortcut, y
         node.conv, node.bn, node.desc, node.pk = conv, bn, d, pk
