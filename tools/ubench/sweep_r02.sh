@@ -1,6 +1,8 @@
 # A/B sweeps of kernel-plan switches on the headline workload (ResNet-50, B=256); one line per setting
 run() { env "$@" python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', d['ms_per_step'])"; }
 run A=0
-run TOK_IGEMM_PER_CU_64=2
-run TOK_IGEMM_PER_CU_64=1
+run TOK_WGRAD_WGS_LONG=768
+run TOK_WGRAD_WGS_LONG=1024
+run TOK_WGRAD_WGS_LONG=384
+run TOK_WGRAD_WGS_LONG=256
 run A=1

@@ -1054,7 +1054,10 @@ Plan make_plan(const tok_conv_desc* d) {
     // (split target: what is resident at once was 768 workgroups on the 128 x 128 tile; 512 measured better on the step — the
     //  partial-sum slabs are a third smaller and the side stream leaves more of every CU to the main chain:
     //  ResNet-50 19.93 -> 19.38 ms/step together with the tap kernels' 256, tools/ubench/sweep_r02.sh)
-    const int target = ring_target() > 0 ? ring_target() : 256 * (per_cu > 2 ? 2 : per_cu);
+    static int long_target = -1;   // TOK_WGRAD_WGS_LONG=<n>: split target of the long-M layers (>= 100 k rows: the main-stream launches)
+    if (long_target < 0) { const char* e = getenv("TOK_WGRAD_WGS_LONG"); long_target = e ? atoi(e) : 0; }
+    const int target = (long_target > 0 && M >= 100000) ? long_target
+                       : ring_target() > 0 ? ring_target() : 256 * (per_cu > 2 ? 2 : per_cu);
     long long split = (target + tiles - 1) / tiles;
     const long long max_split = (M + 8 * 32 - 1) / (8 * 32);        // at least 8 stages per workgroup
     if (split > max_split) split = max_split;
