@@ -202,6 +202,15 @@ int tok_conv_dgrad_subacc_ok(const tok_conv_desc* d);
 int tok_conv_dgrad_subacc(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* dsub,
                           const void* bn_y /* may be NULL */, const uint8_t* mask /* may be NULL */,
                           float* partial /* may be NULL */, int mask_store, void* stream);
+/* Sum of two pointwise data gradients over the same pixels and input width in ONE launch:
+ * dx (+= if accumulate) = dgrad(d1; dy1, w1_dgrad) + dgrad(d2; dy2, w2_dgrad) (+ bias), epilogue options of tok_conv_dgrad_bias
+ * (partial sized with tok_conv_dgrad_stat_rows(d2)).  The fused residual unit's d(input) = dz Wa + z Wb + c.  Served where
+ * tok_conv_dgrad2_ok(d1, d2) returns 1. */
+int tok_conv_dgrad2_ok(const tok_conv_desc* d1, const tok_conv_desc* d2);
+int tok_conv_dgrad2(const tok_conv_desc* d1, const void* dy1, const void* w1_dgrad, const tok_conv_desc* d2, const void* dy2,
+                    const void* w2_dgrad, const float* bias /* may be NULL */, void* dx, int accumulate,
+                    const void* bn_y /* may be NULL */, const uint8_t* bn_mask /* may be NULL */, float* partial /* with bn_y */,
+                    void* stream);
 size_t tok_conv_wgrad_ws_bytes(const tok_conv_desc* d);
 /* dw fp32 [k_real][r][s][c_real] (+= if accumulate) from x, dy; ws = scratch of at least
  * tok_conv_wgrad_ws_bytes(d) bytes.  k_real/c_real/s are the unpadded master dims.        */

@@ -240,6 +240,15 @@ class FakeTok:
         p[0, 1] = dz.float().sum(0)
         return rc
 
+    def tok_conv_dgrad2_ok(self, d1, d2):
+        a, b = _desc(d1), _desc(d2)
+        return 1 if (a.r == 1 and b.r == 1 and a.c == b.c and a.c % 64 == 0 and (a.n, a.h, a.w) == (b.n, b.h, b.w)) else 0
+
+    def tok_conv_dgrad2(self, d1, dy1, w1, d2, dy2, w2, bias, dx, accumulate, bn_y, bn_mask, partial, st):
+        rc = self.tok_conv_dgrad(d1, dy1, w1, dx, accumulate, st)
+        self.calls[-1] = 'conv_dgrad2'
+        return rc or self.tok_conv_dgrad_bias(d2, dy2, w2, bias, dx, 1, bn_y, bn_mask, partial, st)
+
     # ---- stride-2 projection shortcut as a pointwise layer ---------------------------------------------------------------
     def tok_subsample2_fwd(self, x, n, h, w, c, out, st):
         self.calls.append('subsample2_fwd')

@@ -121,3 +121,48 @@ def test_dgrad_subacc_refuses_layers_off_the_ring(libs):
     rc = lib.tok_conv_dgrad_subacc(ctypes.byref(d), t.data_ptr(), wd.data_ptr(), t.data_ptr(), sub.data_ptr(), None, None, None,
                                    0, torch.cuda.current_stream().cuda_stream)
     assert rc != 0 and b'subacc' in lib.tok_last_error()
+
+
+@pytest.mark.parametrize('case', [(8, 112, 112, 64, 256, 64), (3, 200, 180, 64, 256, 64), (8, 113, 111, 128, 128, 64)])
+@pytest.mark.parametrize('mode', ['plain', 'acc', 'bnstats_mask'])
+def test_dgrad2_equals_two_launches(libs, case, mode):
+    """dx = dgrad(dy1, w1) + dgrad(dy2, w2) + bias in one ring launch (the fused residual unit's d(input)): the fp32
+    restatement within bf16 rounding, the two-launch form (which rounds dx twice) within 1e-2, statistics within 4e-3."""
+    lib, fake = libs
+    n, h, w, c, k1, k2 = case
+    d1, d2 = _desc(n, h, w, c, k1, 1, 1, 0), _desc(n, h, w, c, k2, 1, 1, 0)
+    assert lib.tok_conv_dgrad2_ok(ctypes.byref(d1), ctypes.byref(d2)) == 1
+    m = n * h * w
+    st = torch.cuda.current_stream().cuda_stream
+    dy1_h, dy2_h = rnd(m, k1).to(BF16), rnd(m, k2, seed=1).to(BF16)
+    w1_h, w2_h = rnd(c, k1, scale=k1 ** -0.5, seed=2).to(BF16), rnd(c, k2, scale=k2 ** -0.5, seed=3).to(BF16)
+    bias_h = rnd(c, seed=4)
+    old_h = rnd(m, c, seed=5).to(BF16)
+    bn_y_h = rnd(m, c, seed=6).to(BF16)
+    mask_h = torch.randint(0, 256, (m, c // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    dy1, dy2, w1, w2, bias, bn_y, mask = (t.to(DEV) for t in (dy1_h, dy2_h, w1_h, w2_h, bias_h, bn_y_h, mask_h))
+    acc = 1 if mode == 'acc' else 0
+    stats = mode == 'bnstats_mask'
+    rows = lib.tok_conv_dgrad_stat_rows(ctypes.byref(d2))
+    dx1 = old_h.to(DEV).clone()
+    part1 = torch.zeros(2, rows, c, device=DEV)
+    rc = lib.tok_conv_dgrad2(ctypes.byref(d1), dy1.data_ptr(), w1.data_ptr(), ctypes.byref(d2), dy2.data_ptr(), w2.data_ptr(),
+                             bias.data_ptr(), dx1.data_ptr(), acc, bn_y.data_ptr() if stats else None,
+                             mask.data_ptr() if stats else None, part1.data_ptr() if stats else None, st)
+    assert rc == 0, lib.tok_last_error()
+    dx2 = old_h.to(DEV).clone()
+    part2 = torch.zeros(2, rows, c, device=DEV)
+    assert lib.tok_conv_dgrad(ctypes.byref(d1), dy1.data_ptr(), w1.data_ptr(), dx2.data_ptr(), acc, st) == 0
+    assert lib.tok_conv_dgrad_bias(ctypes.byref(d2), dy2.data_ptr(), w2.data_ptr(), bias.data_ptr(), dx2.data_ptr(), 1,
+                                   bn_y.data_ptr() if stats else None, mask.data_ptr() if stats else None,
+                                   part2.data_ptr() if stats else None, st) == 0
+    torch.cuda.synchronize()
+    ref = dy1_h.float() @ w1_h.float().t() + dy2_h.float() @ w2_h.float().t() + bias_h + (old_h.float() if acc else 0)
+    assert relerr(dx1.float(), ref) < 5e-3
+    assert relerr(dx1.float(), dx2.float()) < 1e-2
+    if stats:
+        g1, g2 = part1.sum(1).cpu(), part2.sum(1).cpu()
+        bits = ((mask_h.long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(m, c).float()
+        dz = dx1.float().cpu() * bits
+        assert relerr(g1[0], dz.sum(0)) < 4e-3 and relerr(g1[1], (dz * bn_y_h.float()).sum(0)) < 4e-3
+        assert relerr(g1, g2) < 2e-2

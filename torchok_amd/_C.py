@@ -97,6 +97,8 @@ PROTOTYPES = {
                                     _P, _P, _P, _P, _P]),
     'tok_bn3_bwd_prepare_ws_floats': (c_size_t, [c_int, c_int]),
     'tok_conv_dgrad_bias': (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
+    'tok_conv_dgrad2_ok': (c_int, [POINTER(ConvDesc), POINTER(ConvDesc)]),
+    'tok_conv_dgrad2': (c_int, [POINTER(ConvDesc), _P, _P, POINTER(ConvDesc), _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     'tok_subsample2_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     'tok_subsample2_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_conv_dgrad_subacc_ok': (c_int, [POINTER(ConvDesc)]),

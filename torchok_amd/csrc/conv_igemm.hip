@@ -1251,3 +1251,48 @@ extern "C" int tok_conv_dgrad_subacc(const tok_conv_desc* d, const void* dy, con
   return dgrad_impl(d, dy, w_dgrad, dx, 0, bn_y, mask, partial, stream, "tok_conv_dgrad_subacc", nullptr, nullptr, 0, nullptr,
                     mask_store, dsub);
 }
+
+// ---- sum of two pointwise data gradients in one launch --------------------------------------------------------------------------
+// d(x) = dgrad(d1: dy1, w1) + dgrad(d2: dy2, w2) (+ bias) for two 1x1 / stride-1 layers over the same pixels and the same input
+// width: the fused residual unit's  d(input) = dz Wa + z Wb + c.  The K stages of the second product follow the first's in the
+// ring kernel's tile loop: one store of d(x) instead of a store, a re-read and a second store.  Epilogue options as
+// tok_conv_dgrad_bias.  Served where tok_conv_dgrad2_ok(d1, d2) (64-wide tiles on the ring).
+
+namespace {
+bool dgrad2_geometry(const tok_conv_desc* d1, const tok_conv_desc* d2) {
+  if (d1 == nullptr || d2 == nullptr) return false;
+  for (const tok_conv_desc* d : {d1, d2})
+    if (!(d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->k % 8 == 0 && d->c % 64 == 0)) return false;
+  if (d1->n != d2->n || d1->h != d2->h || d1->w != d2->w || d1->c != d2->c) return false;
+  const long long rows = (long long)d1->n * d1->h * d1->w;
+  // the second layer alone must sit on the 64-wide ring too: its statistics-row count is the one the caller sizes `partial` with
+  const int gridM = tok_cdiv(rows, 128);
+  if (pick_bn(d2->c, d2->k, gridM) != 64) return false;
+  return pw_serves(64, rows, d1->k, d1->c) && pw_serves(64, rows, d2->k, d2->c);
+}
+}  // namespace
+
+extern "C" int tok_conv_dgrad2_ok(const tok_conv_desc* d1, const tok_conv_desc* d2) { return dgrad2_geometry(d1, d2) ? 1 : 0; }
+
+extern "C" int tok_conv_dgrad2(const tok_conv_desc* d1, const void* dy1, const void* w1_dgrad, const tok_conv_desc* d2,
+                               const void* dy2, const void* w2_dgrad, const float* bias, void* dx, int accumulate,
+                               const void* bn_y, const uint8_t* bn_mask, float* partial, void* stream) {
+  TOK_CHECK_ARG(dgrad2_geometry(d1, d2), "tok_conv_dgrad2: layers not served (ask tok_conv_dgrad2_ok)");
+  TOK_CHECK_ARG(dy1 && w1_dgrad && dy2 && w2_dgrad && dx, "tok_conv_dgrad2: null pointer");
+  TOK_CHECK_ARG((bn_y == nullptr) == (partial == nullptr), "tok_conv_dgrad2: bn_y and partial go together");
+  const long long rows = (long long)d1->n * d1->h * d1->w;
+  PwArgs p = {};
+  p.x = (const bf16*)dy1; p.w = (const bf16*)w1_dgrad; p.C = d1->k;
+  p.x2 = (const bf16*)dy2; p.w2 = (const bf16*)w2_dgrad; p.C2 = d2->k;
+  p.y = (bf16*)dx; p.bias = bias; p.stats = partial;
+  p.M = (int)rows; p.N = d1->c;
+  p.gridM = tok_cdiv(rows, 128); p.gridN = tok_cdiv(d1->c, 64);
+  p.stat_rows = pw_ring_grid(64, p.gridM, p.gridN) / p.gridN;
+  p.e1 = accumulate ? (const bf16*)dx : nullptr;
+  p.accumulate = accumulate;
+  p.e2 = (const bf16*)bn_y; p.mask_in = bn_mask;
+  const int rc = pw_ring_launch(p, 64, tok_stream(stream));
+  if (rc != 0) { tok_set_error("tok_conv_dgrad2: ring kernel refused the launch (%d)", rc); return TOK_ERR_INVALID; }
+  TOK_CHECK_LAUNCH("tok_conv_dgrad2");
+  return TOK_OK;
+}

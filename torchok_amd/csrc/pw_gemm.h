@@ -22,6 +22,12 @@ struct PwArgs {
   // row m = (b, h, w) of y receives e1[b][h/2][w/2] when h and w are even and nothing otherwise (accumulate must be set)
   int e1_sub, sub_H, sub_W;
   int mask_store;       // store relu_mask * y, sum it into stats row 0
+  // second reduction source (may be null): Y += X2 W2^T with X2 [M][C2], W2 [N][C2] — its K stages follow those of (x, w) in
+  // the same tile, so a sum of two pointwise products is one launch and one store of Y (the fused residual unit's
+  // d(input) = dz Wa + z Wb)
+  const bf16* x2;
+  const bf16* w2;
+  int C2;
   int M, C, N;
   int gridM, gridN;
 };

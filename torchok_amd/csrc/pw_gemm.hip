@@ -59,7 +59,8 @@ __device__ __forceinline__ uint32_t lds_read_u8(uint32_t addr) {
 template <int BN, bool BNEP>
 __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwArgs a, uint32_t x_bytes, uint32_t w_bytes,
                                                                              uint32_t y_bytes, uint32_t m_bytes, int KT,
-                                                                             int SPT, uint32_t e1_bytes, PwDiv fd_hw, PwDiv fd_w) {
+                                                                             int SPT, uint32_t e1_bytes, PwDiv fd_hw, PwDiv fd_w,
+                                                                             uint32_t x2_bytes, uint32_t w2_bytes, int KT1) {
   constexpr int NT = 256;
   constexpr int WGN = BN / 64;
   constexpr int WGM = (NT / 64) / WGN;
@@ -92,6 +93,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
 
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x2 ? a.x2 : a.x), 0, a.x2 ? x2_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w2 ? a.w2 : a.w), 0, a.w2 ? w2_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t e1srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e1 ? a.e1 : a.x), 0, a.e1 ? e1_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t e2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e2 ? a.e2 : a.x), 0, a.e2 ? y_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t msrd =
@@ -120,21 +123,26 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
     const bool kstage = ksL < KT;
     const bool last = ksL == SPT - 1;
     if (kstage) {
-      const int kcol = ksL * BK + kcA * 8;
+      const bool second = ksL >= KT1;            // wave-uniform: K stages of the second (x2, w2) source
+      const int kl = second ? ksL - KT1 : ksL;
+      const int Cc = second ? a.C2 : a.C;
+      const __amdgpu_buffer_rsrc_t xs = second ? x2srd : xsrd;
+      const __amdgpu_buffer_rsrc_t ws = second ? w2srd : wsrd;
+      const int kcol = kl * BK + kcA * 8;
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) {
         const int m = m0 + lrow + RSTEP * i;
-        uint32_t off = (live && m < a.M && kcol < a.C) ? (uint32_t)(m * a.C + kcol) * 2u : 0xFFFFFFF0u;
+        uint32_t off = (live && m < a.M && kcol < Cc) ? (uint32_t)(m * Cc + kcol) * 2u : 0xFFFFFFF0u;
         asm volatile("" : "+v"(off));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xs, (lds_void*)(Adst + i * (RSTEP * 128)), 16, off, 0, 0, 0);
       }
-      const int wcol = ksL * BK + kcW * 8;
+      const int wcol = kl * BK + kcW * 8;
 #pragma unroll
       for (int j = 0; j < WROWS; ++j) {
         const int n = n0 + lrow + RSTEP * j;
-        uint32_t off = (live && n < a.N && wcol < a.C) ? (uint32_t)(n * a.C + wcol) * 2u : 0xFFFFFFF0u;
+        uint32_t off = (live && n < a.N && wcol < Cc) ? (uint32_t)(n * Cc + wcol) * 2u : 0xFFFFFFF0u;
         asm volatile("" : "+v"(off));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ws, (lds_void*)(Wdst + j * (RSTEP * 128)), 16, off, 0, 0, 0);
       }
     } else {
       // epilogue operand tile: channels n0 .. n0+63 in the A region, n0+64 .. n0+127 (BN = 128) in the W region
@@ -437,11 +445,14 @@ int launch_ring(const PwArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
-  const int KT = tok_cdiv(a.C, BK);
+  const int KT1 = tok_cdiv(a.C, BK);
+  const int KT = KT1 + (a.x2 != nullptr ? tok_cdiv(a.C2, BK) : 0);
   const int SPT = KT + (a.e1 ? 1 : 0) + (a.e2 ? 1 : 0);
   const unsigned long long xb = (unsigned long long)a.M * a.C * 2, wb = (unsigned long long)a.N * a.C * 2,
                            yb = (unsigned long long)a.M * a.N * 2, mb = (unsigned long long)a.M * (a.N / 8);
   if (xb >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull || yb >= 0xFFFFFFF0ull) return 1;
+  const unsigned long long x2b = a.x2 ? (unsigned long long)a.M * a.C2 * 2 : 0, w2b = a.x2 ? (unsigned long long)a.N * a.C2 * 2 : 0;
+  if (x2b >= 0xFFFFFFF0ull) return 1;
   unsigned long long e1b = yb;
   PwDiv fd_hw = {0, 0}, fd_w = {0, 0};
   if (a.e1_sub) {
@@ -452,7 +463,7 @@ int launch_ring(const PwArgs& a, hipStream_t st) {
   }
   const int grid = pw_ring_grid(BN, a.gridM, a.gridN);
   hipLaunchKernelGGL((pw_gemm_ring_kernel<BN, BNEP>), dim3(grid), dim3(256), smem, st, a, (uint32_t)xb, (uint32_t)wb, (uint32_t)yb,
-                     (uint32_t)mb, KT, SPT, (uint32_t)e1b, fd_hw, fd_w);
+                     (uint32_t)mb, KT, SPT, (uint32_t)e1b, fd_hw, fd_w, (uint32_t)x2b, (uint32_t)w2b, KT1);
   return 0;
 }
 
@@ -475,6 +486,7 @@ int pw_ring_launch(const PwArgs& a, int bn_tile, hipStream_t st) {
   if (a.C % 8 != 0 || a.N % 8 != 0) return 1;
   if (a.mask_in != nullptr && a.N % 64 != 0) return 1;       // mask rows are fetched as aligned 4 / 16-byte pieces
   if (a.accumulate && a.e1 == nullptr) return 1;
+  if ((a.x2 == nullptr) != (a.w2 == nullptr) || (a.x2 != nullptr && (a.C2 <= 0 || a.C2 % 8 != 0))) return -1;
   if (a.e1_sub && (!a.accumulate || a.ep_scale != nullptr || a.sub_H <= 0 || a.sub_W <= 0 ||
                    a.M % (a.sub_H * a.sub_W) != 0)) return -1;
   const bool bnep = a.ep_scale != nullptr;

@@ -492,6 +492,7 @@ FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
 SIDE_IN_GRAPH = os.environ.get('TOK_SIDE_IN_GRAPH', '0') == '1'
 BIAS_IN_WGRAD = os.environ.get('TOK_BIAS_IN_WGRAD', '1') != '0'
 COLSUM_IN_ACT = os.environ.get('TOK_COLSUM_IN_ACT', '1') != '0'
+DGRAD2 = os.environ.get('TOK_DGRAD2', '1') != '0'
 # the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
 # it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
 UNIT3_MIN_ROWS = int(os.environ.get('TOK_UNIT3_MIN_ROWS', '100000'))   # measured: 0 -> 22.4, 40000 -> 22.0, 100000 -> 21.8, plain 23.2 ms/step
@@ -615,8 +616,22 @@ class _Unit3Node(Node):
         fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
                 and prod.fused_partial is None and prod.fused_coef is None)
         tgt, acc = grad_target(x)
-        _C.check(lib.tok_conv_dgrad(d, ptr(dz), ptr(wa), ptr(tgt), acc, st), 'tok_conv_dgrad')
         dpp = _pointwise_desc(x, p)
+        if DGRAD2 and lib.tok_conv_dgrad2_ok(d, dpp):
+            # both products in one launch of the ring kernel: d(x) is stored once
+            part2 = None
+            if fuse:
+                rows2 = lib.tok_conv_dgrad_stat_rows(dpp)
+                part2 = torch.empty((2, rows2, p), dtype=F32, device=dev)
+            _C.check(lib.tok_conv_dgrad2(d, ptr(dz), ptr(wa), dpp, ptr(x.data), ptr(wb), ptr(cvec), ptr(tgt), acc,
+                                         ptr(prod.y) if fuse else None, ptr(prod.mask) if (fuse and prod.relu) else None,
+                                         ptr(part2), st), 'tok_conv_dgrad2')
+            if fuse:
+                prod.fused_partial = (part2, rows2)
+            if self.region is not None:
+                self.region.keep_until_join(dz, wa, wb, cvec, G, scratch)
+            return
+        _C.check(lib.tok_conv_dgrad(d, ptr(dz), ptr(wa), ptr(tgt), acc, st), 'tok_conv_dgrad')
         if fuse:
             rows2 = lib.tok_conv_dgrad_stat_rows(dpp)
             part2 = torch.empty((2, rows2, p), dtype=F32, device=dev)
