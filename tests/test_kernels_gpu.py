@@ -1338,3 +1338,38 @@ def test_bn_act_fwd_colsum(libs, m, c, relu):
     assert torch.equal(out1, out2) and torch.equal(mk1, mk2)
     assert not torch.isnan(part).any()
     assert relerr(part.sum(0), out2.float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('p,k', [(64, 256), (128, 512), (256, 512), (72, 136)])
+def test_bn3_bwd_prepare(libs, p, k):
+    """Backward coefficients of the fused residual unit from G = dz^T z, W, W Z and the column sums: dgamma / dbeta, the three
+    apply coefficients, dW, and the operands of d(input) = dz Wa + z Wb + c — block-per-row product (p in {64, 128, 256}) and the
+    tiled product + split reduce."""
+    lib, fake = libs
+    m = 4000
+    z = rnd(m, p).to(BF16).float() + 0.2
+    dz = rnd(m, k, seed=1).to(BF16).float()
+    w = rnd(k, p, scale=p ** -0.5, seed=2)
+    wq = w.to(BF16).float()
+    G = (dz.double().t() @ z.double()).float()
+    Z = (z.double().t() @ z.double()).float()
+    wz = (wq.double() @ Z.double()).float()
+    zsum = z.double().sum(0).float()
+    rows = 3
+    partial = torch.zeros(2, rows, k)
+    partial[0, 1] = dz.double().sum(0).float()
+    y = z @ wq.t()
+    mean = y.mean(0)
+    rstd = 1.0 / torch.sqrt(y.var(0, unbiased=False) + 1e-5)
+    gamma = rnd(k, seed=3) + 1
+    outs = dict(dgamma=torch.zeros(k), dbeta=torch.zeros(k), coef=torch.zeros(3, k), dw=torch.zeros(k, p),
+                wa=torch.zeros(p, k, dtype=BF16), wb=torch.zeros(p, p, dtype=BF16), cvec=torch.zeros(p))
+    ws = torch.zeros(int(lib.tok_bn3_bwd_prepare_ws_floats(p, k)) + 16)
+    dv = both(libs, 'tok_bn3_bwd_prepare',
+              lambda f: [f(G), f(w), f(wz), f(zsum), f(partial), rows, m, p, k, f(gamma), f(mean), f(rstd), f(outs['dgamma']),
+                         f(outs['dbeta']), 0, f(outs['coef']), f(outs['dw']), 0, f(outs['wa']), f(outs['wb']), f(outs['cvec']),
+                         f(ws), None])
+    for name in ('dgamma', 'dbeta', 'coef', 'dw', 'cvec'):
+        assert relerr(dv[id(outs[name])], outs[name]) < 2e-4, name
+    for name in ('wa', 'wb'):
+        assert relerr(dv[id(outs[name])].float(), outs[name].float()) < 4e-3, name

@@ -211,6 +211,32 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_block_kernel(
   }
 }
 
+// [Wb ; c] = At^T W_bf16 ((P + 1) x P, reduction over the K output channels) for P in {64, 128, 256}: one block per output ROW
+// r — thread (slice, p) sums a slice of the reduction for column p (W rows read coalesced, At[k][r] is a broadcast), slices
+// folded through LDS in slice order.  Replaces the tiled product + its split-reduce launch (two dependent launches of
+// latency on the backward chain of every fused unit).
+__global__ __launch_bounds__(256) void bn3_wb_block_kernel(const float* __restrict__ At, const float* __restrict__ w, int P, int K,
+                                                           bf16* __restrict__ wb, float* __restrict__ cvec) {
+  __shared__ float red[256];
+  const int r = blockIdx.x;                 // 0 .. P: row of [Wb ; c]
+  const int tid = threadIdx.x;
+  const int p = tid % P, sl = tid / P;
+  const int slices = 256 / P;
+  const int kper = (K + slices - 1) / slices;
+  const int k0 = sl * kper, k1 = min(K, k0 + kper);
+  float acc = 0.f;
+#pragma unroll 8
+  for (int k = k0; k < k1; ++k) acc = fmaf(At[(size_t)k * (P + 1) + r], round_bf16(w[(size_t)k * P + p]), acc);
+  red[tid] = acc;
+  __syncthreads();
+  if (sl == 0) {
+    float t = red[p];
+    for (int s_ = 1; s_ < slices; ++s_) t += red[s_ * P + p];
+    if (r < P) wb[(size_t)r * P + p] = f2bf(t);
+    else cvec[p] = t;
+  }
+}
+
 // dz = mask ? dout : 0 (in place allowed) and per-block partial sums of dz: partial[0][gridDim.x][C] (row 1 zero-filled so
 // that the buffer has the layout of the other BatchNorm-backward partials).  Geometry of bn_bwd_reduce_kernel.
 __global__ __launch_bounds__(256) void relu_mask_reduce_kernel(const bf16* dout, const uint8_t* __restrict__ mask, int64_t M,
@@ -415,6 +441,11 @@ extern "C" int tok_bn3_bwd_prepare(const float* G, const float* w, const float* 
                      p, k, gamma, mean, rstd, dgamma, dbeta, param_accumulate, coef, dw, dw_accumulate, (bf16*)wa, At);
   TOK_CHECK_LAUNCH("tok_bn3_bwd_prepare(rows)");
   // [wb ; cvec] = At^T W_bf16   ((p + 1) x p, reduction over k)
+  if (p == 64 || p == 128 || p == 256) {
+    hipLaunchKernelGGL(bn3_wb_block_kernel, dim3(p + 1), dim3(256), 0, st, (const float*)At, w, p, k, (bf16*)wb, cvec);
+    TOK_CHECK_LAUNCH("tok_bn3_bwd_prepare(wb)");
+    return TOK_OK;
+  }
   launch_gemm<true, false, true>(At, p + 1, w, p, p + 1, p, k, nullptr, 0, 1, p, (bf16*)wb, p, cvec, parts, st);
   TOK_CHECK_LAUNCH("tok_bn3_bwd_prepare(wb)");
   return TOK_OK;
