@@ -258,6 +258,12 @@ int tok_bn_act_fwd(const void* y, const float* scale, const float* shift,
                    void* stream);
 /* tok_bn_act_fwd that also leaves per-block column sums of `out` (the fused residual unit's colsum(z) without a pass over z):
  * partial fp32 [tok_bn_act_fwd_colsum_rows(m, c)][c], folded by tok_colsum_f32 */
+/* Completion events carried by a launch: tok_next_launch_event(ev) makes the calling thread's NEXT tok_bn_bwd_apply signal ev
+ * when the kernel finishes (no separate record packet on that stream); tok_stream_wait_event orders another stream behind it. */
+void* tok_event_create(void);
+int tok_event_destroy(void* ev);
+int tok_next_launch_event(void* ev);
+int tok_stream_wait_event(void* stream, void* ev);
 int tok_bn_act_fwd_colsum_rows(int64_t m, int c);
 int tok_bn_act_fwd_colsum(const void* y, const float* scale, const float* shift, const void* shortcut, int relu, void* out,
                           uint8_t* mask, int64_t m, int c, float* partial, void* stream);

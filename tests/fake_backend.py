@@ -449,6 +449,18 @@ class FakeTok:
             _t(mask, (m, c // 8), torch.uint8).copy_((bits << torch.arange(8)).sum(-1).to(torch.uint8))
         return 0
 
+    def tok_event_create(self):
+        return 1
+
+    def tok_event_destroy(self, ev):
+        return 0
+
+    def tok_next_launch_event(self, ev):
+        return 0
+
+    def tok_stream_wait_event(self, stream, ev):
+        return 0
+
     def tok_bn_act_fwd_colsum_rows(self, m, c):
         return 3
 

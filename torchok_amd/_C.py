@@ -75,6 +75,10 @@ PROTOTYPES = {
     'tok_bn_stats': (c_int, [_P, c_int64, c_int, _P, _P]),
     'tok_bn_act_fwd': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P]),
     'tok_bn_act_fwd_colsum_rows': (c_int, [c_int64, c_int]),
+    'tok_event_create': (_P, []),
+    'tok_event_destroy': (c_int, [_P]),
+    'tok_next_launch_event': (c_int, [_P]),
+    'tok_stream_wait_event': (c_int, [_P, _P]),
     'tok_bn_act_fwd_colsum': (c_int, [_P, _P, _P, _P, c_int, _P, _P, c_int64, c_int, _P, _P]),
     'tok_bn_bwd_rows': (c_int, [c_int64, c_int]),
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),

@@ -6,7 +6,10 @@
 // Backward:  tok_bn_bwd_reduce (partials) -> tok_bn_bwd_finalize -> tok_bn_bwd_apply
 //            dz = dout * mask ;  dy = a1*dz + a2*y + a3   (a* per channel)
 #include "tok_common.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
+
+static thread_local hipEvent_t t_done_event = nullptr;
 
 namespace {
 
@@ -751,10 +754,35 @@ extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* 
   TOK_CHECK_ARG(dout && y && scale && shift && coef && dy, "tok_bn_bwd_apply: null pointer");
   TOK_CHECK_ARG(m > 0 && c > 0 && c % 8 == 0, "tok_bn_bwd_apply: bad sizes");
   const Geo g = make_geo(c);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
-                     tok_stream(stream), (const bf16*)dout, (const bf16*)y, mask, scale, shift,
-                     coef, relu, (bf16*)dy, (bf16*)dshortcut, dshortcut_accumulate, m, c, g.cge, g.rpb);
+  if (t_done_event != nullptr) {
+    // completion event attached to THIS dispatch (hipExtLaunchKernelGGL stop event): a side stream can wait for the kernel
+    // without a separate event-record packet on the main queue (a ~7 us bubble per fork)
+    hipEvent_t ev = t_done_event;
+    t_done_event = nullptr;
+    hipExtLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0, tok_stream(stream), nullptr, ev,
+                          0, (const bf16*)dout, (const bf16*)y, mask, scale, shift, coef, relu, (bf16*)dy, (bf16*)dshortcut,
+                          dshortcut_accumulate, m, c, g.cge, g.rpb);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
+                       tok_stream(stream), (const bf16*)dout, (const bf16*)y, mask, scale, shift,
+                       coef, relu, (bf16*)dy, (bf16*)dshortcut, dshortcut_accumulate, m, c, g.cge, g.rpb);
+  }
   TOK_CHECK_LAUNCH("tok_bn_bwd_apply");
+  return TOK_OK;
+}
+
+// ---- completion events carried by a launch (two-stream schedule without record packets) ------------------------------------
+extern "C" void* tok_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+  return (void*)ev;
+}
+extern "C" int tok_event_destroy(void* ev) { return ev && hipEventDestroy((hipEvent_t)ev) == hipSuccess ? TOK_OK : TOK_ERR_INVALID; }
+// the NEXT tok_bn_bwd_apply launch of the calling thread signals `ev` on completion
+extern "C" int tok_next_launch_event(void* ev) { t_done_event = (hipEvent_t)ev; return TOK_OK; }
+extern "C" int tok_stream_wait_event(void* stream, void* ev) {
+  TOK_CHECK_ARG(ev != nullptr, "tok_stream_wait_event: null event");
+  if (hipStreamWaitEvent(tok_stream(stream), (hipEvent_t)ev, 0) != hipSuccess) { tok_set_error("hipStreamWaitEvent failed"); return TOK_ERR_INVALID; }
   return TOK_OK;
 }
 

@@ -38,6 +38,9 @@ def host_prof_report():
     return sorted(((k, n, t) for k, (n, t) in _host_prof.items()), key=lambda r: -r[2])
 
 
+_raw_free = []      # library HIP events ready for reuse (Region.raw_event)
+
+
 def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
@@ -345,6 +348,7 @@ class Region:
         self._side = None
         self._deferred = []
         self._wq = []          # main-stream weight-gradient launches held back (defer_wgrad)
+        self._raw_used = []    # library events handed out since the last join (raw_event)
         self._tag = 0            # branch stream index of the units being recorded (0 = main)
         self._streams = {}       # branch index -> stream, for the branches this region used
         self._branch_done = []   # forward: (event, stream) of every closed branch, joined in output()
@@ -505,18 +509,30 @@ class Region:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def fork_side(self, keep_alive, event=None):
+    def raw_event(self):
+        """A HIP event from the library's pool, for tok_next_launch_event + fork_side(raw_event=...); recycled at the join."""
+        ev = _raw_free.pop() if _raw_free else _C.lib().tok_event_create()
+        if not ev:
+            raise RuntimeError('tok_event_create failed')
+        self._raw_used.append(ev)
+        return ev
+
+    def fork_side(self, keep_alive, event=None, raw_event=None):
         """Context manager: kernels enqueued inside run on this device's side stream, ordered after everything the
         main stream has been given so far (or up to `event`, see mark_side).  `keep_alive` (tensors the side kernels read
         or use as scratch) stay referenced until the join, so the allocator cannot hand their memory to later main-stream
         work."""
         main = torch.cuda.current_stream()
         side = _side_stream(main.device)
-        ev = event
-        if ev is None:
-            ev = torch.cuda.Event()
-            ev.record(main)
-        side.wait_event(ev)
+        if raw_event is not None:
+            # the event is signalled by the completion of a kernel already launched on the main stream (no record packet)
+            _C.check(_C.lib().tok_stream_wait_event(side.cuda_stream, raw_event), 'tok_stream_wait_event')
+        else:
+            ev = event
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+            side.wait_event(ev)
         self._side = (main, side)
         self._deferred.extend(keep_alive)
         return torch.cuda.stream(side)
@@ -546,6 +562,9 @@ class Region:
         if self._side is not None:
             torch.cuda.current_stream().wait_stream(self._side[1])
             self._side = None
+        if self._raw_used:
+            _raw_free.extend(self._raw_used)      # the main stream is behind every waiter now: the events can be reused
+            self._raw_used = []
         self._deferred.clear()
 
 

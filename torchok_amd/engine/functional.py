@@ -298,12 +298,24 @@ class _ConvBnActNode(Node):
                 commit_param_grad(bn.bias, bs, bm)
         self.coef = coef
 
+    def _wgrad_goes_side(self, g, m) -> bool:
+        conv = self.conv
+        if conv.weight.dim() != 4:
+            r = s = 1
+        else:
+            r, s = conv.weight.shape[2], conv.weight.shape[3]
+        side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
+                   (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')))
+        return bool(WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
+                    and not torch.cuda.is_current_stream_capturing())
+
     def backward(self):
         lib, st = _C.lib(), stream_ptr()
         out: TTensor = self.out
         g = out.grad
         if g is None:
             return
+        apply_event = None
         conv, bn, d = self.conv, self.bn, self.desc
         m, kp = self.y.numel() // self.y.shape[-1], self.y.shape[-1]
         x: TTensor = self.x
@@ -334,6 +346,11 @@ class _ConvBnActNode(Node):
             need_dy = w_need or x_need or bias_need
             if need_dy or sc_need:
                 dy = torch.empty_like(self.y)
+                if LAUNCH_EVENTS and w_need and self.pool is None and self._wgrad_goes_side(g, m):
+                    # the weight gradient will be forked to the side stream behind THIS apply pass: the pass carries the
+                    # completion event itself (no event-record packet on the main queue)
+                    apply_event = self.region.raw_event()
+                    lib.tok_next_launch_event(apply_event)
                 ds_ptr, ds_acc = None, 0
                 if sc_need:
                     if sc.grad is None and out.grad_owned:
@@ -402,7 +419,7 @@ class _ConvBnActNode(Node):
                     and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
-                with self.region.fork_side((x.data, dy)):
+                with self.region.fork_side((x.data, dy), raw_event=apply_event):
                     self.region.keep_until_join(run_wgrad())
             elif self.region is not None and g.is_cuda:
                 self.region.defer_wgrad(run_wgrad)     # (the closure keeps x and dy alive)
@@ -492,6 +509,7 @@ FUSE_UNIT3 = os.environ.get('TOK_FUSE_UNIT3', '1') != '0'
 SIDE_IN_GRAPH = os.environ.get('TOK_SIDE_IN_GRAPH', '0') == '1'
 BIAS_IN_WGRAD = os.environ.get('TOK_BIAS_IN_WGRAD', '1') != '0'
 COLSUM_IN_ACT = os.environ.get('TOK_COLSUM_IN_ACT', '1') != '0'
+LAUNCH_EVENTS = os.environ.get('TOK_LAUNCH_EVENTS', '1') != '0'
 DGRAD2 = os.environ.get('TOK_DGRAD2', '1') != '0'
 # the fused unit trades ~27 tensor-units of HBM traffic for a handful of small launches (Gram matrix, two K x P x P products):
 # it pays where the 4P-channel maps are large (ResNet-50 at batch 256: layers 1-2 and, marginally, 3)
