@@ -126,6 +126,79 @@ def build_task(backbone: str, num_classes: int):
     return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
 
 
+def build_c5_task(kind: str):
+    """BASELINE.json configs[4] at the per-rank shape (bs 1024 over 8 GPUs = 128 / GPU, 3x224x224): ResNet-50 +
+    PoolingLinear(512) + ArcFaceHead(11318) + CrossEntropyLoss (`representation_arcface_sop.yaml:1-24`), or
+    ResNet-50 + Pooling + LinearHead(512, normalize) + ContrastiveLoss under PairwiseLearnTask (`pairwise_sop.yaml`)."""
+    import torchok_amd as T
+    from torchok_amd.constructor.config import apply_schema
+    bb = {'backbone_name': 'resnet50', 'backbone_params': {'pretrained': False, 'in_channels': 3},
+          'inputs': [{'shape': [3, 224, 224], 'dtype': 'float32'}]}
+    if kind == 'arcface':
+        task = {'name': 'ClassificationTask',
+                'params': dict(bb, pooling_name='PoolingLinear', pooling_params={'out_channels': 512},
+                               head_name='ArcFaceHead', head_params={'num_classes': 11318})}
+        loss = {'name': 'CrossEntropyLoss', 'mapping': {'input': 'prediction', 'target': 'target'}}
+    else:
+        task = {'name': 'PairwiseLearnTask',
+                'params': dict(bb, pooling_name='Pooling', head_name='LinearHead',
+                               head_params={'out_channels': 512, 'normalize': True}, num_classes=11318)}
+        loss = {'name': 'ContrastiveLoss', 'params': {'margin': 0.5}, 'mapping': {'emb1': 'emb1', 'emb2': 'emb2', 'R': 'R'}}
+    cfg = apply_schema({'task': task, 'joint_loss': {'losses': [loss]},
+                        'optimization': [{'optimizer': {'name': 'SGD', 'params': {'lr': 0.01, 'momentum': 0.9}}}],
+                        'data': {}, 'trainer': {'precision': 'bf16', 'strategy': 'ddp'}})
+    return T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+
+
+def secondary_block(budget_s: float = 20.0, warmup: int = 3, steps: int = 10):
+    """The other BASELINE.json configs at their per-GPU shapes, 3 + 10 steps each (bounded: a workload is skipped once the
+    budget is spent), so that the driver's record carries them next to the headline: {ms_per_step, frac, bound}."""
+    from torchok_amd.engine.step import train_step
+    plans = [
+        ('swinv2_t_224_bs256_adamw', lambda: build_swin_task(1000, 224), 256, (3, 224, 224), 1000, False,
+         ('mfma', ALG_FLOPS_PER_IMG[('swinv2_custom', 224)], MFMA_PEAK_BF16)),
+        ('hrnet_w48_seg_512x1024_bs24', lambda: build_seg_task('hrnet_w48', 19, 512, 1024), 24, (3, 512, 1024), 19, True,
+         ('hbm', ALG_BYTES_SEG[('hrnet_w48', 512, 1024)], HBM_PEAK)),
+        ('resnet50_arcface11318_bs128', lambda: build_c5_task('arcface'), 128, (3, 224, 224), 11318, False,
+         ('hbm', ALG_BYTES_PER_IMG['resnet50'], HBM_PEAK)),
+        ('resnet50_contrastive_bs128', lambda: build_c5_task('contrastive'), 128, (3, 224, 224), 11318, False,
+         ('hbm', ALG_BYTES_PER_IMG['resnet50'], HBM_PEAK)),
+    ]
+    out, t_start = {}, time.perf_counter()
+    for name, build, bsz, shape, classes, seg, (bound, per_img, peak) in plans:
+        if time.perf_counter() - t_start > budget_s:
+            out[name] = {'skipped': f'secondary budget of {budget_s:.0f} s spent'}
+            continue
+        try:
+            task = build().cuda().train()
+            opt = task.configure_optimizers()[0]['optimizer']
+            g = torch.Generator(device='cuda').manual_seed(4321)
+            batch = {'image': torch.randn(bsz, *shape, generator=g, device='cuda').to(torch.bfloat16),
+                     'target': torch.randint(0, classes, (bsz, *shape[1:]) if seg else (bsz,), generator=g, device='cuda')}
+            for i in range(warmup):
+                train_step(task, opt, batch, i)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for i in range(steps):
+                out_ = train_step(task, opt, batch, warmup + i)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            ach = per_img * bsz / (ms * 1e-3)
+            out[name] = {'ms_per_step': round(ms, 3), 'images_per_sec': round(bsz / ms * 1e3, 1), 'bound': bound,
+                         'frac': round(ach / peak, 4), 'batch': bsz, 'steps': steps, 'warmup': warmup,
+                         'loss_finite': bool(torch.isfinite(out_['loss']))}
+            del task, opt, batch, out_
+        except Exception as e:      # a secondary workload must never take the headline line down with it
+            out[name] = {'error': f'{type(e).__name__}: {e}'[:200]}
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+    out['wall_s'] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
 def _usable_cores() -> int:
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a box can
     show 256 logical CPUs under a much smaller quota; oversubscribing them makes torch crawl)."""
@@ -228,6 +301,7 @@ def main():
     ap.add_argument('--width', type=int, default=0, help='image width when it differs from --res (segmentation)')
     ap.add_argument('--classes', type=int, default=1000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the bounded secondary-workload block of the default line')
     ap.add_argument('--graph', type=int, default=-1, help='1: replay the step as one hipGraph, 0: eager launches '
                     '(default: graph only where the step is host-launch-bound: HRNet below batch 16)')
     args = ap.parse_args()
@@ -287,20 +361,16 @@ def main():
         for g_ in opt.param_groups:          # Adam / AdamW: device-side step count (torch's capturable=True)
             if 'capturable' in g_:
                 g_['capturable'] = True
-        graphed = GraphedTrainingStep(task, opt, batch)
+        graphed = GraphedTrainingStep(task, opt, batch, reducer=reducer)
+
+    from torchok_amd.engine.step import replicas_in_sync, train_step
 
     def step(i):
+        # ONE function for every caller (engine/step.py): training_step -> backward (+ bucketed exchange) -> optimizer ->
+        # on_train_batch_end (the per-step loss mean of reference tasks/base.py:163-173, on the comm stream for N > 1)
         if graphed is not None:
             return graphed(batch)['loss']
-        out = task.training_step(batch, i)
-        opt.zero_grad(set_to_none=True)
-        if reducer is not None:
-            reducer.begin_step()
-        out['loss'].backward()
-        if reducer is not None:
-            reducer.finish_step()
-        opt.step()
-        return out['loss']
+        return train_step(task, opt, batch, i, reducer)['loss']
 
     for i in range(args.warmup):
         loss = step(i)
@@ -321,6 +391,7 @@ def main():
     dt = time.perf_counter() - t0
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     final_loss = float(loss.detach())
+    in_sync = replicas_in_sync(reducer)      # N > 1: every rank must hold bit-identical parameters after the run
     if dist_on:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -372,8 +443,17 @@ def main():
             roofline['mfma_util_pmc'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
         if dist_on:
             line['config']['rccl_ranks'] = dist.get_world_size()
+            line['ranks_in_sync'] = in_sync
+            line['config']['per_step_collectives'] = 'gradient buckets + buffer broadcast + loss mean (async, comm stream)'
             line['config']['grad_exchange'] = f"bucketed all-reduce(AVG), {'bf16' if reducer.bf16 else 'fp32'} payload, " \
                                               f"{sum(len(b) for b in reducer.buckets)} buckets + buffer broadcast"
+        if world == 1 and not dist_on and not args.no_secondary and args.backbone == 'resnet50' and args.batch == 256:
+            # free the headline workload first: the secondary ones need the memory, and their numbers must not depend on it
+            del task, opt, batch, image, target, loss
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            line['secondary'] = secondary_block()
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.backbone, args.classes, args.res, width)
         sys.stdout.flush()

@@ -16,9 +16,7 @@ def pytest_configure(config):
 @pytest.fixture
 def fake_backend():
     """Host-memory stand-in for libtok_gfx950.so (tests/fake_backend.py) — host-logic tests only."""
-    from torchok_amd import _C
-    from fake_backend import FakeTok
-    fake = FakeTok()
-    prev = _C._install_backend(fake)
-    yield fake
-    _C._restore_backend(prev)
+    import fake_backend as fb
+    token = fb.install()
+    yield token[0]
+    fb.uninstall(token)

@@ -3,8 +3,8 @@
 It implements the C ABI of include/tok.h (same names, same argument order, same layouts and
 rounding points) so that the host logic of torchok_amd — tape, gradient fan-in, parameter
 arenas, optimizers, task wiring — can be exercised on a CPU-only box (`-m "not gpu"` tests).
-It is installed through torchok_amd._C._install_backend() by tests only; the product never
-routes through it (a missing native library raises).
+Tests install it with `install()` at the bottom of this file — a monkeypatch applied from the
+tests' side; the product has no hook for it and never routes through it (a missing native library raises).
 """
 import ctypes
 import math
@@ -1523,3 +1523,41 @@ class FakeTok:
     def tok_scale_f32(self, dst, f, count, st):
         _t(dst, (count,), torch.float32).mul_(f)
         return 0
+
+
+# ---- installing the stand-in (tests only; the product has no hook for it) -----------------------------------------------
+# torchok_amd refuses host tensors and always asks torch for the current HIP stream.  A host-logic test therefore patches,
+# from the OUTSIDE, the three names through which the package reaches the device: `_C._lib` (the loaded library object),
+# `stream_ptr` (-> no stream) and `require_device` (-> accepts host tensors) in every module that imported them.
+def install(fake=None):
+    """Route torchok_amd's native calls to a FakeTok.  Returns an undo token for `uninstall`."""
+    import sys
+
+    import torchok_amd  # noqa: F401  (loads the modules that bind stream_ptr / require_device)
+    import torchok_amd.dist  # noqa: F401
+    import torchok_amd.metrics  # noqa: F401
+    import torchok_amd.retrieval  # noqa: F401
+    from torchok_amd import _C
+    fake = fake if fake is not None else FakeTok()
+    undo = [(_C, '_lib', _C._lib)]
+    _C._lib = fake
+
+    def no_stream():
+        return None
+
+    def any_device(t):
+        return None
+    for name, mod in list(sys.modules.items()):
+        if not name.startswith('torchok_amd') or mod is None:
+            continue
+        for attr, repl in (('stream_ptr', no_stream), ('require_device', any_device)):
+            if attr in getattr(mod, '__dict__', {}):
+                undo.append((mod, attr, mod.__dict__[attr]))
+                setattr(mod, attr, repl)
+    return fake, undo
+
+
+def uninstall(token):
+    _, undo = token
+    for mod, attr, old in reversed(undo):
+        setattr(mod, attr, old)

@@ -87,3 +87,24 @@ def deterministic_state(state_dict, seed: int):
         else:                             # BN beta / linear bias
             out[k] = torch.randn(v.shape, generator=g) * 0.1
     return out
+
+
+def record_distance(test: str, tensor: str, hip_vs_autocast=None, hip_vs_fp32=None, autocast_vs_fp32=None, **extra):
+    """Append one measured parity distance (relative L2) to the round's record (JSON lines).  On the GPU box the file lands
+    under gpurun_out/ (the only directory that travels back); tools/parity_record.py folds it into
+    profiles/rNN_parity_distances.json, which is committed — the margins of the gates are on record, not only printed."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get('TOK_PARITY_OUT') or os.path.join(root, 'gpurun_out', 'parity_distances.jsonl')
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = {'test': test, 'tensor': tensor}
+        for k, v in (('hip_vs_autocast', hip_vs_autocast), ('hip_vs_fp32', hip_vs_fp32), ('autocast_vs_fp32', autocast_vs_fp32)):
+            if v is not None:
+                rec[k] = float(v)
+        rec.update(extra)
+        with open(path, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass

@@ -21,9 +21,9 @@ def _worker(rank, world, port, tmp):
     import torchok_amd as T
     from torchok_amd import _C
     from torchok_amd.dist import GradientAllReducer
-    from fake_backend import FakeTok
     from helpers import cls_config, deterministic_state
-    _C._install_backend(FakeTok())
+    import fake_backend as fb
+    fb.install()
     cfg = cls_config('resnet18', 10)
     task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).train()
     # rank 1 starts from different weights: the reducer must broadcast rank 0's

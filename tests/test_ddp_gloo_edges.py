@@ -5,7 +5,8 @@
  * module buffers follow rank 0 after every step (DDP broadcast_buffers=True, one flat broadcast per dtype),
  * bf16 gradient buckets (torch DDP's bf16_compress_hook) stay within bf16 rounding of the fp32 exchange,
  * classification metrics sum their counts over ranks at compute() (torchmetrics dist_reduce_fx='sum'),
- * a parameter group added after the first step joins the exchange."""
+ * a parameter group added after the first step joins the exchange,
+ * without find_unused_parameters a missing gradient raises (torch DDP's behaviour)."""
 import os
 import sys
 
@@ -26,9 +27,9 @@ def _worker(rank, world, port, tmp):
     import torchok_amd as T
     from torchok_amd import _C
     from torchok_amd.dist import GradientAllReducer
-    from fake_backend import FakeTok
     from helpers import cls_config, deterministic_state
-    _C._install_backend(FakeTok())
+    import fake_backend as fb
+    fb.install()
     cfg = cls_config('resnet18', 10)
     task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).train()
     task.load_state_dict(deterministic_state(task.state_dict(), 11))
@@ -37,7 +38,7 @@ def _worker(rank, world, port, tmp):
     u = torch.nn.Parameter(torch.tensor([3.0]))           # used nowhere
     params = list(task.parameters()) + [q, r, u]
     opt = T.OPTIMIZERS.get('SGD')(params, lr=0.1, momentum=0.9)
-    red = GradientAllReducer(opt, bucket_bytes=4 << 20, module=task)
+    red = GradientAllReducer(opt, bucket_bytes=4 << 20, module=task, find_unused_parameters=True)
     g = torch.Generator().manual_seed(200 + rank)
     x, y = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)
 
@@ -75,9 +76,10 @@ def _worker(rank, world, port, tmp):
     # bf16 buckets: same step from the same state, compared with the fp32 exchange
     red.close()
     snap = [p.detach().clone() for p in params]
-    step(1, GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False))
+    step(1, GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False, find_unused_parameters=True))
     g32 = torch.cat([p.grad.flatten() for p in params if p.grad is not None]).clone()
-    red16 = GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False, grad_dtype='bf16')
+    red16 = GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False, grad_dtype='bf16',
+                               find_unused_parameters=True)
     step(1, red16)
     g16 = torch.cat([p.grad.flatten() for p in params if p.grad is not None])
     assert float((g16 - g32).abs().max()) <= float(g32.abs().max()) * 2 ** -7
@@ -102,6 +104,13 @@ def _worker(rank, world, port, tmp):
     opt.step()
     assert torch.allclose(late.detach(), torch.full((3,), 1.0 - 0.1 * 1.5))
     red16.close()
+
+    # the default is torch DDP's find_unused_parameters=False: a parameter without a gradient is an error, not a silent
+    # divergence (`u` is unused on both ranks, so both raise before any straggler bucket is exchanged)
+    strict = GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False)
+    with pytest.raises(RuntimeError, match='find_unused_parameters'):
+        step(3, strict)
+    strict.close()
 
     # metrics: per-rank shards, one value
     acc = T.METRICS.get('Accuracy')(task='multiclass', num_classes=3)

@@ -124,3 +124,116 @@ def test_full_size_training_step_is_bit_reproducible():
         assert torch.isfinite(out['loss'])
         res.append(torch.cat([p.detach().reshape(-1) for p in task.parameters()]))
     assert torch.equal(res[0], res[1])
+
+
+# ---- the other BASELINE.json configs at the sizes their profiles quote (round 3) ---------------------------------------------
+def _swin_task(seed=5, classes=1000):
+    cfg = cls_config('swinv2_custom', classes, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                     backbone_params={'img_size': 224, 'window_size': 7, 'drop_path_rate': 0.0}, inputs_shape=(3, 224, 224))
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, seed)
+    task.load_state_dict(sd, strict=False)
+    return task.cuda()
+
+
+def test_swinv2_t_b256_gradient_is_additive_over_a_batch_split_and_reproducible():
+    """SwinV2-T 224 / window 7 at batch 256 (BASELINE.json configs[2] per GPU).  LayerNorm has no batch statistics, so with
+    stochastic depth off the mean-loss gradient of the batch is EXACTLY the mean of the gradients of its halves in exact
+    arithmetic; on the HIP path the difference is bf16 storage of the token-wise gradients + fp32 split-reduction order.
+    Two runs of the same step give identical bits (fixed-order reductions, two-stream schedule)."""
+    task = _swin_task().train()
+    x, y = _batch(256, seed=2)
+
+    def grads(xs, ys):
+        for p in task.parameters():
+            p.grad = None
+        out = task.forward_with_gt({'image': xs, 'target': ys})
+        task.losses(**out)[0].backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}
+    full, again = grads(x, y), grads(x, y)
+    assert set(full) == set(again) and all(torch.equal(full[n], again[n]) for n in full)       # bit-reproducible
+    a, b = grads(x[:128], y[:128]), grads(x[128:], y[128:])
+    errs = {}
+    for n in full:
+        ref = 0.5 * (a[n] + b[n])
+        if float(ref.norm()) > 0:
+            errs[n] = float((full[n] - ref).norm() / ref.norm())
+    worst = max(errs, key=errs.get)
+    med = sorted(errs.values())[len(errs) // 2]
+    print(f'[swinv2-t B=256 batch-split additivity] {len(errs)} tensors, median {med:.2e}, worst {worst} {errs[worst]:.2e}')
+    from helpers import record_distance
+    record_distance('fullsize/swinv2-t B=256 batch-split additivity', 'all parameter gradients', median=med,
+                    worst=errs[worst], worst_tensor=worst, tensors=len(errs))
+    # bf16 activations / activation gradients: each half-batch pass rounds its own token gradients (2^-9 relative per
+    # element, independent between passes); parameter gradients average that noise over >= 12544 rows
+    assert med < 5e-3 and errs[worst] < 3e-2, (med, worst, errs[worst])
+
+
+def test_hrnet_w48_b24_training_steps_are_bit_reproducible():
+    """HRNet-W48 + neck + head at 512x1024, batch 24 (the size profiles/r0N_hrnet_* quote): two optimizer steps from the same
+    state twice -> identical parameters and BatchNorm buffers (branch streams, side stream, fixed-order reductions)."""
+    import bench
+    res = []
+    for _ in range(2):
+        task = bench.build_seg_task('hrnet_w48', 19, 512, 1024)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 9)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator(device='cuda').manual_seed(4)
+        x = torch.randn(24, 3, 512, 1024, generator=g, device='cuda').to(BF16)
+        y = torch.randint(0, 19, (24, 512, 1024), generator=g, device='cuda')
+        for it in range(2):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad(set_to_none=True)
+            out['loss'].backward()
+            opt.step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out['loss'])
+        res.append((torch.cat([p.detach().reshape(-1) for p in task.parameters()]),
+                    torch.cat([b.detach().double().reshape(-1) for b in task.buffers()])))
+        del task, opt, x, y, out
+        torch.cuda.empty_cache()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('kind', ['arcface', 'contrastive'])
+def test_c5_step_at_the_real_per_rank_shape(kind):
+    """BASELINE.json configs[4] per GPU: 128 x 3 x 224 x 224, ResNet-50, 11318 classes — ArcFace head + CE
+    (representation_arcface_sop.yaml) and LinearHead(normalize) + ContrastiveLoss under PairwiseLearnTask (pairwise_sop.yaml).
+    Properties: finite loss of the right size, every parameter gets a gradient, the relevance matrix / margin column are exact,
+    and the step is bit-reproducible."""
+    import math
+    import bench
+    res = []
+    for _ in range(2):
+        task = bench.build_c5_task(kind)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 21)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator(device='cuda').manual_seed(6)
+        x = torch.randn(128, 3, 224, 224, generator=g, device='cuda').to(BF16)
+        y = torch.randint(0, 40 if kind == 'contrastive' else 11318, (128,), generator=g, device='cuda')
+        fw = task.forward_with_gt({'image': x, 'target': y})
+        if kind == 'contrastive':
+            R = fw['R']
+            assert R.shape == (128, 128) and torch.equal(R, (y[:, None] == y[None, :]).float())        # exact
+        else:
+            pred = fw['prediction'].float()
+            assert pred.shape == (128, 11318)
+            # off the target column the logits are scale * cosine: bounded by the scale; on it the margin lowers them
+            assert float(pred.abs().max()) <= task.head.scale * 1.01
+        out = task.training_step({'image': x, 'target': y}, 0)
+        opt.zero_grad(set_to_none=True)
+        out['loss'].backward()
+        assert all(p.grad is not None for p in task.parameters())
+        opt.step()
+        torch.cuda.synchronize()
+        loss = float(out['loss'])
+        assert math.isfinite(loss) and (loss > 0.5 * math.log(11318) if kind == 'arcface' else loss >= 0.0)
+        res.append(torch.cat([p.detach().reshape(-1) for p in task.parameters()]))
+        del task, opt, x, y, out, fw
+        torch.cuda.empty_cache()
+    assert torch.equal(res[0], res[1])

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import torchok_amd as T
-from helpers import cls_config, deterministic_state
+from helpers import cls_config, deterministic_state, record_distance
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -33,6 +33,8 @@ def test_hip_path_vs_reference_golden(name):
     out = task.training_step({'image': x, 'target': y}, 0)
     fw = task.forward_with_gt({'image': x, 'target': y})
     pred = fw['prediction'].detach().float().cpu().numpy()
+    record_distance(f'golden/{name}', 'logits', hip_vs_fp32=np.linalg.norm(pred - g['prediction']) / np.linalg.norm(g['prediction']))
+    record_distance(f'golden/{name}', 'loss', hip_vs_fp32=abs(float(out['loss'].detach().item()) - float(g['loss'])) / abs(float(g['loss'])))
     assert np.linalg.norm(pred - g['prediction']) < 0.025 * np.linalg.norm(g['prediction'])
     assert abs(float(out['loss'].detach().item()) - float(g['loss'])) < 5e-3 * abs(float(g['loss']))
     out['loss'].backward()
@@ -40,6 +42,8 @@ def test_hip_path_vs_reference_golden(name):
     assert names == [n for n, _ in task.named_parameters()]
     gn = np.array([float(p.grad.detach().double().norm().item()) for _, p in task.named_parameters()])
     dev = np.abs(gn / g['grad_norm'] - 1)
+    record_distance(f'golden/{name}', 'gradient norms (ratio - 1)', median=float(np.median(dev)), p90=float(np.percentile(dev, 90)),
+                    worst=float(dev.max()), tensors=int(dev.size))
     assert np.median(dev) < 0.02 and np.percentile(dev, 90) < 0.08 and dev.max() < 0.25
     fcb = task.head.fc.bias.grad.detach().float().cpu().numpy()
     assert np.abs(fcb - g['grad__head.fc.bias']).max() < 0.015 * np.abs(g['grad__head.fc.bias']).max() + 1e-4

@@ -21,7 +21,7 @@ import oracle.metric_ref as M
 import oracle.swin_ref as S
 import oracle.torchok_ref as R
 import torchok_amd as T
-from helpers import cls_config, deterministic_state, rel_err
+from helpers import cls_config, deterministic_state, record_distance, rel_err
 from torchok_amd.constructor.config import apply_schema
 
 pytestmark = pytest.mark.gpu
@@ -32,6 +32,9 @@ def _grad_gate(tag, ours, g32, gac, slack=0.08):
     errs = {n: rel_err(ours[n], g32[n]) for n in g32 if g32[n] is not None and float(g32[n].norm()) > 0}
     yard = {n: rel_err(gac[n], g32[n]) for n in errs}
     me, my = float(np.median(list(errs.values()))), float(np.median(list(yard.values())))
+    for n in errs:
+        record_distance(f'real_geometry/{tag}', f'd({n})', hip_vs_autocast=rel_err(ours[n], gac[n]), hip_vs_fp32=errs[n],
+                        autocast_vs_fp32=yard[n])
     worst = max(errs, key=lambda n: errs[n] - 1.5 * yard[n])
     print(f'[step {tag}] gradients: {len(errs)} tensors, median rel err HIP {me:.3e} vs autocast yardstick {my:.3e}; '
           f'max HIP {max(errs.values()):.3e} / autocast {max(yard.values()):.3e}; worst over yardstick: {worst} '
@@ -76,6 +79,7 @@ def test_swinv2_t_224_window7_step():
     loss.backward()
     torch.cuda.synchronize()
     e_log, y_log = rel_err(out['prediction'].float(), l32), rel_err(lac, l32)
+    record_distance('real_geometry/swinv2-t 224', 'logits', hip_vs_fp32=e_log, autocast_vs_fp32=y_log)
     print(f'[step swinv2-t 224] logits rel err HIP {e_log:.3e} (autocast {y_log:.3e}); loss HIP {float(loss):.5f} '
           f'fp32 {loss32:.5f} autocast {lossac:.5f}')
     assert e_log < max(1e-2, 1.5 * y_log)
@@ -127,6 +131,7 @@ def test_hrnet_w48_512x1024_step():
     torch.cuda.synchronize()
     assert tuple(pred.shape) == (1, classes, 512, 1024)
     e_log, y_log = rel_err(pred.float(), l32), rel_err(lac, l32)
+    record_distance('real_geometry/hrnet_w48 512x1024', 'logits', hip_vs_fp32=e_log, autocast_vs_fp32=y_log)
     print(f'[step hrnet_w48 512x1024] logits rel err HIP {e_log:.3e} (autocast {y_log:.3e}); loss HIP '
           f'{float(out["loss"]):.5f} fp32 {loss32:.5f} autocast {lossac:.5f}')
     assert e_log < max(2e-2, 1.5 * y_log)
@@ -187,6 +192,8 @@ def test_resnet50_arcface_recipe_step():
     torch.cuda.synchronize()
     e_emb, y_emb = rel_err(out['embeddings'].float(), e32), rel_err(eac, e32)
     e_log, y_log = rel_err(out['prediction'].float(), l32), rel_err(lac, l32)
+    record_distance('real_geometry/resnet50 arcface', 'logits', hip_vs_fp32=e_log, autocast_vs_fp32=y_log)
+    record_distance('real_geometry/resnet50 arcface', 'embeddings', hip_vs_fp32=e_emb, autocast_vs_fp32=y_emb)
     print(f'[step resnet50 arcface] embeddings rel err HIP {e_emb:.3e} (autocast {y_emb:.3e}); logits HIP {e_log:.3e} '
           f'(autocast {y_log:.3e}); loss HIP {float(loss):.5f} fp32 {loss32:.5f} autocast {lossac:.5f}')
     assert e_emb < max(2e-2, 1.5 * y_emb) and e_log < max(2e-2, 1.5 * y_log)

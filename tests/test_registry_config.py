@@ -252,3 +252,49 @@ def test_shipped_recipes_drive_a_training_step(fake_backend, name, extra, make_b
         task.on_validation_epoch_end()
         hit = [v for k, v in task.logged.items() if 'HitAtKMeter' in k]
         assert len(hit) == 1 and 0.0 <= float(hit[0]) <= 1.0, task.logged
+
+
+# ---- the fit loop (torchok_amd/run.py): what `python -m torchok` + create_trainer + Lightning's fit loop do for the hot path ----
+def test_trainer_precision_is_honoured_or_refused():
+    """config_structure.py:141: precision defaults to 32.  This build computes in bf16: bf16 is accepted, 16 runs as bf16 with
+    a note, 32 / 64 (explicit or by default) raise instead of silently changing the recipe's arithmetic."""
+    from torchok_amd.run import resolve_precision, resolve_strategy
+    assert resolve_precision({'precision': 'bf16'}) == 'bf16' and resolve_precision({'precision': 'bf16-mixed'}) == 'bf16'
+    assert resolve_precision({'precision': 16}) == 'bf16' and resolve_precision({'precision': '16-mixed'}) == 'bf16'
+    for bad in (32, '32', 64, '64-true'):
+        with pytest.raises(ValueError, match='precision'):
+            resolve_precision({'precision': bad})
+    with pytest.raises(ValueError, match='precision'):
+        resolve_precision({})                                    # the schema default is 32
+    assert resolve_strategy({'strategy': 'ddp', 'devices': 4})[:2] == (True, 4)      # classification_imagenet.yaml:121-122
+    assert resolve_strategy({})[:2] == (False, 1)
+    with pytest.raises(ValueError):
+        resolve_strategy({'strategy': 'fsdp'})
+    with pytest.raises(NotImplementedError):
+        resolve_strategy({'sync_batchnorm': True})
+
+
+@pytest.mark.skipif(not os.path.exists('/root/reference/examples/configs'), reason='reference checkout: build container only')
+@pytest.mark.parametrize('name,extra,make_batch,make_val', _RECIPES, ids=[r[0] for r in _RECIPES])
+def test_shipped_recipes_run_through_the_fit_loop(fake_backend, name, extra, make_batch, make_val):
+    """Every shipped recipe, unchanged except `pretrained` and `trainer.precision=bf16`, through run.fit for 2 steps
+    (task -> optimizer / scheduler -> steps -> epoch-end hooks); with its own precision (32 by default) it is refused."""
+    import torch
+    from torchok_amd.run import fit
+    os.environ.setdefault('HOME', '/root')
+    ov = dict({'task.params.backbone_params.pretrained': False}, **extra)
+    asked = T.load_config(f'/root/reference/examples/configs/{name}.yaml', overrides=ov)
+    wants = str((asked.trainer or {}).get('precision', 32))
+    if wants in ('32', '64'):
+        with pytest.raises(ValueError, match='precision'):
+            fit(asked, batches=[], max_steps=0, device='cpu')
+    cfg = T.load_config(f'/root/reference/examples/configs/{name}.yaml',
+                        overrides=dict(ov, **{'trainer.precision': 'bf16', 'trainer.devices': 1}))
+    torch.manual_seed(0)
+    seen = []
+    res = fit(cfg, batches=[make_batch(torch) for _ in range(2)], max_steps=2, device='cpu',
+              on_step=lambda i, out: seen.append(float(out['loss'])))
+    assert res['steps'] == 2 and len(seen) == 2 and all(x == x for x in seen)      # finite
+    assert res['world'] == 1 and res['ranks_in_sync'] is None
+    assert any(k.startswith('train/') for k in res['logged'])
+    assert sum(p.grad is not None for p in res['task'].parameters()) > 10

@@ -28,7 +28,7 @@ import oracle.swin_ref as S
 import oracle.timm_min as TM
 import oracle.torchok_ref as R
 import torchok_amd as T
-from helpers import deterministic_state, rel_err
+from helpers import deterministic_state, record_distance, rel_err
 from torchok_amd import engine
 from torchok_amd.engine import functional as EF
 from torchok_amd.engine import resample as ER
@@ -90,6 +90,7 @@ def _ref_unit(unit, x, gout, autocast=False):
 
 
 def _report(tag, what, e_hip, e_yard, e_pair):
+    record_distance(f'units/{tag}', what, hip_vs_autocast=e_pair, hip_vs_fp32=e_hip, autocast_vs_fp32=e_yard)
     print(f'[unit {tag}] {what:34s} HIP-vs-autocast {e_pair:.2e}   HIP-vs-fp32 {e_hip:.2e}   autocast-vs-fp32 {e_yard:.2e}')
 
 

@@ -2,9 +2,7 @@
 
 The library is built in-tree by ``__graft_entry__.build()`` (hipcc --offload-arch=gfx950) and
 lives next to this package (``torchok_amd/lib``).  There is NO fallback: if the shared object
-is missing, or a tensor is not on a HIP device, the product path raises.  (Unit tests may
-install a host-memory stand-in through :func:`_install_backend` to exercise the host logic on
-a CPU-only box; nothing in the package itself does.)
+is missing, or a tensor is not on a HIP device, the product path raises.
 """
 import ctypes
 import os
@@ -196,7 +194,6 @@ class TokError(RuntimeError):
 
 
 _lib = None
-_fake = False
 
 
 def load_library(path=None):
@@ -218,25 +215,6 @@ def lib():
     if _lib is None:
         _lib = load_library()
     return _lib
-
-
-def is_fake():
-    return _fake
-
-
-def _install_backend(backend):
-    """TEST HOOK: replace the native library by an object exposing the same entry points
-    (operating on host memory).  Used by tests/ only; returns the previous backend."""
-    global _lib, _fake
-    prev = (_lib, _fake)
-    _lib = backend
-    _fake = backend is not None and not isinstance(backend, ctypes.CDLL)
-    return prev
-
-
-def _restore_backend(prev):
-    global _lib, _fake
-    _lib, _fake = prev
 
 
 def check(status, what=''):

@@ -50,11 +50,33 @@ __device__ __forceinline__ bf16x8 ldg16(const bf16* p) {
 }
 __device__ __forceinline__ void stg16(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 
-// exact (erf) GELU and its derivative: one definition for tok_act_fwd/_bwd and the fused GEMM epilogues, so that the
-// fused and the unfused paths give the same bits
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf-GELU and its derivative: one definition for tok_act_fwd/_bwd and the fused GEMM epilogues, so that the fused and the
+// unfused paths give the same bits.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 rounding of the
+// surrounding arithmetic and 4 decimal orders below the bf16 storage of the result): 1 - (a1 t + .. + a5 t^5) exp(-z^2),
+// t = 1 / (1 + p |z|), on v_rcp_f32 / v_exp_f32 — ~14 VALU per element where libm's erff + expf cost ~55, which is what
+// made a GELU epilogue as expensive as the elementwise pass it replaces.  exp(-z^2) with z = x / sqrt(2) is exp(-x^2 / 2):
+// the derivative's Gaussian term reuses it.
+__device__ __forceinline__ float tok_erf_core(float z, float& gauss) {   // returns erf(|z|), gauss = exp(-z^2)
+  const float az = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  p *= t;
+  gauss = __builtin_amdgcn_exp2f(az * az * -1.4426950408889634f);
+  return fmaf(-p, gauss, 1.0f);
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float g;
+  const float e = copysignf(tok_erf_core(x * 0.70710678118654752f, g), x);
+  const float hx = 0.5f * x;
+  return fmaf(hx, e, hx);
+}
 __device__ __forceinline__ float gelu_d(float x) {
-  return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+  float g;
+  const float e = copysignf(tok_erf_core(x * 0.70710678118654752f, g), x);
+  return fmaf(x * 0.3989422804014327f, g, fmaf(0.5f, e, 0.5f));
 }
 
 __device__ __forceinline__ bf16x8 zero8() {

@@ -75,9 +75,16 @@ class _BufferArena:
 class GradientAllReducer:
     def __init__(self, optimizer, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True,
                  module: Optional[torch.nn.Module] = None, broadcast_buffers: bool = True,
-                 grad_dtype: Optional[str] = None):
+                 grad_dtype: Optional[str] = None, find_unused_parameters: Optional[bool] = None):
+        """`find_unused_parameters` (torch DDP's flag; Lightning's `strategy: ddp` leaves it False): when True one tiny
+        used-map all-reduce per step lets a parameter that got no gradient on THIS rank still receive the averaged update
+        of the ranks that used it; when False (default) a parameter without a gradient at `finish_step` is an error, as
+        under torch DDP, and the step carries no extra collective and no per-parameter Python scan."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
+        if find_unused_parameters is None:
+            find_unused_parameters = os.environ.get('TOK_DDP_FIND_UNUSED', '0') == '1'
+        self.find_unused = bool(find_unused_parameters)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
@@ -96,6 +103,11 @@ class GradientAllReducer:
         self.comm_stream = torch.cuda.Stream() if self.cuda else None
         self._avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else None
         self._active = False
+        self._events: List = []       # hipEvents of the fork edges, reused round-robin (a step needs a handful)
+        self._ev_next = 0
+        self._small: Dict[int, torch.Tensor] = {}
+        if module is not None:
+            module._grad_reducer = self      # BaseTask.on_train_batch_end puts its loss mean on this comm stream
         self._buffer_arenas: List[_BufferArena] = []
         self._buffer_work = []
         if module is not None and broadcast_buffers:
@@ -142,6 +154,28 @@ class GradientAllReducer:
         n = sum(len(a.params) for a in self.arenas)
         self._used = torch.zeros(n, dtype=torch.float32, device=self.arenas[0].master.device)
         self._flags_dev, self._flags_host = torch.zeros_like(self._used), None
+
+    def _fork_to_comm(self, stream=None):
+        """comm stream waits for everything `stream` (default: the current one) has been given so far."""
+        if len(self._events) < 64:
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._ev_next % len(self._events)]
+        self._ev_next += 1
+        ev.record(stream if stream is not None else torch.cuda.current_stream())
+        self.comm_stream.wait_event(ev)
+
+    def mean_small_async(self, vals: torch.Tensor):
+        """Mean over ranks of a small tensor (the per-step loss values, reference tasks/base.py:163-173) as ONE collective on
+        the comm stream.  Returns (work, tensor): `work.wait()` makes the calling stream wait for the result — no host
+        synchronisation anywhere; the caller consumes it a step later."""
+        if self.cuda:
+            self._fork_to_comm()
+            with torch.cuda.stream(self.comm_stream):
+                vals.record_stream(self.comm_stream)
+                work = self._reduce(vals)
+        else:
+            work = self._reduce(vals)
+        return work, vals, (1.0 if self._avg is not None else 1.0 / self.world)
 
     # ---- per step ---------------------------------------------------------------------------
     def begin_step(self):
@@ -191,9 +225,7 @@ class GradientAllReducer:
             cur = torch.cuda.current_stream()
             b.streams[cur.cuda_stream] = cur
             for s_ in b.streams.values():
-                ev = torch.cuda.Event()
-                ev.record(s_)
-                self.comm_stream.wait_event(ev)
+                self._fork_to_comm(s_)
             with torch.cuda.stream(self.comm_stream):
                 if self.bf16:
                     if b.narrow is None or b.narrow.numel() != view.numel():
@@ -206,10 +238,7 @@ class GradientAllReducer:
             if self.bf16:
                 if b.narrow is None or b.narrow.numel() != view.numel():
                     b.narrow = torch.empty(view.numel(), dtype=torch.bfloat16, device=view.device)
-                if _C.is_fake():
-                    _C.check(lib.tok_cast_f32_bf16(ptr(view), ptr(b.narrow), view.numel(), None), 'tok_cast_f32_bf16')
-                else:
-                    b.narrow.copy_(view)
+                _C.check(lib.tok_cast_f32_bf16(ptr(view), ptr(b.narrow), view.numel(), stream_ptr()), 'tok_cast_f32_bf16')
                 b.work = self._reduce(b.narrow)
             else:
                 b.work = self._reduce(view)
@@ -219,38 +248,47 @@ class GradientAllReducer:
         for ba in self._buffer_arenas:
             ba.rehome()      # a module.to() / load_state_dict may have detached buffers from the flat tensor
             if self.cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self.comm_stream.wait_event(ev)
+                self._fork_to_comm()
                 with torch.cuda.stream(self.comm_stream):
                     self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
             else:
                 self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
 
     def finish_step(self):
-        """Call after backward, before optimizer.step(): flush stragglers, exchange the used-parameter map and the module
-        buffers, join the comm stream."""
-        # which parameters got a gradient on this rank (before the stragglers' slots are zero-filled)
-        flags, any_missing = [], False
-        for arena in self.arenas:
-            for p in arena.params:
-                has = p.grad is not None
-                flags.append(1.0 if has else 0.0)
-                any_missing |= (not has) and p.requires_grad
+        """Call after backward, before optimizer.step(): flush stragglers, exchange the module buffers (and, with
+        find_unused_parameters, the used-parameter map), join the comm stream."""
+        flags, any_missing = None, False
+        if self.find_unused:
+            # which parameters got a gradient on this rank (before the stragglers' slots are zero-filled)
+            flags = []
+            for arena in self.arenas:
+                for p in arena.params:
+                    has = p.grad is not None
+                    flags.append(1.0 if has else 0.0)
+                    any_missing |= (not has) and p.requires_grad
         for ai, blist in enumerate(self.buckets):
             for b in blist:
                 if b.work is None:
+                    if not self.find_unused:
+                        # a bucket nobody completed: either plain-autograd gradients waiting to be adopted (fine) or a
+                        # parameter without a gradient on this rank (the ranks would apply different updates)
+                        arena = self.arenas[ai]
+                        for pi in range(b.first, b.last + 1):
+                            p = arena.params[pi]
+                            if p.requires_grad and p.grad is None:
+                                raise RuntimeError(
+                                    'GradientAllReducer: a parameter received no gradient in this step; pass '
+                                    'find_unused_parameters=True (TOK_DDP_FIND_UNUSED=1) if parts of the model are unused '
+                                    'on some ranks (torch DDP raises the same way)')
                     self._launch(ai, b)
         used_work = None
-        if self.world > 1:
+        if self.find_unused and self.world > 1:
             if flags != self._flags_host:      # uploaded only when the pattern changes (normally: once)
                 self._flags_dev.copy_(torch.tensor(flags, dtype=torch.float32))
                 self._flags_host = flags
             self._used.copy_(self._flags_dev)
             if self.cuda:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self.comm_stream.wait_event(ev)
+                self._fork_to_comm()
                 with torch.cuda.stream(self.comm_stream):
                     used_work = dist.all_reduce(self._used, group=self.group, async_op=True)
             else:
@@ -264,16 +302,10 @@ class GradientAllReducer:
                 view = self.arenas[ai].grad[b.lo:b.hi]
                 scale = 1.0 if self._avg is not None else 1.0 / self.world
                 if self.bf16:
-                    if self.cuda or _C.is_fake():
-                        _C.check(lib.tok_cast_bf16_f32(ptr(b.narrow), ptr(view), scale, view.numel(), stream_ptr()),
-                                 'tok_cast_bf16_f32')
-                    else:
-                        view.copy_(b.narrow.float() * scale)
+                    _C.check(lib.tok_cast_bf16_f32(ptr(b.narrow), ptr(view), scale, view.numel(), stream_ptr()),
+                             'tok_cast_bf16_f32')
                 elif self._avg is None:
-                    if self.cuda or _C.is_fake():
-                        _C.check(lib.tok_scale_f32(ptr(view), scale, view.numel(), stream_ptr()), 'tok_scale_f32')
-                    else:
-                        view.mul_(scale)
+                    _C.check(lib.tok_scale_f32(ptr(view), scale, view.numel(), stream_ptr()), 'tok_scale_f32')
         for w in self._buffer_work:
             w.wait()
         self._buffer_work = []
@@ -291,6 +323,18 @@ class GradientAllReducer:
                             p.grad = arena.grad_view(pi)
                         k += 1
         self._active = False
+
+    def params_checksum(self) -> torch.Tensor:
+        """[min, max] over ranks of a checksum of this rank's parameter arenas (float64 sum of the fp32 masters): equal on
+        every rank iff the replicas hold the same parameters.  One tiny collective; used by bench.py / run.py after a run."""
+        acc = torch.zeros(1, dtype=torch.float64, device=self.arenas[0].master.device)
+        for arena in self.arenas:
+            acc += arena.master.double().sum()
+        lo, hi = acc.clone(), acc.clone()
+        if self.world > 1:
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        return torch.cat([lo, hi])
 
     def close(self):
         if self._on_grad in core.param_grad_hooks:

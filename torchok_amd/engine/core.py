@@ -38,7 +38,7 @@ def host_prof_report():
     return sorted(((k, n, t) for k, (n, t) in _host_prof.items()), key=lambda r: -r[2])
 
 
-_raw_free = []      # library HIP events ready for reuse (Region.raw_event)
+_raw_free = {}      # device index -> library HIP events ready for reuse (Region.raw_event); an event belongs to its device
 
 
 def pad8(c: int) -> int:
@@ -47,13 +47,11 @@ def pad8(c: int) -> int:
 
 def stream_ptr():
     """The HIP stream every kernel of the calling thread is enqueued on (torch's current one)."""
-    if _C.is_fake():
-        return None
     return torch.cuda.current_stream().cuda_stream
 
 
 def require_device(t: torch.Tensor):
-    if t.device.type != 'cuda' and not _C.is_fake():
+    if t.device.type != 'cuda':
         raise RuntimeError(
             f'torchok_amd executes on MI355X (HIP) devices only, got a tensor on "{t.device}". '
             f'There is no CPU path: move the task and the batch to cuda.')
@@ -265,7 +263,7 @@ class _Branch:
     def __enter__(self):
         r = self.region
         dev = r.device
-        self.live = bool(BRANCH_STREAMS and self.idx and dev is not None and dev.type == 'cuda' and not _C.is_fake()
+        self.live = bool(BRANCH_STREAMS and self.idx and dev is not None and dev.type == 'cuda'
                          and not torch.cuda.is_current_stream_capturing())
         if self.live:
             main = torch.cuda.current_stream()
@@ -511,10 +509,12 @@ class Region:
 
     def raw_event(self):
         """A HIP event from the library's pool, for tok_next_launch_event + fork_side(raw_event=...); recycled at the join."""
-        ev = _raw_free.pop() if _raw_free else _C.lib().tok_event_create()
+        dev = torch.cuda.current_device()
+        free = _raw_free.get(dev)
+        ev = free.pop() if free else _C.lib().tok_event_create()
         if not ev:
             raise RuntimeError('tok_event_create failed')
-        self._raw_used.append(ev)
+        self._raw_used.append((dev, ev))
         return ev
 
     def fork_side(self, keep_alive, event=None, raw_event=None):
@@ -563,7 +563,8 @@ class Region:
             torch.cuda.current_stream().wait_stream(self._side[1])
             self._side = None
         if self._raw_used:
-            _raw_free.extend(self._raw_used)      # the main stream is behind every waiter now: the events can be reused
+            for dev, ev in self._raw_used:        # the main stream is behind every waiter now: the events can be reused
+                _raw_free.setdefault(dev, []).append(ev)
             self._raw_used = []
         self._deferred.clear()
 

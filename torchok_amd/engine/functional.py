@@ -349,8 +349,7 @@ class _ConvBnActNode(Node):
                 if LAUNCH_EVENTS and w_need and self.pool is None and self._wgrad_goes_side(g, m):
                     # the weight gradient will be forked to the side stream behind THIS apply pass: the pass carries the
                     # completion event itself (no event-record packet on the main queue)
-                    apply_event = self.region.raw_event()
-                    lib.tok_next_launch_event(apply_event)
+                    apply_event = self.region.raw_event()     # armed right in front of the launch that carries it (below)
                 ds_ptr, ds_acc = None, 0
                 if sc_need:
                     if sc.grad is None and out.grad_owned:
@@ -365,9 +364,15 @@ class _ConvBnActNode(Node):
                     _C.check(lib.tok_bn_pool_bwd_apply(ptr(g), ptr(self.pool), ptr(self.y), ptr(self.scale), ptr(self.shift),
                                                        ptr(coef), n_, h_, w_, kp, ptr(dy), st), 'tok_bn_pool_bwd_apply')
                 else:
-                    _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
-                                                  ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
-                                                  ds_acc, m, kp, st), 'tok_bn_bwd_apply')
+                    if apply_event is not None:
+                        lib.tok_next_launch_event(apply_event)
+                    try:
+                        _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
+                                                      ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
+                                                      ds_acc, m, kp, st), 'tok_bn_bwd_apply')
+                    finally:
+                        if apply_event is not None:
+                            lib.tok_next_launch_event(None)   # never left armed for an unrelated later launch
             else:
                 dy = None
         else:
@@ -433,7 +438,9 @@ class _ConvBnActNode(Node):
             prod = x.node
             fuse = (isinstance(prod, _ConvBnActNode) and is_last_contribution(x) and prod.wants_fused_bwd_stats()
                     and prod.fused_partial is None and prod.fused_coef is None)
-            mask_fuse = isinstance(prod, _Unit3Node) and is_last_contribution(x) and prod.masked_partial is None
+            # (a fused unit WITHOUT activation has no ReLU bits: its d(out) is dz itself and takes the plain path)
+            mask_fuse = (isinstance(prod, _Unit3Node) and prod.relu and prod.mask is not None and is_last_contribution(x)
+                         and prod.masked_partial is None)
             sub = x.grad_sub if getattr(self, 'sub_capable', False) else None
             tgt, acc = grad_target(x, sub_ok=sub is not None)
             if sub is not None:

@@ -30,14 +30,9 @@ class GraphedTrainingStep:
         self.recapture()
 
     def _eager(self):
-        out = self.task.training_step(self.static, self._step_idx)
-        self.optimizer.zero_grad(set_to_none=True)
-        if self.reducer is not None:
-            self.reducer.begin_step()
-        out['loss'].backward()
-        if self.reducer is not None:
-            self.reducer.finish_step()
-        self.optimizer.step()
+        from .step import train_step
+        # (on_train_batch_end's bookkeeping is host-side state: it runs outside the recording, see __call__)
+        out = train_step(self.task, self.optimizer, self.static, self._step_idx, self.reducer, batch_end_hook=False)
         self._step_idx += 1
         return out
 
@@ -64,4 +59,5 @@ class GraphedTrainingStep:
                     self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
         self._step_idx += 1
+        self.task.on_train_batch_end(self.out, batch, self._step_idx - 1)
         return self.out

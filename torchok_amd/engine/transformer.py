@@ -71,7 +71,7 @@ _LIN_PLANS = {}
 
 def _linear_plan(lib, d):
     """(bias gradient rides the weight-gradient kernel?, workspace bytes with / without it) of a token-matrix geometry."""
-    key = (d.n, d.c, d.k, _C.is_fake())
+    key = (d.n, d.c, d.k, id(lib))
     p = _LIN_PLANS.get(key)
     if p is None:
         p = (bool(lib.tok_conv_wgrad_bias_ok(d)), int(lib.tok_conv_wgrad_bias_ws_bytes(d)), int(lib.tok_conv_wgrad_ws_bytes(d)))

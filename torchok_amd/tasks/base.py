@@ -88,24 +88,64 @@ class BaseTask(nn.Module, ABC):
         return self.forward_with_gt(batch)
 
     # ---- per-batch / per-epoch hooks (reference tasks/base.py:163-200) -----------------------------------------
-    def _mean_over_ranks(self, outputs: Dict[str, Tensor]) -> Dict[str, Tensor]:
-        """The reference all_gathers every logged value and takes the mean (tasks/base.py:170,182): the same numbers
-        from ONE collective here — the values are stacked and mean-all-reduced over RCCL (gloo on CPU)."""
+    def _mean_over_ranks_async(self, outputs: Dict[str, Tensor]):
+        """The reference all_gathers every logged value and takes the mean (tasks/base.py:170,182).  Here the values are
+        stacked once and mean-all-reduced as ONE tiny collective; on a GPU job with a GradientAllReducer attached
+        (`strategy: ddp`) that collective goes onto the reducer's comm stream and is consumed a step later — no host
+        synchronisation and nothing blocking on the compute stream.  Returns (tags, values, work or None, scale)."""
         import torch.distributed as dist
         tags = list(outputs)
         if not tags:
-            return {}
+            return tags, None, None, 1.0
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return tags, [outputs[t].detach() for t in tags], None, 1.0      # one rank: the values themselves, no kernels
         vals = torch.stack([outputs[t].detach().float().mean() for t in tags])
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if True:
+            red = getattr(self, '_grad_reducer', None)
+            if red is not None:
+                work, vals, scale = red.mean_small_async(vals)
+                return tags, vals, work, scale
             dist.all_reduce(vals)
-            vals = vals / dist.get_world_size()
+            return tags, vals, None, 1.0 / dist.get_world_size()
+
+    def _mean_over_ranks(self, outputs: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        tags, vals, work, scale = self._mean_over_ranks_async(outputs)
+        if not tags:
+            return {}
+        if work is not None:
+            work.wait()
+        if scale != 1.0:
+            vals = vals * scale
         return {t: vals[i] for i, t in enumerate(tags)}
 
+    def flush_step_logs(self) -> Dict[str, Tensor]:
+        """Consume the pending per-step loss mean (issued by the previous on_train_batch_end): the current stream waits for
+        the collective, the values are logged under `train/<tag>`.  Called by the next on_train_batch_end and at epoch end."""
+        pend = getattr(self, '_pending_loss_mean', None)
+        if pend is None:
+            return {}
+        self._pending_loss_mean = None
+        tags, vals, work, scale, n = pend
+        if work is not None:
+            work.wait()
+        if scale != 1.0:
+            vals = vals * scale
+        out = {t: vals[i] for i, t in enumerate(tags)}
+        for tag, value in out.items():
+            self.log(f'train/{tag}', value, on_step=False, on_epoch=True, batch_size=n)
+        return out
+
     def on_train_batch_end(self, outputs: Dict[str, Tensor], batch, batch_idx: int, dataloader_idx: int = 0):
-        output_dict = self._mean_over_ranks(outputs)
-        for tag, value in output_dict.items():
-            self.log(f'train/{tag}', value, on_step=False, on_epoch=True, batch_size=len(outputs))
-        return output_dict
+        """reference tasks/base.py:163-173.  The collective of THIS step is issued now and consumed at the next call (or at
+        epoch end): returned / logged values lag one step on a multi-rank job and are immediate on one rank."""
+        prev = self.flush_step_logs()
+        tags, vals, work, scale = self._mean_over_ranks_async(outputs)
+        if not tags:
+            return prev
+        self._pending_loss_mean = (tags, vals, work, scale, len(outputs))
+        if work is None:
+            return self.flush_step_logs()
+        return prev
 
     def on_validation_batch_end(self, outputs: Dict[str, Tensor], batch, batch_idx: int, dataloader_idx: int = 0):
         output_dict = self._mean_over_ranks(outputs)
@@ -114,6 +154,7 @@ class BaseTask(nn.Module, ABC):
         return output_dict
 
     def on_train_epoch_end(self) -> None:
+        self.flush_step_logs()
         self.log_dict(self.metrics_manager.on_epoch_end(Phase.TRAIN))
         self.log('step', float(self.current_epoch), on_step=False, on_epoch=True)
 
