@@ -79,6 +79,12 @@ CONV_CASES = [
     (70, 2, 2, 64, 128, 3, 2, 1),      # 1x1 outputs: every staged row is another image
     (2, 30, 26, 96, 48, 3, 1, 1),      # 48-wide tiles of the window weight-gradient kernel (HRNet-W48 branches), ragged rows
     (3, 9, 33, 48, 48, 3, 1, 1),
+    # shared-window 3x3 kernel (conv_win.hip; served with TOK_CONV_WIN_MIN_TILES=1 at these sizes, see the module fixture)
+    (5, 14, 14, 256, 256, 3, 1, 1),    # 16-column tiles, a tile spans two images (flattened rows)
+    (3, 28, 28, 128, 128, 3, 1, 1),    # 32-column tiles, 28 of 32 columns used
+    (1, 40, 72, 96, 96, 3, 1, 1),      # 64-column tiles, two x-tiles (the second ragged), 96 of 128 channels
+    (2, 56, 56, 64, 128, 3, 1, 1),
+    (5, 13, 15, 40, 136, 3, 1, 1),     # C = 40: second chunk a quarter full; K = 136: second channel tile ragged
 ]
 
 
@@ -96,11 +102,13 @@ def test_conv_fwd(libs, case):
     wt = rnd(k, r, r, c, scale=(r * r * c) ** -0.5).to(BF16)
     bias = rnd(k)
     y = torch.zeros(n, d.p, d.q, k, dtype=BF16)
-    rows = libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d))
-    stats = torch.zeros(2, rows, k)
+    # each side lays its partial sums out as [2][its own row count][k]: the buffer holds the larger count, the device result is
+    # read back with the library's row count, and only column sums are compared
+    rows_dev = libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d))
+    stats = torch.zeros(2 * max(rows_dev, libs[1].tok_conv_fwd_stat_rows(d)) * k)
     dv = both(libs, 'tok_conv_fwd', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
                                                f(x), f(wt), f(bias), f(y), f(stats), None])
-    yd, sd = dv[id(y)], dv[id(stats)]
+    yd, sd = dv[id(y)], dv[id(stats)][:2 * rows_dev * k].view(2, rows_dev, k)
     assert relerr(yd.float(), y.float()) < 4e-3
     assert maxrel(yd.float(), y.float(), 0.05) < 3e-2
     # the partial sums are taken over the fp32 accumulators (before the bf16 store): against the
@@ -119,8 +127,8 @@ def test_conv_fwd_stem_c4(libs):
     wt[:, :, 7, :] = 0
     wt[..., 3] = 0
     y = torch.zeros(n, d.p, d.q, k, dtype=BF16)
-    rows = libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d))
-    stats = torch.zeros(2, rows, k)
+    rows = max(libs[0].tok_conv_fwd_stat_rows(ctypes.byref(d)), libs[1].tok_conv_fwd_stat_rows(d))
+    stats = torch.zeros(2 * rows * k)
     dv = both(libs, 'tok_conv_fwd', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
                                                f(x), f(wt), None, f(y), f(stats), None])
     assert relerr(dv[id(y)].float(), y.float()) < 4e-3
@@ -923,9 +931,13 @@ def test_fused_bn_finalize_equals_standalone(libs, case):
         torch.cuda.synchronize()
         res.append((y, mean, rstd, scale, shift, rm, rv, nbt))
     assert int(counters.abs().sum()) == 0
-    assert torch.equal(res[0][0], res[1][0]) and int(res[1][7]) == 1
+    assert int(res[1][7]) == 1
+    # same kernel on both paths -> same bits; where the plain launch rides the shared-window kernel (conv_win.hip sums the
+    # reduction chunk-major, the two-buffer kernel of the fused entry point tap-major) the outputs agree to bf16 rounding
+    same = torch.equal(res[0][0], res[1][0])
+    assert same or relerr(res[1][0].float(), res[0][0].float()) < 3e-3
     for a, b in zip(res[0][1:7], res[1][1:7]):
-        assert relerr(b, a) < 1e-6
+        assert relerr(b, a) < (1e-6 if same else 2e-3)
     # backward: dgrad of this conv completing d(x) for a producer BatchNorm over x's channels
     if c % 8 == 0:
         y, mean_k = res[0][0], None
@@ -952,9 +964,10 @@ def test_fused_bn_finalize_equals_standalone(libs, case):
             torch.cuda.synchronize()
             out.append((dx, dg, db, coef))
         assert int(counters.abs().sum()) == 0
-        assert torch.equal(out[0][0], out[1][0])
+        same = torch.equal(out[0][0], out[1][0])
+        assert same or relerr(out[1][0].float(), out[0][0].float()) < 3e-3
         for a, b in zip(out[0][1:], out[1][1:]):
-            assert relerr(b, a) < 1e-5
+            assert relerr(b, a) < (1e-5 if same else 5e-3)
 
 
 @pytest.mark.parametrize('rows,classes,ld,mode,log_loss,sel', [(5000, 19, 24, 0, 0, None), (777, 5, 8, 0, 1, [0, 3]),

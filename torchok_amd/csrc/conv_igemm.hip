@@ -25,75 +25,11 @@
 // the stores drain (the small-K layers of ResNet are a streaming problem, not a GEMM problem).
 // Staging: global -> registers -> LDS (two buffers, one barrier per K step), 16-byte
 // XOR-swizzled slots so every ds_read_b128 of a fragment is bank-conflict free.
-#include "tok_common.h"
+#include "conv_common.h"
 #include "pw_gemm.h"
 #include <stdlib.h>
 
 namespace {
-
-struct FastDiv {
-  uint32_t mul, shift;
-};
-FastDiv make_fastdiv(uint32_t d) {
-  FastDiv f;
-  if (d <= 1) { f.mul = 0; f.shift = 0; return f; }
-  uint32_t l = 0;
-  while ((1ull << l) < d) ++l;
-  f.mul = (uint32_t)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
-  f.shift = l;
-  return f;
-}
-__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
-  return (uint32_t)(((uint64_t)__umulhi(n, f.mul) + n) >> f.shift);
-}
-
-struct ConvArgs {
-  const bf16* x;
-  const bf16* w;
-  bf16* y;
-  const float* bias;
-  float* stats;  // [2][stat_rows][K] or null
-  bf16* y2;                // PWM 3 forward: act(y) is stored here beside the pre-activation y (fc1 -> GELU)
-  const bf16* act_x;       // PWM 3 dgrad: pre-activation of the tensor whose gradient is produced: dx = dy * act'(act_x)
-  int act;                 // 0 ReLU, 1 GELU (erf)
-  const bf16* bn_y;        // dgrad + BatchNorm-backward statistics: raw conv output of the unit that
-  const uint8_t* bn_mask;  // produced the tensor whose gradient this launch completes, and its ReLU bits
-  // PWM 4 forward ("unit 3": 1x1 conv whose BatchNorm scale / shift are known BEFORE the GEMM): the epilogue applies
-  // out = relu(acc * scale + shift + shortcut) and emits the ReLU bits; the pre-normalisation tensor is never stored
-  const float* ep_scale;
-  const float* ep_shift;
-  const bf16* ep_short;    // may be null: no residual term
-  uint8_t* ep_mask;
-  int ep_relu;
-  // dgrad completing the gradient of such a unit's output: the epilogue stores dz = relu_mask ? dx : 0 (what the unit's
-  // backward and its shortcut both want) and reduces sum(dz) into the statistics rows; bn_y is not needed
-  int mask_store;
-  int force_grid;          // > 0: persistent grid size decided by the caller (statistics rows sized for the ring kernel)
-  // pointwise dgrad on the ring whose result also takes the gradient of the stride-2 pixel subsample of the same tensor
-  // (tok_conv_dgrad_subacc): dx[b][h][w] = acc + (h, w even ? sub[b][h/2][w/2] : 0)
-  const bf16* sub;
-  int H, W, C;   // gathered tensor
-  int K;         // output channels (padded count of y)
-  int R, S;      // S = stored filter width (s_pad)
-  int P, Q;      // output spatial
-  int stride, pad;
-  int M, PQ, Ktot, KT;
-  int gridM, gridN;
-  int accumulate, uniform_taps;
-  uint32_t x_bytes, w_bytes;   // extents of x / w for the buffer descriptors (< 4 GiB)
-  uint32_t s_bytes;            // BNEP: extent of the shortcut tensor
-  FastDiv fd_pq, fd_q;
-  unsigned long long* timing;   // TOK_TIMING builds only: per-phase cycle totals of wave 0
-  int stat_rows;   // workgroups per channel tile = rows of the partial-statistics buffer
-  // fused BatchNorm finalize: the LAST workgroup of a channel tile to deliver its statistics row (device
-  // ticket counter) folds the rows of that tile — saves the separate finalize launch between two dependent
-  // kernels.  fin_mode 0: off, 1: forward (mean/rstd/scale/shift/running stats), 2: backward (dgamma/dbeta/coef)
-  int fin_mode;
-  tok_bn_fused fin;
-  // IN_DIV == 2: per parity class (ph*2 + pw); m-tile index = 4 * (tile inside class) + class
-  int cls_M[4], cls_nw[4], cls_hw[4];
-  FastDiv cls_fd_hw[4], cls_fd_w[4];
-};
 
 constexpr int BK = 64;
 #ifdef TOK_NO_FRAG_ASM
@@ -1012,6 +948,20 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   const int gridM = tok_cdiv((long long)d->n * d->p * d->q, 128);
   const int bn_tile = pick_bn(d->k, d->r * d->s_pad * d->c, gridM, d->h == 1 && d->w == 1);
   const int gridN = tok_cdiv(d->k, bn_tile);
+  if (d->c != 4) {
+    ConvArgs g = {};
+    g.C = d->c; g.K = d->k; g.Ktot = d->r * d->s_pad * d->c; g.M = d->n * d->p * d->q;
+    g.H = d->h; g.W = d->w; g.P = d->p; g.Q = d->q; g.R = d->r; g.S = d->s_pad; g.stride = d->stride; g.pad = d->pad;
+    const unsigned long long xb = (unsigned long long)d->n * d->h * d->w * d->c * 2;
+    g.x_bytes = xb < 0xFFFFFFF0ull ? (uint32_t)xb : 0xFFFFFFF0u;
+    if (conv_win_serves(g)) {
+      int gm, gn;
+      conv_win_tiles(g, &gm, &gn);
+      return conv_win_grid(gm, gn) / gn;
+    }
+    if (bn_tile == 128 && conv_ring_serves(g, false))
+      return conv_ring_grid(tok_cdiv(g.M, 256), tok_cdiv(d->k, 128)) / tok_cdiv(d->k, 128);
+  }
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c != 4 && pw_serves(bn_tile, (long long)d->n * d->p * d->q, d->c, d->k))
     return pw_ring_grid(bn_tile, gridM, gridN) / gridN;
   return plan_grid(bn_tile, gridM, gridN) / gridN;
@@ -1075,7 +1025,24 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
   int rc;
-  if (ep != nullptr || pick_bn(d->k, a.Ktot, a.gridM, d->h == 1 && d->w == 1) == 64) {   // (BN epilogue: 64-wide tiles)
+  const int bn_pick = pick_bn(d->k, a.Ktot, a.gridM, d->h == 1 && d->w == 1);
+  if (!c4 && ep == nullptr && conv_win_serves(a)) {
+    // 3x3 / stride 1 / padding 1: shared input window in LDS (conv_win.hip)
+    rc = conv_win_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH("tok_conv_fwd");
+    return TOK_OK;
+  }
+  if (!c4 && ep == nullptr && bn_pick == 128 && conv_ring_serves(a, false)) {
+    // deep-K layers: 256 x 128 tiles on the three-stage DMA ring (conv_ring.hip)
+    a.gridM = tok_cdiv(a.M, 256);
+    a.gridN = tok_cdiv(d->k, 128);
+    rc = conv_ring_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH("tok_conv_fwd");
+    return TOK_OK;
+  }
+  if (ep != nullptr || bn_pick == 64) {   // (BN epilogue: 64-wide tiles)
     a.gridN = tok_cdiv(d->k, 64);
     rc = c4 ? launch<128, 64, 1, true>(a, st) : launch<128, 64, 1, false>(a, st);
   } else {
@@ -1152,6 +1119,20 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
   }
   hipStream_t st = tok_stream(stream);
   int rc;
+  if (d->stride == 1 && conv_win_serves(a)) {
+    rc = conv_win_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH(who);
+    return TOK_OK;
+  }
+  if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false)) {
+    a.gridM = tok_cdiv(a.M, 256);
+    a.gridN = tok_cdiv(d->c, 128);
+    rc = conv_ring_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH(who);
+    return TOK_OK;
+  }
   if (pl.bn_tile == 64) rc = d->stride == 1 ? launch<128, 64, 1, false>(a, st) : launch<128, 64, 2, false>(a, st);
   else rc = d->stride == 1 ? launch<128, 128, 1, false>(a, st) : launch<128, 128, 2, false>(a, st);
   if (rc) return rc;
@@ -1183,6 +1164,13 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
   ConvArgs a = {};
   DgradPlan pl;
   if (dgrad_fill(d, a, pl)) return TOK_ERR_INVALID;
+  if (d->stride == 1 && conv_win_serves(a)) {
+    int gm, gn;
+    conv_win_tiles(a, &gm, &gn);
+    return conv_win_grid(gm, gn) / gn;
+  }
+  if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false))
+    return conv_ring_grid(tok_cdiv(a.M, 256), tok_cdiv(d->c, 128)) / tok_cdiv(d->c, 128);
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c))
     return pw_ring_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;
   return plan_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;

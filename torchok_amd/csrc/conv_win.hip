@@ -1,0 +1,460 @@
+// 3x3 / stride 1 / padding 1 convolution (forward, and data gradient = the same kernel on the tap-flipped transposed pack)
+// on a SHARED INPUT WINDOW in LDS (gfx950).
+//
+// What bounds the implicit-GEMM kernels on these layers is not the MFMA pipe and not HBM but the path from L2 into the CU:
+// the vector-memory front end delivers ~40 B/clk/CU (tools/ubench/dma_rate.hip: 36-43), and a 128 x 128 x 64 K step stages
+// 32 KB for 512 MFMA cycles = 64 B/clk at the matrix peak (256 x 128: 48).  conv_igemm.hip / conv_ring.hip stage the
+// activation tile once PER TAP — nine copies of (almost) the same pixels (probe: with one of four activation DMA rows real,
+// conv_ring runs 1.2-1.3x faster; profiles/r03_ring_probe.txt).  Here a workgroup owns a 2-D patch of TH x TW = 256 output
+// pixels x 128 output channels and keeps, per 32-channel chunk, the (TH + 2) x (TW + 2) input window in LDS ONCE; the nine
+// taps read their MFMA B fragments from it at shifted pixel offsets.  Staged bytes per 32-channel chunk: window ~25 KB +
+// weights 9 x 8 KB = 97 KB instead of 9 x 24 KB = 216 KB (21 B/clk at the matrix peak), DMA instructions per thread and
+// stage 3 instead of 6.
+//
+//   * tile = TH consecutive rows of the FLATTENED (image, row) axis x TW columns (TW in {16, 32, 64}, TH = 256 / TW): maps
+//     narrower than TW waste the tail columns (14 of 16, 28 of 32, 56 of 64 = 87.5 % on ResNet's maps), wide maps (HRNet) are
+//     walked in x-tiles whose halo columns are real neighbours.  A tile may span several images: a tap row outside the image
+//     (top tap of row 0, bottom tap of row H-1) is SKIPPED per 16-pixel fragment (all pixels of a fragment share a row: the
+//     branch is wave-uniform), the window itself holds the neighbouring image's rows for the fragments that want them.
+//   * stage = (32-channel chunk, tap): one 128 x 32 weight tile (8 KB) on a three-slot ring + one 1-KB piece of the NEXT
+//     chunk's window (two window buffers).  A stage issues two weight DMA instructions per thread plus, at taps 0..6, one
+//     window piece (out-of-range offsets return zeros without traffic): the counted `s_waitcnt vmcnt(2 | 3)` + raw s_barrier
+//     per unrolled tap is exact; two stages stay in flight.
+//     The nine taps are unrolled: ring slot, tap offsets and the window-piece schedule are compile-time constants and a
+//     fragment address is ONE lane-constant base register plus an immediate.
+//   * the window image is lane-linear (pixel p at p * 64 B, no swizzle): a ds_read_b128 of 16 consecutive pixels is 2-way
+//     bank-conflicted (8 LDS cycles instead of 4; 640 of the 1024 MFMA cycles of a stage pair per CU) — cheaper than the
+//     nine VALU instructions per read a swizzle that survives arbitrary pixel shifts would cost.  Weight rows keep
+//     conv_ring.hip's conflict-free XOR swizzle (applied to the DMA source chunk).
+//   * 4 waves = 2 (pixel rows) x 2 (64 channels): a wave owns 128 pixels x 64 channels (128 accumulator registers), weights
+//     are the MFMA A operand (16-byte NHWC stores), persistent XCD-aware tile walk, BatchNorm partial sums folded per tile
+//     into two registers, epilogue options as conv_ring.hip.  80 KB of LDS: two workgroups per CU.
+#include "conv_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int WBN = 128, WBK = 32;
+constexpr int W_STAGE = WBN * WBK * 2;            // 8 KB: one tap's weight tile
+constexpr int WIN_PIECES = 28;                    // 1-KB DMA pieces per window buffer (4 waves x 7 slots)
+constexpr int WIN_BUF = WIN_PIECES * 1024;        // 28 KB >= (TH + 2)(TW + 2) pixels x 64 B for every TW
+constexpr int WIN_SMEM = 3 * W_STAGE + 2 * WIN_BUF;   // 80 KB
+
+__device__ __forceinline__ int win_f(int q) { return (0x78 >> ((q & 3) << 1)) & 3; }   // {0, 2, 3, 1}
+
+template <int OFF>
+__device__ __forceinline__ u32x4 wlds16(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+
+struct WinGeo {
+  int BH;            // B * H: rows of the flattened (image, row) axis
+  int XT;            // x-tiles per row group
+  FastDiv fd_xt, fd_h;
+};
+
+template <int TW>
+__global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo) {
+  constexpr int TH = 256 / TW;
+  constexpr int WW = TW + 2;                      // window pitch in pixels
+  constexpr int WIN_PX = (TH + 2) * WW;
+  static_assert(WIN_PX * 64 <= WIN_BUF, "window does not fit its buffer");
+  constexpr int MT = 8;
+  constexpr int SEGS = TW / 16;                   // 16-pixel fragments per tile row
+  constexpr int WROWS_PER_WAVE = TH / 2;          // tile rows of a wave
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;     // [3 weight stages][2 window buffers]
+  constexpr int WIN0 = 3 * W_STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wn = wv & 1;
+  const int wm = wv >> 1;
+  const int kc = tid & 3;
+  const int lrow = tid >> 2;                      // 0..63
+  const int kcW = kc ^ win_f(lrow >> 3);          // logical chunk of this thread's weight rows
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+  const int bn_fixed = jx % a.gridN, jm = jx / a.gridN;
+  const int S8 = (gridDim.x >> 3) / a.gridN;
+  const int sweep = 8 * S8;
+  const int n0 = bn_fixed * WBN;
+  const int it0 = xcd * S8 + jm;
+  const int ntiles = it0 < a.gridM ? (a.gridM - it0 + sweep - 1) / sweep : 0;
+  const int NC = (a.C + WBK - 1) / WBK;           // 32-channel chunks
+  const int nchunks = ntiles * NC;
+  const int C2 = a.C * 2;                         // pixel pitch of the gathered tensor in bytes
+
+  // ---- window loader: byte offsets (pixel part) of this thread's seven window pieces, for the tile of the NEXT chunk -----
+  int winoff[7];
+  auto setup_window = [&](int it) {
+    // tile it -> (row group, x-tile)
+    const uint32_t rg = fdiv((uint32_t)it, geo.fd_xt);
+    const int xt = it - (int)rg * geo.XT;
+    const int gy0 = (int)rg * TH - 1, gx0 = xt * TW - 1;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int wp = 16 * (j * 4 + wave_u) + (lane >> 2);
+      const int wr = wp / WW, wx = wp - wr * WW;
+      const int gy = gy0 + wr, gx = gx0 + wx;
+      const bool ok = it < a.gridM && wp < WIN_PX && (unsigned)gy < (unsigned)geo.BH && (unsigned)gx < (unsigned)a.W;
+      winoff[j] = ok ? (int)(((uint32_t)gy * (uint32_t)a.W + (uint32_t)gx) * (uint32_t)C2) + kc * 16 : -1;
+    }
+  };
+  // piece j of the window of chunk cc into buffer `wb`
+  auto issue_window = [&](int j, int cc, int wb) {
+    const bool cok = cc * WBK + kc * 8 < a.C;
+    uint32_t off = (winoff[j] >= 0 && cok) ? (uint32_t)(winoff[j] + cc * (WBK * 2)) : 0xFFFFFFF0u;
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(smem + WIN0 + wb * WIN_BUF + (j * 4 + wave_u) * 1024), 16, off, 0, 0,
+                                             0);
+  };
+  // weight tile of (chunk cc, tap) into ring slot `slot`
+  const int wrow_off0 = (n0 + lrow) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
+  const bool wrow_ok0 = n0 + lrow < a.K, wrow_ok1 = n0 + lrow + 64 < a.K;
+  auto issue_weights = [&](int slot, int cc, int tap, bool live) {
+    const int kch = cc * WBK + kcW * 8;
+    const bool kok = live && kch < a.C;
+    const int koff = (tap * a.C + kch) * 2;
+    char* Wdst = smem + slot * W_STAGE + wave_u * 1024;
+    uint32_t o0 = (kok && wrow_ok0) ? (uint32_t)(wrow_off0 + koff) : 0xFFFFFFF0u;
+    uint32_t o1 = (kok && wrow_ok1) ? (uint32_t)(wrow_off1 + koff) : 0xFFFFFFF0u;
+    asm volatile("" : "+v"(o0));
+    asm volatile("" : "+v"(o1));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)Wdst, 16, o0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + 4096), 16, o1, 0, 0, 0);
+  };
+
+  // ---- fragment addressing ---------------------------------------------------------------------------------------------
+  const int sl = lane >> 4;
+  const int li = lane & 15;
+  const int wrow0 = wn * 64 + (li >> 2) * 8 + (li & 3);
+  const uint32_t wfrag = lds_base + (uint32_t)(wrow0 * 64 + ((sl ^ win_f(li >> 2)) << 4));   // + slot * W_STAGE + row imm
+  // window: pixel (wave's first row + row + r) * WW + seg * 16 + li + s, chunk sl; everything but the lane part is an immediate
+  uint32_t afrag = lds_base + WIN0 + (uint32_t)((wm * WROWS_PER_WAVE * WW + li) * 64 + sl * 16);   // window buffer 0
+
+  float s1r = 0.f, s2r = 0.f;
+  f32x4 acc[4][MT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // rows of this wave whose top / bottom tap falls outside their image (bit = row of the wave), for the tile being computed
+  uint32_t top_mask = 0, bot_mask = 0;
+  int gyC = 0, gxC = 0;                           // first output row (flattened) / column of the tile being computed
+  auto setup_compute = [&](int it) {
+    const uint32_t rg = fdiv((uint32_t)it, geo.fd_xt);
+    const int xt = it - (int)rg * geo.XT;
+    gyC = (int)rg * TH;
+    gxC = xt * TW;
+    uint32_t tm = 0, bm = 0;
+#pragma unroll
+    for (int rr = 0; rr < WROWS_PER_WAVE; ++rr) {
+      const int gy = gyC + wm * WROWS_PER_WAVE + rr;
+      const uint32_t b = fdiv((uint32_t)gy, geo.fd_h);
+      const int y = gy - (int)b * a.H;
+      tm |= (y == 0 ? 1u : 0u) << rr;
+      bm |= (y == a.H - 1 ? 1u : 0u) << rr;
+    }
+    top_mask = __builtin_amdgcn_readfirstlane(tm);
+    bot_mask = __builtin_amdgcn_readfirstlane(bm);
+  };
+
+  // one stage: tap (R, S) of the current chunk out of weight slot SLOT
+  auto compute = [&](auto tapc, auto slotc) {
+    constexpr int TAP = decltype(tapc)::value, SLOT = decltype(slotc)::value;
+    constexpr int R = TAP / 3, S = TAP % 3;
+    u32x4 wf[4], af[MT];
+    wf[0] = wlds16<SLOT * W_STAGE + 0 * 64>(wfrag);
+    wf[1] = wlds16<SLOT * W_STAGE + 4 * 64>(wfrag);
+    wf[2] = wlds16<SLOT * W_STAGE + 32 * 64>(wfrag);
+    wf[3] = wlds16<SLOT * W_STAGE + 36 * 64>(wfrag);
+#define TOK_AF(mt) af[mt] = wlds16<(((mt) / SEGS + R) * WW + ((mt) % SEGS) * 16 + S) * 64>(afrag)
+    TOK_AF(0); TOK_AF(1); TOK_AF(2); TOK_AF(3); TOK_AF(4); TOK_AF(5); TOK_AF(6); TOK_AF(7);
+#undef TOK_AF
+    const uint32_t skip = R == 0 ? top_mask : (R == 2 ? bot_mask : 0u);
+    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
+                                                             acc[t][mt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 4; mt < MT; ++mt) {
+      if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
+                                                             acc[t][mt], 0, 0, 0);
+    }
+  };
+
+  // epilogue of the tile being computed: lane (sl, li) holds channels nb + {0..7}, nb + 32 + {0..7} of pixel
+  // (gyC + wave row + mt / SEGS, gxC + (mt % SEGS) * 16 + li)
+  auto epilogue = [&]() {
+    const int nb = n0 + wn * 64 + sl * 8;
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const int n = nb + (c >> 3) * 32 + (c & 7);
+        const float bv = n < a.K ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
+      }
+    }
+    const bool want_old = a.accumulate != 0;
+    const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
+    const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
+    float s1[16], s2[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < MT; g += 2) {
+      bf16x8 pre_old[2][2], pre_y[2][2];
+      unsigned pre_bits[2][2];
+      size_t pix[2];
+      bool pok[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int mt = g + q;
+        const int gy = gyC + wm * WROWS_PER_WAVE + mt / SEGS, gx = gxC + (mt % SEGS) * 16 + li;
+        pok[q] = gy < geo.BH && gx < a.W;
+        pix[q] = (size_t)gy * a.W + gx;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const bool ok = pok[q] && nb + half * 32 + 8 <= a.K;
+          const size_t eoff = pix[q] * a.K + nb + half * 32;
+          pre_old[q][half] = (ok && want_old) ? ldg16(a.y + eoff) : zero8();
+          pre_y[q][half] = (ok && want_y) ? ldg16(a.bn_y + eoff) : zero8();
+          pre_bits[q][half] = (ok && want_bits) ? (unsigned)a.bn_mask[eoff >> 3] : 0xffu;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int mt = g + q;
+        if (!pok[q]) continue;
+        bf16* yp = a.y + pix[q] * a.K + nb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (nb + half * 32 + 8 > a.K) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = acc[half * 2 + (e >> 2)][mt][e & 3];
+          if (a.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bf2f(pre_old[q][half][e]);
+          }
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+          if (a.mask_store) {
+            const unsigned bits = pre_bits[q][half];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
+              s1[half * 8 + e] += bf2f(o[e]);
+            }
+          }
+          stg16(yp + half * 32, o);
+          if (a.stats != nullptr && !a.mask_store) {
+            if (a.bn_y != nullptr) {
+              const unsigned bits = pre_bits[q][half];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
+                s1[half * 8 + e] += dz;
+                s2[half * 8 + e] = fmaf(dz, bf2f(pre_y[q][half][e]), s2[half * 8 + e]);
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float r = bf2f(o[e]);
+                s1[half * 8 + e] += r;
+                s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
+              }
+            }
+          }
+        }
+      }
+    }
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        const int off = 8 >> step;
+        const int cnt = 8 >> step;
+        const bool up = (li & off) != 0;
+#pragma unroll
+        for (int j = 0; j < cnt; ++j) {
+          const float send1 = up ? s1[j] : s1[j + cnt];
+          const float send2 = up ? s2[j] : s2[j + cnt];
+          const float keep1 = up ? s1[j + cnt] : s1[j];
+          const float keep2 = up ? s2[j + cnt] : s2[j];
+          s1[j] = keep1 + __shfl_xor(send1, off, 64);
+          s2[j] = keep2 + __shfl_xor(send2, off, 64);
+        }
+      }
+      s1r += s1[0];
+      s2r += s2[0];
+    }
+  };
+
+  // ---- prologue: window of the first chunk (buffer 0), weight stages of its taps 0 and 1 ------------------------------------
+  setup_window(it0);
+#pragma unroll
+  for (int j = 0; j < 7; ++j) issue_window(j, 0, 0);
+  issue_weights(0, 0, 0, ntiles > 0);
+  issue_weights(1, 0, 1, ntiles > 0);
+  zero_acc();
+  if (ntiles > 0) setup_compute(it0);
+
+  // ---- chunk loop: nine unrolled stages ------------------------------------------------------------------------------------
+  int itC = it0, ccC = 0;                          // chunk being computed
+  int itN = it0, ccN = 0;                          // the chunk after it (its window is loaded during this iteration)
+  int wb = 0;                                      // window buffer of the chunk being computed
+  for (int ch = 0; ch < nchunks; ++ch) {
+    // next chunk
+    ccN = ccC + 1;
+    itN = itC;
+    const bool new_tile = ccN == NC;
+    if (new_tile) { ccN = 0; itN = itC + sweep; setup_window(itN); }
+    const bool liveN = ch + 1 < nchunks;
+
+#define TOK_STAGE(TAP)                                                                                                          \
+    {                                                                                                                           \
+      /* newer than this stage's data: what the previous stage issued (2 weight rows + a window piece at taps 0..6) */          \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((TAP == 0 || TAP == 8) ? 2 : 3) : "memory");                          \
+      __builtin_amdgcn_s_barrier();                                                                                             \
+      /* weights of stage + 2: taps 2..8 of this chunk, taps 0, 1 of the next one */                                            \
+      if (TAP + 2 < 9) issue_weights((TAP + 2) % 3, ccC, TAP + 2, true);                                                        \
+      else issue_weights((TAP + 2) % 3, ccN, TAP + 2 - 9, liveN);                                                               \
+      /* one piece of the next chunk's window into the other buffer (its last reader finished before this barrier) */          \
+      if (TAP < 7) issue_window(TAP, ccN, wb ^ 1);                                                                              \
+      compute(std::integral_constant<int, TAP>{}, std::integral_constant<int, TAP % 3>{});                                      \
+    }
+    TOK_STAGE(0) TOK_STAGE(1) TOK_STAGE(2) TOK_STAGE(3) TOK_STAGE(4) TOK_STAGE(5) TOK_STAGE(6) TOK_STAGE(7) TOK_STAGE(8)
+#undef TOK_STAGE
+
+    if (new_tile) {
+      epilogue();
+      zero_acc();
+      if (liveN) setup_compute(itN);
+    }
+    itC = itN;
+    ccC = ccN;
+    wb ^= 1;
+    afrag = wb ? afrag + WIN_BUF : afrag - WIN_BUF;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // ---- BatchNorm partial sums -> one row per workgroup --------------------------------------------------------------------
+  if (a.stats != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);     // [2][2][WBN]: the rings are drained
+    const int nl = wn * 64 + (li >> 3) * 32 + sl * 8 + (li & 7);
+    red[(0 * 2 + wm) * WBN + nl] = s1r;
+    red[(1 * 2 + wm) * WBN + nl] = s2r;
+    __syncthreads();
+    if (tid < 2 * WBN) {
+      const int which = tid / WBN;
+      const int c = tid - which * WBN;
+      const float t = red[(which * 2 + 0) * WBN + c] + red[(which * 2 + 1) * WBN + c];
+      const int row = xcd * S8 + jm;
+      const int n = n0 + c;
+      if (n < a.K) a.stats[((size_t)which * a.stat_rows + row) * a.K + n] = t;
+    }
+  }
+}
+
+int win_flag() {   // TOK_CONV_WIN=0: 3x3 layers stay on the implicit-GEMM kernels (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_CONV_WIN"); v = e ? atoi(e) : 1; }
+  return v;
+}
+int win_min_tiles() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("TOK_CONV_WIN_MIN_TILES"); v = e ? atoi(e) : 200; }
+  return v;
+}
+
+int pick_tw(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
+
+}  // namespace
+
+// geometry of the 3x3 window kernel for an (H x W, C -> K) layer over B images; gathered tensor = (B, H, W, C)
+bool conv_win_serves(const ConvArgs& a) {
+  if (!win_flag()) return false;
+  if (!(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1)) return false;
+  if (a.H != a.P || a.W != a.Q) return false;
+  if (a.C % 8 != 0 || a.K % 8 != 0 || a.K < 96 || a.C < 32) return false;
+  if (a.W < 12) return false;                       // 7 x 7 maps would use 7 of 16 columns
+  if (a.x_bytes >= 0x7FFFFFF0u) return false;       // window offsets are kept as non-negative ints
+  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
+  const int tw = pick_tw(a.W), th = 256 / tw;
+  const long long bh = (long long)(a.M / (a.H * a.W)) * a.H;
+  const long long tiles = ((bh + th - 1) / th) * ((a.W + tw - 1) / tw) * ((a.K + WBN - 1) / WBN);
+  return tiles >= win_min_tiles();
+}
+
+int conv_win_grid(int gridM, int gridN) {
+  const int unit = 8 * gridN;
+  int G = 512;                                    // two workgroups per CU
+  const long long need = (long long)gridM * gridN;
+  if (need < G) G = (int)((need + unit - 1) / unit) * unit;
+  G = G / unit * unit;
+  if (G < unit) G = unit;
+  return G;
+}
+
+// tile counts of a layer: gridM = row groups x x-tiles, gridN = 128-channel tiles
+void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN) {
+  const int tw = pick_tw(a.W), th = 256 / tw;
+  const long long bh = (long long)(a.M / (a.H * a.W)) * a.H;
+  *gridM = (int)(((bh + th - 1) / th) * ((a.W + tw - 1) / tw));
+  *gridN = (a.K + WBN - 1) / WBN;
+}
+
+int conv_win_launch(ConvArgs& a, hipStream_t st) {
+  const int tw = pick_tw(a.W), th = 256 / tw;
+  WinGeo g;
+  g.BH = (a.M / (a.H * a.W)) * a.H;
+  g.XT = (a.W + tw - 1) / tw;
+  g.fd_xt = make_fastdiv(g.XT);
+  g.fd_h = make_fastdiv(a.H);
+  conv_win_tiles(a, &a.gridM, &a.gridN);
+  (void)th;
+  const int grid = conv_win_grid(a.gridM, a.gridN);
+  a.stat_rows = grid / a.gridN;
+  static bool attr_set[3] = {false, false, false};
+  const int vi = tw == 16 ? 0 : (tw == 32 ? 1 : 2);
+  if (!attr_set[vi]) {
+    if (tw == 16) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
+    else if (tw == 32) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
+    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
+    attr_set[vi] = true;
+  }
+  if (tw == 16) hipLaunchKernelGGL((conv_win_kernel<16>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
+  else if (tw == 32) hipLaunchKernelGGL((conv_win_kernel<32>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
+  else hipLaunchKernelGGL((conv_win_kernel<64>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
+  return 0;
+}

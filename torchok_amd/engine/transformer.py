@@ -192,10 +192,11 @@ class _LinearNode(Node):
 
 
 # GELU / ReLU in the epilogues of the GEMMs around it (tok_conv_fwd_act / tok_conv_dgrad_act).  Bit-identical to the separate
-# launches and measured NEUTRAL on MI355X (SwinV2-T B=256: 29.0 vs 29.0 ms/step, DaViT-T 27.4 vs 27.1): the erf / exp
-# arithmetic of 128 values per lane stretches the GEMM epilogue by what the deleted passes cost (their reads were served by
-# the 256 MB Infinity Cache).  Off by default; TOK_FUSE_ACT=1 turns it on.
-FUSE_ACT = os.environ.get('TOK_FUSE_ACT', '0') == '1'
+# launches.  Round 2 measured it NEUTRAL with libm's erff / expf (SwinV2-T B=256: 29.0 vs 29.0 ms/step — ~55 VALU per element
+# stretched the epilogue by what the deleted passes cost); with the 14-instruction erf of tok_common.h (round 3) the fused form
+# wins: SwinV2-T 24.87 -> 24.59, DaViT-T 24.14 -> 23.95 ms/step, and 12 activation-sized tensor passes per block leave the
+# step's HBM traffic.  On by default; TOK_FUSE_ACT=0 restores the separate launches.
+FUSE_ACT = os.environ.get('TOK_FUSE_ACT', '1') == '1'
 DGRAD_FIRST = os.environ.get('TOK_DGRAD_FIRST', '0') == '1'   # measured neutral (SwinV2-T 24.98 vs 24.97, DaViT-T 24.33 vs 24.20 ms): off
 
 
