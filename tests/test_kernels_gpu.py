@@ -85,6 +85,8 @@ CONV_CASES = [
     (1, 40, 72, 96, 96, 3, 1, 1),      # 64-column tiles, two x-tiles (the second ragged), 96 of 128 channels
     (2, 56, 56, 64, 128, 3, 1, 1),
     (5, 13, 15, 40, 136, 3, 1, 1),     # C = 40: second chunk a quarter full; K = 136: second channel tile ragged
+    (2, 56, 56, 64, 64, 3, 1, 1),      # 64-channel form of the window kernel (4 x 1 waves): ResNet stage 1
+    (1, 40, 72, 48, 48, 3, 1, 1),      # HRNet-W48's high-resolution branch: 48 of 64 channels, C = 32 + 16
 ]
 
 

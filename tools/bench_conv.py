@@ -52,6 +52,16 @@ def swinv2t_linears(B):
     return out
 
 
+def hrnet_w48_convs(B):
+    """The 3x3 / stride-1 convolutions of HRNet-W48's four branches at 512x1024 input (BasicBlocks: 2 per block, 4 blocks per
+    module; modules 1 / 4 / 3 for stages 2 / 3 / 4) — the layers the shared-window kernel serves."""
+    out = []
+    for (h, w, c), cnt in (((128, 256, 48), 64), ((64, 128, 96), 64), ((32, 64, 192), 56), ((16, 32, 384), 24)):
+        for _ in range(cnt):
+            out.append(dict(name=f'b{c}', n=B, h=h, w=w, c=c, k=c, r=3, stride=1, pad=1))
+    return out
+
+
 def timeit(fn, iters=8, warm=2):
     for _ in range(warm):
         fn()
@@ -70,26 +80,28 @@ def main():
     ap.add_argument('--lib', default=None)
     ap.add_argument('--what', default='fwd,dgrad,wgrad')
     ap.add_argument('--batch', type=int, default=256)
-    ap.add_argument('--net', default='resnet50', choices=['resnet50', 'swinv2t'])
+    ap.add_argument('--net', default='resnet50', choices=['resnet50', 'swinv2t', 'hrnet_w48'])
     args = ap.parse_args()
     lib = _C.load_library(args.lib)
     what = args.what.split(',')
     st = torch.cuda.current_stream().cuda_stream
     shapes = OrderedDict()
-    for c in (resnet50_convs if args.net == 'resnet50' else swinv2t_linears)(args.batch):
-        key = (c['h'], c['c'], c['k'], c['r'], c['stride'])
+    nets = {'resnet50': resnet50_convs, 'swinv2t': swinv2t_linears, 'hrnet_w48': hrnet_w48_convs}
+    for c in nets[args.net](args.batch):
+        key = (c['h'], c['w'], c['c'], c['k'], c['r'], c['stride'])
         shapes.setdefault(key, [c, 0])
         shapes[key][1] += 1
     totals = {w: 0.0 for w in what}
     ideal = {w: 0.0 for w in what}
-    print(f'{"shape(h,c,k,r,s)":>24} {"cnt":>3} ' + ' '.join(f'{w + "_us":>9} {"GB/s":>6} {"TF/s":>6}' for w in what))
+    print(f'{"shape(h,w,c,k,r,s)":>28} {"cnt":>3} ' + ' '.join(f'{w + "_us":>9} {"GB/s":>6} {"TF/s":>6}' for w in what))
     for key, (c, cnt) in shapes.items():
         n, h, w_, cin, k, r, stride, pad = c['n'], c['h'], c['w'], c['c'], c['k'], c['r'], c['stride'], c['pad']
         p = (h + 2 * pad - r) // stride + 1
+        q = (w_ + 2 * pad - r) // stride + 1
         s_pad = 8 if cin == 4 else r
-        d = _C.ConvDesc(n, h, w_, cin, k, r, r, p, p, stride, pad, s_pad)
+        d = _C.ConvDesc(n, h, w_, cin, k, r, r, p, q, stride, pad, s_pad)
         x = torch.randn(n, h, w_, cin, device='cuda').to(BF16)
-        y = torch.randn(n, p, p, k, device='cuda').to(BF16)
+        y = torch.randn(n, p, q, k, device='cuda').to(BF16)
         wf = (torch.randn(k, r, s_pad, cin, device='cuda') * 0.05).to(BF16)
         wd = (torch.randn(cin, r, r, k, device='cuda') * 0.05).to(BF16) if cin != 4 else None
         rows = lib.tok_conv_fwd_stat_rows(ctypes.byref(d))
@@ -98,7 +110,7 @@ def main():
         wsb = lib.tok_conv_wgrad_ws_bytes(ctypes.byref(d))
         ws = torch.empty(max(wsb // 4, 16), device='cuda')
         xb, yb = x.numel() * 2, y.numel() * 2
-        flops = 2.0 * n * p * p * k * r * r * (3 if cin == 4 else cin)
+        flops = 2.0 * n * p * q * k * r * r * (3 if cin == 4 else cin)
         cols = []
         for wname in what:
             if wname == 'fwd':
@@ -116,7 +128,7 @@ def main():
             totals[wname] += us * cnt
             ideal[wname] += max((xb + yb) / 5.5e12, flops / 1.0e15) * 1e6 * cnt
             cols.append(f'{us:9.1f} {(xb + yb) / us / 1e3:6.0f} {flops / us / 1e6:6.0f}')
-        print(f'{str(key):>24} {cnt:3d} ' + ' '.join(cols))
+        print(f'{str(key):>28} {cnt:3d} ' + ' '.join(cols))
     for wname in what:
         print(f'{wname}: {totals[wname] / 1e3:.3f} ms/step   (bound max(5.5 TB/s, 1 PF/s): {ideal[wname] / 1e3:.3f} ms)')
 

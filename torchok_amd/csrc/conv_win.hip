@@ -29,17 +29,18 @@
 //   * 4 waves = 2 (pixel rows) x 2 (64 channels): a wave owns 128 pixels x 64 channels (128 accumulator registers), weights
 //     are the MFMA A operand (16-byte NHWC stores), persistent XCD-aware tile walk, BatchNorm partial sums folded per tile
 //     into two registers, epilogue options as conv_ring.hip.  80 KB of LDS: two workgroups per CU.
+//     (s_setprio(1) around the MFMA clusters: measured neutral to -3 % — the two waves of a SIMD belong to different
+//     workgroups at unrelated phases; not kept.)
 #include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
-constexpr int WBN = 128, WBK = 32;
-constexpr int W_STAGE = WBN * WBK * 2;            // 8 KB: one tap's weight tile
+constexpr int WBK = 32;
 constexpr int WIN_PIECES = 28;                    // 1-KB DMA pieces per window buffer (4 waves x 7 slots)
 constexpr int WIN_BUF = WIN_PIECES * 1024;        // 28 KB >= (TH + 2)(TW + 2) pixels x 64 B for every TW
-constexpr int WIN_SMEM = 3 * W_STAGE + 2 * WIN_BUF;   // 80 KB
+constexpr int win_smem(int bn) { return 3 * bn * WBK * 2 + 2 * WIN_BUF; }   // 80 KB (128 channels) / 68 KB (64)
 
 __device__ __forceinline__ int win_f(int q) { return (0x78 >> ((q & 3) << 1)) & 3; }   // {0, 2, 3, 1}
 
@@ -56,15 +57,21 @@ struct WinGeo {
   FastDiv fd_xt, fd_h;
 };
 
-template <int TW>
+// BN = 128: 2 (pixel rows) x 2 (64 channels) waves of 128 pixels x 64 channels; BN = 64 (layers of <= 64 output channels: the
+// high-resolution HRNet branches, ResNet's first stage): 4 x 1 waves of 64 pixels x 64 channels.
+template <int TW, int WBN>
 __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo) {
+  constexpr int W_STAGE = WBN * WBK * 2;          // one tap's weight tile: 8 / 4 KB
+  constexpr int WGN = WBN / 64, WGM = 4 / WGN;
+  constexpr int WROWS = WBN / 64;                 // weight DMA instructions per thread and stage
   constexpr int TH = 256 / TW;
   constexpr int WW = TW + 2;                      // window pitch in pixels
   constexpr int WIN_PX = (TH + 2) * WW;
   static_assert(WIN_PX * 64 <= WIN_BUF, "window does not fit its buffer");
-  constexpr int MT = 8;
+  constexpr int MT = 256 / (WGM * 16);            // 16-pixel fragments per wave: 8 / 4
   constexpr int SEGS = TW / 16;                   // 16-pixel fragments per tile row
-  constexpr int WROWS_PER_WAVE = TH / 2;          // tile rows of a wave
+  constexpr int WROWS_PER_WAVE = TH / WGM;        // tile rows of a wave
+  static_assert(WROWS_PER_WAVE * SEGS == MT && WROWS_PER_WAVE >= 1, "wave tiling");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) char lds_char;
@@ -75,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = tid >> 6;
-  const int wn = wv & 1;
-  const int wm = wv >> 1;
+  const int wn = wv % WGN;
+  const int wm = wv / WGN;
   const int kc = tid & 3;
   const int lrow = tid >> 2;                      // 0..63
   const int kcW = kc ^ win_f(lrow >> 3);          // logical chunk of this thread's weight rows
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     asm volatile("" : "+v"(o0));
     asm volatile("" : "+v"(o1));
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)Wdst, 16, o0, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + 4096), 16, o1, 0, 0, 0);
+    if (WROWS == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, (lds_void*)(Wdst + 4096), 16, o1, 0, 0, 0);
   };
 
   // ---- fragment addressing ---------------------------------------------------------------------------------------------
@@ -184,13 +191,14 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     wf[2] = wlds16<SLOT * W_STAGE + 32 * 64>(wfrag);
     wf[3] = wlds16<SLOT * W_STAGE + 36 * 64>(wfrag);
 #define TOK_AF(mt) af[mt] = wlds16<(((mt) / SEGS + R) * WW + ((mt) % SEGS) * 16 + S) * 64>(afrag)
-    TOK_AF(0); TOK_AF(1); TOK_AF(2); TOK_AF(3); TOK_AF(4); TOK_AF(5); TOK_AF(6); TOK_AF(7);
+    TOK_AF(0); TOK_AF(1); TOK_AF(2); TOK_AF(3);
+    if constexpr (MT == 8) { TOK_AF(4); TOK_AF(5); TOK_AF(6); TOK_AF(7); }
 #undef TOK_AF
     const uint32_t skip = R == 0 ? top_mask : (R == 2 ? bot_mask : 0u);
-    asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT / 2) : "memory");      // weights + the first half of the pixel tiles
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT / 2; ++mt) {
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -201,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 4; mt < MT; ++mt) {
+    for (int mt = MT / 2; mt < MT; ++mt) {
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -342,8 +350,8 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 
 #define TOK_STAGE(TAP)                                                                                                          \
     {                                                                                                                           \
-      /* newer than this stage's data: what the previous stage issued (2 weight rows + a window piece at taps 0..6) */          \
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((TAP == 0 || TAP == 8) ? 2 : 3) : "memory");                          \
+      /* newer than this stage's data: what the previous stage issued (the weight rows + a window piece at taps 0..6) */          \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((TAP == 0 || TAP == 8) ? WROWS : WROWS + 1) : "memory");                  \
       __builtin_amdgcn_s_barrier();                                                                                             \
       /* weights of stage + 2: taps 2..8 of this chunk, taps 0, 1 of the next one */                                            \
       if (TAP + 2 < 9) issue_weights((TAP + 2) % 3, ccC, TAP + 2, true);                                                        \
@@ -370,15 +378,17 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   // ---- BatchNorm partial sums -> one row per workgroup --------------------------------------------------------------------
   if (a.stats != nullptr) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);     // [2][2][WBN]: the rings are drained
+    float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
     const int nl = wn * 64 + (li >> 3) * 32 + sl * 8 + (li & 7);
-    red[(0 * 2 + wm) * WBN + nl] = s1r;
-    red[(1 * 2 + wm) * WBN + nl] = s2r;
+    red[(0 * WGM + wm) * WBN + nl] = s1r;
+    red[(1 * WGM + wm) * WBN + nl] = s2r;
     __syncthreads();
     if (tid < 2 * WBN) {
       const int which = tid / WBN;
       const int c = tid - which * WBN;
-      const float t = red[(which * 2 + 0) * WBN + c] + red[(which * 2 + 1) * WBN + c];
+      float t = 0.f;
+#pragma unroll
+      for (int w_ = 0; w_ < WGM; ++w_) t += red[(which * WGM + w_) * WBN + c];
       const int row = xcd * S8 + jm;
       const int n = n0 + c;
       if (n < a.K) a.stats[((size_t)which * a.stat_rows + row) * a.K + n] = t;
@@ -393,11 +403,23 @@ int win_flag() {   // TOK_CONV_WIN=0: 3x3 layers stay on the implicit-GEMM kerne
 }
 int win_min_tiles() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_WIN_MIN_TILES"); v = e ? atoi(e) : 200; }
+  if (v < 0) { const char* e = getenv("TOK_CONV_WIN_MIN_TILES"); v = e ? atoi(e) : 128; }
   return v;
 }
 
 int pick_tw(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
+int pick_wbn(int K) { return K <= 64 ? 64 : 128; }
+
+template <int TW, int BN>
+void launch_variant(const ConvArgs& a, const WinGeo& g, int grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<TW, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              win_smem(BN));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_win_kernel<TW, BN>), dim3(grid), dim3(256), win_smem(BN), st, a, g);
+}
 
 }  // namespace
 
@@ -406,14 +428,14 @@ bool conv_win_serves(const ConvArgs& a) {
   if (!win_flag()) return false;
   if (!(a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1)) return false;
   if (a.H != a.P || a.W != a.Q) return false;
-  if (a.C % 8 != 0 || a.K % 8 != 0 || a.K < 96 || a.C < 32) return false;
+  if (a.C % 8 != 0 || a.K % 8 != 0 || a.K < 32 || a.C < 32) return false;
+  if (a.K > 64 && a.K < 96) return false;          // 72 / 80 / 88 channels would leave 128-wide tiles a third empty
   if (a.W < 12) return false;                       // 7 x 7 maps would use 7 of 16 columns
   if (a.x_bytes >= 0x7FFFFFF0u) return false;       // window offsets are kept as non-negative ints
   if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
-  const int tw = pick_tw(a.W), th = 256 / tw;
-  const long long bh = (long long)(a.M / (a.H * a.W)) * a.H;
-  const long long tiles = ((bh + th - 1) / th) * ((a.W + tw - 1) / tw) * ((a.K + WBN - 1) / WBN);
-  return tiles >= win_min_tiles();
+  int gm, gn;
+  conv_win_tiles(a, &gm, &gn);
+  return (long long)gm * gn >= win_min_tiles();
 }
 
 int conv_win_grid(int gridM, int gridN) {
@@ -426,35 +448,32 @@ int conv_win_grid(int gridM, int gridN) {
   return G;
 }
 
-// tile counts of a layer: gridM = row groups x x-tiles, gridN = 128-channel tiles
+// tile counts of a layer: gridM = row groups x x-tiles, gridN = channel tiles (128 wide; 64 for layers of <= 64 channels)
 void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN) {
-  const int tw = pick_tw(a.W), th = 256 / tw;
+  const int tw = pick_tw(a.W), th = 256 / tw, bn = pick_wbn(a.K);
   const long long bh = (long long)(a.M / (a.H * a.W)) * a.H;
   *gridM = (int)(((bh + th - 1) / th) * ((a.W + tw - 1) / tw));
-  *gridN = (a.K + WBN - 1) / WBN;
+  *gridN = (a.K + bn - 1) / bn;
 }
 
 int conv_win_launch(ConvArgs& a, hipStream_t st) {
-  const int tw = pick_tw(a.W), th = 256 / tw;
+  const int tw = pick_tw(a.W), bn = pick_wbn(a.K);
   WinGeo g;
   g.BH = (a.M / (a.H * a.W)) * a.H;
   g.XT = (a.W + tw - 1) / tw;
   g.fd_xt = make_fastdiv(g.XT);
   g.fd_h = make_fastdiv(a.H);
   conv_win_tiles(a, &a.gridM, &a.gridN);
-  (void)th;
   const int grid = conv_win_grid(a.gridM, a.gridN);
   a.stat_rows = grid / a.gridN;
-  static bool attr_set[3] = {false, false, false};
-  const int vi = tw == 16 ? 0 : (tw == 32 ? 1 : 2);
-  if (!attr_set[vi]) {
-    if (tw == 16) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
-    else if (tw == 32) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, WIN_SMEM);
-    attr_set[vi] = true;
+  if (bn == 128) {
+    if (tw == 16) launch_variant<16, 128>(a, g, grid, st);
+    else if (tw == 32) launch_variant<32, 128>(a, g, grid, st);
+    else launch_variant<64, 128>(a, g, grid, st);
+  } else {
+    if (tw == 16) launch_variant<16, 64>(a, g, grid, st);
+    else if (tw == 32) launch_variant<32, 64>(a, g, grid, st);
+    else launch_variant<64, 64>(a, g, grid, st);
   }
-  if (tw == 16) hipLaunchKernelGGL((conv_win_kernel<16>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
-  else if (tw == 32) hipLaunchKernelGGL((conv_win_kernel<32>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
-  else hipLaunchKernelGGL((conv_win_kernel<64>), dim3(grid), dim3(256), WIN_SMEM, st, a, g);
   return 0;
 }
