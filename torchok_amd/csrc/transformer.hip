@@ -451,19 +451,29 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
   const int bg = blockIdx.x / (a.heads * a.nW);
   const int N = a.N;
   const int l15 = lane & 15, g = lane >> 4, qi = wv;
-  const float scale = a.plain ? 0.17677669529663687f : expf(fminf(logit_scale[h], 4.605170185988092f));
+  constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+  // logits in log2 units: exp(x) = exp2(x log2 e) on v_exp_f32 (one instruction; libm's expf is ~20)
+  const float scale = (a.plain ? 0.17677669529663687f : expf(fminf(logit_scale[h], 4.605170185988092f))) * LOG2E;
   // additive logit terms of this wave's query tile (position bias + shift mask; -inf on padding): loaded once per
-  // workgroup, reused for every image it walks.  element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15
+  // workgroup, reused for every image it walks.  element (reg, kj): query i = qi*16 + 4g + reg, key j = kj*16 + l15.
+  // Straight-line loads on clamped indices + selects (a branch per element costs one exposed L2 round trip each).
   float addt[4][4];
   {
     const float* bh = bias ? bias + (size_t)h * N * N : nullptr;
     const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
+    const bool any_add = bh != nullptr || mw != nullptr;
+    const float bsel = bh ? 1.f : 0.f, msel = mw ? 1.f : 0.f;
+    const float* bp = bh ? bh : mw;
+    const float* mp = mw ? mw : bp;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const int i = qi * 16 + 4 * g + reg, j = kj * 16 + l15;
-        addt[reg][kj] = (i < N && j < N) ? (bh ? bh[i * N + j] : 0.f) + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
+        const int idx = (i < N ? i : N - 1) * N + (j < N ? j : N - 1);
+        float v = 0.f;
+        if (any_add) v = (bsel * bp[idx] + msel * mp[idx]) * LOG2E;
+        addt[reg][kj] = (i < N && j < N) ? v : -INFINITY;
       }
   }
   for (int bb = 0; bb < bpw; ++bb) {
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       float sum = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
-        const float p = (i < N) ? expf(sc[kj][reg] - mx) : 0.f;
+        const float p = (i < N) ? __builtin_amdgcn_exp2f(sc[kj][reg] - mx) : 0.f;
         sc[kj][reg] = p;
         sum += p;
       }
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
-      if (i < N && l15 == 0) lse[unit * N + i] = rmax[reg] + logf(rsum[reg]);
+      if (i < N && l15 == 0) lse[unit * N + i] = (rmax[reg] + __builtin_amdgcn_logf(rsum[reg])) * LN2;   // natural-log units
     }
     __syncthreads();                     // before the next image overwrites q / k / v^T
   }
@@ -597,14 +607,27 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) dsa[reg][kj] = 0.f;
-  float addt[4][4];        // position bias + shift mask of this wave's query tile (-inf on padding), loaded once
+  // position bias + shift mask of this wave's query tile (-inf on padding), loaded once, in log2 units (P = exp2(..)): straight-
+  // line loads on clamped indices + selects — a branch per element puts an s_waitcnt (one L2 round trip) in front of each load
+  constexpr float LOG2E = 1.4426950408889634f;
+  float addt[4][4];
+  {
+    const bool any_add = bh != nullptr || mw != nullptr;
+    const float bsel = bh ? 1.f : 0.f, msel = mw ? 1.f : 0.f;
+    const float* bp = bh ? bh : mw;
+    const float* mp = mw ? mw : bp;
 #pragma unroll
-  for (int reg = 0; reg < 4; ++reg)
+    for (int reg = 0; reg < 4; ++reg)
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-      const int i = wv * 16 + 4 * g + reg, j = kj * 16 + l15;
-      addt[reg][kj] = (i < N && j < N) ? (bh ? bh[i * N + j] : 0.f) + (mw ? mw[i * N + j] : 0.f) : -INFINITY;
-    }
+      for (int kj = 0; kj < 4; ++kj) {
+        const int i = wv * 16 + 4 * g + reg, j = kj * 16 + l15;
+        const int idx = (i < N ? i : N - 1) * N + (j < N ? j : N - 1);
+        float v = 0.f;
+        if (any_add) v = (bsel * bp[idx] + msel * mp[idx]) * LOG2E;
+        addt[reg][kj] = (i < N && j < N) ? v : -INFINITY;
+      }
+  }
+  const float scale2 = scale * LOG2E;
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
     if (b >= a.B) break;                 // uniform for the workgroup
@@ -638,12 +661,12 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
-      const float li = i < N ? lse[unit * N + i] : 0.f;
+      const float li = i < N ? lse[unit * N + i] * LOG2E : 0.f;
       float p[4], dl = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const int j = kj * 16 + l15;
-        p[kj] = (i < N && j < N) ? expf(fmaf(sc[kj][reg], scale, addt[reg][kj]) - li) : 0.f;
+        p[kj] = (i < N && j < N) ? __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li) : 0.f;
         dl = fmaf(p[kj], dp[kj][reg], dl);
       }
 #pragma unroll
