@@ -19,6 +19,10 @@
  *    pads).  Convolution weights: bf16 [K][R][S][C] ("KRSC") for fwd, bf16 [C][R][S][K]
  *    spatially flipped for dgrad (tok_pack_weight_* produce both from the fp32 master).
  *    Statistics, gradients of parameters, optimizer state: fp32.
+ *  - No communication entry point: the data-parallel gradient exchange (SURVEY.md section 8(b) sketched an
+ *    ncclComm_t + stream + event call) stays on the host side of this boundary, in torchok_amd/dist/ddp.py over
+ *    torch.distributed (backend "nccl" = RCCL): buckets are contiguous ranges of the gradient arena this library writes
+ *    into, so the exchange needs no kernel of its own beyond tok_cast_f32_bf16 / tok_cast_bf16_f32 / tok_scale_f32.
  *  - Thread-safety: all entry points are re-entrant (PyTorch calls backward from an
  *    autograd worker thread); there is no global mutable state except the thread-local
  *    error string.

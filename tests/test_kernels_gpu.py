@@ -1307,6 +1307,36 @@ def test_bn_gram_finalize(libs, p, k):
     assert int(dv[id(nbt)].item()) == 1 and int(nbt.item()) == 1
 
 
+@pytest.mark.parametrize('p,k', [(64, 256), (256, 512)])
+def test_bn_gram_finalize_large_mean_channel(libs, p, k):
+    """an input channel with |mean| >> std (here mean 2, std 0.05 — bf16 storage leaves ~0.05 of spread —, 200 000 rows, Gram matrix in fp32) must not
+    lose the variance to E[y^2] - mean^2 cancellation: the kernel centres the Gram row in fp64 before the w products."""
+    m = 200000
+    g = torch.Generator().manual_seed(p + k)
+    z = (torch.randn(m, p, generator=g) * 0.05 + 2.0).to(BF16).float()
+    Z = (z.t() @ z)                                             # fp32 accumulation, as the weight-gradient launch leaves it
+    zsum = z.double().sum(0).float()
+    w = rnd(k, p, scale=p ** -0.5, seed=2)
+    gamma, beta = torch.ones(k), torch.zeros(k)
+    rm, rv = torch.zeros(k), torch.ones(k)
+    nbt = torch.zeros(1, dtype=torch.int64)
+    mean, rstd, scale, shift = (torch.zeros(k, device=DEV) for _ in range(4))
+    wz = torch.zeros(k, p, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    d = lambda t: t.to(DEV)  # noqa: E731
+    Zd, zd, wd, gd, bd, rmd, rvd, nd = d(Z), d(zsum), d(w), d(gamma), d(beta), d(rm), d(rv), d(nbt)
+    assert libs[0].tok_bn_gram_finalize(Zd.data_ptr(), zd.data_ptr(), wd.data_ptr(), m, p, k, gd.data_ptr(), bd.data_ptr(),
+                                        rmd.data_ptr(), rvd.data_ptr(), nd.data_ptr(), 0.1, 1e-5, mean.data_ptr(),
+                                        rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), wz.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    y = z.double() @ w.to(BF16).double().t()                    # what the unit's GEMM produces, exactly
+    var = y.var(0, unbiased=False)
+    want = 1.0 / torch.sqrt(var + 1e-5)
+    # fp32 Gram entries carry ~1e-7 relative noise on 1600 * m; after centring, the variance (~0.05^2 |w|^2) survives
+    assert relerr(rstd.cpu().double(), want) < 5e-2
+    assert float(rstd.max()) < 0.5 / (1e-5 ** 0.5)             # nowhere near the clamp value 1 / sqrt(eps)
+
+
 @pytest.mark.parametrize('decoupled', [0, 1])
 def test_adam_capturable(libs, decoupled):
     """Device-side step count: three successive launches + tok_step_advance equal the host-step kernel (and torch's update

@@ -967,6 +967,8 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
   return plan_grid(bn_tile, gridM, gridN) / gridN;
 }
 
+extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d);
+
 namespace {
 int check_fused(const tok_bn_fused* bn, int k, bool fwd, const char* who) {
   TOK_CHECK_ARG(bn->counters && bn->count > 0 && bn->c_real > 0 && bn->c_real <= k && bn->gamma && bn->mean && bn->rstd,
@@ -1041,6 +1043,13 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
     if (rc) return rc;
     TOK_CHECK_LAUNCH("tok_conv_fwd");
     return TOK_OK;
+  }
+  if (a.fin_mode != 0) {
+    // "last workgroup finalizes" stays on this file's kernels; the caller sized `stats` with tok_conv_fwd_stat_rows, which may
+    // describe the (smaller) grid of conv_win / conv_ring: never write more rows than that
+    const int rows_q = tok_conv_fwd_stat_rows(d);
+    const int gn = tok_cdiv(d->k, bn_pick);
+    if (rows_q > 0 && rows_q * gn < plan_grid(bn_pick, a.gridM, gn)) a.force_grid = rows_q * gn;
   }
   if (ep != nullptr || bn_pick == 64) {   // (BN epilogue: 64-wide tiles)
     a.gridN = tok_cdiv(d->k, 64);
@@ -1132,6 +1141,10 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     if (rc) return rc;
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
+  }
+  if (a.fin_mode != 0) {
+    const int rows_q = tok_conv_dgrad_stat_rows(d);
+    if (rows_q > 0 && rows_q * pl.gridN < plan_grid(pl.bn_tile, pl.gridM, pl.gridN)) a.force_grid = rows_q * pl.gridN;
   }
   if (pl.bn_tile == 64) rc = d->stride == 1 ? launch<128, 64, 1, false>(a, st) : launch<128, 64, 2, false>(a, st);
   else rc = d->stride == 1 ? launch<128, 128, 1, false>(a, st) : launch<128, 128, 2, false>(a, st);

@@ -160,25 +160,38 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_block_kernel(
     float* __restrict__ running_var, int64_t* __restrict__ nbt, float momentum, float eps, float* __restrict__ mean,
     float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ float red[256];
+  __shared__ double cred[256];
   __shared__ double dred[2][4];
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int p = tid % P, sl = tid / P;
   const int slices = 256 / P, qper = P / slices;
   const float* wk = w + (size_t)k * P;
+  // T_k = w_k Z in fp32 (an operand of the backward products) and, beside it, the CENTRED row w_k (Z - zsum zsum^T / M) in
+  // fp64: var_k = w_k^T (Z / M - mu mu^T) w_k from E[y^2] - mean^2 cancels catastrophically for a channel with |mean| >> std
+  // (fp32 Z over ~1e6 rows), and a negative result clamped to 0 would make rstd 1 / sqrt(eps)
   float acc = 0.f;
+  double accc = 0.0;
+  const double inv_m = 1.0 / (double)count;
+  const double zp = (double)zsum[p] * inv_m;
   const int q0 = sl * qper;
-#pragma unroll 8
-  for (int q = q0; q < q0 + qper; ++q) acc = fmaf(round_bf16(wk[q]), Z[(size_t)q * P + p], acc);
+#pragma unroll 4
+  for (int q = q0; q < q0 + qper; ++q) {
+    const float wq = round_bf16(wk[q]), z = Z[(size_t)q * P + p];
+    acc = fmaf(wq, z, acc);
+    accc += (double)wq * ((double)z - (double)zsum[q] * zp);
+  }
   red[tid] = acc;
+  cred[tid] = accc;
   __syncthreads();
   double e2 = 0.0, m = 0.0;
   if (sl == 0) {
     float t = red[p];
-    for (int s_ = 1; s_ < slices; ++s_) t += red[s_ * P + p];
+    double tc = cred[p];
+    for (int s_ = 1; s_ < slices; ++s_) { t += red[s_ * P + p]; tc += cred[s_ * P + p]; }
     T[(size_t)k * P + p] = t;
     const double wq = (double)round_bf16(wk[p]);
-    e2 = (double)t * wq;
+    e2 = tc * wq;                     // centred: sums to M * var_k
     m = wq * (double)zsum[p];
   }
 #pragma unroll
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_block_kernel(
     m = dred[1][0] + dred[1][1] + dred[1][2] + dred[1][3];
     const double inv = 1.0 / (double)count;
     m *= inv;
-    double var = e2 * inv - m * m;
+    double var = e2 * inv;
     if (var < 0.0) var = 0.0;
     const float muf = (float)m;
     const float rs = (float)(1.0 / sqrt(var + (double)eps));

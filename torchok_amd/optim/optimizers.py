@@ -62,8 +62,10 @@ class _ArenaOptimizer(Optimizer):
         """torch's loader leaves stand-alone copies of the state tensors in `self.state`; the step kernels read the
         arena slots, so the loaded moments are copied there and `self.state` is re-pointed at the slots."""
         super().load_state_dict(state_dict)
-        self._built = False
-        self._ensure_built()
+        self._built = False      # re-homed (and the loaded moments copied into the arena slots) by the next step() / begin_step():
+        #                          loading before .cuda() is legal, as with torch.optim
+        if all(p.is_cuda for g in self.param_groups for p in g['params']):
+            self._ensure_built()
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -179,17 +181,18 @@ class _AdamBase(_ArenaOptimizer):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, maximize=maximize,
                         capturable=bool(capturable))
         super().__init__(params, defaults)
-        self._step_dev = {}      # id(arena) -> int64 device scalar: steps already taken (capturable groups)
 
     def _arena_step(self, arena, step_of):
         """Device step counter of a capturable group's arena, created from the (uniform) host-side step of its parameters."""
-        t = self._step_dev.get(id(arena))
+        # the counter lives ON the arena object: it disappears with the arena when parameters are re-homed (no stale entry
+        # under a recycled id()) and is re-seeded from state['step'] after unpickling / load_state_dict (ADVICE r02)
+        t = getattr(arena, '_step_dev', None)
         if t is None or t.device != arena.master.device:
             steps = {step_of(i) for i in range(len(arena.params))}
             if len(steps) > 1:
                 raise NotImplementedError('capturable Adam: the parameters of a group must share one step count')
             t = torch.full((1,), steps.pop() if steps else 0, dtype=torch.int64, device=arena.master.device)
-            self._step_dev[id(arena)] = t
+            arena._step_dev = t
         return t
 
     def _restore_state(self, old_state):
