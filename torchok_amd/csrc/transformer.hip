@@ -448,6 +448,26 @@ __device__ __forceinline__ float load_head_row(const bf16* __restrict__ src, boo
   return inv;
 }
 
+// the same in two halves, so that the NEXT image's rows can be in flight while the current one is computed
+__device__ __forceinline__ void load_head_raw(const bf16* __restrict__ src, bool valid, bf16x8 (&o)[4]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = valid ? ldg16(src + d * 8) : zero8();
+}
+__device__ __forceinline__ float finish_head_row(bool normalise, bf16x8 (&o)[4]) {
+  if (!normalise) return 1.f;
+  float f[HD], ss = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; d += 8)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f[d + e] = bf2f(o[d >> 3][e]); ss = fmaf(f[d + e], f[d + e], ss); }
+  const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int d = 0; d < HD; d += 8)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[d >> 3][e] = f2bf(f[d + e] * inv);
+  return inv;
+}
+
 __device__ __forceinline__ void put_row(bf16* rowmaj, bf16* trans, int t, const bf16x8 (&v)[4]) {
 #pragma unroll
   for (int d = 0; d < HD; d += 8) {
@@ -582,15 +602,44 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
   }
 }
 
-// Backward: recomputes P from (Qn, Kn, lse); dP = dO V^T on the same accumulator layout, dS = P (dP - delta) in
-// registers; dV = P^T dO, dKn = dS^T Qn, dQn = dS Kn through bf16 LDS staging; F.normalize backward on the
-// accumulators.  A workgroup walks `bpw` images of its (window, head) and sums d(logits) into ONE [N][N] scratch tile
-// (L2-resident read-modify-write by the owning lane), so the d(bias) scratch is bpw times smaller.
-constexpr int BW_ROWMAJ = 4 * 64 * QPITCH;            // qn, kn, v, dO (bf16 elements); later reused: dS, dS^T staging
-constexpr int BW_TRANS = 3 * 32 * PPITCH;             // Qn^T, Kn^T, dO^T
-constexpr int BW_PT = 64 * PPITCH;                    // P^T staging
-constexpr int MFMA_BWD_LDS = (BW_ROWMAJ + BW_TRANS + BW_PT) * 2 + (2 * 64 + 4) * 4;   // + qinv, kinv, 4 partial sums
-static_assert(2 * 64 * PPITCH <= BW_ROWMAJ, "staging must fit the row-major region");
+// Backward: recomputes P from (Qn, Kn, lse); dP = dO V^T on the same accumulator layout, dS = P (dP - delta) in registers.
+// Round 3: the three products whose reduction index is a token — dV^T = dO^T P, dKn^T = Qn^T dS, dQn^T = Kn^T dS^T — take
+// their operands with ds_read_b64_tr_b16 from the ROW-MAJOR tiles (conv_wgrad.hip's recipe: k-slot (g, e) <-> token
+// 32s + (e < 4 ? 4g + e : 16 + 4g + e - 4) for both operands): no transposed copies of Qn / Kn / dO (96 scalar LDS stores per
+// image), P and dS staged once as [key][query] with 8-byte stores (the accumulator layout holds four consecutive queries of a
+// key), and the TRANSPOSED results put four consecutive dims of one token in a lane: 8-byte global stores straight from the
+// accumulators, F.normalize's backward with two cross-lane steps.  A workgroup walks `bpw` images of its (window, head) and
+// sums d(logits) into ONE [N][N] scratch tile, so the d(bias) scratch is bpw times smaller.
+constexpr int BW_ROWMAJ = 4 * 64 * QPITCH;            // qn, kn, v, dO (bf16 elements), row-major [token][QPITCH]
+constexpr int BW_ST = 64 * PPITCH;                    // dS^T staging: [key][PPITCH queries]
+constexpr int BW_PT = 64 * PPITCH;                    // P^T staging:  [key][PPITCH queries]
+constexpr int MFMA_BWD_LDS = (BW_ROWMAJ + BW_ST + BW_PT) * 2 + (2 * 64 + 4) * 4;   // + qinv, kinv, 4 partial sums
+
+typedef __attribute__((address_space(3))) bf16x4 attn_lds_bf16x4;
+__device__ __forceinline__ bf16x4 attn_tr4(const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((attn_lds_bf16x4*)(p)); }
+// fragment of a row-major [token][pitch] tile whose k-slots are tokens 32 ks .. and whose MFMA row / column index is the
+// tile column c0 + l15
+__device__ __forceinline__ bf16x8 attn_tr_frag(const bf16* tile, int pitch, int ks, int c0, int g, int l15) {
+  const bf16* p = tile + (32 * ks + 4 * g + (l15 >> 2)) * pitch + c0 + (l15 & 3) * 4;
+  const bf16x4 lo = attn_tr4(p), hi = attn_tr4(p + 16 * pitch);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+// the same k-slot order read along a ROW of a [row][pitch] tile: tokens 32 ks + 4g .. +3 and 32 ks + 16 + 4g .. +3
+__device__ __forceinline__ bf16x8 attn_row_frag(const bf16* tile, int pitch, int row, int ks, int g) {
+  const bf16* p = tile + row * pitch + 32 * ks + 4 * g;
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+__device__ __forceinline__ void put_row_major(bf16* rowmaj, int t, const bf16x8 (&v)[4]) {
+#pragma unroll
+  for (int d = 0; d < HD; d += 8) *reinterpret_cast<bf16x8*>(rowmaj + t * QPITCH + d) = v[d >> 3];
+}
 
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
                                                             const bf16* __restrict__ dout,
@@ -604,15 +653,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   bf16* ks = qs + 64 * QPITCH;
   bf16* vs = ks + 64 * QPITCH;
   bf16* gs = vs + 64 * QPITCH;           // dO row-major
-  bf16* qt = gs + 64 * QPITCH;           // [32][PPITCH]
-  bf16* kt = qt + 32 * PPITCH;
-  bf16* gt = kt + 32 * PPITCH;
-  bf16* pt = gt + 32 * PPITCH;           // P^T [key][query]
-  float* qinv = reinterpret_cast<float*>(pt + 64 * PPITCH);
+  bf16* dst = gs + 64 * QPITCH;          // dS^T * scale [key][query]
+  bf16* pt = dst + BW_ST;                // P^T [key][query]
+  float* qinv = reinterpret_cast<float*>(pt + BW_PT);
   float* kinv = qinv + 64;
   float* wsum = kinv + 64;
-  bf16* dsr = qs;                        // dS  [query][key]  (aliases the row-major region after the fragment loads)
-  bf16* dst = qs + 64 * PPITCH;          // dS^T [key][query]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int N = a.N;
   const int h = blockIdx.x % a.heads;
@@ -650,22 +695,56 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       }
   }
   const float scale2 = scale * LOG2E;
+  // this lane's row of the image being staged (wave 0: q, 1: k, 2: v, 3: dO) and the log-sum-exp of its four queries are
+  // requested one image AHEAD: global latency (and the mid-kernel lse round trip) sit under the previous image's arithmetic
+  const int64_t tok_sp = token_row(a, 0, win, lane < N ? lane : 0);        // row inside image 0; + b * H * W per image
+  const int64_t img_rows = (int64_t)a.H * a.W;
+  bf16x8 rnext[4];
+  float lse_next[4];
+  auto request = [&](int b) {
+    const int64_t row = tok_sp + (int64_t)b * img_rows;
+    const bf16* src = wv < 3 ? qkv + row * a.ld + h * HD + wv * a.C : dout + row * a.C + h * HD;
+    load_head_raw(src, lane < N, rnext);
+    const size_t u = ((size_t)b * a.nW + win) * a.heads + h;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int i = wv * 16 + 4 * g + reg;
+      lse_next[reg] = lse[u * N + (i < N ? i : 0)];
+    }
+  };
+  if (bg * bpw < a.B) request(bg * bpw);
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
     if (b >= a.B) break;                 // uniform for the workgroup
-    const size_t unit = ((size_t)b * a.nW + win) * a.heads + h;
-    {   // wave 0: q, wave 1: k (normalised, + transposes, + 1/norm); wave 2: v; wave 3: dO (+ transpose)
+    float lsev[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) lsev[reg] = lse_next[reg] * LOG2E;
+    {   // row-major tiles only (q, k normalised, + 1/norm)
       const int t = lane;
       bf16x8 r8[4];
-      const int64_t row = token_row(a, b, win, t < N ? t : 0);
-      const bf16* src = wv < 3 ? qkv + row * a.ld + h * HD + wv * a.C : dout + row * a.C + h * HD;
-      const float inv = load_head_row(src, t < N, wv < 2 && !a.plain, r8);
-      if (wv == 0) { put_row(qs, qt, t, r8); qinv[t] = inv; }
-      else if (wv == 1) { put_row(ks, kt, t, r8); kinv[t] = inv; }
-      else if (wv == 2) put_row(vs, nullptr, t, r8);
-      else put_row(gs, gt, t, r8);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) r8[d] = rnext[d];
+      const float inv = finish_head_row(wv < 2 && !a.plain, r8);
+      if (wv == 0) { put_row_major(qs, t, r8); qinv[t] = inv; }
+      else if (wv == 1) { put_row_major(ks, t, r8); kinv[t] = inv; }
+      else if (wv == 2) put_row_major(vs, t, r8);
+      else put_row_major(gs, t, r8);
     }
+    if (bb + 1 < bpw && b + 1 < a.B) request(b + 1);
     __syncthreads();
+#ifdef TOK_ATTN_PROBE
+    {   // timing probe: the memory pattern only
+      const int t = wv * 16 + (lane >> 2), ch = (lane & 3) * 8;
+      if (t < N) {
+        bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD + ch;
+        stg16(dr, *reinterpret_cast<const bf16x8*>(qs + t * QPITCH + ch));
+        stg16(dr + a.C, *reinterpret_cast<const bf16x8*>(ks + t * QPITCH + ch));
+        stg16(dr + 2 * a.C, *reinterpret_cast<const bf16x8*>(gs + t * QPITCH + ch));
+      }
+      __syncthreads();
+      continue;
+    }
+#endif
     const int qi = wv;
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
     const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gs + (qi * 16 + l15) * QPITCH + g * 8);
@@ -678,98 +757,97 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
       dp[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, z, 0, 0, 0);
     }
-    __syncthreads();                     // every wave has its fragments: the row-major region becomes staging
     // ---- P, dP, dS on the accumulator layout: query i = qi*16 + 4g + reg, key j = kj*16 + l15 ----
+    float pv[4][4], dsv[4][4];           // [kj][reg]
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
-      const float li = i < N ? lse[unit * N + i] * LOG2E : 0.f;
-      float p[4], dl = 0.f;
+      const float li = lsev[reg];
+      float dl = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const int j = kj * 16 + l15;
-        p[kj] = (i < N && j < N) ? __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li) : 0.f;
-        dl = fmaf(p[kj], dp[kj][reg], dl);
+        pv[kj][reg] = (i < N && j < N) ? __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li) : 0.f;
+        dl = fmaf(pv[kj][reg], dp[kj][reg], dl);
       }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off, 64);
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
-        const int j = kj * 16 + l15;
-        const float ds = p[kj] * (dp[kj][reg] - dl);
+        const float ds = pv[kj][reg] * (dp[kj][reg] - dl);
         dsa[reg][kj] += ds;
         dsc = fmaf(ds, sc[kj][reg], dsc);
-        const bf16 dsb = f2bf(ds * scale);     // d(qn kn^T) = d(logits) * scale
-        dsr[i * PPITCH + j] = dsb;
-        dst[j * PPITCH + i] = dsb;
-        pt[j * PPITCH + i] = f2bf(p[kj]);
+        dsv[kj][reg] = ds * scale;       // d(qn kn^T) = d(logits) * scale
       }
+    }
+    // [key][query] staging: this lane holds queries qi*16 + 4g .. +3 of key kj*16 + l15 -> one 8-byte store per matrix and kj
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+      bf16x4 p4, d4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { p4[reg] = f2bf(pv[kj][reg]); d4[reg] = f2bf(dsv[kj][reg]); }
+      const int off = (kj * 16 + l15) * PPITCH + qi * 16 + 4 * g;
+      *reinterpret_cast<bf16x4*>(pt + off) = p4;
+      *reinterpret_cast<bf16x4*>(dst + off) = d4;
     }
     __syncthreads();
-    // ---- wave mt: dV, dKn of key tile mt (= P^T dO, dS^T Qn) and dQn of query tile mt (= dS Kn); K-slots 64 = 2 x 32 ----
+    // ---- wave mt: dV^T, dKn^T of key tile mt (= dO^T P, Qn^T dS) and dQn^T of query tile mt (= Kn^T dS^T) ----
     {
       const int mt = wv;
-      bf16x8 pa[2], dsta[2], dsra[2];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        pa[kk] = *reinterpret_cast<const bf16x8*>(pt + (mt * 16 + l15) * PPITCH + kk * 32 + g * 8);
-        dsta[kk] = *reinterpret_cast<const bf16x8*>(dst + (mt * 16 + l15) * PPITCH + kk * 32 + g * 8);
-        dsra[kk] = *reinterpret_cast<const bf16x8*>(dsr + (mt * 16 + l15) * PPITCH + kk * 32 + g * 8);
-      }
+      const int t = mt * 16 + l15;        // the token (key for dv / dk, query for dq) of this lane's accumulator column
       f32x4 dv[2], dk[2], dq[2];
 #pragma unroll
-      for (int dj = 0; dj < 2; ++dj) {
-        dv[dj] = dk[dj] = dq[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int dj = 0; dj < 2; ++dj) dv[dj] = dk[dj] = dq[dj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const bf16x8 gtf = *reinterpret_cast<const bf16x8*>(gt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-          const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(qt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-          const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(kt + (dj * 16 + l15) * PPITCH + kk * 32 + g * 8);
-          dv[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kk], gtf, dv[dj], 0, 0, 0);
-          dk[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsta[kk], qtf, dk[dj], 0, 0, 0);
-          dq[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsra[kk], ktf, dq[dj], 0, 0, 0);
-        }
-      }
-      // accumulator element (reg, dj): token t = mt*16 + 4g + reg, dim = dj*16 + l15
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int t = mt * 16 + 4 * g + reg;
-        float qn[2], kn[2], dotq = 0.f, dotk = 0.f;
+      for (int kk = 0; kk < 2; ++kk) {
+        const bf16x8 pb = attn_row_frag(pt, PPITCH, t, kk, g);                    // P[q][key t], q in k-slot order
+        const bf16x8 db = attn_row_frag(dst, PPITCH, t, kk, g);                   // dS[q][key t] * scale
+        const bf16x8 dtb = attn_tr_frag(dst, PPITCH, kk, mt * 16, g, l15);        // dS^T[key][query t] * scale, keys in k-slot order
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
-          qn[dj] = bf2f(qt[(dj * 16 + l15) * PPITCH + t]);
-          kn[dj] = bf2f(kt[(dj * 16 + l15) * PPITCH + t]);
-          dotq = fmaf(qn[dj], dq[dj][reg], dotq);
-          dotk = fmaf(kn[dj], dk[dj][reg], dotk);
-        }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { dotq += __shfl_xor(dotq, off, 64); dotk += __shfl_xor(dotk, off, 64); }
-        {
-          // rows mt*16.. of dS, dS^T and P^T were read by this wave only (its A fragments above): they take the
-          // 16 x 32 dq / dk / dv tiles so that the global stores below are 16 bytes per lane
-          const float qi_ = qinv[t < 64 ? t : 0], ki_ = kinv[t < 64 ? t : 0];
-#pragma unroll
-          for (int dj = 0; dj < 2; ++dj) {
-            const int d = dj * 16 + l15;
-            dsr[t * PPITCH + d] = f2bf(a.plain ? dq[dj][reg] : (dq[dj][reg] - qn[dj] * dotq) * qi_);
-            dst[t * PPITCH + d] = f2bf(a.plain ? dk[dj][reg] : (dk[dj][reg] - kn[dj] * dotk) * ki_);
-            pt[t * PPITCH + d] = f2bf(dv[dj][reg]);
-          }
+          const bf16x8 gta = attn_tr_frag(gs, QPITCH, kk, dj * 16, g, l15);       // dO^T[dim][q]
+          const bf16x8 qta = attn_tr_frag(qs, QPITCH, kk, dj * 16, g, l15);       // Qn^T[dim][q]
+          const bf16x8 kta = attn_tr_frag(ks, QPITCH, kk, dj * 16, g, l15);       // Kn^T[dim][key]
+          dv[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gta, pb, dv[dj], 0, 0, 0);
+          dk[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qta, db, dk[dj], 0, 0, 0);
+          dq[dj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kta, dtb, dq[dj], 0, 0, 0);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      {
-        const int t = mt * 16 + (lane >> 2), ch = (lane & 3) * 8;
-        if (t < N) {
-          bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD + ch;
-          stg16(dr, *reinterpret_cast<const bf16x8*>(dsr + t * PPITCH + ch));
-          stg16(dr + a.C, *reinterpret_cast<const bf16x8*>(dst + t * PPITCH + ch));
-          stg16(dr + 2 * a.C, *reinterpret_cast<const bf16x8*>(pt + t * PPITCH + ch));
+      // accumulator element (dj, reg): dim dj*16 + 4g + reg of token t.  F.normalize backward: d = (dn - n <n, dn>) / |x|
+      float qn[2][4], kn[2][4], dotq = 0.f, dotk = 0.f;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const bf16x4 q4 = *reinterpret_cast<const bf16x4*>(qs + t * QPITCH + dj * 16 + 4 * g);
+        const bf16x4 k4 = *reinterpret_cast<const bf16x4*>(ks + t * QPITCH + dj * 16 + 4 * g);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          qn[dj][reg] = bf2f(q4[reg]);
+          kn[dj][reg] = bf2f(k4[reg]);
+          dotq = fmaf(qn[dj][reg], dq[dj][reg], dotq);
+          dotk = fmaf(kn[dj][reg], dk[dj][reg], dotk);
+        }
+      }
+      dotq += __shfl_xor(dotq, 16, 64); dotq += __shfl_xor(dotq, 32, 64);
+      dotk += __shfl_xor(dotk, 16, 64); dotk += __shfl_xor(dotk, 32, 64);
+      if (t < N) {
+        const float qi_ = qinv[t], ki_ = kinv[t];
+        bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD + 4 * g;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+          bf16x4 oq, ok, ov;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) {
+            oq[reg] = f2bf(a.plain ? dq[dj][reg] : (dq[dj][reg] - qn[dj][reg] * dotq) * qi_);
+            ok[reg] = f2bf(a.plain ? dk[dj][reg] : (dk[dj][reg] - kn[dj][reg] * dotk) * ki_);
+            ov[reg] = f2bf(dv[dj][reg]);
+          }
+          *reinterpret_cast<bf16x4*>(dr + dj * 16) = oq;
+          *reinterpret_cast<bf16x4*>(dr + a.C + dj * 16) = ok;
+          *reinterpret_cast<bf16x4*>(dr + 2 * a.C + dj * 16) = ov;
         }
       }
     }
-    __syncthreads();                     // before the next image overwrites the staging
+    __syncthreads();                     // before the next image overwrites the tiles / the staging
   }
   if (dS != nullptr) {
 #pragma unroll
@@ -927,11 +1005,24 @@ __global__ __launch_bounds__(64) void cpb_bias_bwd_kernel(const float* __restric
     if (threadIdx.x == 0) dtable[(size_t)t * ld + h] = f2bf(0.f);
     return;
   }
+  // eight positions per lane and iteration, every load unconditional (select afterwards): the branchy one-at-a-time form was a
+  // chain of 38 dependent L2 round trips per block (68 us per launch on the SwinV2-T step's main queue); the summation order per
+  // lane is unchanged (ascending p), so the result keeps its bits
   float acc = 0.f;
-  for (int p = threadIdx.x; p < nn; p += 64) {
-    // transposed: dbias is stored [h][j][i] (what tok_window_attn_bwd's scratch reduces to)
-    const int ij = transposed ? (p % n) * n + p / n : p;
-    if (index[ij] == t) acc += dbias[(size_t)h * nn + p];
+  for (int p0 = threadIdx.x; p0 < nn; p0 += 64 * 8) {
+    int64_t idx[8];
+    float dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int p = p0 + 64 * u;
+      const int pc = p < nn ? p : nn - 1;
+      // transposed: dbias is stored [h][j][i] (what tok_window_attn_bwd's scratch reduces to)
+      const int ij = transposed ? (pc % n) * n + pc / n : pc;
+      idx[u] = index[ij];
+      dv[u] = dbias[(size_t)h * nn + pc];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (p0 + 64 * u < nn && idx[u] == t) ? dv[u] : 0.f;
   }
   acc = wave_sum(acc);
   if (threadIdx.x == 0) {
