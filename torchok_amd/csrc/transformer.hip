@@ -732,19 +732,6 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
     }
     if (bb + 1 < bpw && b + 1 < a.B) request(b + 1);
     __syncthreads();
-#ifdef TOK_ATTN_PROBE
-    {   // timing probe: the memory pattern only
-      const int t = wv * 16 + (lane >> 2), ch = (lane & 3) * 8;
-      if (t < N) {
-        bf16* dr = dqkv + token_row(a, b, win, t) * a.ld + h * HD + ch;
-        stg16(dr, *reinterpret_cast<const bf16x8*>(qs + t * QPITCH + ch));
-        stg16(dr + a.C, *reinterpret_cast<const bf16x8*>(ks + t * QPITCH + ch));
-        stg16(dr + 2 * a.C, *reinterpret_cast<const bf16x8*>(gs + t * QPITCH + ch));
-      }
-      __syncthreads();
-      continue;
-    }
-#endif
     const int qi = wv;
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
     const bf16x8 gf = *reinterpret_cast<const bf16x8*>(gs + (qi * 16 + l15) * QPITCH + g * 8);
