@@ -528,6 +528,20 @@ int tok_conv_fwd_act(const tok_conv_desc* d, const void* x, const void* w, const
 int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgrad, const void* act_x, int kind,
                        void* dx, void* stream);
 
+/* ---- the whole Mlp with its hidden tile on chip (csrc/mlp_fused.hip) -------------------------------------------------
+ * [timm 0.6.13] models/layers/mlp.py: Mlp.forward = fc2(GELU(fc1(x))), drop = 0, as SwinTransformerBlock / DaViT's blocks
+ * call it (models/backbones/swin.py:18,238; davit.py:16,196).  x, y: bf16 [rows][c]; w1 = fc1 forward pack [hidden][c],
+ * w2 = fc2 forward pack [c][hidden] (tok_pack_weight_fwd), b1 [hidden] / b2 [c] fp32.  The 4c-wide hidden tensor is never
+ * read back: pre / act = NULL (inference) it is never stored; with pre / act [rows][hidden] given (training) the bf16
+ * pre-activation and activation rows are written for the backward GEMMs (tok_conv_dgrad_act, the two weight gradients)
+ * while fc2 consumes them out of registers.  Rounding points (pre-activation and activation to bf16) and results are
+ * those of tok_conv_fwd_act + tok_conv_fwd, bit for bit.
+ * tok_mlp_serves: 1 when the geometry has a kernel (c in {96, 192, 384}, hidden = 4c), else the caller stays on the two
+ * GEMM launches.                                                                                                         */
+int tok_mlp_serves(int64_t rows, int c, int hidden);
+int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, void* pre,
+                void* act, int64_t rows, int c, int hidden, void* stream);
+
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:
  * softmax(q k^T / sqrt(32)) v on unshifted windows, no cosine normalisation (ds_scratch / dscale_part unused).

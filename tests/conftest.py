@@ -17,6 +17,7 @@ os.environ.setdefault('TOK_CONV_WIN_MIN_TILES', '1')
 os.environ.setdefault('TOK_CONV_RING', '1')            # off by default in the product (measured neutral); kept tested
 os.environ.setdefault('TOK_CONV_RING_MIN_TILES', '1')
 os.environ.setdefault('TOK_CONV_RING_MIN_K', '64')
+os.environ.setdefault('TOK_MLP_MIN_ROWS', '1')          # the fused MLP serves the small test shapes too
 
 
 def pytest_configure(config):

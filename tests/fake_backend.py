@@ -150,6 +150,21 @@ class FakeTok:
         dd = _desc(d)
         return rc or self.tok_act_fwd(kind, y, y_act, dd.n * dd.p * dd.q * dd.k, st)
 
+    def tok_mlp_serves(self, rows, c, hidden):
+        import os
+        return int(c in (96, 192, 384) and hidden == 4 * c and rows >= int(os.environ.get('TOK_MLP_MIN_ROWS', '32768')))
+
+    def tok_mlp_fwd(self, x, w1, b1, w2, b2, y, pre, act, rows, c, hidden, st):
+        self.calls.append('mlp_fwd')
+        xv = _t(x, (rows, c), BF16).float()
+        p = _bf(xv @ _t(w1, (hidden, c), BF16).float().t() + _t(b1, (hidden,), torch.float32))
+        h = _bf(F.gelu(p.float()))
+        _t(y, (rows, c), BF16).copy_(_bf(h.float() @ _t(w2, (c, hidden), BF16).float().t() + _t(b2, (c,), torch.float32)))
+        if pre is not None:
+            _t(pre, (rows, hidden), BF16).copy_(p)
+            _t(act, (rows, hidden), BF16).copy_(h)
+        return 0
+
     def tok_conv_dgrad_act(self, d, dy, wd, act_x, kind, dx, st):
         rc = self.tok_conv_dgrad(d, dy, wd, dx, 0, st)
         dd = _desc(d)

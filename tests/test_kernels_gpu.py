@@ -1155,6 +1155,46 @@ def test_gemm_activation_epilogues_equal_the_unfused_pair(libs, rows, c, k, kind
     assert lib.tok_conv_fwd_act(d3, P(x), P(w), None, P(y1), P(a1), kind, st) != 0         # 3x3: refused
 
 
+@pytest.mark.parametrize('rows,c', [(1000, 96), (77, 192), (4133, 384), (256, 96), (70000, 96), (33000, 192), (16500, 384)])
+@pytest.mark.parametrize('save', [False, True])
+def test_fused_mlp_equals_the_two_gemm_launches(libs, rows, c, save):
+    """tok_mlp_fwd == tok_conv_fwd_act (fc1 + GELU) + tok_conv_fwd (fc2), bit for bit, ragged row counts included (tiles of
+    256 / 128 tokens, several tiles per workgroup at the larger counts); with pre / act given those rows are the unfused
+    launches' too.  Against the fp32 restatement (fake_backend: torch matmul + F.gelu on the same rounding points) <= 1e-2."""
+    lib, fake = libs
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: t_.data_ptr() if t_ is not None else None   # noqa: E731
+    h = 4 * c
+    assert lib.tok_mlp_serves(rows, c, h) == 1
+    assert lib.tok_mlp_serves(rows, c, 2 * c) == 0 and lib.tok_mlp_serves(rows, 768, 3072) == 0 and lib.tok_mlp_serves(rows, 100, 400) == 0
+    x = rnd(rows, c).to(BF16).cuda()
+    w1 = (rnd(h, c, seed=1) * c ** -0.5).to(BF16).cuda()
+    w2 = (rnd(c, h, seed=2) * h ** -0.5).to(BF16).cuda()
+    b1, b2 = (rnd(h, seed=3) * 0.3).cuda(), (rnd(c, seed=4) * 0.3).cuda()
+    d1, d2 = _desc(rows, 1, 1, c, h, 1, 1, 0), _desc(rows, 1, 1, h, c, 1, 1, 0)
+    pre0, act0, pre1, act1 = (torch.full((rows, h), 7.0, dtype=BF16, device='cuda') for _ in range(4))
+    y0, y1 = (torch.empty(rows, c, dtype=BF16, device='cuda') for _ in range(2))
+    guard = torch.full((4096,), 3.0, dtype=BF16, device='cuda')          # lands right behind y1 in most allocators; checked below
+    assert lib.tok_conv_fwd_act(d1, P(x), P(w1), P(b1), P(pre0), P(act0), 1, st) == 0, lib.tok_last_error()
+    assert lib.tok_conv_fwd(d2, P(act0), P(w2), P(b2), P(y0), None, st) == 0, lib.tok_last_error()
+    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), P(pre1) if save else None, P(act1) if save else None,
+                           rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if save:
+        assert torch.equal(pre0, pre1) and torch.equal(act0, act1)
+    else:
+        assert bool((pre1 == 7.0).all()) and bool((act1 == 7.0).all())
+    assert bool((guard == 3.0).all())
+    n = min(rows, 2048)
+    yh = torch.empty(n, c, dtype=BF16)
+    xc, w1c, w2c, b1c, b2c = x[:n].cpu(), w1.cpu(), w2.cpu(), b1.cpu(), b2.cpu()
+    assert fake.tok_mlp_fwd(P(xc), P(w1c), P(b1c), P(w2c), P(b2c), P(yh), None, None, n, c, h, None) == 0
+    assert relerr(y1[:n].float(), yh.float()) < 1e-2
+    # only one of pre / act: refused
+    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), P(pre1), None, rows, c, h, st) != 0
+
+
 @pytest.mark.parametrize('n,h,w,c', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128), (4, 112, 112, 64)])
 def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     """tok_bn_relu_maxpool_fwd == tok_bn_act_fwd + tok_maxpool3x3s2_fwd; tok_bn_pool_bwd_reduce / _apply ==

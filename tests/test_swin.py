@@ -208,3 +208,65 @@ def test_fused_activation_epilogues_leave_training_bit_identical(monkeypatch):
     assert finals[0][0] == finals[1][0]
     for n in finals[0][1]:
         assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+
+
+@pytest.mark.gpu
+def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
+    """The whole Mlp from one launch (engine.transformer.FUSE_MLP, csrc/mlp_fused.hip) against fc1 + GELU and fc2 as two
+    launches: 5 AdamW steps on widths 96 / 192 / 384 (served) and 768 (not served), identical losses and parameters."""
+    from helpers import cls_config
+    from torchok_amd.engine import transformer as ET
+    finals = []
+    for fuse in (True, False):
+        monkeypatch.setattr(ET, 'FUSE_MLP', fuse)
+        cfg = cls_config('swinv2_custom', 5, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                         backbone_params=dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0),
+                         inputs_shape=(3, 64, 64))
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+        sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 9)
+        task.load_state_dict(sd, strict=False)
+        task.cuda().train()
+        opt = task.configure_optimizers()[0]['optimizer']
+        g = torch.Generator().manual_seed(4)
+        x, y = torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 5, (8,), generator=g).cuda()
+        losses = []
+        for it in range(5):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad()
+            out['loss'].backward()
+            opt.step()
+            losses.append(float(out['loss'].detach()))
+        finals.append((losses, {n: p.detach().clone() for n, p in task.named_parameters()}))
+    assert finals[0][0] == finals[1][0]
+    for n in finals[0][1]:
+        assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+
+
+def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_backend):
+    """Host logic (CPU stand-in for the library): mlp_module's served branch launches once and leaves the same outputs,
+    input gradient and parameter gradients as fc1 + GELU / fc2; an evaluation pass asks for no saved rows."""
+    from torchok_amd.engine import transformer as ET
+    from torchok_amd.engine.core import Region
+    from torchok_amd.models.backbones.swin import Mlp
+    fake = fake_backend
+    if True:
+        res = []
+        for fuse in (True, False):
+            monkeypatch.setattr(ET, 'FUSE_MLP', fuse)
+            torch.manual_seed(3)
+            m = Mlp(96, 384)
+            xt = torch.randn(40, 96).to(torch.bfloat16).requires_grad_(True)
+            gd = torch.randn(40, 96).to(torch.bfloat16)
+            fake.calls.clear()
+            r = Region()
+            y = r.output(m.run(r, r.input(xt)))
+            assert ('mlp_fwd' in fake.calls) == fuse
+            y.backward(gd)
+            res.append((y.detach().clone(), xt.grad.clone(), [p.grad.clone() for p in m.parameters()]))
+            with torch.no_grad():
+                r2 = Region()
+                y2 = r2.output(m.run(r2, r2.input(xt.detach())))
+            assert torch.equal(y2, y.detach())
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        for a, b in zip(res[0][2], res[1][2]):
+            assert torch.equal(a, b)

@@ -50,13 +50,31 @@ __device__ __forceinline__ bf16x8 ldg16(const bf16* p) {
 }
 __device__ __forceinline__ void stg16(bf16* p, bf16x8 v) { *reinterpret_cast<bf16x8*>(p) = v; }
 
-// erf-GELU and its derivative: one definition for tok_act_fwd/_bwd and the fused GEMM epilogues, so that the fused and the
-// unfused paths give the same bits.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 rounding of the
-// surrounding arithmetic and 4 decimal orders below the bf16 storage of the result): 1 - (a1 t + .. + a5 t^5) exp(-z^2),
-// t = 1 / (1 + p |z|), on v_rcp_f32 / v_exp_f32 — ~14 VALU per element where libm's erff + expf cost ~55, which is what
-// made a GELU epilogue as expensive as the elementwise pass it replaces.  exp(-z^2) with z = x / sqrt(2) is exp(-x^2 / 2):
-// the derivative's Gaussian term reuses it.
-__device__ __forceinline__ float tok_erf_core(float z, float& gauss) {   // returns erf(|z|), gauss = exp(-z^2)
+// erf-GELU and its derivative: one definition for tok_act_fwd/_bwd, the fused GEMM epilogues and the fused MLP, so that all
+// paths give the same bits.  GELU(x) = x Phi(x) with the lower tail Phi(-a) = 0.5 erfc(a / sqrt 2) = exp2(P5(a)), a = min(|x|, 5.6):
+// a degree-5 polynomial of log2 Phi(-a) (weighted minimax fit, |error in Phi| <= 3e-7 over the whole range; beyond 5.6 the tail is
+// < 2e-8) and ONE v_exp_f32, then GELU(x) = max(x, 0) - a Phi(-a) for either sign.  8 VALU + 1 transcendental per element (the
+// Abramowitz-Stegun 7.1.26 form of round 3a cost 12 + 2, libm's erff + expf ~55): in the GEMM epilogues and in the fused MLP the
+// activation's VALU time is what competes with the MFMA pipe.  All of it is fma / med3, so the two-wide form (v_pk_fma_f32)
+// rounds identically.  A NaN input gives 0 (med3 / max drop it); the residual stream next to every GELU here keeps the NaN.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define TOK_GELU_C0 (-1.0000008344650269f)
+#define TOK_GELU_C1 (-1.1510831117630005f)
+#define TOK_GELU_C2 (-0.45927679538726807f)
+#define TOK_GELU_C3 (-0.05253789573907852f)
+#define TOK_GELU_C4 (0.007387148682028055f)
+#define TOK_GELU_C5 (-0.0005188509239815176f)
+#define TOK_GELU_AMAX 5.6f
+__device__ __forceinline__ float tok_gelu_tail(float a) {   // Phi(-a), 0 <= a <= 5.6
+  float q = fmaf(a, TOK_GELU_C5, TOK_GELU_C4);
+  q = fmaf(q, a, TOK_GELU_C3);
+  q = fmaf(q, a, TOK_GELU_C2);
+  q = fmaf(q, a, TOK_GELU_C1);
+  q = fmaf(q, a, TOK_GELU_C0);
+  return __builtin_amdgcn_exp2f(q);
+}
+#ifdef TOK_GELU_AS726   // A/B: the Abramowitz-Stegun 7.1.26 form (rcp + exp per element)
+__device__ __forceinline__ float tok_erf_core(float z, float& gauss) {
   const float az = fabsf(z);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
   float p = fmaf(t, 1.061405429f, -1.453152027f);
@@ -77,6 +95,40 @@ __device__ __forceinline__ float gelu_d(float x) {
   float g;
   const float e = copysignf(tok_erf_core(x * 0.70710678118654752f, g), x);
   return fmaf(x * 0.3989422804014327f, g, fmaf(0.5f, e, 0.5f));
+}
+#else
+__device__ __forceinline__ float gelu_f(float x) {
+  const float a = __builtin_amdgcn_fmed3f(fabsf(x), 0.f, TOK_GELU_AMAX);
+  const float m = __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff());
+  return fmaf(-a, tok_gelu_tail(a), m);
+}
+__device__ __forceinline__ float gelu_d(float x) {           // Phi(x) + x phi(x)
+  const float a = __builtin_amdgcn_fmed3f(fabsf(x), 0.f, TOK_GELU_AMAX);
+  const float t = tok_gelu_tail(a);
+  const float cdf = x >= 0.f ? 1.f - t : t;
+  const float pdf = __builtin_amdgcn_exp2f(fmaf(x * x, -0.72134752044448170f, -1.3257480647361593f));
+  return fmaf(x, pdf, cdf);
+}
+#endif
+// two elements per instruction where the ISA has a packed form
+__device__ __forceinline__ f32x2 tok_gelu_tail2(f32x2 a) {
+  f32x2 q = __builtin_elementwise_fma(a, (f32x2)(TOK_GELU_C5), (f32x2)(TOK_GELU_C4));
+  q = __builtin_elementwise_fma(q, a, (f32x2)(TOK_GELU_C3));
+  q = __builtin_elementwise_fma(q, a, (f32x2)(TOK_GELU_C2));
+  q = __builtin_elementwise_fma(q, a, (f32x2)(TOK_GELU_C1));
+  q = __builtin_elementwise_fma(q, a, (f32x2)(TOK_GELU_C0));
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(q.x);
+  e.y = __builtin_amdgcn_exp2f(q.y);
+  return e;
+}
+__device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
+  f32x2 a, m;
+  a.x = __builtin_amdgcn_fmed3f(fabsf(x.x), 0.f, TOK_GELU_AMAX);
+  a.y = __builtin_amdgcn_fmed3f(fabsf(x.y), 0.f, TOK_GELU_AMAX);
+  m.x = __builtin_amdgcn_fmed3f(x.x, 0.f, __builtin_inff());
+  m.y = __builtin_amdgcn_fmed3f(x.y, 0.f, __builtin_inff());
+  return __builtin_elementwise_fma(-a, tok_gelu_tail2(a), m);
 }
 
 __device__ __forceinline__ bf16x8 zero8() {

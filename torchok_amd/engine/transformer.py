@@ -226,6 +226,15 @@ def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Option
                  'tok_conv_fwd_act')
     else:
         _C.check(lib.tok_conv_fwd(d, ptr(x.data), ptr(pk.fwd), ptr(bias_vec), ptr(y), None, st), 'tok_conv_fwd')
+    out = _record_linear(region, x, weight, bias_sinks, y, d, pk)
+    if act is None:
+        return out
+    return activation(region, out, act, precomputed=y_act)
+
+
+def _record_linear(region: Region, x: TTensor, weight: nn.Parameter, bias_sinks, y: torch.Tensor, d, pk) -> TTensor:
+    """The tape entry of y = x W^T + b, whoever launched it."""
+    k = weight.shape[0]
     req = region.grad_mode and (x.requires_grad or weight.requires_grad or any(p.requires_grad for p, _ in bias_sinks))
     out = TTensor(y, k, requires_grad=req)
     if req:
@@ -236,15 +245,52 @@ def linear_op(region: Region, x: TTensor, weight: nn.Parameter, bias_vec: Option
         if x.requires_grad:
             x.uses += 1
         region.add(node)
-    if act is None:
-        return out
-    return activation(region, out, act, precomputed=y_act)
+    return out
 
 
 def linear_module(region: Region, x: TTensor, fc: nn.Linear, act: Optional[int] = None) -> TTensor:
     if fc.bias is None:
         return linear_op(region, x, fc.weight, act=act)
     return linear_op(region, x, fc.weight, fc.bias.detach(), [(fc.bias, 0)], act=act)
+
+
+# The whole Mlp from one launch (csrc/mlp_fused.hip): fc2 consumes GELU(fc1(x)) out of registers; in training the bf16
+# pre-activation and activation rows are still written (the backward GEMMs read them), so the tape is the one the separate
+# launches record and every tensor on it has the same bits.  Measured per call on the SwinV2-T B=256 shapes (fused+saved vs
+# fc1+GELU launch + fc2 launch): C=96 366 vs 543 us, C=192 269 vs 368, C=384 203 vs 239.  TOK_FUSE_MLP=0: separate launches.
+FUSE_MLP = os.environ.get('TOK_FUSE_MLP', '1') == '1'
+
+
+def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TTensor:
+    """fc2(GELU(fc1(x))) — [timm 0.6.13] models/layers/mlp.py: Mlp.forward with drop = 0."""
+    lib = _C.lib()
+    n, cp = x.shape
+    c, hid = fc1.in_features, fc1.out_features
+    served = (FUSE_MLP and FUSE_ACT and fc1.bias is not None and fc2.bias is not None and cp == c
+              and fc2.in_features == hid and fc2.out_features == c and bool(lib.tok_mlp_serves(n, c, hid)))
+    if not served:
+        h = linear_module(region, x, fc1, act=GELU)      # fc1 + GELU: one launch; fc2's dgrad applies GELU'
+        return linear_module(region, h, fc2)
+    st = stream_ptr()
+    params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+    train = region.grad_mode and (x.requires_grad or any(p.requires_grad for p in params))
+    pk1 = get_packs(fc1.weight, None, hid, 1, cp, want_dgrad=region.grad_mode and x.requires_grad, refresh=True)
+    pk2 = get_packs(fc2.weight, None, c, 1, hid, want_dgrad=train, refresh=True)
+    dev = x.data.device
+    y = torch.empty((n, c), dtype=BF16, device=dev)
+    pre = act = None
+    if train:
+        pre = torch.empty((n, hid), dtype=BF16, device=dev)
+        act = torch.empty_like(pre)
+    _C.check(lib.tok_mlp_fwd(ptr(x.data), ptr(pk1.fwd), ptr(fc1.bias.detach()), ptr(pk2.fwd), ptr(fc2.bias.detach()), ptr(y),
+                             ptr(pre), ptr(act), n, c, hid, st), 'tok_mlp_fwd')
+    if not train:
+        return TTensor(y, c, requires_grad=False)
+    d1 = _C.ConvDesc(n, 1, 1, cp, hid, 1, 1, 1, 1, 1, 0, 1)
+    d2 = _C.ConvDesc(n, 1, 1, hid, c, 1, 1, 1, 1, 1, 0, 1)
+    h_pre = _record_linear(region, x, fc1.weight, [(fc1.bias, 0)], pre, d1, pk1)
+    h = activation(region, h_pre, GELU, precomputed=act)
+    return _record_linear(region, h, fc2.weight, [(fc2.bias, 0)], y, d2, pk2)
 
 
 # ---- layer norm (+ residual, + stochastic depth) ---------------------------------------------------------------------

@@ -68,8 +68,7 @@ class Mlp(nn.Module):
         self.drop2 = nn.Dropout(drop)
 
     def run(self, r, x):
-        h = ET.linear_module(r, x, self.fc1, act=ET.GELU)      # fc1 + GELU: one launch; fc2's dgrad applies GELU'
-        return ET.linear_module(r, h, self.fc2)
+        return ET.mlp_module(r, x, self.fc1, self.fc2)         # one launch where the geometry is served (csrc/mlp_fused.hip)
 
 
 class PatchEmbed(nn.Module):
