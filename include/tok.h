@@ -541,6 +541,13 @@ int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgr
 int tok_mlp_serves(int64_t rows, int c, int hidden);
 int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, void* pre,
                 void* act, int64_t rows, int c, int hidden, void* stream);
+/* Backward of that Mlp to its input, one launch: d(pre) = bf16(bf16(dy W2) * GELU'(pre)), dx (+)= d(pre) W1 with d(pre) in
+ * registers between the two products.  w2_dgrad = fc2's dgrad pack [hidden][c], w1_dgrad = fc1's dgrad pack [c][hidden]
+ * (tok_pack_weight_both), pre = the rows tok_mlp_fwd saved, accumulate != 0: dx already holds a gradient contribution.
+ * dpre [rows][hidden] != NULL: the d(pre) rows are also written (the weight gradients of fc1 read them).  Results are
+ * those of tok_conv_dgrad_act + tok_conv_dgrad, bit for bit.                                                              */
+int tok_mlp_bwd_dx(const void* dy, const void* w2_dgrad, const void* pre, const void* w1_dgrad, void* dx, int accumulate,
+                   void* dpre, int64_t rows, int c, int hidden, void* stream);
 
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:

@@ -165,6 +165,19 @@ class FakeTok:
             _t(act, (rows, hidden), BF16).copy_(h)
         return 0
 
+    def tok_mlp_bwd_dx(self, dy, w2d, pre, w1d, dx, accumulate, dpre, rows, c, hidden, st):
+        self.calls.append('mlp_bwd_dx')
+        g = _t(dy, (rows, c), BF16).float()
+        o = _bf(g @ _t(w2d, (hidden, c), BF16).float().t()).float()
+        v = _t(pre, (rows, hidden), BF16).float()
+        d = 0.5 * (1 + torch.erf(v * 0.7071067811865476)) + v * 0.3989422804014327 * torch.exp(-0.5 * v * v)
+        dp = _bf(o * d)
+        out = _t(dx, (rows, c), BF16)
+        out.copy_(_bf(dp.float() @ _t(w1d, (c, hidden), BF16).float().t() + (out.float() if accumulate else 0)))
+        if dpre is not None:
+            _t(dpre, (rows, hidden), BF16).copy_(dp)
+        return 0
+
     def tok_conv_dgrad_act(self, d, dy, wd, act_x, kind, dx, st):
         rc = self.tok_conv_dgrad(d, dy, wd, dx, 0, st)
         dd = _desc(d)

@@ -1195,6 +1195,40 @@ def test_fused_mlp_equals_the_two_gemm_launches(libs, rows, c, save):
     assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), P(pre1), None, rows, c, h, st) != 0
 
 
+@pytest.mark.parametrize('rows,c', [(1000, 96), (77, 192), (4133, 384), (70000, 96), (33000, 192), (16500, 384)])
+@pytest.mark.parametrize('acc', [0, 1])
+def test_fused_mlp_backward_equals_the_two_dgrad_launches(libs, rows, c, acc):
+    """tok_mlp_bwd_dx == tok_conv_dgrad_act (fc2, GELU') + tok_conv_dgrad (fc1), bit for bit: dx (fresh or accumulated onto
+    an earlier contribution) and, when asked for, the d(pre) rows; against the fp32 restatement <= 1e-2."""
+    lib, fake = libs
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: t_.data_ptr() if t_ is not None else None   # noqa: E731
+    h = 4 * c
+    dy = rnd(rows, c).to(BF16).cuda()
+    pre = (rnd(rows, h, seed=5) * 1.5).to(BF16).cuda()
+    w2d = (rnd(h, c, seed=1) * h ** -0.5).to(BF16).cuda()           # fc2 dgrad pack [hidden][c]
+    w1d = (rnd(c, h, seed=2) * c ** -0.5).to(BF16).cuda()           # fc1 dgrad pack [c][hidden]
+    base = rnd(rows, c, seed=6).to(BF16).cuda()
+    d1, d2 = _desc(rows, 1, 1, c, h, 1, 1, 0), _desc(rows, 1, 1, h, c, 1, 1, 0)
+    dpre0 = torch.empty(rows, h, dtype=BF16, device='cuda')
+    dpre1 = torch.full((rows, h), 7.0, dtype=BF16, device='cuda')
+    dx0, dx1, dx2 = base.clone(), base.clone(), base.clone()
+    assert lib.tok_conv_dgrad_act(d2, P(dy), P(w2d), P(pre), 1, P(dpre0), st) == 0, lib.tok_last_error()
+    assert lib.tok_conv_dgrad(d1, P(dpre0), P(w1d), P(dx0), acc, st) == 0, lib.tok_last_error()
+    assert lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx1), acc, P(dpre1), rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and torch.equal(dpre0, dpre1)
+    dpre1.fill_(7.0)
+    assert lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx2), acc, None, rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx2) and bool((dpre1 == 7.0).all())
+    n = min(rows, 2048)
+    dxh = base[:n].cpu().clone()
+    dyc, prec, w2c, w1c = dy[:n].cpu(), pre[:n].cpu(), w2d.cpu(), w1d.cpu()
+    assert fake.tok_mlp_bwd_dx(P(dyc), P(w2c), P(prec), P(w1c), P(dxh), acc, None, n, c, h, None) == 0
+    assert relerr(dx1[:n].float(), dxh.float()) < 1e-2
+
+
 @pytest.mark.parametrize('n,h,w,c', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128), (4, 112, 112, 64)])
 def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     """tok_bn_relu_maxpool_fwd == tok_bn_act_fwd + tok_maxpool3x3s2_fwd; tok_bn_pool_bwd_reduce / _apply ==

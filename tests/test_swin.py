@@ -262,6 +262,7 @@ def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_b
             y = r.output(m.run(r, r.input(xt)))
             assert ('mlp_fwd' in fake.calls) == fuse
             y.backward(gd)
+            assert ('mlp_bwd_dx' in fake.calls) == fuse
             res.append((y.detach().clone(), xt.grad.clone(), [p.grad.clone() for p in m.parameters()]))
             with torch.no_grad():
                 r2 = Region()

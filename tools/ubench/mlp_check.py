@@ -50,6 +50,30 @@ def run(rows, c):
     t_f = timeit(lambda: lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y), None, None, rows, c, h, st))
     t_s = timeit(lambda: lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(ys), P(pre_s), P(act_s), rows, c, h, st))
     t_u = timeit(unfused)
+    # backward to the input
+    dy = torch.randn(rows, c, device='cuda', generator=g).to(BF)
+    w2d = w2.t().contiguous(); w1d = w1.t().contiguous()          # dgrad packs: [H][C] and [C][H]
+    base = torch.randn(rows, c, device='cuda', generator=g).to(BF)
+    res = {}
+    for accf in (0, 1):
+        dpre_u = torch.empty(rows, h, device='cuda', dtype=BF); dx_u = base.clone()
+        _C.check(lib.tok_conv_dgrad_act(ctypes.byref(d2), P(dy), P(w2d), P(pre), 1, P(dpre_u), st), 'dgrad_act')
+        _C.check(lib.tok_conv_dgrad(ctypes.byref(d1), P(dpre_u), P(w1d), P(dx_u), accf, st), 'dgrad')
+        dpre_f = torch.empty_like(dpre_u); dx_f = base.clone(); dx_n = base.clone()
+        _C.check(lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx_f), accf, P(dpre_f), rows, c, h, st), 'mlp_bwd_dx')
+        _C.check(lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx_n), accf, None, rows, c, h, st), 'mlp_bwd_dx')
+        torch.cuda.synchronize()
+        res[accf] = (bool((dx_f == dx_u).all()), bool((dpre_f == dpre_u).all()), bool((dx_n == dx_u).all()),
+                     (dx_f.float() - dx_u.float()).abs().max().item())
+    dpre_u = torch.empty(rows, h, device='cuda', dtype=BF); dx_u = torch.empty_like(y); dpre_f = torch.empty_like(dpre_u); dx_f = torch.empty_like(y)
+    def unfused_b():
+        lib.tok_conv_dgrad_act(ctypes.byref(d2), P(dy), P(w2d), P(pre), 1, P(dpre_u), st)
+        lib.tok_conv_dgrad(ctypes.byref(d1), P(dpre_u), P(w1d), P(dx_u), 0, st)
+    tb_u = timeit(unfused_b)
+    tb_s = timeit(lambda: lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx_f), 0, P(dpre_f), rows, c, h, st))
+    tb_n = timeit(lambda: lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx_f), 0, None, rows, c, h, st))
+    print(f'   bwd_dx identical (dx, dpre, dx no-save | max diff) acc0 {res[0]} acc1 {res[1]} | fused+dpre {tb_s:.1f} us fused {tb_n:.1f} us '
+          f'unfused {tb_u:.1f} us', flush=True)
     flops = 2 * 2 * rows * c * h
     print(f'rows {rows} c {c}: |fused-ref| {e_f:.4f} |unfused-ref| {e_u:.4f} |fused-unfused| {d_fu:.4f} (differ {neq:.2e}) '
           f'save-mode identical {save_ok} | fused {t_f:.1f} us ({flops / t_f * 1e-6:.0f} TF/s) fused+save {t_s:.1f} us unfused {t_u:.1f} us', flush=True)

@@ -35,6 +35,7 @@ struct MlpArgs {
   bf16* pre;            // (T, H)   fc1 output (bf16) and its GELU, for the backward GEMMs; SAVE kernels only
   bf16* act;
   uint32_t x_bytes, w_bytes, h_bytes;
+  int accumulate;       // backward: dx += (the rows already there)
   int T, H, ntiles;
 };
 
@@ -87,26 +88,27 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // C: model width; HC: hidden units per ring stage; NT: 16-token blocks per wave; WAVES per workgroup; PF: next tile's
-// tokens are requested three stages before the tile ends (short tiles only: registers for a second copy of x)
-// SAVE: the bf16 pre-activation and activation rows are also written out (training: the backward GEMMs read them)
-template <int C, int HC, int NT, int WAVES, bool PF, bool SAVE>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel(MlpArgs a) {
+// tokens are requested three stages before the tile ends (short tiles only: registers for a second copy of the rows).
+// MODE 0, forward: in = x, A1 = fc1 pack, elementwise = + b1, bf16, GELU, bf16, A2 = fc2 pack, out = y + b2; SAVE writes the
+//   pre-activation and activation rows.
+// MODE 1, backward to the input: in = dy, A1 = fc2's dgrad pack (W2^T, [H][C]), elementwise = bf16, * GELU'(pre) with the saved
+//   pre-activation rows (requested two stages ahead, 16 bytes per lane = the D-register layout), bf16, A2 = fc1's dgrad pack
+//   (W1^T, [C][H]), out = dx (+ the rows already there: ACCUMULATE at run time); SAVE writes d(pre) for the weight gradients.
+// Both reproduce the separate launches bit for bit (same rounding points, same accumulation order).
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(MlpArgs a) {
   constexpr int KS = C / 32, CB = C / 16, SUB = HC / 32;
-  constexpr int FR_SUB = 2 * KS + CB;            // fragments of one 32-hidden sub-chunk: W1 (2 blocks x KS), W2 (CB)
+  constexpr int FR_SUB = 2 * KS + CB;            // fragments of one 32-hidden sub-chunk: A1 (2 blocks x KS), A2 (CB)
   constexpr int NF = SUB * FR_SUB;
   constexpr int STAGE = NF * 1024;
   static_assert(NF % WAVES == 0, "fragments per stage must divide among the waves");
   constexpr int NI = NF / WAVES;                 // DMA instructions per wave and stage
-  constexpr int NX = NT * KS;                    // token loads per wave and tile
-  constexpr int NST = NT * CB / 2;               // stores per wave and tile
   constexpr int TILE = WAVES * NT * 16;
-  constexpr int SPS = SAVE ? SUB * 2 * NT : 0;   // pre / act stores per wave and stage
-  constexpr int WMAX = NI + 2 * SPS + (NST > NX ? NST : NX);
-  static_assert(WMAX <= 63, "vmcnt range");
+  constexpr bool BWD = MODE == 1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
-  const uint32_t b1_base = lds_base + 3 * STAGE;               // H floats
+  const uint32_t b1_base = lds_base + 3 * STAGE;               // H floats   (forward)
   const uint32_t b2_base = b1_base + (uint32_t)a.H * 4;        // C floats
 
   const int tid = threadIdx.x;
@@ -119,16 +121,27 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
   const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w1srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, a.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t w2srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)(SAVE ? a.pre : a.y), 0, SAVE ? a.h_bytes : 0, 0x00020000);
+  const bool hrows = SAVE || BWD;
+  const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)(hrows ? a.pre : a.y), 0, hrows ? a.h_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc((void*)(SAVE ? a.act : a.y), 0, SAVE ? a.h_bytes : 0, 0x00020000);
 
   // ---- biases into LDS (read back as float4 per lane) -------------------------------------------------------------------
-  {
+  if constexpr (!BWD) {
     float* b1s = reinterpret_cast<float*>(smem + 3 * STAGE);
     for (int i = tid; i < a.H; i += WAVES * 64) b1s[i] = a.b1[i];
     float* b2s = b1s + a.H;
     for (int i = tid; i < C; i += WAVES * 64) b2s[i] = a.b2[i];
   }
+
+  // ---- vector-memory ledger: every load / store / DMA instruction of this wave gets a sequence number; "everything up to
+  // mark m has landed" is s_waitcnt vmcnt(issued - m) (the counter retires in issue order).  Stage- and tile-dependent
+  // wait counts come out of this arithmetic instead of case analysis.
+  int issued = 0;
+  auto wait_until = [&](int mark) {
+    int n = issued - mark;
+    n = n < 0 ? 0 : (n > 63 ? 63 : n);
+    wait_vm_dyn<0, 63>(n);
+  };
 
   // ---- weight DMA: fragment f = j * WAVES + wave of a stage ------------------------------------------------------------------
   uint32_t voff[NI];
@@ -151,26 +164,51 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
       isw1[j] = false;
     }
   }
-  auto issue = [&](int s, int slot, bool live) {
+  int dma_mark[3] = {0, 0, 0};
+  auto issue = [&](int s, auto slotc, bool live) {
+    constexpr int SLOT = decltype(slotc)::value;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       uint32_t off = live ? voff[j] + (uint32_t)(s * vinc[j]) : 0xFFFFFFF0u;
       asm volatile("" : "+v"(off));
-      lds_void* dst = (lds_void*)(smem + slot * STAGE + (j * WAVES + wave) * 1024);
+      lds_void* dst = (lds_void*)(smem + SLOT * STAGE + (j * WAVES + wave) * 1024);
       if (isw1[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(w1srd, dst, 16, off, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(w2srd, dst, 16, off, 0, 0, 0);
     }
+    issued += NI;
+    dma_mark[SLOT] = issued;
   };
 
   // ---- tokens of a tile: lane (r, g) holds channels ks * 32 + 8 g .. + 8 of token t0 + 16 n + r ------------------------------
   u32x4 xf[NT][KS], xn[PF ? NT : 1][PF ? KS : 1];
-  auto row_off = [&](int tile, int n) { return ((uint32_t)(tile * TILE + wave * (NT * 16) + n * 16 + r) * C + 8 * g) * 2; };
+  int x_mark = 0;
+  auto tok_row = [&](int tile, int n) { return (uint32_t)(tile * TILE + wave * (NT * 16) + n * 16 + r); };
   auto load_x = [&](u32x4 (*dst)[KS], int tile) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const uint32_t o = row_off(tile, n);
+      const uint32_t o = (tok_row(tile, n) * C + 8 * g) * 2;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) dst[n][ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, o + ks * 64, 0, 0);
+    }
+    issued += NT * KS;
+    x_mark = issued;
+  };
+
+  // ---- backward: saved pre-activation rows of a stage, one register set per ring slot --------------------------------------
+  u32x4 pp[BWD ? 3 : 1][SUB][NT];
+  int pre_mark[3] = {0, 0, 0};
+  auto load_pre = [&](auto slotc, int tile, int sk, bool live) {
+    constexpr int SLOT = decltype(slotc)::value;
+    if constexpr (BWD) {
+#pragma unroll
+      for (int sc = 0; sc < SUB; ++sc)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          uint32_t off = live ? (tok_row(tile, n) * (uint32_t)a.H + (uint32_t)(sk * HC + sc * 32 + 8 * g)) * 2 : 0xFFFFFFF0u;
+          pp[SLOT][sc][n] = __builtin_amdgcn_raw_buffer_load_b128(psrd, off, 0, 0);
+        }
+      issued += SUB * NT;
+      pre_mark[SLOT] = issued;
     }
   };
 
@@ -183,18 +221,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
     constexpr int SLOT = decltype(slotc)::value;
     const uint32_t sbase = frag + (uint32_t)(SLOT * STAGE);
     const uint32_t bia = b1_lane + (uint32_t)(h0 * 4);
-    // fragment groups of the stage in consumption order — per sub-chunk KS fc1 groups (the two row blocks of one 32-channel
-    // step), then CB / 2 fc2 groups (two output blocks) — on a three-deep register ring: two groups are in flight while one is
-    // consumed (one group = 4 NT MFMAs = 64 NT cycles of matrix pipe; an LDS round trip under load is longer than that), and
-    // the first two fc2 groups of a sub-chunk travel under its GELU.
+    // fragment groups of the stage in consumption order — per sub-chunk KS first-product groups (the two row blocks of one
+    // 32-channel step), then CB / 2 second-product groups (two output blocks) — on a three-deep register ring: two groups are
+    // in flight while one is consumed (one group = 4 NT MFMAs = 64 NT cycles of matrix pipe; an LDS round trip under load
+    // is longer than that), and the first two second-product groups of a sub-chunk travel under its elementwise part.
     constexpr int GPS = KS + CB / 2;               // groups per sub-chunk
     constexpr int M = SUB * GPS;
-    f32x4 bv[SUB][2];
-    static_for<0, SUB>([&](auto scc) {
-      constexpr int SC = decltype(scc)::value;
-      bv[SC][0] = lds_read16fo<SC * 128>(bia);
-      bv[SC][1] = lds_read16fo<SC * 128 + 16>(bia);
-    });
+    f32x4 bv[BWD ? 1 : SUB][2];
+    if constexpr (!BWD) {
+      static_for<0, SUB>([&](auto scc) {
+        constexpr int SC = decltype(scc)::value;
+        bv[SC][0] = lds_read16fo<SC * 128>(bia);
+        bv[SC][1] = lds_read16fo<SC * 128 + 16>(bia);
+      });
+    }
     u32x4 wf[3][2];
     auto request = [&](auto idxc) {
       constexpr int idx = decltype(idxc)::value;
@@ -238,29 +278,44 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
             d[b][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[idx % 3][b]),
                                                               __builtin_bit_cast(bf16x8, xf[n][w]), d[b][n], 0, 0, 0);
         if constexpr (w == KS - 1) {
-          // bias, bf16 rounding of the pre-activation, GELU, bf16: the D registers become the B fragment of fc2
+          // the D registers become the B fragment of the second product.  Forward: bias, bf16 rounding of the
+          // pre-activation, GELU, bf16.  Backward: bf16 rounding of d(act), times GELU'(pre), bf16.
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            u32x4 pp;
+            u32x4 prw;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
 #pragma unroll
               for (int jp = 0; jp < 2; ++jp) {
                 bf16x2 pr;
-                pr[0] = f2bf(d[b][n][2 * jp] + bv[SC][b][2 * jp]);
-                pr[1] = f2bf(d[b][n][2 * jp + 1] + bv[SC][b][2 * jp + 1]);
+                if constexpr (!BWD) {
+                  pr[0] = f2bf(d[b][n][2 * jp] + bv[SC][b][2 * jp]);
+                  pr[1] = f2bf(d[b][n][2 * jp + 1] + bv[SC][b][2 * jp + 1]);
+                } else {
+                  pr[0] = f2bf(d[b][n][2 * jp]);
+                  pr[1] = f2bf(d[b][n][2 * jp + 1]);
+                }
                 const uint32_t u = __builtin_bit_cast(uint32_t, pr);
-                pp[2 * b + jp] = u;
-                hf[n][4 * b + 2 * jp] = f2bf(gelu_f(__builtin_bit_cast(float, u << 16)));
-                hf[n][4 * b + 2 * jp + 1] = f2bf(gelu_f(__builtin_bit_cast(float, u & 0xFFFF0000u)));
+                const float v0 = __builtin_bit_cast(float, u << 16), v1 = __builtin_bit_cast(float, u & 0xFFFF0000u);
+                if constexpr (!BWD) {
+                  prw[2 * b + jp] = u;
+                  hf[n][4 * b + 2 * jp] = f2bf(gelu_f(v0));
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(gelu_f(v1));
+                } else {
+                  const uint32_t q = pp[SLOT][SC][n][2 * b + jp];
+                  const float p0 = __builtin_bit_cast(float, q << 16), p1 = __builtin_bit_cast(float, q & 0xFFFF0000u);
+                  hf[n][4 * b + 2 * jp] = f2bf(v0 * gelu_d(p0));
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(v1 * gelu_d(p1));
+                }
               }
             }
             if constexpr (SAVE) {
-              const uint32_t off = ((uint32_t)(tile * TILE + wave * (NT * 16) + n * 16 + r) * (uint32_t)a.H + (uint32_t)(h0 + SC * 32 + 8 * g)) * 2;
-              __builtin_amdgcn_raw_buffer_store_b128(pp, psrd, off, 0, 0);
+              const uint32_t off = (tok_row(tile, n) * (uint32_t)a.H + (uint32_t)(h0 + SC * 32 + 8 * g)) * 2;
+              if constexpr (!BWD) __builtin_amdgcn_raw_buffer_store_b128(prw, psrd, off, 0, 0);
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hf[n]), asrd, off, 0, 0);
             }
           }
+          if constexpr (SAVE) issued += (BWD ? 1 : 2) * NT;
         }
       } else {
         constexpr int cg = w - KS;
@@ -274,35 +329,52 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
     });
   };
 
-  // y tile out: lane (r, g) holds channels 16 cb + 4 g .. + 4 of its token; v_permlane16_swap trades the two blocks of a pair
+  // output tile: lane (r, g) holds channels 16 cb + 4 g .. + 4 of its token; v_permlane16_swap trades the two blocks of a pair
   // between neighbouring lane rows so that every lane owns 8 consecutive channels = one 16-byte store (half as many store
   // instructions: the tail of a tile is store-ISSUE bound)
   auto epilogue = [&](int tile) {
     const uint32_t b2_lane = b2_base + (uint32_t)(4 * g * 4);
     static_for<0, CB / 2>([&](auto cpc) {
       constexpr int cp = decltype(cpc)::value;
-      const f32x4 bva = lds_read16fo<(2 * cp) * 64>(b2_lane);
-      const f32x4 bvb = lds_read16fo<(2 * cp + 1) * 64>(b2_lane);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+      f32x4 bva = (f32x4){0.f, 0.f, 0.f, 0.f}, bvb = bva;
+      if constexpr (!BWD) {
+        bva = lds_read16fo<(2 * cp) * 64>(b2_lane);
+        bvb = lds_read16fo<(2 * cp + 1) * 64>(b2_lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
+        const uint32_t rowb = tok_row(tile, n) * C * 2;
+        f32x4 va = acc[2 * cp][n] + bva, vb = acc[2 * cp + 1][n] + bvb;
+        if (BWD && a.accumulate) {
+          // the rows already in dx, in this lane's own (pre-swap) channels
+          const u32x2 oa = __builtin_amdgcn_raw_buffer_load_b64(ysrd, rowb + ((2 * cp) * 16 + 4 * g) * 2, 0, 0);
+          const u32x2 ob = __builtin_amdgcn_raw_buffer_load_b64(ysrd, rowb + ((2 * cp + 1) * 16 + 4 * g) * 2, 0, 0);
+          issued += 2;
+          const bf16x4 fa = __builtin_bit_cast(bf16x4, oa), fb = __builtin_bit_cast(bf16x4, ob);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            va[j] += bf2f(fa[j]);
+            vb[j] += bf2f(fb[j]);
+          }
+        }
         bf16x4 oa, ob;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          oa[j] = f2bf(acc[2 * cp][n][j] + bva[j]);
-          ob[j] = f2bf(acc[2 * cp + 1][n][j] + bvb[j]);
+          oa[j] = f2bf(va[j]);
+          ob[j] = f2bf(vb[j]);
         }
         const u32x2 ua = __builtin_bit_cast(u32x2, oa), ub = __builtin_bit_cast(u32x2, ob);
         const u32x2 s0 = __builtin_amdgcn_permlane16_swap(ua[0], ub[0], false, false);
         const u32x2 s1 = __builtin_amdgcn_permlane16_swap(ua[1], ub[1], false, false);
         const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-        const uint32_t off = ((uint32_t)(tile * TILE + wave * (NT * 16) + n * 16 + r) * C + (2 * cp + (g & 1)) * 16 + 4 * (g & 2)) * 2;
-        __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ysrd, rowb + ((2 * cp + (g & 1)) * 16 + 4 * (g & 2)) * 2, 0, 0);
         acc[2 * cp][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc[2 * cp + 1][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     });
+    issued += NT * CB / 2;
   };
 
   // ---- persistent walk -------------------------------------------------------------------------------------------------
@@ -310,8 +382,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
   const int mine = tile0 < a.ntiles ? (a.ntiles - tile0 + tstep - 1) / tstep : 0;
   const int total = mine * NS;
   if (mine > 0) load_x(xf, tile0);
-  issue(0, 0, total > 0);
-  issue(1, 1, total > 1);
+  issue(0, std::integral_constant<int, 0>{}, total > 0);
+  issue(1, std::integral_constant<int, 1>{}, total > 1);
+  load_pre(std::integral_constant<int, 0>{}, tile0, 0, total > 0);
+  load_pre(std::integral_constant<int, 1>{}, tile0, 1, total > 1);
 #pragma unroll
   for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -325,26 +399,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
 #define TOK_MLP_STAGE(K)                                                                                                        \
       {                                                                                                                         \
         const int sk = s + K;                                                                                                   \
-        /* allowed in flight behind this stage's weights: the weight stage issued after them, the pre / act rows of the */      \
-        /* last two stages, the previous tile's y rows (first two stages of a tile), the requested tokens of the next */        \
-        /* tile (last two stages); a tile without token prefetch starts from an empty queue */                                   \
+        /* this stage's weights (and, backward, its pre-activation rows; first stage of a tile: its tokens) have landed */     \
         {                                                                                                                       \
-          int allow = NI + (gi >= 2 ? 2 : gi) * SPS;                                                                            \
-          if (PF && sk < 2 && it > 0) allow += NST;                                                                             \
-          if (PF && sk >= NS - 2 && has_next) allow += NX;                                                                      \
-          if (!PF && sk == 0) allow = 0;                                                                                        \
-          wait_vm_dyn<0, WMAX>(allow);                                                                                          \
+          int need = dma_mark[K];                                                                                               \
+          if (BWD && pre_mark[K] > need) need = pre_mark[K];                                                                    \
+          if (sk == 0 && x_mark > need) need = x_mark;                                                                          \
+          wait_until(need);                                                                                                     \
         }                                                                                                                       \
         __builtin_amdgcn_s_barrier();                                                                                           \
         {                                                                                                                       \
-          int s2 = sk + 2;                                                                                                      \
-          if (s2 >= NS) s2 -= NS;                                                                                               \
-          issue(s2, (K + 2) % 3, gi + 2 < total);                                                                               \
+          int s2 = sk + 2, t2 = tile;                                                                                           \
+          if (s2 >= NS) { s2 -= NS; t2 += tstep; }                                                                              \
+          issue(s2, std::integral_constant<int, (K + 2) % 3>{}, gi + 2 < total);                                                \
+          load_pre(std::integral_constant<int, (K + 2) % 3>{}, t2, s2, gi + 2 < total);                                         \
         }                                                                                                                       \
         if constexpr (PF) {                                                                                                     \
           if (sk == NS - 3 && has_next) load_x(xn, tile + tstep);                                                               \
         }                                                                                                                       \
-        compute(std::integral_constant<int, K>{}, sk * HC, tile);                                                                                                    \
+        compute(std::integral_constant<int, K>{}, sk * HC, tile);                                                               \
         ++gi;                                                                                                                   \
       }
       TOK_MLP_STAGE(0) TOK_MLP_STAGE(1) TOK_MLP_STAGE(2)
@@ -365,13 +437,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_fwd_kernel
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int C, int HC, int NT, int WAVES, bool PF, bool SAVE>
-void launch_fwd_v(const MlpArgs& a, hipStream_t st) {
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE>
+void launch_v(const MlpArgs& a, hipStream_t st) {
   constexpr int STAGE = (HC / 32) * (2 * (C / 32) + C / 16) * 1024;
-  const int smem = 3 * STAGE + (a.H + C) * 4;
+  const int smem = 3 * STAGE + (MODE == 0 ? (a.H + C) * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fwd_kernel<C, HC, NT, WAVES, PF, SAVE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
@@ -380,13 +452,24 @@ void launch_fwd_v(const MlpArgs& a, hipStream_t st) {
   b.ntiles = (a.T + TILE - 1) / TILE;
   const int cap = WAVES == 4 ? 512 : 256;
   const int grid = b.ntiles < cap ? b.ntiles : cap;
-  hipLaunchKernelGGL((mlp_fwd_kernel<C, HC, NT, WAVES, PF, SAVE>), dim3(grid), dim3(WAVES * 64), smem, st, b);
+  hipLaunchKernelGGL((mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE>), dim3(grid), dim3(WAVES * 64), smem, st, b);
 }
 
-template <int C, int HC, int NT, int WAVES, bool PF>
-void launch_fwd(const MlpArgs& a, hipStream_t st) {
-  if (a.pre != nullptr) launch_fwd_v<C, HC, NT, WAVES, PF, true>(a, st);
-  else launch_fwd_v<C, HC, NT, WAVES, PF, false>(a, st);
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE>
+void launch_m(const MlpArgs& a, hipStream_t st) {
+  if (a.act != nullptr) launch_v<C, HC, NT, WAVES, PF, MODE, true>(a, st);
+  else launch_v<C, HC, NT, WAVES, PF, MODE, false>(a, st);
+}
+
+template <int MODE>
+void launch_c(const MlpArgs& a, int c, hipStream_t st) {
+  static int w4 = -1;
+  if (w4 < 0) { const char* e = getenv("TOK_MLP_W4"); w4 = e ? atoi(e) : 0; }
+  if (c == 96 && w4) launch_m<96, 64, 2, 4, true, MODE>(a, st);
+  else if (c == 192 && w4) launch_m<192, 32, 2, 4, false, MODE>(a, st);
+  else if (c == 96) launch_m<96, 64, 2, 8, true, MODE>(a, st);
+  else if (c == 192) launch_m<192, 32, 2, 8, false, MODE>(a, st);
+  else launch_m<384, 32, 1, 8, false, MODE>(a, st);
 }
 
 int mlp_min_rows() {   // below this the serial chain of hidden chunks of one tile is longer than the two GEMM launches
@@ -423,14 +506,27 @@ extern "C" int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const
   a.T = (int)rows; a.H = hidden; a.ntiles = 0;
   a.x_bytes = (uint32_t)(rows * c * 2);
   a.w_bytes = (uint32_t)((long long)hidden * c * 2);
-  hipStream_t st = tok_stream(stream);
-  static int w4 = -1;
-  if (w4 < 0) { const char* e = getenv("TOK_MLP_W4"); w4 = e ? atoi(e) : 0; }
-  if (c == 96 && w4) launch_fwd<96, 64, 2, 4, true>(a, st);
-  else if (c == 192 && w4) launch_fwd<192, 32, 2, 4, false>(a, st);
-  else if (c == 96) launch_fwd<96, 64, 2, 8, true>(a, st);
-  else if (c == 192) launch_fwd<192, 32, 2, 8, false>(a, st);
-  else launch_fwd<384, 32, 1, 8, false>(a, st);
+  a.accumulate = 0;
+  launch_c<0>(a, c, tok_stream(stream));
   TOK_CHECK_LAUNCH("tok_mlp_fwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_mlp_bwd_dx(const void* dy, const void* w2_dgrad, const void* pre, const void* w1_dgrad, void* dx, int accumulate,
+                              void* dpre, int64_t rows, int c, int hidden, void* stream) {
+  TOK_CHECK_ARG(dy && w2_dgrad && pre && w1_dgrad && dx, "tok_mlp_bwd_dx: null pointer");
+  TOK_CHECK_ARG(tok_mlp_serves(rows, c, hidden), "tok_mlp_bwd_dx: geometry (%lld, %d, %d) is not served (tok_mlp_serves)",
+                (long long)rows, c, hidden);
+  MlpArgs a;
+  a.x = (const bf16*)dy; a.w1 = (const bf16*)w2_dgrad; a.b1 = nullptr; a.w2 = (const bf16*)w1_dgrad; a.b2 = nullptr;
+  a.y = (bf16*)dx;
+  a.pre = (bf16*)pre; a.act = (bf16*)dpre;
+  a.h_bytes = (uint32_t)(rows * hidden * 2);
+  a.T = (int)rows; a.H = hidden; a.ntiles = 0;
+  a.x_bytes = (uint32_t)(rows * c * 2);
+  a.w_bytes = (uint32_t)((long long)hidden * c * 2);
+  a.accumulate = accumulate;
+  launch_c<1>(a, c, tok_stream(stream));
+  TOK_CHECK_LAUNCH("tok_mlp_bwd_dx");
   return TOK_OK;
 }

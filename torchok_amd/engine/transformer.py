@@ -81,6 +81,8 @@ def _linear_plan(lib, d):
 
 class _LinearNode(Node):
     needs_backward = True
+    mlp_first = None        # fc2 of a fused Mlp: the node of its fc1 (tok_mlp_bwd_dx covers both data gradients)
+    dx_done = False         # fc1 of a fused Mlp: its data gradient was produced by fc2's backward launch
 
     def backward(self):
         lib, st = _C.lib(), stream_ptr()
@@ -171,15 +173,30 @@ class _LinearNode(Node):
         ev = self.region.mark_side() if early else None
         if not early:
             param_grads()
-        if x.requires_grad:
+        if x.requires_grad and self.dx_done:
+            pass            # fc1 of a fused Mlp: fc2's backward launch already sent this gradient on (tok_mlp_bwd_dx)
+        elif x.requires_grad:
             an = x.node
+            first = self.mlp_first
             if (FUSE_ACT and isinstance(an, _ActNode) and an.out is x and an.kind in (RELU, GELU) and x.uses == 1 and
                     x.grad is None and an.x.requires_grad and an.x.uses == 1 and an.x.grad is None):
-                # this layer consumes act(h) and nothing else does: its dgrad epilogue multiplies by act'(h) and writes
-                # d(h) — the gradient of act(h) is never materialised, the activation node finds nothing to do
-                tgt, _ = grad_target(an.x)
-                _C.check(lib.tok_conv_dgrad_act(d, ptr(g), ptr(self.pk.dgrad), ptr(an.x.data), an.kind, ptr(tgt), st),
-                         'tok_conv_dgrad_act')
+                if (first is not None and FUSE_MLP_BWD and an.kind == GELU and an.x is first.out and first.x.requires_grad
+                        and first.pk.dgrad is not None):
+                    # fc2 of a fused Mlp: d(pre) = (dy W2) * GELU'(pre) stays in registers and goes straight through W1 to the
+                    # Mlp's input; the d(pre) rows are written only if fc1's parameter gradients will read them
+                    w1, sinks = first.weight, first.bias_sinks
+                    need_dpre = w1.requires_grad or any(p.requires_grad for p, _ in sinks)
+                    tgt = grad_target(an.x)[0] if need_dpre else None
+                    tgt_x, acc_x = grad_target(first.x)
+                    _C.check(lib.tok_mlp_bwd_dx(ptr(g), ptr(self.pk.dgrad), ptr(an.x.data), ptr(first.pk.dgrad), ptr(tgt_x), acc_x,
+                                                ptr(tgt), m, d.k, d.c, st), 'tok_mlp_bwd_dx')
+                    first.dx_done = True
+                else:
+                    # this layer consumes act(h) and nothing else does: its dgrad epilogue multiplies by act'(h) and writes
+                    # d(h) — the gradient of act(h) is never materialised, the activation node finds nothing to do
+                    tgt, _ = grad_target(an.x)
+                    _C.check(lib.tok_conv_dgrad_act(d, ptr(g), ptr(self.pk.dgrad), ptr(an.x.data), an.kind, ptr(tgt), st),
+                             'tok_conv_dgrad_act')
             else:
                 tgt, acc = grad_target(x)
                 _C.check(lib.tok_conv_dgrad(d, ptr(g), ptr(self.pk.dgrad), ptr(tgt), acc, st), 'tok_conv_dgrad')
@@ -188,7 +205,7 @@ class _LinearNode(Node):
         self.out.grad = None
 
     def release(self):
-        self.x = self.out = self.pk = None
+        self.x = self.out = self.pk = self.mlp_first = None
 
 
 # GELU / ReLU in the epilogues of the GEMMs around it (tok_conv_fwd_act / tok_conv_dgrad_act).  Bit-identical to the separate
@@ -259,6 +276,9 @@ def linear_module(region: Region, x: TTensor, fc: nn.Linear, act: Optional[int] 
 # launches record and every tensor on it has the same bits.  Measured per call on the SwinV2-T B=256 shapes (fused+saved vs
 # fc1+GELU launch + fc2 launch): C=96 366 vs 543 us, C=192 269 vs 368, C=384 203 vs 239.  TOK_FUSE_MLP=0: separate launches.
 FUSE_MLP = os.environ.get('TOK_FUSE_MLP', '1') == '1'
+# ... and its backward to the input from one launch too (tok_mlp_bwd_dx replaces tok_conv_dgrad_act + tok_conv_dgrad; the d(pre)
+# rows are still written for fc1's weight gradient).  Per call: C=96 360 vs 600 us, C=192 267 vs 373, C=384 216 vs 242.
+FUSE_MLP_BWD = os.environ.get('TOK_FUSE_MLP_BWD', '1') == '1'
 
 
 def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TTensor:
@@ -290,7 +310,10 @@ def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TT
     d2 = _C.ConvDesc(n, 1, 1, hid, c, 1, 1, 1, 1, 1, 0, 1)
     h_pre = _record_linear(region, x, fc1.weight, [(fc1.bias, 0)], pre, d1, pk1)
     h = activation(region, h_pre, GELU, precomputed=act)
-    return _record_linear(region, h, fc2.weight, [(fc2.bias, 0)], y, d2, pk2)
+    out = _record_linear(region, h, fc2.weight, [(fc2.bias, 0)], y, d2, pk2)
+    if out.node is not None and h_pre.node is not None:
+        out.node.mlp_first = h_pre.node
+    return out
 
 
 # ---- layer norm (+ residual, + stochastic depth) ---------------------------------------------------------------------
