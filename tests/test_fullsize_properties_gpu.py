@@ -170,6 +170,48 @@ def test_swinv2_t_b256_gradient_is_additive_over_a_batch_split_and_reproducible(
     assert med < 5e-3 and errs[worst] < 3e-2, (med, worst, errs[worst])
 
 
+def test_swinv2_t_b256_branch_stream_schedule_gives_the_single_stream_bits():
+    """SwinV2-T's parameter-only prologue of every attention unit (position-bias chain + qkv bias) runs on a branch stream,
+    two blocks ahead (swin.py: WindowAttention.prepare), its backward on that stream too.  Same kernels, same operands:
+    logits, loss and every parameter gradient must equal the single-stream schedule bit for bit — in grad mode and in
+    no-grad mode, where no unit keeps the branch's output buffers alive (round 3: a qkv bias vector from the branch stream's
+    pool was recycled under the main stream's queued GEMM until await_ready told the allocator about the reader)."""
+    from torchok_amd.engine import core as EC
+    task = _swin_task().train()
+    x, y = _batch(256, seed=2)
+
+    def step():
+        for p in task.parameters():
+            p.grad = None
+        out = task.forward_with_gt({'image': x, 'target': y})
+        loss = task.losses(**out)[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return out['prediction'].detach().clone(), {n: p.grad.detach().clone() for n, p in task.named_parameters()
+                                                    if p.grad is not None}
+
+    def feats():
+        with torch.no_grad():
+            f = task.backbone.forward_features(x)
+        torch.cuda.synchronize()
+        return [t.clone() for t in f[1:]]
+    saved = EC.BRANCH_STREAMS
+    try:
+        EC.BRANCH_STREAMS = False
+        ref_pred, ref_grads = step()
+        ref_feats = feats()
+        EC.BRANCH_STREAMS = True
+        for _ in range(3):
+            pred, grads = step()
+            assert torch.equal(pred, ref_pred)
+            assert set(grads) == set(ref_grads)
+            bad = [n for n in grads if not torch.equal(grads[n], ref_grads[n])]
+            assert not bad, bad[:5]
+            assert all(torch.equal(a, b) for a, b in zip(feats(), ref_feats))
+    finally:
+        EC.BRANCH_STREAMS = saved
+
+
 def test_hrnet_w48_b24_training_steps_are_bit_reproducible():
     """HRNet-W48 + neck + head at 512x1024, batch 24 (the size profiles/r0N_hrnet_* quote): two optimizer steps from the same
     state twice -> identical parameters and BatchNorm buffers (branch streams, side stream, fixed-order reductions)."""

@@ -850,6 +850,60 @@ def test_window_attention(libs, b, h, w, heads, ws, shift):
     assert float(dsp_d[:, 0].abs().max()) == 0.0                         # clamped head: zero gradient
 
 
+@pytest.mark.parametrize('b,h,w,heads,ws,shift', [(256, 14, 14, 12, 7, 3), (256, 14, 14, 12, 7, 0), (128, 28, 28, 6, 7, 3),
+                                                  (64, 56, 56, 3, 7, 3), (256, 7, 7, 24, 7, 0)])
+def test_window_attention_is_bit_reproducible(libs, b, h, w, heads, ws, shift):
+    """The SwinV2-T stage geometries at sizes where a workgroup walks several images (units >= 8192): the same launch, six
+    times, gives the same bits in d(qkv), the d(logits) partial rows and the d(logit_scale) partials, and every element is
+    written.  Round 3 found a few hundred wrong d(q) / d(k) elements per launch, different ones every run (a register reused
+    under two ds_bpermute in flight, transformer.hip: the value barrier after the delta reduction); only the full-size model
+    test saw it."""
+    lib, _ = libs
+    c, n, nw = heads * 32, ws * ws, (h // ws) * (w // ws)
+    gen = torch.Generator(device='cuda').manual_seed(1)
+    qkv = torch.randn(b * h * w, 3 * c, device='cuda', generator=gen).to(BF16)
+    g = torch.randn(b * h * w, c, device='cuda', generator=gen).to(BF16)
+    ls = torch.full((heads,), 2.3, device='cuda')
+    bias = torch.randn(heads, n, n, device='cuda', generator=gen)
+    mask = None
+    if shift:
+        img = torch.zeros(1, h, w, 1)
+        cnt = 0
+        for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, h // ws, ws, w // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, n)
+        am = mw.unsqueeze(1) - mw.unsqueeze(2)
+        mask = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).contiguous().cuda()
+    P = lambda t_: None if t_ is None else t_.data_ptr()   # noqa: E731
+    st = torch.cuda.current_stream().cuda_stream
+    fw = []
+    for _ in range(3):
+        out = torch.full((b * h * w, c), float('nan'), dtype=BF16, device='cuda')
+        lse = torch.full((b * nw * heads * n,), float('nan'), device='cuda')
+        assert lib.tok_window_attn_fwd(P(qkv), b, h, w, c, heads, ws, shift, 3 * c, P(ls), P(bias), P(mask), P(out), P(lse),
+                                       st) == 0, lib.tok_last_error()
+        fw.append((out, lse))
+    torch.cuda.synchronize()
+    assert not fw[0][0].isnan().any() and not fw[0][1].isnan().any()
+    assert all(torch.equal(fw[0][0], o) and torch.equal(fw[0][1], l_) for o, l_ in fw[1:])
+    rows = lib.tok_window_attn_bwd_rows(b, h, w, heads, ws)
+    res = []
+    for _ in range(6):
+        dq = torch.full((b * h * w, 3 * c), float('nan'), dtype=BF16, device='cuda')
+        scr = torch.full((rows, heads * n * n), float('nan'), device='cuda')
+        dsp = torch.full((rows, heads), float('nan'), device='cuda')
+        assert lib.tok_window_attn_bwd(P(qkv), P(g), b, h, w, c, heads, ws, shift, 3 * c, P(ls), P(bias), P(mask), P(fw[0][1]),
+                                       P(dq), P(scr), P(dsp), st) == 0, lib.tok_last_error()
+        res.append((dq, scr, dsp))
+    torch.cuda.synchronize()
+    assert not any(t_.isnan().any() for t_ in res[0])
+    for r_ in res[1:]:
+        for a_, b_ in zip(res[0], r_):
+            assert torch.equal(a_, b_), int((a_ != b_).sum())
+
+
 def test_cpb_bias_and_patch_merge(libs):
     heads, ws = 3, 4
     n, T_ = ws * ws, (2 * ws - 1) ** 2

@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef TOK_MLP_PROBE
+#define TOK_MLP_PROBE 0   // timing probes (results are garbage): 1 no weight DMA, 2 no GELU, 3 no stage barrier, 4 no LDS fragment reads
+#endif
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -95,8 +99,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 //   pre-activation rows (requested two stages ahead, 16 bytes per lane = the D-register layout), bf16, A2 = fc1's dgrad pack
 //   (W1^T, [C][H]), out = dx (+ the rows already there: ACCUMULATE at run time); SAVE writes d(pre) for the weight gradients.
 // Both reproduce the separate launches bit for bit (same rounding points, same accumulation order).
-template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(MlpArgs a) {
+// two workgroups of four waves per CU while the output accumulators + token rows of a lane leave room for it (256 registers
+// per lane at two waves per SIMD); the wide 4-wave forms run one wave per SIMD on the whole 512-register file
+template <int C, int NT, int WAVES>
+constexpr int mlp_min_blocks() { return (WAVES == 4 && (C / 16) * NT * 4 + (C / 32) * NT * 4 <= 160) ? 2 : 1; }
+
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE, int RD>
+__global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<C, NT, WAVES>())) void mlp_kernel(MlpArgs a) {
   constexpr int KS = C / 32, CB = C / 16, SUB = HC / 32;
   constexpr int FR_SUB = 2 * KS + CB;            // fragments of one 32-hidden sub-chunk: A1 (2 blocks x KS), A2 (CB)
   constexpr int NF = SUB * FR_SUB;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
     constexpr int SLOT = decltype(slotc)::value;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      uint32_t off = live ? voff[j] + (uint32_t)(s * vinc[j]) : 0xFFFFFFF0u;
+      uint32_t off = (live && TOK_MLP_PROBE != 1) ? voff[j] + (uint32_t)(s * vinc[j]) : 0xFFFFFFF0u;
       asm volatile("" : "+v"(off));
       lds_void* dst = (lds_void*)(smem + SLOT * STAGE + (j * WAVES + wave) * 1024);
       if (isw1[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(w1srd, dst, 16, off, 0, 0, 0);
@@ -235,33 +244,33 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
         bv[SC][1] = lds_read16fo<SC * 128 + 16>(bia);
       });
     }
-    u32x4 wf[3][2];
+    u32x4 wf[RD][2];
     auto request = [&](auto idxc) {
       constexpr int idx = decltype(idxc)::value;
       constexpr int SC = idx / GPS, w = idx % GPS;
       constexpr int FB = SC * FR_SUB * 1024;
-      if constexpr (w < KS) {
-        wf[idx % 3][0] = lds_read16o<FB + w * 1024>(sbase);
-        wf[idx % 3][1] = lds_read16o<FB + (KS + w) * 1024>(sbase);
+      if constexpr (TOK_MLP_PROBE == 4) {
+        wf[idx % RD][0] = (u32x4){sbase, (uint32_t)idx, sbase, sbase};
+        wf[idx % RD][1] = (u32x4){sbase, sbase, (uint32_t)idx, sbase};
+      } else if constexpr (w < KS) {
+        wf[idx % RD][0] = lds_read16o<FB + w * 1024>(sbase);
+        wf[idx % RD][1] = lds_read16o<FB + (KS + w) * 1024>(sbase);
       } else {
-        wf[idx % 3][0] = lds_read16o<FB + (2 * KS + 2 * (w - KS)) * 1024>(sbase);
-        wf[idx % 3][1] = lds_read16o<FB + (2 * KS + 2 * (w - KS) + 1) * 1024>(sbase);
+        wf[idx % RD][0] = lds_read16o<FB + (2 * KS + 2 * (w - KS)) * 1024>(sbase);
+        wf[idx % RD][1] = lds_read16o<FB + (2 * KS + 2 * (w - KS) + 1) * 1024>(sbase);
       }
     };
-    request(std::integral_constant<int, 0>{});
-    request(std::integral_constant<int, 1>{});
+    static_for<0, RD - 1>([&](auto ic) { request(ic); });
     f32x4 d[2][NT];
     bf16x8 hf[NT];
     static_for<0, M>([&](auto idxc) {
       constexpr int idx = decltype(idxc)::value;
       constexpr int SC = idx / GPS, w = idx % GPS;
-      if constexpr (idx + 2 < M) {
-        request(std::integral_constant<int, idx + 2>{});
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-      } else if constexpr (idx + 1 < M) {
-        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // RD - 1 groups (two reads each) stay in flight behind the one consumed now
+      if constexpr (idx + RD - 1 < M) request(std::integral_constant<int, idx + RD - 1>{});
+      {
+        constexpr int ahead = (M - 1 - idx) < (RD - 1) ? (M - 1 - idx) : (RD - 1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * ahead) : "memory");
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (w < KS) {
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            d[b][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[idx % 3][b]),
+            d[b][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[idx % RD][b]),
                                                               __builtin_bit_cast(bf16x8, xf[n][w]), d[b][n], 0, 0, 0);
         if constexpr (w == KS - 1) {
           // the D registers become the B fragment of the second product.  Forward: bias, bf16 rounding of the
@@ -299,13 +308,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
                 const float v0 = __builtin_bit_cast(float, u << 16), v1 = __builtin_bit_cast(float, u & 0xFFFF0000u);
                 if constexpr (!BWD) {
                   prw[2 * b + jp] = u;
-                  hf[n][4 * b + 2 * jp] = f2bf(gelu_f(v0));
-                  hf[n][4 * b + 2 * jp + 1] = f2bf(gelu_f(v1));
+                  hf[n][4 * b + 2 * jp] = f2bf(TOK_MLP_PROBE == 2 ? v0 : gelu_f(v0));
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(TOK_MLP_PROBE == 2 ? v1 : gelu_f(v1));
                 } else {
                   const uint32_t q = pp[SLOT][SC][n][2 * b + jp];
                   const float p0 = __builtin_bit_cast(float, q << 16), p1 = __builtin_bit_cast(float, q & 0xFFFF0000u);
-                  hf[n][4 * b + 2 * jp] = f2bf(v0 * gelu_d(p0));
-                  hf[n][4 * b + 2 * jp + 1] = f2bf(v1 * gelu_d(p1));
+                  hf[n][4 * b + 2 * jp] = f2bf(v0 * (TOK_MLP_PROBE == 2 ? p0 : gelu_d(p0)));
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(v1 * (TOK_MLP_PROBE == 2 ? p1 : gelu_d(p1)));
                 }
               }
             }
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[2 * cg + c2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[idx % 3][c2]), hf[n],
+            acc[2 * cg + c2][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[idx % RD][c2]), hf[n],
                                                                           acc[2 * cg + c2][n], 0, 0, 0);
       }
     });
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
           if (sk == 0 && x_mark > need) need = x_mark;                                                                          \
           wait_until(need);                                                                                                     \
         }                                                                                                                       \
-        __builtin_amdgcn_s_barrier();                                                                                           \
+        if (TOK_MLP_PROBE != 3) __builtin_amdgcn_s_barrier();                                                                   \
         {                                                                                                                       \
           int s2 = sk + 2, t2 = tile;                                                                                           \
           if (s2 >= NS) { s2 -= NS; t2 += tstep; }                                                                              \
@@ -437,32 +446,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void mlp_kernel(Mlp
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE>
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE, int RD>
 void launch_v(const MlpArgs& a, hipStream_t st) {
   constexpr int STAGE = (HC / 32) * (2 * (C / 32) + C / 16) * 1024;
   const int smem = 3 * STAGE + (MODE == 0 ? (a.H + C) * 4 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE, RD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_set = true;
   }
   MlpArgs b = a;
   constexpr int TILE = WAVES * NT * 16;
   b.ntiles = (a.T + TILE - 1) / TILE;
-  const int cap = WAVES == 4 ? 512 : 256;
+  const int cap = 256 * mlp_min_blocks<C, NT, WAVES>();
   const int grid = b.ntiles < cap ? b.ntiles : cap;
-  hipLaunchKernelGGL((mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE>), dim3(grid), dim3(WAVES * 64), smem, st, b);
+  hipLaunchKernelGGL((mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE, RD>), dim3(grid), dim3(WAVES * 64), smem, st, b);
 }
 
-template <int C, int HC, int NT, int WAVES, bool PF, int MODE>
+template <int C, int HC, int NT, int WAVES, bool PF, int MODE, int RD = 3>
 void launch_m(const MlpArgs& a, hipStream_t st) {
-  if (a.act != nullptr) launch_v<C, HC, NT, WAVES, PF, MODE, true>(a, st);
-  else launch_v<C, HC, NT, WAVES, PF, MODE, false>(a, st);
+  static_assert(RD >= 2 && RD <= 8, "lgkmcnt is a 4-bit counter: at most 14 fragment reads in flight");
+  if (a.act != nullptr) launch_v<C, HC, NT, WAVES, PF, MODE, true, RD>(a, st);
+  else launch_v<C, HC, NT, WAVES, PF, MODE, false, RD>(a, st);
 }
 
 template <int MODE>
 void launch_c(const MlpArgs& a, int c, hipStream_t st) {
+  // measured and not kept (round 3, per call at the SwinV2-T stage shapes; tools/ubench/exp_mlp.sh): 4-wave workgroups with twice
+  // the tokens per wave on the whole 512-register file (C = 384: 241 vs 223 us, C = 192: 323 vs 290 — one wave per SIMD cannot
+  // overlap its own MFMA / VALU / LDS phases, and the C = 192 form spills); a deeper fragment register ring (RD 4 .. 8: 198..201
+  // vs 199 us — the LDS round trip is not what the waves wait for).  Timing probes (TOK_MLP_PROBE): no weight DMA -20 %, no GELU
+  // -8 % (C = 384) / -28 % (C = 192), no stage barrier -7 %: no single bound, the stage's three phases serialise per wave.
   static int w4 = -1;
   if (w4 < 0) { const char* e = getenv("TOK_MLP_W4"); w4 = e ? atoi(e) : 0; }
   if (c == 96 && w4) launch_m<96, 64, 2, 4, true, MODE>(a, st);

@@ -538,6 +538,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
     }
+    // the logits leave the accumulator file here, in one go: no v_accvgpr_read between the ds_bpermute / ds_write of the
+    // softmax below (see the note at the delta reduction of attn_bwd_mfma_kernel; tools/isa_lint.py)
+    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
     float rsum[4], rmax[4];
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -744,6 +747,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
       dp[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, vf, z, 0, 0, 0);
     }
+    // logits and dP leave the accumulator file in one go (no v_accvgpr_read among the ds_bpermute / ds_write below)
+    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(dp[0]), "+v"(dp[1]), "+v"(dp[2]), "+v"(dp[3]));
     // ---- P, dP, dS on the accumulator layout: query i = qi*16 + 4g + reg, key j = kj*16 + l15 ----
     float pv[4][4], dsv[4][4];           // [kj][reg]
 #pragma unroll
@@ -759,6 +764,14 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       }
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off, 64);
+      // Value barrier: the reduced delta is materialised in a register of its own before its consumers.  Without it hipcc
+      // (ROCm 7.2) pairs the butterfly's last steps with the d(logits) arithmetic and overwrites the address register of two
+      // ds_bpermute in flight with a v_accvgpr_read of the next accumulator ("ds_bpermute v152, v20, v144; ds_bpermute v153,
+      // v20, v145; v_accvgpr_read_b32 v20, a6"): under load the last quarter-wave (lanes 48-63) of the second permute then
+      // reads a stale index and rows 12..15 of a query tile get delta = 0 for one key tile — a few hundred wrong d(q) / d(k)
+      // elements per launch, different ones every run (found by tests/test_fullsize_properties_gpu.py's bit-reproducibility
+      // check; tests/test_kernels_gpu.py::test_window_attention_is_bit_reproducible pins it at the kernel level).
+      asm volatile("" : "+v"(dl));
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
         const float ds = pv[kj][reg] * (dp[kj][reg] - dl);

@@ -2,7 +2,7 @@
 import threading
 from contextlib import contextmanager
 
-from .core import Region, TTensor, pad8, require_device, stream_ptr  # noqa: F401
+from .core import Region, TTensor, await_ready, mark_padded, pad8, require_device, stream_ptr  # noqa: F401
 
 _tls = threading.local()
 

@@ -78,7 +78,7 @@ class TTensor:
         self.uses = 0       # in-region consumers that will send a gradient (counted in forward)
         self.arrived = 0    # gradient contributions received so far (backward)
         self.ready = None   # (event, stream): produced on a branch stream (forward), see Region.branch
-        self.gevents = None  # [(event, stream)]: gradient contributions written on other streams (backward)
+        self.gevents = None  # [(stream, unit number)]: who wrote gradient contributions (multi-stream backward)
         self.sub_closers = 0  # consumers whose data gradient can absorb a pending half-resolution contribution (forward)
         self.grad_sub = None  # pending contribution: gradient of the stride-2 pixel subsample of this tensor (backward)
         self.colsum_part = None  # (partial [rows][C] fp32, rows): per-block column sums left by the pass that produced `data`
@@ -117,19 +117,69 @@ def _await(events):
 
 
 def await_ready(*tensors):
-    """Forward: make the current stream wait for tensors that were produced on a branch stream."""
+    """Forward: make the current stream wait for tensors that were produced on a branch stream, and tell the caching
+    allocator about the new reader: the buffers belong to the branch stream's pool, and without `record_stream` a buffer
+    whose last reference dies on the launch thread (no-grad mode; operands no unit keeps for its backward, like a bias
+    vector) is handed to the branch stream's NEXT allocation while the consumer's kernel is still queued.
+    Arguments: TTensors, or objects with `ready` and a `tensors` tuple (Region.branch's publish)."""
+    cur = None
     for t in tensors:
         if t is not None and t.ready is not None:
             _await((t.ready,))
+            if cur is None:
+                cur = torch.cuda.current_stream()
+            if t.ready[1] != cur:
+                for d in (t.tensors if hasattr(t, 'tensors') else (t.data,)):
+                    if d is not None and d.is_cuda:
+                        d.record_stream(cur)
+
+
+def _sync_writers(writers, cur):
+    """Multi-stream backward: make stream `cur` wait for the work that the streams in `writers` ([(stream, seq)]: a unit
+    numbered `seq` of that stream's backward wrote something `cur` is about to touch) had been given.  Events are recorded
+    LAZILY, at the first cross-stream consumer: a step whose units all sit on one stream records none (an event record
+    costs its stream a few microseconds of bubble; one per unit was 300+ per transformer step), and an event that already
+    covers the writer is reused.  The record point is later than the write, i.e. conservative."""
+    for w, seq in writers:
+        if w == cur:
+            continue
+        have = _ms.waited.get((cur, w), -1)
+        if have >= seq:
+            continue                              # `cur` already waited for an event of `w` that covers the write
+        ev_seq, ev = _ms.events.get(w, (-1, None))
+        now = _ms.seq.get(w, 0)
+        if ev_seq < seq:
+            ev = torch.cuda.Event()
+            ev.record(w)
+            ev_seq = now
+            _ms.events[w] = (ev_seq, ev)
+        cur.wait_event(ev)
+        _ms.waited[(cur, w)] = ev_seq
 
 
 def _touch(x: 'TTensor'):
     if getattr(_ms, 'active', False):
         if x.gevents:
-            _await(x.gevents)                     # an earlier contribution may still be in flight on another stream
-            if x.grad is not None:
-                x.grad.record_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            _sync_writers(x.gevents, cur)         # an earlier contribution may still be in flight on another stream
+            if x.grad is not None and any(w != cur for w, _ in x.gevents):
+                x.grad.record_stream(cur)
         _ms.touched.append(x)
+
+
+def written_mark():
+    """Multi-stream backward: a token for "what the current unit has enqueued so far" (None on a single stream); a unit of
+    another stream that reads it passes the token to `await_mark` first.  For hand-offs that do not travel through a
+    TTensor's gradient (window attention -> position-bias unit)."""
+    if getattr(_ms, 'active', False):
+        cur = torch.cuda.current_stream()
+        return (cur, _ms.seq.get(cur, 0))
+    return None
+
+
+def await_mark(mark):
+    if mark is not None and getattr(_ms, 'active', False):
+        _sync_writers((mark,), torch.cuda.current_stream())
 
 
 def flush_sub(x: TTensor):
@@ -253,8 +303,8 @@ def _branch_stream(device, idx: int) -> 'torch.cuda.Stream':
 
 
 class _Branch:
-    def __init__(self, region: 'Region', idx: int):
-        self.region, self.idx, self.out, self.ctx, self.prev = region, idx, [], None, 0
+    def __init__(self, region: 'Region', idx: int, fork: bool = True):
+        self.region, self.idx, self.out, self.ctx, self.prev, self.fork = region, idx, [], None, 0, fork
 
     def publish(self, *tensors):
         self.out.extend(t for t in tensors if t is not None)
@@ -266,11 +316,11 @@ class _Branch:
         self.live = bool(BRANCH_STREAMS and self.idx and dev is not None and dev.type == 'cuda'
                          and not torch.cuda.is_current_stream_capturing())
         if self.live:
-            main = torch.cuda.current_stream()
             b = _branch_stream(dev, self.idx)
-            ev = torch.cuda.Event()
-            ev.record(main)
-            b.wait_event(ev)
+            if self.fork or self.idx not in r._streams:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                b.wait_event(ev)
             r._streams[self.idx] = b
             self.prev, r._tag = r._tag, self.idx
             self.ctx = torch.cuda.stream(b)
@@ -400,13 +450,16 @@ class Region:
         self.nodes.append(node)
 
     # -- branch streams ----------------------------------------------------------------------------
-    def branch(self, idx: int):
+    def branch(self, idx: int, fork: bool = True):
         """Context manager: the units recorded inside run on branch stream `idx` (forward now, their backward later),
         concurrently with what the main stream is given meanwhile.  For sub-graphs that are independent of the main
-        chain: the projection shortcut of a residual block, the parallel branches of an HRNet module.  Publish the
-        tensors that leave the branch with `.publish(...)`: their consumers wait for the branch automatically.
+        chain: the projection shortcut of a residual block, the parallel branches of an HRNet module, the parameter-only
+        position-bias chain of a SwinV2 block.  Publish what leaves the branch with `.publish(...)` (TTensors, or any
+        object with a `ready` attribute): consumers wait for the branch through `await_ready`.
+        fork=False: the units read nothing the main stream produced inside this region (parameters only), so only the
+        region's first entry into the stream is ordered behind the main stream — no event record on the main queue.
         No-op on the host stand-in, inside a hipGraph capture, for idx 0 or with TOK_BRANCH_STREAMS=0."""
-        return _Branch(self, idx)
+        return _Branch(self, idx, fork)
 
     def _join_forward(self):
         if self._branch_done:
@@ -456,8 +509,9 @@ class Region:
 
     def _run_backward_multi(self):
         """Backward of a region that used branch streams: every unit runs on the stream it was recorded on; a unit waits
-        for the gradient contributions other streams wrote into its output, and leaves an event on every gradient
-        buffer it wrote.  Units of branch streams are released only after the join (their tensors may be in flight)."""
+        for the gradient contributions other streams wrote into its output (`_sync_writers`: events are recorded lazily,
+        only for edges that cross streams).  Units of branch streams are released only after the join (their tensors may
+        be in flight)."""
         main = torch.cuda.current_stream()
         ev0 = torch.cuda.Event()
         ev0.record(main)
@@ -465,33 +519,38 @@ class Region:
             b.wait_event(ev0)
         held = []
         _ms.active, _ms.touched = True, []
+        _ms.seq, _ms.events, _ms.waited = {}, {}, {}
+        cur = main
         try:
             for node in reversed(self.nodes):
                 s = self._streams.get(node.stream_tag, main) if node.stream_tag else main
-                with torch.cuda.stream(s):
-                    if node.needs_backward:
-                        out = getattr(node, 'out', None)
-                        if out is not None and out.gevents:
-                            _await(out.gevents)
-                            if out.grad is not None:
-                                out.grad.record_stream(s)
-                        _ms.touched = []
-                        if out is not None and out.grad_sub is not None:
-                            flush_sub(out)
-                        node.backward()
-                        if _ms.touched:
-                            ev = torch.cuda.Event()
-                            ev.record(s)
-                            for t in _ms.touched:
-                                if t.gevents is None:
-                                    t.gevents = []
-                                t.gevents.append((ev, s))
+                if node.needs_backward:
+                    if s is not cur:
+                        torch.cuda.set_stream(s)
+                        cur = s
+                    _ms.seq[s] = seq = _ms.seq.get(s, 0) + 1
+                    out = getattr(node, 'out', None)
+                    if out is not None and out.gevents:
+                        _sync_writers(out.gevents, s)
+                        if out.grad is not None and any(w != s for w, _ in out.gevents):
+                            out.grad.record_stream(s)
+                    _ms.touched = []
+                    if out is not None and out.grad_sub is not None:
+                        flush_sub(out)
+                    node.backward()
+                    for t in _ms.touched:
+                        if t.gevents is None:
+                            t.gevents = []
+                        t.gevents.append((s, seq))
                 if s is main:
                     node.release()
                 else:
                     held.append(node)
         finally:
+            if cur is not main:
+                torch.cuda.set_stream(main)
             _ms.active, _ms.touched = False, []
+            _ms.seq, _ms.events, _ms.waited = {}, {}, {}
         for b in self._streams.values():
             main.wait_stream(b)
         self.nodes = []

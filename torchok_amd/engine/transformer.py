@@ -19,8 +19,8 @@ import torch
 from torch import nn
 
 from .. import _C
-from .core import (BF16, Node, Region, TTensor, commit_param_grad, donate_grad, grad_target, pad8, param_grad_target,
-                   ptr, stream_ptr)
+from .core import (BF16, Node, Region, TTensor, await_mark, await_ready, commit_param_grad, donate_grad, grad_target,
+                   pad8, param_grad_target, ptr, stream_ptr, written_mark)
 from .functional import BIAS_IN_WGRAD, _krsc, get_packs
 
 F32 = torch.float32
@@ -442,24 +442,49 @@ def activation(region: Region, x: TTensor, kind: int, precomputed: Optional[torc
 
 # ---- continuous relative position bias ------------------------------------------------------------------------------------
 class _CpbBiasNode(Node):
+    """Backward of the position-bias unit.  The attention unit that consumed the bias leaves its per-workgroup partial
+    rows of d(logits) and d(logit_scale) here (`scratch`, `dscale`, `mark`); their fixed-order folds, d(logit_scale) and
+    the gather back onto the cpb_mlp output run on THIS unit's stream — a branch stream in SwinV2 (swin.py), so the
+    dependent chain of the main stream carries none of these small launches."""
     needs_backward = True
 
     def backward(self):
-        if self.dbias is None or not self.table.requires_grad:
+        if self.scratch is None:
             return
-        rows, ld = self.table.shape
+        lib, st = _C.lib(), stream_ptr()
+        await_mark(self.mark)
+        rows, heads, n = self.scratch.shape[0], self.heads, self.n
+        dev = self.scratch.device
+        ls = self.logit_scale
+        if ls is not None and ls.requires_grad:
+            slot, mode = param_grad_target(ls)
+            if mode == 2:
+                tmp = torch.empty_like(slot)
+                _C.check(lib.tok_colsum_f32(ptr(self.dscale), rows, heads, ptr(tmp), 0, st), 'tok_colsum_f32')
+                ls.grad.add_(tmp)
+                commit_param_grad(ls, slot, 1)
+            else:
+                _C.check(lib.tok_colsum_f32(ptr(self.dscale), rows, heads, ptr(slot), 1 if mode == 1 else 0, st),
+                         'tok_colsum_f32')
+                commit_param_grad(ls, slot, mode)
+        if not self.table.requires_grad:
+            return
+        dbias = torch.empty(heads * n * n, dtype=F32, device=dev)
+        _C.check(lib.tok_colsum_f32(ptr(self.scratch), rows, heads * n * n, ptr(dbias), 0, st), 'tok_colsum_f32')
+        trows, ld = self.table.shape
         tgt, acc = grad_target(self.table)
         if acc:
             raise RuntimeError('cpb_bias: the cpb_mlp output has a single consumer')
-        _C.check(_C.lib().tok_cpb_bias_bwd(ptr(self.dbias), 0, ptr(self.table.data), ld, ptr(self.index), self.heads,
-                                           self.n, rows, ptr(tgt), stream_ptr()), 'tok_cpb_bias_bwd')
+        _C.check(lib.tok_cpb_bias_bwd(ptr(dbias), 0, ptr(self.table.data), ld, ptr(self.index), heads, n, trows, ptr(tgt), st),
+                 'tok_cpb_bias_bwd')
 
     def release(self):
-        self.table = self.index = self.bias = self.dbias = None
+        self.table = self.index = self.bias = self.scratch = self.dscale = self.mark = self.logit_scale = None
 
 
 def cpb_bias(region: Region, table: TTensor, index: torch.Tensor, heads: int, n_tokens: int):
-    """(bias fp32 [heads][N][N], node).  The attention unit hands d(bias) back through `node.dbias`."""
+    """(bias fp32 [heads][N][N], node).  The attention unit hands its d(logits) / d(logit_scale) partial rows back through
+    the node (see _CpbBiasNode)."""
     rows, ld = table.shape
     bias = torch.empty((heads, n_tokens, n_tokens), dtype=F32, device=table.data.device)
     _C.check(_C.lib().tok_cpb_bias_fwd(ptr(table.data), ld, ptr(index), heads, n_tokens, ptr(bias), stream_ptr()),
@@ -467,7 +492,8 @@ def cpb_bias(region: Region, table: TTensor, index: torch.Tensor, heads: int, n_
     node = None
     if region.grad_mode and table.requires_grad:
         node = _CpbBiasNode()
-        node.table, node.index, node.heads, node.n, node.bias, node.dbias = table, index, heads, n_tokens, bias, None
+        node.table, node.index, node.heads, node.n, node.bias = table, index, heads, n_tokens, bias
+        node.scratch = node.dscale = node.mark = node.logit_scale = None
         table.uses += 1
         region.add(node)
     return bias, node
@@ -505,12 +531,12 @@ class _WindowAttnNode(Node):
                                          ptr(scratch), ptr(dscale), st), 'tok_window_attn_bwd')
         if qkv.cp != 3 * c:
             tgt[:, 3 * c:] = 0
-        if self.bias_node is not None:
-            dbias = torch.empty(heads * n * n, dtype=F32, device=dev)
-            _C.check(lib.tok_colsum_f32(ptr(scratch), rows, heads * n * n, ptr(dbias), 0, st), 'tok_colsum_f32')
-            self.bias_node.dbias = dbias
         ls = self.logit_scale
-        if ls.requires_grad:
+        bn = self.bias_node
+        if bn is not None:
+            # folds and parameter gradients happen in the position-bias unit's backward (its own stream)
+            bn.scratch, bn.dscale, bn.logit_scale, bn.mark = scratch, dscale, ls, written_mark()
+        elif ls.requires_grad:
             slot, mode = param_grad_target(ls)
             if mode == 2:
                 tmp = torch.empty_like(slot)

@@ -45,11 +45,37 @@ class DropPath(nn.Module):
     def sample_scale(self, batch: int, device):
         if self.drop_prob == 0. or not self.training:
             return None
+        pre, self._drawn = getattr(self, '_drawn', None), None
+        if pre is not None and pre.shape[0] == batch and pre.device == device:
+            return pre                                   # drawn with the whole step's vectors (draw_drop_scales)
         keep = 1 - self.drop_prob
         mask = torch.empty(batch, dtype=torch.float32, device=device).bernoulli_(keep)
         if keep > 0.0 and self.scale_by_keep:
             mask.div_(keep)
         return mask
+
+
+_drop_consts = {}     # (device, drop probabilities ...) -> [2][n][1] fp32: keep probability, scale of a kept sample
+
+
+def draw_drop_scales(paths, batch: int, device):
+    """The keep/scale vectors of every active DropPath of a model in three launches instead of two per module (44 small
+    launches on the dependent chain of a SwinV2-T step): one uniform draw for all of them, row i kept where u < keep_i and
+    scaled by 1 / keep_i.  Same distribution as the per-module bernoulli_; each module's next `sample_scale` returns its
+    row."""
+    live = [p for p in paths if isinstance(p, DropPath) and p.training and p.drop_prob > 0.]
+    if not live:
+        return
+    key = (device,) + tuple((p.drop_prob, p.scale_by_keep) for p in live)
+    kv = _drop_consts.get(key)
+    if kv is None:
+        keep = [[1. - p.drop_prob] for p in live]
+        val = [[1. / (1. - p.drop_prob) if (p.scale_by_keep and p.drop_prob < 1.) else 1.] for p in live]
+        kv = _drop_consts[key] = torch.tensor([keep, val], dtype=torch.float32).to(device)
+    u = torch.rand((len(live), batch), dtype=torch.float32, device=device)
+    scales = torch.where(u < kv[0], kv[1], 0.)
+    for i, p in enumerate(live):
+        p._drawn = scales[i]
 
 
 def _scale_of(dp, batch, device):
@@ -135,25 +161,57 @@ class WindowAttention(nn.Module):
         self.proj_drop = nn.Dropout(proj_drop)
         self.softmax = nn.Softmax(dim=-1)
 
+    def prepare(self, r, stream: int = 1):
+        """The part of the forward that reads parameters only — continuous position bias (cpb_mlp over the (2w-1)^2
+        coordinate table, 16 * sigmoid, index gather) and the concatenated qkv bias: seven small launches, recorded on
+        branch stream `stream` so that they (and their backward) stay off the dependent chain of the main stream.  `run`
+        picks the result up; a model calls this one block AHEAD of `run` (SwinTransformerV2._run)."""
+        with r.branch(stream, fork=False) as br:
+            tab = self.relative_coords_table
+            pad = getattr(self, '_table_pad', None)
+            if pad is None or pad.device != tab.device:
+                # bf16 rows padded to 8 channels once (the table is a constant buffer): Region.input takes the view as is
+                pad = torch.zeros((tab.numel() // 2, 8), dtype=torch.bfloat16, device=tab.device)
+                pad[:, :2] = tab.view(-1, 2)
+                engine.mark_padded(pad)
+                self._table_pad = pad
+            table_in = r.input(pad[:, :2])
+            t = ET.linear_module(r, table_in, self.cpb_mlp[0])
+            t = ET.activation(r, t, ET.RELU)
+            t = ET.linear_module(r, t, self.cpb_mlp[2])
+            n = self.window_size[0] * self.window_size[0]
+            bias, bias_node = ET.cpb_bias(r, t, self.relative_position_index, self.num_heads, n)
+            qkv_bias = None
+            if self.q_bias is not None:
+                qkv_bias = torch.cat((self.q_bias.detach(), self.k_bias, self.v_bias.detach()))
+            self._prepared = br.publish(_Prepared(bias, bias_node, qkv_bias))
+
     def run(self, r, x, batch: int, res, shift: int, mask):
         """x: token rows (B*H*W, C) in raster order -> attention + proj, same order."""
         H, W = res
         ws = self.window_size[0]
-        n = ws * ws
-        # continuous position bias: cpb_mlp over the (2w-1)^2 coordinate table, then 16 * sigmoid and the index gather
-        table_in = r.input(self.relative_coords_table.view(-1, 2))
-        t = ET.linear_module(r, table_in, self.cpb_mlp[0])
-        t = ET.activation(r, t, ET.RELU)
-        t = ET.linear_module(r, t, self.cpb_mlp[2])
-        bias, bias_node = ET.cpb_bias(r, t, self.relative_position_index, self.num_heads, n)
-        if self.q_bias is not None:
-            qkv_bias = torch.cat((self.q_bias.detach(), self.k_bias, self.v_bias.detach()))
-            qkv = ET.linear_op(r, x, self.qkv.weight, qkv_bias, [(self.q_bias, 0), (self.v_bias, 2 * self.dim)])
+        if getattr(self, '_prepared', None) is None:
+            self.prepare(r)
+        pre, self._prepared = self._prepared, None
+        engine.await_ready(pre)            # (+ record_stream: bias / qkv_bias live in the branch stream's pool)
+        if pre.qkv_bias is not None:
+            qkv = ET.linear_op(r, x, self.qkv.weight, pre.qkv_bias, [(self.q_bias, 0), (self.v_bias, 2 * self.dim)])
         else:
             qkv = ET.linear_op(r, x, self.qkv.weight)
-        a = ET.window_attention(r, qkv, (batch, H, W, self.dim, self.num_heads, ws, shift), self.logit_scale, bias,
-                                bias_node, mask)
+        a = ET.window_attention(r, qkv, (batch, H, W, self.dim, self.num_heads, ws, shift), self.logit_scale, pre.bias,
+                                pre.bias_node, mask)
         return ET.linear_module(r, a, self.proj)
+
+
+class _Prepared:
+    __slots__ = ('bias', 'bias_node', 'qkv_bias', 'ready')
+
+    def __init__(self, bias, bias_node, qkv_bias):
+        self.bias, self.bias_node, self.qkv_bias, self.ready = bias, bias_node, qkv_bias, None
+
+    @property
+    def tensors(self):
+        return (self.bias, self.qkv_bias)
 
 
 def window_partition(x, window_size):
@@ -247,9 +305,13 @@ class BasicLayer(nn.Module):
         self.downsample = downsample(input_resolution, dim=dim, norm_layer=norm_layer) if downsample is not None \
             else nn.Identity()
 
-    def run(self, r, x, batch: int):
-        """swin.py:71-81: (downsample(x), x)."""
+    def run(self, r, x, batch: int, ahead=None):
+        """swin.py:71-81: (downsample(x), x).  `ahead`: iterator over the model's blocks whose attention units have not
+        been prepared yet (WindowAttention.prepare runs two blocks ahead of its consumer)."""
         for blk in self.blocks:
+            nxt = next(ahead, None) if ahead is not None else None
+            if nxt is not None:
+                nxt.attn.prepare(r)
             x = blk.run(r, x, batch)
         down = self.downsample.run(r, x, batch) if isinstance(self.downsample, PatchMerging) else x
         return down, x
@@ -328,10 +390,20 @@ class SwinTransformerV2(BaseBackbone):
 
     def _run(self, r, image: torch.Tensor, all_features: bool):
         batch = image.shape[0]
+        blocks = [blk for layer in self.layers for blk in layer.blocks]
+        if self.training:
+            draw_drop_scales([p for blk in blocks for p in (blk.drop_path1, blk.drop_path2)], batch, image.device)
+        for blk in blocks:
+            blk.attn._prepared = None
+        # the parameter-only part of every attention unit runs one block ahead of its consumer, on a branch stream
+        r.device = image.device
+        ahead = iter(blocks)
+        for blk in blocks[:2]:
+            next(ahead).attn.prepare(r)
         t = self.patch_embed.run(r, image)
         feats = []
         for i, layer in enumerate(self.layers):
-            t, a = layer.run(r, t, batch)
+            t, a = layer.run(r, t, batch, ahead)
             if all_features or i == self.num_layers - 1:
                 feats.append(self._to_map(r, a, i))
         return feats
