@@ -456,6 +456,10 @@ int tok_colsum_partial_rows(int64_t m, int n_pad);
 int tok_colsum_partial(const void* dy, int64_t m, int n_pad, float* partial, void* stream);
 /* dst[col] (+)= sum_r src[r][col]: fixed-order fp64 fold of fp32 partial rows                           */
 int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream);
+/* two folds of the same geometry in one launch (the d(weight) / d(bias) rows of an nn.LayerNorm backward,
+ * torch.nn.functional.layer_norm's grad_weight / grad_bias: swin.py blocks' norm1 / norm2)                */
+int tok_colsum_f32_pair(const float* src0, const float* src1, int64_t rows, int cols, float* dst0, int accumulate0,
+                        float* dst1, int accumulate1, void* stream);
 /* kind 0: ReLU (cpb_mlp), 1: GELU erf (Mlp); count % 8 == 0.  tok_act_bwd also takes kind 2 = identity
  * (dx (+)= dout: the pass-through branch of a residual)                                                  */
 int tok_act_fwd(int kind, const void* x, void* out, size_t count, void* stream);

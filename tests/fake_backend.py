@@ -1306,6 +1306,10 @@ class FakeTok:
         d.copy_(d + v if accumulate else v)
         return 0
 
+    def tok_colsum_f32_pair(self, src0, src1, rows, cols, dst0, acc0, dst1, acc1, st):
+        self.tok_colsum_f32(src0, rows, cols, dst0, acc0, st)
+        return self.tok_colsum_f32(src1, rows, cols, dst1, acc1, st)
+
     def tok_act_fwd(self, kind, x, out, count, st):
         v = _t(x, (count,), BF16).float()
         _t(out, (count,), BF16).copy_(_bf(v.clamp_min(0) if kind == 0 else F.gelu(v)))

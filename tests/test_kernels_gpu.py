@@ -944,6 +944,17 @@ def test_colsum_partial(libs, m, n):
     torch.cuda.synchronize()
     ref = x.double().sum(0)
     assert float((out.double() - ref).abs().max()) < 1e-4 * float(x.double().abs().sum(0).max())
+    # the pair launch gives the bits of two single launches (second one accumulating)
+    part2 = torch.randn(rows, n, device='cuda')
+    base = torch.randn(n, device='cuda')
+    a0, a1 = torch.empty(n, device='cuda'), base.clone()
+    b0, b1 = torch.empty(n, device='cuda'), base.clone()
+    assert lib.tok_colsum_f32(part.data_ptr(), rows, n, a0.data_ptr(), 0, st) == 0
+    assert lib.tok_colsum_f32(part2.data_ptr(), rows, n, a1.data_ptr(), 1, st) == 0
+    assert lib.tok_colsum_f32_pair(part.data_ptr(), part2.data_ptr(), rows, n, b0.data_ptr(), 0, b1.data_ptr(), 1, st) == 0, \
+        lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
 
 
 @pytest.mark.parametrize('case', [(4, 16, 16, 64, 64, 3, 1, 1), (2, 14, 14, 256, 512, 1, 1, 0), (3, 9, 11, 32, 24, 3, 2, 1),

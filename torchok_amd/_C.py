@@ -138,6 +138,7 @@ PROTOTYPES = {
     'tok_colsum_partial_rows': (c_int, [c_int64, c_int]),
     'tok_colsum_partial': (c_int, [_P, c_int64, c_int, _P, _P]),
     'tok_colsum_f32': (c_int, [_P, c_int64, c_int, _P, c_int, _P]),
+    'tok_colsum_f32_pair': (c_int, [_P, _P, c_int64, c_int, _P, c_int, _P, c_int, _P]),
     'tok_act_fwd': (c_int, [c_int, _P, _P, c_size_t, _P]),
     'tok_act_bwd': (c_int, [c_int, _P, _P, _P, c_int, c_size_t, _P]),
     'tok_window_attn_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -263,10 +263,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ do
   }
 }
 
-// dst[col] (+)= sum_r src[r][col], fixed order, fp64 accumulation
+// dst[col] (+)= sum_r src[r][col], fixed order, fp64 accumulation.  blockIdx.y = 1: the second (src, dst, accumulate) of a pair
+// launch (LayerNorm's d(gamma) and d(beta) rows in one launch: 48 small launches less per SwinV2-T step)
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, int64_t rows, int cols,
-                                                         float* dst, int accumulate) {
+                                                         float* dst, int accumulate, const float* __restrict__ src1,
+                                                         float* dst1, int accumulate1) {
   __shared__ double red[256];
+  if (blockIdx.y == 1) { src = src1; dst = dst1; accumulate = accumulate1; }
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int col = blockIdx.x * 16 + cl;
   double a = 0.0;
@@ -1140,8 +1143,17 @@ extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* m
 extern "C" int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream) {
   TOK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "tok_colsum_f32: bad args");
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(256), 0, tok_stream(stream), src, rows, cols, dst,
-                     accumulate);
+                     accumulate, (const float*)nullptr, (float*)nullptr, 0);
   TOK_CHECK_LAUNCH("tok_colsum_f32");
+  return TOK_OK;
+}
+
+extern "C" int tok_colsum_f32_pair(const float* src0, const float* src1, int64_t rows, int cols, float* dst0, int accumulate0,
+                                   float* dst1, int accumulate1, void* stream) {
+  TOK_CHECK_ARG(src0 && src1 && dst0 && dst1 && rows > 0 && cols > 0, "tok_colsum_f32_pair: bad args");
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16, 2), dim3(256), 0, tok_stream(stream), src0, rows, cols, dst0,
+                     accumulate0, src1, dst1, accumulate1);
+  TOK_CHECK_LAUNCH("tok_colsum_f32_pair");
   return TOK_OK;
 }
 

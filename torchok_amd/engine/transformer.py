@@ -342,6 +342,14 @@ class _LayerNormNode(Node):
             def run_param_grads():
                 st_ = stream_ptr()
                 keep = []
+                if ln.weight.requires_grad and ln.bias.requires_grad:
+                    (sw, mw), (sb, mb) = param_grad_target(ln.weight), param_grad_target(ln.bias)
+                    if mw != 2 and mb != 2:        # both folds in one launch
+                        _C.check(lib.tok_colsum_f32_pair(ptr(partial[0]), ptr(partial[1]), nrows, c, ptr(sw), 1 if mw == 1 else 0,
+                                                         ptr(sb), 1 if mb == 1 else 0, st_), 'tok_colsum_f32_pair')
+                        commit_param_grad(ln.weight, sw, mw)
+                        commit_param_grad(ln.bias, sb, mb)
+                        return keep
                 for p, part in ((ln.weight, partial[0]), (ln.bias, partial[1])):
                     if p.requires_grad:
                         slot, mode = param_grad_target(p)
