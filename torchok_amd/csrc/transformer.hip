@@ -481,19 +481,34 @@ __device__ __forceinline__ void put_row(bf16* rowmaj, bf16* trans, int t, const 
   }
 }
 
+// Workgroup -> unit.  A 32-wide head slice of a token row is 64 bytes: the heads of a window share 128-byte lines (and a row's
+// q / k / v parts are contiguous), so when consecutive workgroups — which the dispatcher deals round-robin to the eight XCDs,
+// each with its own L2 — take consecutive heads, every line is fetched by two L2s: PMC read traffic of the round-3 kernels was
+// 2.0x the q, k, v, dO bytes (4.43 GB against 2.2 for the SwinV2-T forward launches of a step).  Unit u = (xcd, slot) with
+// xcd = blockIdx % 8 instead: each XCD walks a contiguous range of units, so the heads of one window are neighbours in time on
+// ONE L2.  The grid is 8 * ceil(units / 8) workgroups; the surplus ones leave at once.  (Speed only: nothing depends on where
+// a workgroup really runs.)
+__device__ __forceinline__ int attn_unit(int units) {
+  const int per = (units + 7) >> 3;
+  return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
                                                             const float* __restrict__ logit_scale,
                                                             const float* __restrict__ bias, const float* __restrict__ mask,
-                                                            bf16* __restrict__ out, float* __restrict__ lse, int bpw) {
+                                                            bf16* __restrict__ out, float* __restrict__ lse, int bpw,
+                                                            int units) {
   extern __shared__ char smraw[];
   bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
   bf16* vt = ks + 64 * QPITCH;          // [32 dims][PPITCH keys]
   bf16* ps = vt + 32 * PPITCH;          // [64 queries][PPITCH keys]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int h = blockIdx.x % a.heads;
-  const int win = (blockIdx.x / a.heads) % a.nW;
-  const int bg = blockIdx.x / (a.heads * a.nW);
+  const int unit_id = attn_unit(units);
+  if (unit_id >= units) return;
+  const int h = unit_id % a.heads;
+  const int win = (unit_id / a.heads) % a.nW;
+  const int bg = unit_id / (a.heads * a.nW);
   const int N = a.N;
   const int l15 = lane & 15, g = lane >> 4, qi = wv;
   constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
                                                             const float* __restrict__ bias, const float* __restrict__ mask,
                                                             const float* __restrict__ lse, bf16* __restrict__ dqkv,
                                                             float* __restrict__ ds_scratch, float* __restrict__ dscale_part,
-                                                            int bpw) {
+                                                            int bpw, int units) {
   extern __shared__ char smraw[];
   bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
@@ -666,14 +681,16 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   float* wsum = kinv + 64;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l15 = lane & 15, g = lane >> 4;
   const int N = a.N;
-  const int h = blockIdx.x % a.heads;
-  const int win = (blockIdx.x / a.heads) % a.nW;
-  const int bg = blockIdx.x / (a.heads * a.nW);
+  const int unit_id = attn_unit(units);
+  if (unit_id >= units) return;
+  const int h = unit_id % a.heads;
+  const int win = (unit_id / a.heads) % a.nW;
+  const int bg = unit_id / (a.heads * a.nW);
   const float raw_ls = a.plain ? 0.f : logit_scale[h];
   const float scale = a.plain ? 0.17677669529663687f : expf(fminf(raw_ls, 4.605170185988092f));
   const float* bh = bias ? bias + (size_t)h * N * N : nullptr;
   const float* mw = mask ? mask + (size_t)win * N * N : nullptr;
-  float* dS = ds_scratch ? ds_scratch + (size_t)blockIdx.x * N * N : nullptr;
+  float* dS = ds_scratch ? ds_scratch + (size_t)unit_id * N * N : nullptr;
   float dsc = 0.f;
   float dsa[4][4];         // d(logits) of this wave's query tile summed over the images the workgroup walks (-> d(bias))
 #pragma unroll
@@ -865,7 +882,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
   if (lane == 0) wsum[wv] = dsc;
   __syncthreads();
   if (threadIdx.x == 0 && dscale_part != nullptr)
-    dscale_part[blockIdx.x] = raw_ls < 4.605170185988092f ? (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale : 0.f;
+    dscale_part[unit_id] = raw_ls < 4.605170185988092f ? (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale : 0.f;
 }
 
 // backward, phase A (lane = query i): dS row -> scratch dS[(b,w)][h][i][j] (fp32), dq; partial dscale
@@ -1196,8 +1213,8 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
   if (a.N <= 64 && (a.plain || !tok_attn_scalar())) {
     const int bpw = attn_bpw(a);
     const int groups = tok_cdiv(batch, bpw) * a.nW * heads;
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(groups), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
-                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse, bpw);
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(8 * tok_cdiv(groups, 8)), dim3(256), MFMA_FWD_LDS, tok_stream(stream), a,
+                       (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse, bpw, groups);
     TOK_CHECK_LAUNCH("tok_window_attn_fwd(mfma)");
     return TOK_OK;
   }
@@ -1235,8 +1252,9 @@ extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch,
     static bool attr_m = false;
     if (!attr_m) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
-    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(waves), dim3(256), MFMA_BWD_LDS, tok_stream(stream), a, (const bf16*)qkv,
-                       (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch, dscale_part, bpw);
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(8 * tok_cdiv(waves, 8)), dim3(256), MFMA_BWD_LDS, tok_stream(stream), a,
+                       (const bf16*)qkv, (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch, dscale_part, bpw,
+                       waves);
     TOK_CHECK_LAUNCH("tok_window_attn_bwd(mfma)");
     return TOK_OK;
   }
