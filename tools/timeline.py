@@ -45,7 +45,7 @@ def main():
     byq = defaultdict(list)
     for r in step:
         byq[(r[3], r[4])].append(r)
-    main_q = max(byq, key=lambda q: len(byq[q]))
+    main_q = max(byq, key=lambda q: sum(r[2] - r[1] for r in byq[q]))     # the dependent chain: most busy time
     for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
         busy = sum(r[2] - r[1] for r in rs)
         print(f'  queue {q}: {len(rs):4d} dispatches, busy {busy / 1e6:7.3f} ms, span {(rs[0][1] - t0) / 1e6:.2f}..{(max(r[2] for r in rs) - t0) / 1e6:.2f} ms'
