@@ -45,9 +45,53 @@ def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream_ptr():
-    """The HIP stream every kernel of the calling thread is enqueued on (torch's current one)."""
+    """The HIP stream every kernel of the calling thread is enqueued on (torch's current one).  Through the raw accessor:
+    `torch.cuda.current_stream()` builds a Stream object via three Python frames of device-index resolution (9 us under
+    cProfile, 800 calls per HRNet-W48 step = a tenth of that step's launch-thread time)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+_stream_objs = {}
+
+
+def cur_stream():
+    """torch's current Stream object of the calling thread, through the raw accessor and a table of the Stream objects seen
+    so far (main / side / branch / comm streams live as long as the process): `torch.cuda.current_stream()` costs the launch
+    thread ~9 us, and the engine asks 950 times per HRNet-W48 step."""
+    if _raw_stream is None or _raw_device is None:
+        return torch.cuda.current_stream()
+    dev = _raw_device()
+    key = (dev, _raw_stream(dev))
+    s = _stream_objs.get(key)
+    if s is None:
+        s = _stream_objs[key] = torch.cuda.current_stream()
+    return s
+
+
+class _StreamCtx:
+    """`with torch.cuda.stream(s)` without its per-entry device bookkeeping (one device per process)."""
+    __slots__ = ('s', 'prev')
+
+    def __init__(self, s):
+        self.s, self.prev = s, None
+
+    def __enter__(self):
+        self.prev = cur_stream()
+        if self.prev is not self.s:
+            torch.cuda.set_stream(self.s)
+        return self.s
+
+    def __exit__(self, *exc):
+        if self.prev is not self.s:
+            torch.cuda.set_stream(self.prev)
+        return False
 
 
 def require_device(t: torch.Tensor):
@@ -110,7 +154,7 @@ _ms = threading.local()      # multi-stream backward bookkeeping (Region.run_bac
 
 
 def _await(events):
-    cur = torch.cuda.current_stream()
+    cur = cur_stream()
     for ev, s in events:
         if s != cur:
             cur.wait_event(ev)
@@ -127,7 +171,7 @@ def await_ready(*tensors):
         if t is not None and t.ready is not None:
             _await((t.ready,))
             if cur is None:
-                cur = torch.cuda.current_stream()
+                cur = cur_stream()
             if t.ready[1] != cur:
                 for d in (t.tensors if hasattr(t, 'tensors') else (t.data,)):
                     if d is not None and d.is_cuda:
@@ -160,7 +204,7 @@ def _sync_writers(writers, cur):
 def _touch(x: 'TTensor'):
     if getattr(_ms, 'active', False):
         if x.gevents:
-            cur = torch.cuda.current_stream()
+            cur = cur_stream()
             _sync_writers(x.gevents, cur)         # an earlier contribution may still be in flight on another stream
             if x.grad is not None and any(w != cur for w, _ in x.gevents):
                 x.grad.record_stream(cur)
@@ -172,14 +216,14 @@ def written_mark():
     another stream that reads it passes the token to `await_mark` first.  For hand-offs that do not travel through a
     TTensor's gradient (window attention -> position-bias unit)."""
     if getattr(_ms, 'active', False):
-        cur = torch.cuda.current_stream()
+        cur = cur_stream()
         return (cur, _ms.seq.get(cur, 0))
     return None
 
 
 def await_mark(mark):
     if mark is not None and getattr(_ms, 'active', False):
-        _sync_writers((mark,), torch.cuda.current_stream())
+        _sync_writers((mark,), cur_stream())
 
 
 def flush_sub(x: TTensor):
@@ -320,11 +364,11 @@ class _Branch:
             b = _branch_stream(dev, self.idx)
             if self.fork or self.idx not in r._streams:
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev.record(cur_stream())
                 b.wait_event(ev)
             r._streams[self.idx] = b
             self.prev, r._tag = r._tag, self.idx
-            self.ctx = torch.cuda.stream(b)
+            self.ctx = _StreamCtx(b)
             self.ctx.__enter__()
             self.stream = b
         return self
@@ -464,7 +508,7 @@ class Region:
 
     def _join_forward(self):
         if self._branch_done:
-            cur = torch.cuda.current_stream()
+            cur = cur_stream()
             for ev, b in self._branch_done:
                 if b != cur:
                     cur.wait_event(ev)
@@ -513,7 +557,7 @@ class Region:
         for the gradient contributions other streams wrote into its output (`_sync_writers`: events are recorded lazily,
         only for edges that cross streams).  Units of branch streams are released only after the join (their tensors may
         be in flight)."""
-        main = torch.cuda.current_stream()
+        main = cur_stream()
         ev0 = torch.cuda.Event()
         ev0.record(main)
         for b in self._streams.values():
@@ -572,7 +616,7 @@ class Region:
         """An event on the main stream NOW, for a later fork_side(..., event=...): the side kernels are then ordered after
         the main stream's work up to this point only, although the host enqueues them after further main-stream launches."""
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev.record(cur_stream())
         return ev
 
     def raw_event(self):
@@ -590,7 +634,7 @@ class Region:
         main stream has been given so far (or up to `event`, see mark_side).  `keep_alive` (tensors the side kernels read
         or use as scratch) stay referenced until the join, so the allocator cannot hand their memory to later main-stream
         work."""
-        main = torch.cuda.current_stream()
+        main = cur_stream()
         side = _side_stream(main.device)
         if raw_event is not None:
             # the event is signalled by the completion of a kernel already launched on the main stream (no record packet)
@@ -603,7 +647,7 @@ class Region:
             side.wait_event(ev)
         self._side = (main, side)
         self._deferred.extend(keep_alive)
-        return torch.cuda.stream(side)
+        return _StreamCtx(side)
 
     def keep_until_join(self, *tensors):
         self._deferred.extend(tensors)
@@ -628,7 +672,7 @@ class Region:
     def join_side(self):
         self.flush_wgrads()
         if self._side is not None:
-            torch.cuda.current_stream().wait_stream(self._side[1])
+            cur_stream().wait_stream(self._side[1])
             self._side = None
         if self._raw_used:
             for dev, ev in self._raw_used:        # the main stream is behind every waiter now: the events can be reused
