@@ -212,6 +212,33 @@ def test_swinv2_t_b256_branch_stream_schedule_gives_the_single_stream_bits():
         EC.BRANCH_STREAMS = saved
 
 
+def test_davit_t_b256_gradients_are_bit_reproducible():
+    """DaViT-T 224 / window 7 at batch 256 (the size profiles/r03_davit_* quote): window attention in the plain mode, channel
+    attention (Gram / apply kernels), fused Mlp, strided patch embeds — three passes of the same step give identical bits
+    in the logits and in every parameter gradient."""
+    cfg = cls_config('davit_t', 1000, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
+                     backbone_params={'img_size': 224, 'window_size': 7, 'drop_path_rate': 0.0}, inputs_shape=(3, 224, 224))
+    task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
+    sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')}, 6)
+    task.load_state_dict(sd, strict=False)
+    task = task.cuda().train()
+    x, y = _batch(256, seed=3)
+    runs = []
+    for _ in range(3):
+        for p in task.parameters():
+            p.grad = None
+        out = task.forward_with_gt({'image': x, 'target': y})
+        task.losses(**out)[0].backward()
+        torch.cuda.synchronize()
+        runs.append((out['prediction'].detach().clone(),
+                     {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}))
+    assert torch.isfinite(runs[0][0].float()).all()
+    for pred, grads in runs[1:]:
+        assert torch.equal(pred, runs[0][0])
+        bad = [n for n in grads if not torch.equal(grads[n], runs[0][1][n])]
+        assert not bad, bad[:5]
+
+
 def test_hrnet_w48_b24_training_steps_are_bit_reproducible():
     """HRNet-W48 + neck + head at 512x1024, batch 24 (the size profiles/r0N_hrnet_* quote): two optimizer steps from the same
     state twice -> identical parameters and BatchNorm buffers (branch streams, side stream, fixed-order reductions)."""
