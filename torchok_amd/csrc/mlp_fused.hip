@@ -478,11 +478,14 @@ void launch_c(const MlpArgs& a, int c, hipStream_t st) {
   // overlap its own MFMA / VALU / LDS phases, and the C = 192 form spills); a deeper fragment register ring (RD 4 .. 8: 198..201
   // vs 199 us — the LDS round trip is not what the waves wait for).  Timing probes (TOK_MLP_PROBE): no weight DMA -20 %, no GELU
   // -8 % (C = 384) / -28 % (C = 192), no stage barrier -7 %: no single bound, the stage's three phases serialise per wave.
+  // C = 192 forward on 64 hidden units per stage (half the stage barriers: 259 vs 292 us in save mode; the backward spills at
+  // that stage size: 349 vs 278 us; C = 96 with 128 per stage: 406 vs 376 us)
   static int w4 = -1;
   if (w4 < 0) { const char* e = getenv("TOK_MLP_W4"); w4 = e ? atoi(e) : 0; }
   if (c == 96 && w4) launch_m<96, 64, 2, 4, true, MODE>(a, st);
   else if (c == 192 && w4) launch_m<192, 32, 2, 4, false, MODE>(a, st);
   else if (c == 96) launch_m<96, 64, 2, 8, true, MODE>(a, st);
+  else if (c == 192 && MODE == 0) launch_m<192, 64, 2, 8, false, MODE>(a, st);
   else if (c == 192) launch_m<192, 32, 2, 8, false, MODE>(a, st);
   else launch_m<384, 32, 1, 8, false, MODE>(a, st);
 }
