@@ -34,7 +34,7 @@ import torch.distributed as dist
 from .. import _C
 from ..engine import core
 from ..engine.arena import ParamArena
-from ..engine.core import ptr, stream_ptr
+from ..engine.core import cur_stream, pick_stream, ptr, stream_ptr
 
 
 class _Bucket:
@@ -100,7 +100,7 @@ class GradientAllReducer:
             for arena in self.arenas:
                 dist.broadcast(arena.master, src=0, group=process_group)
         self.cuda = self.arenas[0].master.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.cuda else None
+        self.comm_stream = pick_stream(torch.device('cuda', torch.cuda.current_device())) if self.cuda else None
         self._avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else None
         self._active = False
         self._events: List = []       # hipEvents of the fork edges, reused round-robin (a step needs a handful)
@@ -201,7 +201,7 @@ class GradientAllReducer:
         if self.cuda:
             # weight gradients are produced on the engine's side stream, BatchNorm / bias gradients on the main one:
             # the exchange has to wait for every stream that wrote into the bucket
-            cur = torch.cuda.current_stream()
+            cur = cur_stream()
             b.streams[cur.cuda_stream] = cur
         b.pending -= 1
         if b.pending == 0:
@@ -222,7 +222,7 @@ class GradientAllReducer:
         view = arena.grad[b.lo:b.hi]
         lib = _C.lib()
         if self.cuda:
-            cur = torch.cuda.current_stream()
+            cur = cur_stream()
             b.streams[cur.cuda_stream] = cur
             for s_ in b.streams.values():
                 self._fork_to_comm(s_)

@@ -339,11 +339,63 @@ BRANCH_STREAMS = os.environ.get('TOK_BRANCH_STREAMS', '1') == '1'
 LAZY_EVENTS = os.environ.get('TOK_LAZY_EVENTS', '1') == '1'
 
 
+# ---- streams on distinct hardware queues -------------------------------------------------------------------------------
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and two streams on one
+# queue run strictly one after the other.  With the gradient reducer's comm stream and RCCL's own streams created first, the
+# engine's side stream landed on the MAIN stream's queue: the weight gradients of a SwinV2-T step then ran between the main
+# chain's kernels instead of beside them (24.7 vs 21.7 ms/step; more hardware queues are no answer: 8 or 16 cost ResNet-50
+# under the reducer 29.6 vs 18.5 ms and HRNet-W48 112 vs 77 ms).  Every engine / reducer stream is therefore PROBED when it
+# is first needed: a candidate shares a queue with stream `a` iff an event recorded on the idle candidate completes only
+# after a spin kernel given to `a` before it.  The pick never shares with the main stream if any of eight candidates
+# avoids it, and shares with as few (and as recently picked) of the streams already handed out as possible.
+PICK_STREAMS = os.environ.get('TOK_PICK_STREAMS', '1') == '1'
+_picked = {}          # device -> streams handed out by pick_stream
+_main_hint = {}       # device -> the stream regions are opened on (Region.input): what "beside the main stream" refers to
+
+
+def _shares_queue(a: 'torch.cuda.Stream', b: 'torch.cuda.Stream') -> bool:
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    a.synchronize()
+    b.synchronize()
+    with torch.cuda.stream(a):
+        e0.record(a)
+        torch.cuda._sleep(600000)           # a few hundred microseconds of spinning
+        ea.record(a)
+    eb.record(b)
+    a.synchronize()
+    b.synchronize()
+    return e0.elapsed_time(eb) > 0.5 * e0.elapsed_time(ea)
+
+
+def pick_stream(device, main: Optional['torch.cuda.Stream'] = None) -> 'torch.cuda.Stream':
+    """A new stream for work that is meant to run BESIDE the calling (main) stream and beside the streams picked before."""
+    if (not PICK_STREAMS or torch.cuda.is_current_stream_capturing()):
+        return torch.cuda.Stream(device=device)
+    with torch.cuda.device(device):
+        if main is None:
+            main = _main_hint.get(str(device)) or torch.cuda.current_stream()
+        others = _picked.setdefault(str(device), [])
+        best, best_cost = None, None
+        for _ in range(8):
+            c = torch.cuda.Stream(device=device)
+            cost = 100 * int(_shares_queue(main, c))
+            if cost < 100:
+                # when sharing cannot be avoided (five streams on four queues: HRNet's three branch streams + the side
+                # stream), share with the stream picked last — the HRNet branches are handed out busiest first
+                cost += sum((len(others) - i) * int(_shares_queue(o, c)) for i, o in enumerate(others))
+            if best is None or cost < best_cost:
+                best, best_cost = c, cost
+            if cost == 0:
+                break
+        others.append(best)
+    return best
+
+
 def _branch_stream(device, idx: int) -> 'torch.cuda.Stream':
     key = (device, idx)
     s = _branch_streams.get(key)
     if s is None:
-        s = _branch_streams[key] = torch.cuda.Stream(device=device)
+        s = _branch_streams[key] = pick_stream(device)
     return s
 
 
@@ -389,7 +441,7 @@ class _Branch:
 def _side_stream(device) -> 'torch.cuda.Stream':
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
+        s = _side_streams[device] = pick_stream(device)
     return s
 
 
@@ -450,6 +502,8 @@ class Region:
     def input(self, x: torch.Tensor, c_pad_to: int = 8) -> TTensor:
         require_device(x)
         self.device = x.device
+        if x.is_cuda and self._tag == 0 and str(x.device) not in _main_hint:
+            _main_hint[str(x.device)] = cur_stream()
         need = self.grad_mode and x.requires_grad
         if x.dim() == 4:
             n, c, h, w = x.shape
