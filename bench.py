@@ -347,7 +347,10 @@ def main():
     reducer = None
     if dist_on:
         from torchok_amd.dist import GradientAllReducer
-        reducer = GradientAllReducer(opt, module=task)     # + DDP's rank-0 buffer broadcast (one flat collective per dtype)
+        # (the transformer backbones keep per-stage feature norms that a classification forward never runs: torch DDP needs
+        # find_unused_parameters=True for them as well, reference swin.py:129-148)
+        reducer = GradientAllReducer(opt, module=task,     # + DDP's rank-0 buffer broadcast (one flat collective per dtype)
+                                     find_unused_parameters=True if swin else None)
 
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
     image = torch.randn(args.batch, 3, args.res, width, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
