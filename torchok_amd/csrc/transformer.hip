@@ -623,6 +623,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
   }
 }
 
+// (Occupancy: 228 registers = two workgroups per CU.  Forcing three or four with __launch_bounds__ spills: 3.85 vs 2.44 ms per
+// SwinV2-T step in isolation, tools/ubench/attn_time.py; the forward at six instead of five: no change.)
 // Backward: recomputes P from (Qn, Kn, lse); dP = dO V^T on the same accumulator layout, dS = P (dP - delta) in registers.
 // Round 3: the three products whose reduction index is a token — dV^T = dO^T P, dKn^T = Qn^T dS, dQn^T = Kn^T dS^T — take
 // their operands with ds_read_b64_tr_b16 from the ROW-MAJOR tiles (conv_wgrad.hip's recipe: k-slot (g, e) <-> token
