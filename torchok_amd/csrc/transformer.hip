@@ -15,6 +15,35 @@
 
 namespace {
 
+// Reductions over the 16 lanes of a DPP row (the lanes that share lane >> 4: the 16 keys of an accumulator column block), every
+// lane gets the result: four rotate-and-combine steps on the VALU (row_ror 8 / 4 / 2 / 1).  A __shfl_xor butterfly costs five
+// VALU instructions + a ds_bpermute round trip per step, all on the unit's dependent chain.
+__device__ __forceinline__ float row16_ror(float v, int sel) {
+  switch (sel) {
+    case 8: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+    case 4: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));
+    case 2: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));
+    default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));
+  }
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += row16_ror(v, 8); v += row16_ror(v, 4); v += row16_ror(v, 2); v += row16_ror(v, 1);
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, row16_ror(v, 8)); v = fmaxf(v, row16_ror(v, 4)); v = fmaxf(v, row16_ror(v, 2)); v = fmaxf(v, row16_ror(v, 1));
+  return v;
+}
+
+// sum over the LPR (16 / 32 / 64) consecutive lanes that hold one LayerNorm row
+template <int LPR>
+__device__ __forceinline__ float lpr_sum(float v) {
+  v = row16_sum(v);
+  if constexpr (LPR > 16) v += __shfl_xor(v, 16, 64);
+  if constexpr (LPR > 32) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm.  16-byte vector lanes: a row of c channels is covered by LPR lanes (16 / 32 / 64) holding VPL vectors
 // of 8 channels each, so a wave normalises 64 / LPR rows at once and every global access is a full 16-byte lane
@@ -44,8 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const bf16* __restrict_
       for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
     }
   }
-#pragma unroll
-  for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
+  s = lpr_sum<LPR>(s);
   const float mu = s / (float)c;
   float q = 0.f;
 #pragma unroll
@@ -53,8 +81,7 @@ __global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const bf16* __restrict_
     if (sub + u * LPR < cg)
 #pragma unroll
       for (int e = 0; e < 8; ++e) { const float d = v[u][e] - mu; q = fmaf(d, d, q); }
-#pragma unroll
-  for (int off = 1; off < LPR; off <<= 1) q += __shfl_xor(q, off, 64);
+  q = lpr_sum<LPR>(q);
   const float rs = rsqrtf(q / (float)c + eps);
   if (!live) return;
   if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -152,8 +179,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const bf16* __restrict_
           for (int e = 0; e < 8; ++e) { xh[u][e] = 0.f; gg[u][e] = 0.f; }
         }
       }
-#pragma unroll
-      for (int off = 1; off < LPR; off <<= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+      s1 = lpr_sum<LPR>(s1);
+      s2 = lpr_sum<LPR>(s2);
       const float m1 = s1 / (float)c, m2 = s2 / (float)c;
       if (live)
 #pragma unroll
@@ -570,8 +597,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
         sc[kj][reg] = v;
         mx = fmaxf(mx, v);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      mx = row16_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
@@ -579,8 +605,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
         sc[kj][reg] = p;
         sum += p;
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) sum += __shfl_xor(sum, off, 64);
+      sum = row16_sum(sum);
       rsum[reg] = sum;
       rmax[reg] = mx;
 #pragma unroll
@@ -784,15 +809,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
         pv[kj][reg] = (i < N && j < N) ? __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li) : 0.f;
         dl = fmaf(pv[kj][reg], dp[kj][reg], dl);
       }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) dl += __shfl_xor(dl, off, 64);
-      // Value barrier: the reduced delta is materialised in a register of its own before its consumers.  Without it hipcc
-      // (ROCm 7.2) pairs the butterfly's last steps with the d(logits) arithmetic and overwrites the address register of two
-      // ds_bpermute in flight with a v_accvgpr_read of the next accumulator ("ds_bpermute v152, v20, v144; ds_bpermute v153,
-      // v20, v145; v_accvgpr_read_b32 v20, a6"): under load the last quarter-wave (lanes 48-63) of the second permute then
-      // reads a stale index and rows 12..15 of a query tile get delta = 0 for one key tile — a few hundred wrong d(q) / d(k)
-      // elements per launch, different ones every run (found by tests/test_fullsize_properties_gpu.py's bit-reproducibility
-      // check; tests/test_kernels_gpu.py::test_window_attention_is_bit_reproducible pins it at the kernel level).
+      dl = row16_sum(dl);
+      // Value barrier (kept with the DPP reduction; it was found with the __shfl_xor butterfly that stood here): the reduced
+      // delta is materialised in a register of its own before its consumers.  Without it hipcc (ROCm 7.2) paired the
+      // butterfly's last steps with the d(logits) arithmetic and overwrote the address register of two ds_bpermute in flight
+      // with a v_accvgpr_read of the next accumulator ("ds_bpermute v152, v20, v144; ds_bpermute v153, v20, v145;
+      // v_accvgpr_read_b32 v20, a6"): under load the last quarter-wave (lanes 48-63) of the second permute then read a stale
+      // index and rows 12..15 of a query tile got delta = 0 for one key tile — a few hundred wrong d(q) / d(k) elements per
+      // launch, different ones every run (found by tests/test_fullsize_properties_gpu.py's bit-reproducibility check;
+      // tests/test_kernels_gpu.py::test_window_attention_is_bit_reproducible pins it at the kernel level).
       asm volatile("" : "+v"(dl));
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
