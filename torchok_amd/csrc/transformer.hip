@@ -470,7 +470,9 @@ __device__ __forceinline__ float load_head_row(const bf16* __restrict__ src, boo
 #pragma unroll
     for (int d = 0; d < HD; ++d) f[d] = 0.f;
   }
-  const float inv = normalise ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+  // F.normalize: 1 / max(|x|, 1e-12) = min(rsqrt(|x|^2), 1e12) — one v_rsq_f32 (the forward and the backward's recomputation
+  // use the same expression: the recomputed probabilities are normalised by the forward's log-sum-exp)
+  const float inv = normalise ? fminf(__builtin_amdgcn_rsqf(ss), 1e12f) : 1.f;
 #pragma unroll
   for (int d = 0; d < HD; d += 8)
 #pragma unroll
@@ -490,7 +492,7 @@ __device__ __forceinline__ float finish_head_row(bool normalise, bf16x8 (&o)[4])
   for (int d = 0; d < HD; d += 8)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { f[d + e] = bf2f(o[d >> 3][e]); ss = fmaf(f[d + e], f[d + e], ss); }
-  const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+  const float inv = fminf(__builtin_amdgcn_rsqf(ss), 1e12f);
 #pragma unroll
   for (int d = 0; d < HD; d += 8)
 #pragma unroll
@@ -620,6 +622,11 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
     // the 16 x 32 output tile goes back through this wave's own (now consumed) P rows so that a lane stores 16 bytes
     // of one token instead of sixteen lanes storing 2 bytes each
+    // 1 / rowsum once per query row (v_rcp_f32, 1 ulp): eight IEEE division sequences per lane and image were a tenth of
+    // this instruction-bound kernel's VALU work
+    float rinv[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) rinv[reg] = __builtin_amdgcn_rcpf(rsum[reg]);
 #pragma unroll
     for (int dj = 0; dj < 2; ++dj) {
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -630,7 +637,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg)
-        ps[(qi * 16 + 4 * g + reg) * PPITCH + dj * 16 + l15] = f2bf(o[reg] / rsum[reg]);
+        ps[(qi * 16 + 4 * g + reg) * PPITCH + dj * 16 + l15] = f2bf(o[reg] * rinv[reg]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
