@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(AttnArgs a, const bf16* __
 // occupancy, every latency exposed.)
 constexpr int QPITCH = 40;    // bf16 elements per Q/K row in LDS (32 + 8: spreads 16 rows over the banks)
 constexpr int PPITCH = 72;    // P rows / transposed rows: 64 + 8
-constexpr int MFMA_FWD_LDS = (2 * 64 * QPITCH + 32 * PPITCH + 64 * PPITCH) * 2;   // bytes per workgroup
+constexpr int MFMA_FWD_LDS = (3 * 64 * QPITCH + 64 * PPITCH) * 2;   // bytes per workgroup: q, k, v row-major + P^T
 
 // token t of the unit: loads one 32-wide head slice, optionally L2-normalises it (F.normalize, eps 1e-12)
 __device__ __forceinline__ float load_head_row(const bf16* __restrict__ src, bool valid, bool normalise, bf16x8 (&o)[4]) {
@@ -510,6 +510,32 @@ __device__ __forceinline__ void put_row(bf16* rowmaj, bf16* trans, int t, const 
   }
 }
 
+typedef __attribute__((address_space(3))) bf16x4 attn_lds_bf16x4;
+__device__ __forceinline__ bf16x4 attn_tr4(const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((attn_lds_bf16x4*)(p)); }
+// fragment of a row-major [token][pitch] tile whose k-slots are tokens 32 ks .. and whose MFMA row / column index is the
+// tile column c0 + l15
+__device__ __forceinline__ bf16x8 attn_tr_frag(const bf16* tile, int pitch, int ks, int c0, int g, int l15) {
+  const bf16* p = tile + (32 * ks + 4 * g + (l15 >> 2)) * pitch + c0 + (l15 & 3) * 4;
+  const bf16x4 lo = attn_tr4(p), hi = attn_tr4(p + 16 * pitch);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+// the same k-slot order read along a ROW of a [row][pitch] tile: tokens 32 ks + 4g .. +3 and 32 ks + 16 + 4g .. +3
+__device__ __forceinline__ bf16x8 attn_row_frag(const bf16* tile, int pitch, int row, int ks, int g) {
+  const bf16* p = tile + row * pitch + 32 * ks + 4 * g;
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
+  return r;
+}
+__device__ __forceinline__ void put_row_major(bf16* rowmaj, int t, const bf16x8 (&v)[4]) {
+#pragma unroll
+  for (int d = 0; d < HD; d += 8) *reinterpret_cast<bf16x8*>(rowmaj + t * QPITCH + d) = v[d >> 3];
+}
+
 // Workgroup -> unit.  A 32-wide head slice of a token row is 64 bytes: the heads of a window share 128-byte lines (and a row's
 // q / k / v parts are contiguous), so when consecutive workgroups — which the dispatcher deals round-robin to the eight XCDs,
 // each with its own L2 — take consecutive heads, every line is fetched by two L2s: PMC read traffic of the round-3 kernels was
@@ -530,8 +556,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
   extern __shared__ char smraw[];
   bf16* qs = reinterpret_cast<bf16*>(smraw);
   bf16* ks = qs + 64 * QPITCH;
-  bf16* vt = ks + 64 * QPITCH;          // [32 dims][PPITCH keys]
-  bf16* ps = vt + 32 * PPITCH;          // [64 queries][PPITCH keys]
+  bf16* vs = ks + 64 * QPITCH;          // V row-major [token][QPITCH]
+  bf16* pt = vs + 64 * QPITCH;          // P^T [64 keys][PPITCH queries]: a wave owns the 16 columns of its query tile
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int unit_id = attn_unit(units);
   if (unit_id >= units) return;
@@ -565,17 +591,26 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
         addt[reg][kj] = (i < N && j < N) ? v : -INFINITY;
       }
   }
+  // rows of the image being staged (wave 0: q, 1: k, 2: v) are requested one image ahead, as in the backward
+  const int64_t tok_sp = token_row(a, 0, win, lane < N ? lane : 0);
+  const int64_t img_rows = (int64_t)a.H * a.W;
+  bf16x8 rnext[4];
+  auto request = [&](int b) {
+    if (wv < 3) load_head_raw(qkv + (tok_sp + (int64_t)b * img_rows) * a.ld + h * HD + wv * a.C, lane < N, rnext);
+  };
+  if (bg * bpw < a.B) request(bg * bpw);
   for (int bb = 0; bb < bpw; ++bb) {
     const int b = bg * bpw + bb;
     if (b >= a.B) break;                 // uniform for the workgroup
     const size_t unit = ((size_t)b * a.nW + win) * a.heads + h;
-    if (wv < 3) {   // wave 0: q (normalised), wave 1: k (normalised), wave 2: v^T
-      const int t = lane;
+    if (wv < 3) {   // wave 0: q (normalised), wave 1: k (normalised), wave 2: v — all row-major
       bf16x8 r8[4];
-      const bf16* src = qkv + token_row(a, b, win, t < N ? t : 0) * a.ld + h * HD + wv * a.C;
-      load_head_row(src, t < N, wv < 2 && !a.plain, r8);
-      put_row(wv == 0 ? qs : (wv == 1 ? ks : nullptr), wv == 2 ? vt : nullptr, t, r8);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) r8[d] = rnext[d];
+      finish_head_row(wv < 2 && !a.plain, r8);
+      put_row_major(wv == 0 ? qs : (wv == 1 ? ks : vs), lane, r8);
     }
+    if (bb + 1 < bpw && b + 1 < a.B) request(b + 1);
     __syncthreads();
     const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qs + (qi * 16 + l15) * QPITCH + g * 8);
     f32x4 sc[4];
@@ -585,8 +620,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       sc[kj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
     }
-    // the logits leave the accumulator file here, in one go: no v_accvgpr_read between the ds_bpermute / ds_write of the
-    // softmax below (see the note at the delta reduction of attn_bwd_mfma_kernel; tools/isa_lint.py)
+    // the logits leave the accumulator file here, in one go: no v_accvgpr_read among the LDS traffic of the softmax below
+    // (see the note at the delta reduction of attn_bwd_mfma_kernel; tools/isa_lint.py)
     asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]));
     float rsum[4], rmax[4];
 #pragma unroll
@@ -610,48 +645,48 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, const bf
       sum = row16_sum(sum);
       rsum[reg] = sum;
       rmax[reg] = mx;
+      // normalised probabilities (v_rcp_f32 once per query row; what the backward recomputes from the log-sum-exp)
+      const float rinv = (i < N) ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
-      for (int kj = 0; kj < 4; ++kj) ps[i * PPITCH + kj * 16 + l15] = f2bf(sc[kj][reg]);
+      for (int kj = 0; kj < 4; ++kj) sc[kj][reg] *= rinv;
+    }
+    // P^T [key][query]: this lane holds queries qi*16 + 4g .. +3 of key kj*16 + l15 -> one 8-byte store per key tile (sixteen
+    // 2-byte stores in the [query][key] layout of round 2)
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+      bf16x4 p4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) p4[reg] = f2bf(sc[kj][reg]);
+      *reinterpret_cast<bf16x4*>(pt + (kj * 16 + l15) * PPITCH + qi * 16 + 4 * g) = p4;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();      // P rows of this query tile are produced and consumed by the same wave
-    // ---- O = P V : A = P[query][key slots], B = V^T[dim][key slots] ----
-    bf16x8 pf[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
-      pf[kt] = *reinterpret_cast<const bf16x8*>(ps + (qi * 16 + l15) * PPITCH + kt * 32 + g * 8);
-    // the 16 x 32 output tile goes back through this wave's own (now consumed) P rows so that a lane stores 16 bytes
-    // of one token instead of sixteen lanes storing 2 bytes each
-    // 1 / rowsum once per query row (v_rcp_f32, 1 ulp): eight IEEE division sequences per lane and image were a tenth of
-    // this instruction-bound kernel's VALU work
-    float rinv[4];
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) rinv[reg] = __builtin_amdgcn_rcpf(rsum[reg]);
-#pragma unroll
-    for (int dj = 0; dj < 2; ++dj) {
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vt + (dj * 16 + l15) * PPITCH + kt * 32 + g * 8);
-        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kt], vf, o, 0, 0, 0);
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        ps[(qi * 16 + 4 * g + reg) * PPITCH + dj * 16 + l15] = f2bf(o[reg] * rinv[reg]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_wave_barrier();      // the P^T columns of this query tile are produced and consumed by the same wave
+    // ---- O^T[dim][query] = V^T P^T: both operands by transpose reads from the row-major tiles (k-slots = keys), and the
+    // accumulator puts four consecutive dims of ONE query in a lane: 8-byte global stores, no staging of the output tile ----
     {
-      const int i = qi * 16 + (lane >> 2), ch = (lane & 3) * 8;
-      if (i < N)
-        stg16(out + token_row(a, b, win, i) * a.C + h * HD + ch, *reinterpret_cast<const bf16x8*>(ps + i * PPITCH + ch));
+      bf16x8 pb[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) pb[kt] = attn_tr_frag(pt, PPITCH, kt, qi * 16, g, l15);
+      const int t = qi * 16 + l15;
+      bf16* orow = out + token_row(a, b, win, t < N ? t : 0) * a.C + h * HD + 4 * g;
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+          o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(vs, QPITCH, kt, dj * 16, g, l15), pb[kt], o, 0, 0, 0);
+        bf16x4 o4;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) o4[reg] = f2bf(o[reg]);
+        if (t < N) *reinterpret_cast<bf16x4*>(orow + dj * 16) = o4;
+      }
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
       const int i = qi * 16 + 4 * g + reg;
       if (i < N && l15 == 0) lse[unit * N + i] = (rmax[reg] + __builtin_amdgcn_logf(rsum[reg])) * LN2;   // natural-log units
     }
-    __syncthreads();                     // before the next image overwrites q / k / v^T
+    __syncthreads();                     // before the next image overwrites q / k / v
   }
 }
 
@@ -669,32 +704,6 @@ constexpr int BW_ROWMAJ = 4 * 64 * QPITCH;            // qn, kn, v, dO (bf16 ele
 constexpr int BW_ST = 64 * PPITCH;                    // dS^T staging: [key][PPITCH queries]
 constexpr int BW_PT = 64 * PPITCH;                    // P^T staging:  [key][PPITCH queries]
 constexpr int MFMA_BWD_LDS = (BW_ROWMAJ + BW_ST + BW_PT) * 2 + (2 * 64 + 4) * 4;   // + qinv, kinv, 4 partial sums
-
-typedef __attribute__((address_space(3))) bf16x4 attn_lds_bf16x4;
-__device__ __forceinline__ bf16x4 attn_tr4(const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((attn_lds_bf16x4*)(p)); }
-// fragment of a row-major [token][pitch] tile whose k-slots are tokens 32 ks .. and whose MFMA row / column index is the
-// tile column c0 + l15
-__device__ __forceinline__ bf16x8 attn_tr_frag(const bf16* tile, int pitch, int ks, int c0, int g, int l15) {
-  const bf16* p = tile + (32 * ks + 4 * g + (l15 >> 2)) * pitch + c0 + (l15 & 3) * 4;
-  const bf16x4 lo = attn_tr4(p), hi = attn_tr4(p + 16 * pitch);
-  bf16x8 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
-  return r;
-}
-// the same k-slot order read along a ROW of a [row][pitch] tile: tokens 32 ks + 4g .. +3 and 32 ks + 16 + 4g .. +3
-__device__ __forceinline__ bf16x8 attn_row_frag(const bf16* tile, int pitch, int row, int ks, int g) {
-  const bf16* p = tile + row * pitch + 32 * ks + 4 * g;
-  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(p), hi = *reinterpret_cast<const bf16x4*>(p + 16);
-  bf16x8 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { r[e] = lo[e]; r[4 + e] = hi[e]; }
-  return r;
-}
-__device__ __forceinline__ void put_row_major(bf16* rowmaj, int t, const bf16x8 (&v)[4]) {
-#pragma unroll
-  for (int d = 0; d < HD; d += 8) *reinterpret_cast<bf16x8*>(rowmaj + t * QPITCH + d) = v[d >> 3];
-}
 
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf16* __restrict__ qkv,
                                                             const bf16* __restrict__ dout,
