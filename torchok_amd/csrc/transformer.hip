@@ -821,8 +821,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a, const bf
       float dl = 0.f;
 #pragma unroll
       for (int kj = 0; kj < 4; ++kj) {
-        const int j = kj * 16 + l15;
-        pv[kj][reg] = (i < N && j < N) ? __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li) : 0.f;
+        // (padding: addt is -inf there and the staged rows / the clamped log-sum-exp are finite, so exp2 gives exactly 0)
+        pv[kj][reg] = __builtin_amdgcn_exp2f(fmaf(sc[kj][reg], scale2, addt[reg][kj]) - li);
         dl = fmaf(pv[kj][reg], dp[kj][reg], dl);
       }
       dl = row16_sum(dl);
