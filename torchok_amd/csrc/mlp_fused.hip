@@ -306,15 +306,19 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<C, NT, WAVES>())) void 
                 }
                 const uint32_t u = __builtin_bit_cast(uint32_t, pr);
                 const float v0 = __builtin_bit_cast(float, u << 16), v1 = __builtin_bit_cast(float, u & 0xFFFF0000u);
+                // the activation two elements per instruction (v_pk_fma_f32 for the polynomial: the elementwise part is
+                // what competes with the MFMA pipe here); same operations as gelu_f / gelu_d, same bits
                 if constexpr (!BWD) {
                   prw[2 * b + jp] = u;
-                  hf[n][4 * b + 2 * jp] = f2bf(TOK_MLP_PROBE == 2 ? v0 : gelu_f(v0));
-                  hf[n][4 * b + 2 * jp + 1] = f2bf(TOK_MLP_PROBE == 2 ? v1 : gelu_f(v1));
+                  const f32x2 gv = TOK_MLP_PROBE == 2 ? (f32x2){v0, v1} : gelu_f2((f32x2){v0, v1});
+                  hf[n][4 * b + 2 * jp] = f2bf(gv.x);
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(gv.y);
                 } else {
                   const uint32_t q = pp[SLOT][SC][n][2 * b + jp];
                   const float p0 = __builtin_bit_cast(float, q << 16), p1 = __builtin_bit_cast(float, q & 0xFFFF0000u);
-                  hf[n][4 * b + 2 * jp] = f2bf(v0 * (TOK_MLP_PROBE == 2 ? p0 : gelu_d(p0)));
-                  hf[n][4 * b + 2 * jp + 1] = f2bf(v1 * (TOK_MLP_PROBE == 2 ? p1 : gelu_d(p1)));
+                  const f32x2 dv = TOK_MLP_PROBE == 2 ? (f32x2){p0, p1} : gelu_d2((f32x2){p0, p1});
+                  hf[n][4 * b + 2 * jp] = f2bf(v0 * dv.x);
+                  hf[n][4 * b + 2 * jp + 1] = f2bf(v1 * dv.y);
                 }
               }
             }

@@ -131,6 +131,21 @@ __device__ __forceinline__ f32x2 gelu_f2(f32x2 x) {
   return __builtin_elementwise_fma(-a, tok_gelu_tail2(a), m);
 }
 
+__device__ __forceinline__ f32x2 gelu_d2(f32x2 x) {          // the two-wide gelu_d: same operations, same bits
+  f32x2 a;
+  a.x = __builtin_amdgcn_fmed3f(fabsf(x.x), 0.f, TOK_GELU_AMAX);
+  a.y = __builtin_amdgcn_fmed3f(fabsf(x.y), 0.f, TOK_GELU_AMAX);
+  const f32x2 t = tok_gelu_tail2(a);
+  f32x2 cdf;
+  cdf.x = x.x >= 0.f ? 1.f - t.x : t.x;
+  cdf.y = x.y >= 0.f ? 1.f - t.y : t.y;
+  const f32x2 e = __builtin_elementwise_fma(x * x, (f32x2)(-0.72134752044448170f), (f32x2)(-1.3257480647361593f));
+  f32x2 pdf;
+  pdf.x = __builtin_amdgcn_exp2f(e.x);
+  pdf.y = __builtin_amdgcn_exp2f(e.y);
+  return __builtin_elementwise_fma(x, pdf, cdf);
+}
+
 __device__ __forceinline__ bf16x8 zero8() {
   bf16x8 z;
 #pragma unroll
