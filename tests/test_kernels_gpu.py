@@ -853,7 +853,7 @@ def test_window_attention(libs, b, h, w, heads, ws, shift):
 @pytest.mark.parametrize('b,h,w,heads,ws,shift', [(256, 14, 14, 12, 7, 3), (256, 14, 14, 12, 7, 0), (128, 28, 28, 6, 7, 3),
                                                   (64, 56, 56, 3, 7, 3), (256, 7, 7, 24, 7, 0)])
 def test_window_attention_is_bit_reproducible(libs, b, h, w, heads, ws, shift):
-    """The SwinV2-T stage geometries at sizes where a workgroup walks several images (units >= 8192): the same launch, six
+    """The SwinV2-T stage geometries at sizes where a workgroup walks several images (units >= 3072): the same launch, six
     times, gives the same bits in d(qkv), the d(logits) partial rows and the d(logit_scale) partials, and every element is
     written.  Round 3 found a few hundred wrong d(q) / d(k) elements per launch, different ones every run (a register reused
     under two ds_bpermute in flight, transformer.hip: the value barrier after the delta reduction); only the full-size model

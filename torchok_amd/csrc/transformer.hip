@@ -1237,8 +1237,14 @@ extern "C" int tok_act_bwd(int kind, const void* dout, const void* x, void* dx, 
 namespace {
 int attn_bpw(const AttnArgs& a) {     // images per wave on the MFMA path
   const long long units = (long long)a.B * a.nW * a.heads;
-  long long bpw = units / 4096;
-  bpw = bpw < 1 ? 1 : (bpw > 8 ? 8 : bpw);
+  // images a workgroup walks: about 1536 workgroups per launch (three rounds of the backward's 512 resident ones), at most 16
+  // images each — the per-workgroup prologue (sixteen bias / mask loads per lane) and the first image's exposed load are paid
+  // once per workgroup.  Measured per SwinV2-T step in isolation (tools/ubench/attn_time.py): units / 4096 capped at 8 (rounds
+  // 2-3) 1.00 / 2.36 ms forward / backward, / 1536 capped at 16: 0.95 / 1.99 ms; / 1024 cap 8: 0.96 / 2.06; / 8192: 1.15 / 2.84.
+  static int div = 0, cap = 0;
+  if (!div) { const char* e = getenv("TOK_ATTN_BPW_DIV"); div = e ? atoi(e) : 1536; e = getenv("TOK_ATTN_BPW_CAP"); cap = e ? atoi(e) : 16; }
+  long long bpw = units / div;
+  bpw = bpw < 1 ? 1 : (bpw > cap ? cap : bpw);
   return (int)(bpw > a.B ? a.B : bpw);
 }
 }  // namespace
