@@ -1167,7 +1167,11 @@ extern "C" int tok_layernorm_fwd(const void* x, const void* shortcut, const floa
 extern "C" int tok_layernorm_bwd_rows(int64_t rows, int c) {
   const int64_t b = (rows + 3) / 4;
   (void)c;
-  return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));      // eight blocks per CU: the pass is pure streaming
+  static int cap = 0;
+  // four blocks per CU = what is resident at 102 registers; the partial d(gamma) / d(beta) rows the fold reads scale with the
+  // grid (SwinV2-T B=256, ms/step: 512 20.42, 1024 20.37, 2048 20.43, 4096 20.59, 8192 20.97)
+  if (!cap) { const char* e = getenv("TOK_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; }
+  return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
 extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* mean, const float* rstd,
