@@ -28,15 +28,21 @@ import torch  # noqa: E402
 
 ALG_BYTES_PER_IMG = {'resnet50': 309.7e6, 'resnet18': 70.6e6}   # SURVEY.md App. C (Model F + weights @B=256)
 ALG_BYTES_SEG = {('hrnet_w48', 512, 1024): 8.08e9}               # HRNet-W48 seg 512x1024
+# BASELINE.json configs[4] at its per-rank batch of 128 (SURVEY.md App. C byte model): activations 306.8 MB/img (Model F,
+# independent of the batch) + 30 bytes per parameter and step / 128 images + the head's per-image rows.
+#   ArcFace recipe: ResNet-50 trunk 23.51 M + PoolingLinear 2048x512 1.05 M + ArcFaceHead 11318x512 5.79 M = 30.35 M
+#     parameters -> 7.11 MB/img; cosine / logit rows 11318 x (2 + 2 + 4) B = 0.09 MB/img.
+#   Contrastive recipe: trunk + LinearHead 2048x512 = 24.56 M parameters -> 5.76 MB/img; the 128 x 128 distance matrix is nothing.
+ALG_BYTES_C5 = {'arcface': 306.8e6 + 30 * 30.35e6 / 128 + 11318 * 8, 'contrastive': 306.8e6 + 30 * 24.56e6 / 128}
 HBM_PEAK = 8.0e12
 # PMC-measured HBM bytes of ONE step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command,
 # summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md).  One file per workload, newest round first.
 PMC_FILES = {
-    ('resnet50', 224, 224, 256): ['r03_resnet50_bs256_pmc_traffic.json', 'r02_resnet50_bs256_pmc_traffic.json',
+    ('resnet50', 224, 224, 256): ['r04_resnet50_bs256_pmc_traffic.json', 'r03_resnet50_bs256_pmc_traffic.json', 'r02_resnet50_bs256_pmc_traffic.json',
                                  'r01_resnet50_bs256_pmc_traffic.json'],
-    ('swinv2_custom', 224, 224, 256): ['r03_swinv2t_224_bs256_pmc_traffic.json', 'r02_swinv2t_224_bs256_pmc_traffic.json'],
+    ('swinv2_custom', 224, 224, 256): ['r04_swinv2t_224_bs256_pmc_traffic.json', 'r03_swinv2t_224_bs256_pmc_traffic.json', 'r02_swinv2t_224_bs256_pmc_traffic.json'],
     ('davit_t', 224, 224, 256): ['r02_davit_t_224_bs256_pmc_traffic.json'],
-    ('hrnet_w48', 512, 1024, 24): ['r03_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r02_hrnet_w48_512x1024_bs24_pmc_traffic.json'],
+    ('hrnet_w48', 512, 1024, 24): ['r04_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r03_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r02_hrnet_w48_512x1024_bs24_pmc_traffic.json'],
     ('hrnet_w48', 512, 1024, 8): ['r02_hrnet_w48_512x1024_bs8_pmc_traffic.json'],
 }
 
@@ -49,6 +55,16 @@ def measured_traffic(backbone: str, res: int, width: int, batch: int):
             with open(path) as f:
                 return round(json.load(f)['hbm_bytes_per_step'] / 1e9, 2), 'profiles/' + name
     return None, None
+
+
+def traffic_note(traffic_file):
+    """`roofline.traffic` is NOT measured by the run that prints it: rocprofv3 collects PMC counters from outside the process
+    (separate FETCH_SIZE / WRITE_SIZE passes, tools/profile_workload.sh).  The line carries the committed figure of the same
+    command on the build it was profiled on and says so."""
+    if not traffic_file:
+        return None
+    return (f'committed profile {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 per '
+            'MI355X_MICROARCH.md, calibrated on the optimizer kernel); a constant of the profiled build, not measured in this run')
 
 
 def measured_mfma_util(backbone: str, res: int, width: int, batch: int):
@@ -161,9 +177,9 @@ def secondary_block(budget_s: float = 20.0, warmup: int = 3, steps: int = 10):
         ('hrnet_w48_seg_512x1024_bs24', lambda: build_seg_task('hrnet_w48', 19, 512, 1024), 24, (3, 512, 1024), 19, True,
          ('hbm', ALG_BYTES_SEG[('hrnet_w48', 512, 1024)], HBM_PEAK)),
         ('resnet50_arcface11318_bs128', lambda: build_c5_task('arcface'), 128, (3, 224, 224), 11318, False,
-         ('hbm', ALG_BYTES_PER_IMG['resnet50'], HBM_PEAK)),
+         ('hbm', ALG_BYTES_C5['arcface'], HBM_PEAK)),
         ('resnet50_contrastive_bs128', lambda: build_c5_task('contrastive'), 128, (3, 224, 224), 11318, False,
-         ('hbm', ALG_BYTES_PER_IMG['resnet50'], HBM_PEAK)),
+         ('hbm', ALG_BYTES_C5['contrastive'], HBM_PEAK)),
     ]
     out, t_start = {}, time.perf_counter()
     for name, build, bsz, shape, classes, seg, (bound, per_img, peak) in plans:
@@ -188,7 +204,9 @@ def secondary_block(budget_s: float = 20.0, warmup: int = 3, steps: int = 10):
             ms = e0.elapsed_time(e1) / steps
             ach = per_img * bsz / (ms * 1e-3)
             out[name] = {'ms_per_step': round(ms, 3), 'images_per_sec': round(bsz / ms * 1e3, 1), 'bound': bound,
-                         'frac': round(ach / peak, 4), 'batch': bsz, 'steps': steps, 'warmup': warmup,
+                         'frac': round(ach / peak, 4),
+                         'algorithmic_per_img': f'{per_img / 1e9:.2f} GFLOP' if bound == 'mfma' else f'{per_img / 1e6:.1f} MB',
+                         'batch': bsz, 'steps': steps, 'warmup': warmup,
                          'loss_finite': bool(torch.isfinite(out_['loss']))}
             del task, opt, batch, out_
         except Exception as e:      # a secondary workload must never take the headline line down with it
@@ -413,13 +431,14 @@ def main():
             ach = flops * args.batch / (ev_ms * 1e-3) / 1e12
             roofline = {'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_PEAK_BF16 / 1e12, 'unit': 'TFLOP/s',
                         'frac': round(ach * 1e12 / MFMA_PEAK_BF16, 4), 'traffic': traffic,
-                        'traffic_unit': f'GB/step (PMC, {traffic_file})' if traffic_file else None,
+                        'traffic_unit': 'GB/step' if traffic_file else None, 'traffic_source': traffic_note(traffic_file),
                         'launch': f'one training step, HIP-event avg {ev_ms:.3f} ms'}
         elif alg is not None:
             achieved = alg * args.batch / (ev_ms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                         'frac': round(achieved * 1e9 / HBM_PEAK, 4),
-                        'traffic': traffic, 'traffic_unit': f'GB/step (PMC, {traffic_file})' if traffic_file else None,
+                        'traffic': traffic, 'traffic_unit': 'GB/step' if traffic_file else None,
+                        'traffic_source': traffic_note(traffic_file),
                         'algorithmic': round(alg * args.batch / 1e9, 2), 'algorithmic_unit': 'GB/step',
                         'launch': 'one training step (all kernels of fwd+bwd+optimizer on the step stream), '
                                   f'HIP-event avg {ev_ms:.3f} ms'}
@@ -444,7 +463,9 @@ def main():
             'roofline': roofline,
         }
         if roofline is not None:
-            roofline['mfma_util_pmc'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
+            # (a constant read from the committed PMC pass of this workload, like `traffic`: counters cannot be collected
+            #  from inside the timed process)
+            roofline['mfma_util_committed_profile'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
         if dist_on:
             line['config']['rccl_ranks'] = dist.get_world_size()
             line['ranks_in_sync'] = in_sync

@@ -24,8 +24,11 @@
  *    torch.distributed (backend "nccl" = RCCL): buckets are contiguous ranges of the gradient arena this library writes
  *    into, so the exchange needs no kernel of its own beyond tok_cast_f32_bf16 / tok_cast_bf16_f32 / tok_scale_f32.
  *  - Thread-safety: all entry points are re-entrant (PyTorch calls backward from an
- *    autograd worker thread); there is no global mutable state except the thread-local
- *    error string.
+ *    autograd worker thread).  Mutable state is thread-local only (the error string; the
+ *    event armed by tok_next_launch_event).  Process-wide state is write-once: environment
+ *    knobs (TOK_*) and the per-kernel hipFuncSetAttribute calls are function-local
+ *    `static const` values, initialised exactly once under the C++11 guarantee for local
+ *    statics — a knob changed after its first use has no effect.
  */
 #ifndef TOK_H_
 #define TOK_H_

@@ -73,8 +73,48 @@ def _worker(rank, world, port, tmp):
     sd = task.state_dict()
     assert any(k.endswith('running_mean') for k in sd)
 
+    # steady state of find_unused_parameters: this rank's pattern of missing gradients does not change, so the reduced used-map
+    # is not read on the host again (one blocking copy per step under torch DDP) and the per-parameter scan does not run;
+    # the averaged update still reaches `r` on rank 0 and the replicas stay identical
+    reads, scans = [], []
+    real_cpu, real_flags = torch.Tensor.cpu, GradientAllReducer._local_flags
+    torch.Tensor.cpu = lambda t, *a, **k: (reads.append(1), real_cpu(t, *a, **k))[1]
+
+    def counted_flags(self_):
+        f, ch = real_flags(self_)
+        scans.append(ch)
+        return f, ch
+    GradientAllReducer._local_flags = counted_flags
+    for i in range(3):
+        step(10 + i, red)
+        assert r.grad is not None and torch.allclose(r.grad, torch.tensor([2.0])) and u.grad is None
+        opt.step()
+    torch.Tensor.cpu, GradientAllReducer._local_flags = real_cpu, real_flags
+    assert reads == [] and scans == [False, False, False]
+    flat = torch.cat([p.detach().flatten() for p in params])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    # a change on the OTHER rank that this rank cannot see (rank 1 stops using `r`; rank 0 never had a gradient for it) is
+    # caught by the device-side comparison and reported by the next finish_step on the rank whose cache was stale; rank 1
+    # saw its own pattern change and re-read the map
+    out = task.training_step({'image': x, 'target': y}, 20)
+    loss = out['loss'] + (q * torch.tensor([1.0 + rank, 2.0])).sum()
+    opt.zero_grad()
+    red.begin_step()
+    loss.backward()
+    red.finish_step()
+    if rank == 0:
+        with pytest.raises(RuntimeError, match='static_unused_pattern'):
+            red._poll_late_check()
+    else:
+        red._poll_late_check()
+        assert r.grad is None          # unused everywhere now
+    dist.barrier()
+
     # bf16 buckets: same step from the same state, compared with the fp32 exchange
     red.close()
+    assert not hasattr(task, '_grad_reducer')      # a closed reducer no longer receives the task's loss-mean collectives
     snap = [p.detach().clone() for p in params]
     step(1, GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False, find_unused_parameters=True))
     g32 = torch.cat([p.grad.flatten() for p in params if p.grad is not None]).clone()

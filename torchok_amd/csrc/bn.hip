@@ -635,8 +635,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_reduce_pooled_kernel(const bf
 
 static int stream_cap() {   // blocks of the elementwise kernels (TOK_BN_BLOCKS overrides).  1024 = 4 per CU = half the wave slots: the
                             // weight-gradient kernels of the side stream run beside them (2048 measured 1.7 % slower end to end)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_BN_BLOCKS"); v = e ? atoi(e) : 1024; }
+  static const int v = [] { const char* e = getenv("TOK_BN_BLOCKS"); return (int)(e ? atoi(e) : 1024); }();
   return v;
 }
 #define kStreamCap stream_cap()

@@ -781,8 +781,7 @@ __global__ __launch_bounds__(256, (BN == 64 && PWM != 4) ? 3 : 2) void conv_igem
 // Persistent grid: 2 (128x128 tile) or 3 (128x64) workgroups per CU, rounded to a multiple of
 // 8 * gridN so every XCD holds whole (channel tile, m-slot) groups; never more than the tiles need.
 int plan_grid(int bn_tile, int gridM, int gridN, int per_cu = 0) {
-  static int pc64 = -1;      // TOK_IGEMM_PER_CU_64=<n>: persistent workgroups per CU of the 128 x 64 tile (experiment; default 3)
-  if (pc64 < 0) { const char* e = getenv("TOK_IGEMM_PER_CU_64"); pc64 = e ? atoi(e) : 0; }
+  static const int pc64 = [] { const char* e = getenv("TOK_IGEMM_PER_CU_64"); return (int)(e ? atoi(e) : 0); }();      // TOK_IGEMM_PER_CU_64=<n>: persistent workgroups per CU of the 128 x 64 tile (experiment; default 3)
   if (per_cu == 0 && bn_tile == 64 && pc64 > 0) per_cu = pc64;
   const int unit = 8 * gridN;
   int G = 256 * (per_cu > 0 ? per_cu : (bn_tile == 64 ? 3 : 2));
@@ -796,12 +795,12 @@ int plan_grid(int bn_tile, int gridM, int gridN, int per_cu = 0) {
 template <int BM, int BN, int IN_DIV, bool C4, int PW>
 int launch_pw(ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * (BM + BN) * BK * 2 + 2 * 4 * BN * 4 + (PW == 4 ? 2 * BM * BN * 2 : 0);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, IN_DIV, C4, PW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   const int grid = a.force_grid > 0 ? a.force_grid
                                     : plan_grid(BN, a.gridM, a.gridN, PW == 4 ? 2 : 0);   // (PW 4: two shortcut tiles in LDS -> 2 per CU)
   a.stat_rows = grid / a.gridN;
@@ -838,8 +837,7 @@ static long long pw_min_rows() {
   return v;
 }
 static int pw_ring128() {   // TOK_PW_RING_BN128=<k>: 128-wide tiles with a reduction depth >= k also ride the ring (experiment; 0 = off)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_PW_RING_BN128"); v = e ? atoi(e) : 0; }
+  static const int v = [] { const char* e = getenv("TOK_PW_RING_BN128"); return (int)(e ? atoi(e) : 0); }();
   return v;
 }
 static bool pw_serves(int bn_tile, long long rows, int c_red, int n_out) {
@@ -893,8 +891,7 @@ int launch(ConvArgs& a, hipStream_t st) {
 
 // experiment knob: TOK_BN64=1 forces the 128x64 tile for every layer
 static int force_bn64() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_BN64"); v = (e && e[0] == '1') ? 1 : 0; }
+  static const int v = [] { const char* e = getenv("TOK_BN64"); return (int)((e && e[0] == '1') ? 1 : 0); }();
   return v;
 }
 
@@ -902,14 +899,12 @@ static int force_bn64() {
 // workgroups per CU) keeps more loads/stores in flight; deep-K layers are MFMA-bound and want the
 // 128x128 tile's operand reuse.  (Measured on the ResNet-50 shapes, tools/bench_conv.py.)
 static int short_k() {   // TOK_SHORT_K=<k>: reduction depths up to k take the 128x64 tile (default 400: ResNet-50 B=256 sweep 100 / 260 / 400 / 520 / 768 -> 20.4 / 19.8 / 19.9 / 20.1 / 20.0 ms)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_SHORT_K"); v = e ? atoi(e) : 400; }
+  static const int v = [] { const char* e = getenv("TOK_SHORT_K"); return (int)(e ? atoi(e) : 400); }();
   return v;
 }
 
 static int small_m_tiles() {   // TOK_SMALLM_TILES=<n>: layers with fewer 128x128 tiles than n take the 128x64 tile
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_SMALLM_TILES"); v = e ? atoi(e) : 0; }
+  static const int v = [] { const char* e = getenv("TOK_SMALLM_TILES"); return (int)(e ? atoi(e) : 0); }();
   return v;
 }
 

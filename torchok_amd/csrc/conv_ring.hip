@@ -381,18 +381,15 @@ __global__ __launch_bounds__(256, 2) void conv_ring_kernel(ConvArgs a) {
 // the four activation DMA rows real the ring runs 1.2-1.3x faster.  That probe is what conv_win.hip (shared input window for
 // the 3x3 layers) is built on; this kernel stays as the tested basis for larger pointwise tiles.
 int ring_flag() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_RING"); v = e ? atoi(e) : 0; }
+  static const int v = [] { const char* e = getenv("TOK_CONV_RING"); return (int)(e ? atoi(e) : 0); }();
   return v;
 }
 int ring_min_k() {  // reduction depth from which the 256 x 128 ring serves a layer
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_RING_MIN_K"); v = e ? atoi(e) : 256; }
+  static const int v = [] { const char* e = getenv("TOK_CONV_RING_MIN_K"); return (int)(e ? atoi(e) : 256); }();
   return v;
 }
 int ring_min_tiles() {   // fewer 256 x 128 tiles than this cannot fill the chip: the smaller tiles of conv_igemm serve the layer
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_RING_MIN_TILES"); v = e ? atoi(e) : 384; }
+  static const int v = [] { const char* e = getenv("TOK_CONV_RING_MIN_TILES"); return (int)(e ? atoi(e) : 384); }();
   return v;
 }
 
@@ -422,12 +419,12 @@ int conv_ring_grid(int gridM256, int gridN128) {
 int conv_ring_launch(ConvArgs& a, hipStream_t st) {
   constexpr int smem = RNST * (RBM + RBN) * RBK * 2;
   const bool pw = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[pw ? 1 : 0]) {
-    if (pw) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    else (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set[pw ? 1 : 0] = true;
-  }
+  static const bool attr_set = [] {   // once per process (thread-safe function-local static), both instantiations
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    return true;
+  }();
+  (void)attr_set;
   a.KT = tok_cdiv(a.Ktot, RBK);
   const int grid = conv_ring_grid(a.gridM, a.gridN);
   a.stat_rows = grid / a.gridN;

@@ -988,24 +988,20 @@ struct Plan {
 };
 
 static int taps_enabled() {   // TOK_WGRAD_TAPS=0: 3x3 layers stay on the two-buffer kernel (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS"); v = e ? atoi(e) : 1; }
+  static const int v = [] { const char* e = getenv("TOK_WGRAD_TAPS"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
 static int taps_target() {    // TOK_WGRAD_TAPS_WGS=<n>: workgroups the split aims at (default 256; 512 is faster in isolation, 256 on the step)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_WGRAD_TAPS_WGS"); v = e ? atoi(e) : 256; }
+  static const int v = [] { const char* e = getenv("TOK_WGRAD_TAPS_WGS"); return (int)(e ? atoi(e) : 256); }();
   return v;
 }
 
 static int ring_enabled() {   // TOK_WGRAD_RING=0: the two-buffer kernels of round 1 (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_WGRAD_RING"); v = e ? atoi(e) : 1; }   // 2: every layer
+  static const int v = [] { const char* e = getenv("TOK_WGRAD_RING"); return (int)(e ? atoi(e) : 1); }();   // 2: every layer
   return v;
 }
 static int ring_target() {    // TOK_WGRAD_WGS=<n>: workgroups the split aims at (default: what is resident at once)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_WGRAD_WGS"); v = e ? atoi(e) : 0; }
+  static const int v = [] { const char* e = getenv("TOK_WGRAD_WGS"); return (int)(e ? atoi(e) : 0); }();
   return v;
 }
 
@@ -1054,8 +1050,7 @@ Plan make_plan(const tok_conv_desc* d) {
     // (split target: what is resident at once was 768 workgroups on the 128 x 128 tile; 512 measured better on the step — the
     //  partial-sum slabs are a third smaller and the side stream leaves more of every CU to the main chain:
     //  ResNet-50 19.93 -> 19.38 ms/step together with the tap kernels' 256, tools/ubench/sweep_r02.sh)
-    static int long_target = -1;   // TOK_WGRAD_WGS_LONG=<n>: split target of the long-M layers (>= 100 k rows: the main-stream launches)
-    if (long_target < 0) { const char* e = getenv("TOK_WGRAD_WGS_LONG"); long_target = e ? atoi(e) : 0; }
+    static const int long_target = [] { const char* e = getenv("TOK_WGRAD_WGS_LONG"); return (int)(e ? atoi(e) : 0); }();   // TOK_WGRAD_WGS_LONG=<n>: split target of the long-M layers (>= 100 k rows: the main-stream launches)
     const int target = (long_target > 0 && M >= 100000) ? long_target
                        : ring_target() > 0 ? ring_target() : 256 * (per_cu > 2 ? 2 : per_cu);
     long long split = (target + tiles - 1) / tiles;
@@ -1075,13 +1070,11 @@ Plan make_plan(const tok_conv_desc* d) {
   p.tilesN = tok_cdiv(d->k, p.TN);
   p.tilesK = tok_cdiv(Ktot, p.TK);
   const int tiles = p.tilesN * p.tilesK;
-  static int tb_target = -1;     // TOK_WGRAD_2BUF_WGS=<n>: workgroups the split of the two-buffer kernel aims at
-  if (tb_target < 0) { const char* e = getenv("TOK_WGRAD_2BUF_WGS"); tb_target = e ? atoi(e) : 1024; }
+  static const int tb_target = [] { const char* e = getenv("TOK_WGRAD_2BUF_WGS"); return (int)(e ? atoi(e) : 1024); }();     // TOK_WGRAD_2BUF_WGS=<n>: workgroups the split of the two-buffer kernel aims at
   long long split = (tb_target + tiles - 1) / tiles;  // aim at ~4 workgroups per CU
   // reduction rows per barrier: 64 on the long-M layers (twice the MFMAs per barrier), 32 where M is
   // short and occupancy (4 workgroups per CU instead of 2) matters more
-  static int ms64_any = -1;     // TOK_WGRAD_MS64_ANY=1: 64 rows per barrier on every long-M tile shape (experiment)
-  if (ms64_any < 0) { const char* e = getenv("TOK_WGRAD_MS64_ANY"); ms64_any = e ? atoi(e) : 0; }
+  static const int ms64_any = [] { const char* e = getenv("TOK_WGRAD_MS64_ANY"); return (int)(e ? atoi(e) : 0); }();     // TOK_WGRAD_MS64_ANY=1: 64 rows per barrier on every long-M tile shape (experiment)
   p.MS = (M >= 100000 && ((p.TN == 128 && p.TK == 128) || ms64_any)) ? 64 : 32;
   const long long max_split = (M + 8 * p.MS - 1) / (8 * p.MS);   // at least 8 steps per workgroup
   if (split > max_split) split = max_split;
@@ -1100,12 +1093,12 @@ Plan make_plan(const tok_conv_desc* d) {
 template <int TN, int TK, bool PWK>
 void launch_ring_pw(const WgradArgs& a, hipStream_t st) {
   constexpr int smem = 3 * 32 * (TN + TK) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TN, TK, PWK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   hipLaunchKernelGGL((conv_wgrad_ring_kernel<TN, TK, PWK>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
 }
 
@@ -1118,12 +1111,12 @@ void launch_ring(const WgradArgs& a, hipStream_t st) {
 template <int TN, int TK, bool C4, int MS, bool DMA_T, bool PWK>
 void launch_wgrad_pw(const WgradArgs& a, hipStream_t st) {
   constexpr int smem = 2 * MS * ((TN + 16) * 2 + (TK + 16) * 2);   // (the unpadded DMA layout needs less)
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<TN, TK, C4, MS, DMA_T, PWK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   hipLaunchKernelGGL((conv_wgrad_kernel<TN, TK, C4, MS, DMA_T, PWK>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256),
                      smem, st, a);
 }
@@ -1233,24 +1226,24 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   const bool c4 = d->c == 4;
   if (p.taps) {
     constexpr int smem = 3 * 10 * 32 * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_taps_kernel<0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-      attr_set = true;
-    }
+      return true;
+    }();   // once per process (thread-safe function-local static)
+    (void)attr_set;
     const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W &&
                       (unsigned long long)a.M * a.C * 2 < 0xFFFFFFF0ull && taps_enabled() != 2;
     if (same) {
       constexpr int smem_w = 3 * (32 * 128 + 128 * 128) + 128;
-      static bool attr_w = false;
-      if (!attr_w) {
+      static const bool attr_w = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   smem_w);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   smem_w);
-        attr_w = true;
-      }
+        return true;
+      }();   // once per process (thread-safe function-local static)
+      (void)attr_w;
       if (p.TN == 48) hipLaunchKernelGGL(conv_wgrad_win_kernel<3>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
       else hipLaunchKernelGGL(conv_wgrad_win_kernel<4>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
     } else {

@@ -397,13 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 }
 
 int win_flag() {   // TOK_CONV_WIN=0: 3x3 layers stay on the implicit-GEMM kernels (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_WIN"); v = e ? atoi(e) : 1; }
+  static const int v = [] { const char* e = getenv("TOK_CONV_WIN"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
 int win_min_tiles() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_CONV_WIN_MIN_TILES"); v = e ? atoi(e) : 128; }
+  static const int v = [] { const char* e = getenv("TOK_CONV_WIN_MIN_TILES"); return (int)(e ? atoi(e) : 128); }();
   return v;
 }
 
@@ -412,12 +410,12 @@ int pick_wbn(int K) { return K <= 64 ? 64 : 128; }
 
 template <int TW, int BN>
 void launch_variant(const ConvArgs& a, const WinGeo& g, int grid, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<TW, BN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               win_smem(BN));
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   hipLaunchKernelGGL((conv_win_kernel<TW, BN>), dim3(grid), dim3(256), win_smem(BN), st, a, g);
 }
 

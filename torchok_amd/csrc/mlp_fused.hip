@@ -454,12 +454,12 @@ template <int C, int HC, int NT, int WAVES, bool PF, int MODE, bool SAVE, int RD
 void launch_v(const MlpArgs& a, hipStream_t st) {
   constexpr int STAGE = (HC / 32) * (2 * (C / 32) + C / 16) * 1024;
   const int smem = 3 * STAGE + (MODE == 0 ? (a.H + C) * 4 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_kernel<C, HC, NT, WAVES, PF, MODE, SAVE, RD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   MlpArgs b = a;
   constexpr int TILE = WAVES * NT * 16;
   b.ntiles = (a.T + TILE - 1) / TILE;
@@ -484,24 +484,24 @@ void launch_c(const MlpArgs& a, int c, hipStream_t st) {
   // -8 % (C = 384) / -28 % (C = 192), no stage barrier -7 %: no single bound, the stage's three phases serialise per wave.
   // C = 192 forward on 64 hidden units per stage (half the stage barriers: 259 vs 292 us in save mode; the backward spills at
   // that stage size: 349 vs 278 us; C = 96 with 128 per stage: 406 vs 376 us)
-  static int w4 = -1;
-  if (w4 < 0) { const char* e = getenv("TOK_MLP_W4"); w4 = e ? atoi(e) : 0; }
+  static const int w4 = [] { const char* e = getenv("TOK_MLP_W4"); return (int)(e ? atoi(e) : 0); }();
   if (c == 96 && w4) launch_m<96, 64, 2, 4, true, MODE>(a, st);
   else if (c == 192 && w4) launch_m<192, 32, 2, 4, false, MODE>(a, st);
   else if (c == 96) launch_m<96, 64, 2, 8, true, MODE>(a, st);
-  else if (c == 192 && MODE == 0) launch_m<192, 64, 2, 8, false, MODE>(a, st);
-  else if (c == 192) launch_m<192, 32, 2, 8, false, MODE>(a, st);
+  else if (c == 192) {
+    // (if constexpr: the 64-per-stage backward form spills 44-58 VGPRs and must not even be instantiated)
+    if constexpr (MODE == 0) launch_m<192, 64, 2, 8, false, MODE>(a, st);
+    else launch_m<192, 32, 2, 8, false, MODE>(a, st);
+  }
   else launch_m<384, 32, 1, 8, false, MODE>(a, st);
 }
 
 int mlp_min_rows() {   // below this the serial chain of hidden chunks of one tile is longer than the two GEMM launches
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_MLP_MIN_ROWS"); v = e ? atoi(e) : 32768; }
+  static const int v = [] { const char* e = getenv("TOK_MLP_MIN_ROWS"); return (int)(e ? atoi(e) : 32768); }();
   return v;
 }
 int mlp_flag() {   // TOK_MLP_FUSED=0: the MLP stays on the two GEMM launches (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_MLP_FUSED"); v = e ? atoi(e) : 1; }
+  static const int v = [] { const char* e = getenv("TOK_MLP_FUSED"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
 

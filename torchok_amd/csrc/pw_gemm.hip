@@ -430,8 +430,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
 }
 
 int ring_flag() {   // TOK_PW_RING=0: every pointwise launch stays on conv_igemm's two-buffer loop (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_PW_RING"); v = e ? atoi(e) : 1; }
+  static const int v = [] { const char* e = getenv("TOK_PW_RING"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
 
@@ -439,12 +438,12 @@ template <int BN, bool BNEP>
 int launch_ring(const PwArgs& a, hipStream_t st) {
   constexpr int STAGE = BM * BK * 2 + BN * BK * 2 + (BN == 64 ? 1024 : 4096);
   constexpr int smem = 3 * STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_ring_kernel<BN, BNEP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   const int KT1 = tok_cdiv(a.C, BK);
   const int KT = KT1 + (a.x2 != nullptr ? tok_cdiv(a.C2, BK) : 0);
   const int SPT = KT + (a.e1 ? 1 : 0) + (a.e2 ? 1 : 0);

@@ -1123,8 +1123,7 @@ inline int blocks_for(size_t total) {
 
 // TOK_ATTN_SCALAR=1 forces the VALU reference kernels (debugging aid)
 inline bool tok_attn_scalar() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("TOK_ATTN_SCALAR"); v = (e && e[0] == '1') ? 1 : 0; }
+  static const int v = [] { const char* e = getenv("TOK_ATTN_SCALAR"); return (int)((e && e[0] == '1') ? 1 : 0); }();
   return v == 1;
 }
 
@@ -1167,10 +1166,9 @@ extern "C" int tok_layernorm_fwd(const void* x, const void* shortcut, const floa
 extern "C" int tok_layernorm_bwd_rows(int64_t rows, int c) {
   const int64_t b = (rows + 3) / 4;
   (void)c;
-  static int cap = 0;
   // four blocks per CU = what is resident at 102 registers; the partial d(gamma) / d(beta) rows the fold reads scale with the
   // grid (SwinV2-T B=256, ms/step: 512 20.42, 1024 20.37, 2048 20.43, 4096 20.59, 8192 20.97)
-  if (!cap) { const char* e = getenv("TOK_LN_BWD_BLOCKS"); cap = e ? atoi(e) : 1024; }
+  static const int cap = [] { const char* e = getenv("TOK_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 1024; return v < 1 ? 1 : v; }();
   return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
@@ -1245,8 +1243,9 @@ int attn_bpw(const AttnArgs& a) {     // images per wave on the MFMA path
   // images each — the per-workgroup prologue (sixteen bias / mask loads per lane) and the first image's exposed load are paid
   // once per workgroup.  Measured per SwinV2-T step in isolation (tools/ubench/attn_time.py): units / 4096 capped at 8 (rounds
   // 2-3) 1.00 / 2.36 ms forward / backward, / 1536 capped at 16: 0.95 / 1.99 ms; / 1024 cap 8: 0.96 / 2.06; / 8192: 1.15 / 2.84.
-  static int div = 0, cap = 0;
-  if (!div) { const char* e = getenv("TOK_ATTN_BPW_DIV"); div = e ? atoi(e) : 1536; e = getenv("TOK_ATTN_BPW_CAP"); cap = e ? atoi(e) : 16; }
+  // (parsed once, clamped to >= 1: tok_window_attn_bwd_rows and the launch must agree on this number for the life of the process)
+  static const int div = [] { const char* e = getenv("TOK_ATTN_BPW_DIV"); const int v = e ? atoi(e) : 1536; return v < 1 ? 1 : v; }();
+  static const int cap = [] { const char* e = getenv("TOK_ATTN_BPW_CAP"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
   long long bpw = units / div;
   bpw = bpw < 1 ? 1 : (bpw > cap ? cap : bpw);
   return (int)(bpw > a.B ? a.B : bpw);
@@ -1273,9 +1272,12 @@ extern "C" int tok_window_attn_fwd(const void* qkv, int batch, int h, int w, int
   }
   const size_t smem = (size_t)a.N * HD * 3 * sizeof(float);
   TOK_CHECK_ARG(smem <= 160 * 1024, "tok_window_attn_fwd: window %d too large", ws);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static const bool attr = [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(batch * a.nW * heads), dim3(64), smem, tok_stream(stream), a,
                      (const bf16*)qkv, logit_scale, bias, mask, (bf16*)out, lse);
   TOK_CHECK_LAUNCH("tok_window_attn_fwd");
@@ -1302,9 +1304,12 @@ extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch,
   if (a.N <= 64 && (a.plain || !tok_attn_scalar())) {
     const int bpw = attn_bpw(a);
     const int waves = tok_cdiv(batch, bpw) * a.nW * heads;
-    static bool attr_m = false;
-    if (!attr_m) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_m = true; }
+    static const bool attr_m = [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_mfma_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      return true;
+    }();   // once per process (thread-safe function-local static)
+    (void)attr_m;
     hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(8 * tok_cdiv(waves, 8)), dim3(256), MFMA_BWD_LDS, tok_stream(stream), a,
                        (const bf16*)qkv, (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch, dscale_part, bpw,
                        waves);
@@ -1313,9 +1318,12 @@ extern "C" int tok_window_attn_bwd(const void* qkv, const void* dout, int batch,
   }
   const size_t smem = ((size_t)a.N * HD * 4 + (size_t)a.N * 4) * sizeof(float);
   TOK_CHECK_ARG(smem <= 160 * 1024, "tok_window_attn_bwd: window %d too large", ws);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  static const bool attr = [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * a.nW * heads), dim3(64), smem, tok_stream(stream), a,
                      (const bf16*)qkv, (const bf16*)dout, logit_scale, bias, mask, lse, (bf16*)dqkv, ds_scratch,
                      dscale_part);

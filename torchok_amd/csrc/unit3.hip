@@ -442,12 +442,12 @@ extern "C" int tok_bn3_bwd_prepare(const float* G, const float* w, const float* 
   TOK_CHECK_ARG(rows > 0 && count > 0 && p > 0 && p <= 2048 && k > 0 && k % 8 == 0, "tok_bn3_bwd_prepare: bad sizes");
   hipStream_t st = tok_stream(stream);
   const size_t smem = (size_t)PR_CH * p * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const bool attr_set = [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bn3_prepare_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               PR_CH * 2048 * 4);
-    attr_set = true;
-  }
+    return true;
+  }();   // once per process (thread-safe function-local static)
+  (void)attr_set;
   float* At = ws;                                   // [k][p + 1]
   float* parts = ws + (size_t)k * (p + 1);          // split-reduction partials of the (p + 1) x p product
   hipLaunchKernelGGL(bn3_prepare_rows_kernel, dim3(tok_cdiv(k, PR_CH)), dim3(256), smem, st, G, w, wz, zsum, partial, rows, count,

@@ -75,16 +75,27 @@ class _BufferArena:
 class GradientAllReducer:
     def __init__(self, optimizer, bucket_bytes: int = 32 << 20, process_group=None, broadcast_params: bool = True,
                  module: Optional[torch.nn.Module] = None, broadcast_buffers: bool = True,
-                 grad_dtype: Optional[str] = None, find_unused_parameters: Optional[bool] = None):
+                 grad_dtype: Optional[str] = None, find_unused_parameters: Optional[bool] = None,
+                 static_unused_pattern: Optional[bool] = None):
         """`find_unused_parameters` (torch DDP's flag; Lightning's `strategy: ddp` leaves it False): when True one tiny
         used-map all-reduce per step lets a parameter that got no gradient on THIS rank still receive the averaged update
         of the ranks that used it; when False (default) a parameter without a gradient at `finish_step` is an error, as
-        under torch DDP, and the step carries no extra collective and no per-parameter Python scan."""
+        under torch DDP, and the step carries no extra collective and no per-parameter Python scan.
+
+        `static_unused_pattern` (default True; `TOK_DDP_UNUSED_STATIC=0` turns it off): torch DDP reads the reduced used-map
+        on the host in every step (a blocking device-to-host copy in its `finalize_backward`).  Here the host reads it only
+        in a step where THIS rank's own pattern of missing gradients changed (normally: the first step); afterwards the
+        cached answer is used and the reduced map of every step is compared with it ON THE DEVICE, the one-byte verdict
+        travelling to pinned memory behind an event that the next `finish_step` polls.  A change on another rank that this
+        rank could not see (its own pattern stayed the same) is therefore detected one step late and raises."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         if find_unused_parameters is None:
             find_unused_parameters = os.environ.get('TOK_DDP_FIND_UNUSED', '0') == '1'
         self.find_unused = bool(find_unused_parameters)
+        if static_unused_pattern is None:
+            static_unused_pattern = os.environ.get('TOK_DDP_UNUSED_STATIC', '1') != '0'
+        self.static_unused = bool(static_unused_pattern)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
@@ -105,7 +116,8 @@ class GradientAllReducer:
         self._active = False
         self._events: List = []       # hipEvents of the fork edges, reused round-robin (a step needs a handful)
         self._ev_next = 0
-        self._small: Dict[int, torch.Tensor] = {}
+        self._small: Dict = {}
+        self._module = module
         if module is not None:
             module._grad_reducer = self      # BaseTask.on_train_batch_end puts its loss mean on this comm stream
         self._buffer_arenas: List[_BufferArena] = []
@@ -154,6 +166,14 @@ class GradientAllReducer:
         n = sum(len(a.params) for a in self.arenas)
         self._used = torch.zeros(n, dtype=torch.float32, device=self.arenas[0].master.device)
         self._flags_dev, self._flags_host = torch.zeros_like(self._used), None
+        # find_unused_parameters bookkeeping (see finish_step): signature of the gradient hooks of a step, the parameters
+        # whose gradients never come through a hook, the reduced used-map last read on the host and its device copy
+        self._hooked: List[int] = []
+        self._sig = None
+        self._foreign, self._foreign_flags = None, None
+        self._any_missing = False
+        self._used_host, self._used_ref_dev, self._adopt = None, None, []
+        self._late = None             # (pinned verdict, event) of the device-side comparison issued by the previous step
 
     def _fork_to_comm(self, stream=None):
         """comm stream waits for everything `stream` (default: the current one) has been given so far."""
@@ -189,6 +209,7 @@ class GradientAllReducer:
                 b.pending = sum(1 for pi in range(b.first, b.last + 1) if arena.params[pi].requires_grad)
                 b.work = None
                 b.streams = {}
+        self._hooked = []
         self._active = True
 
     def _on_grad(self, p):
@@ -198,6 +219,8 @@ class GradientAllReducer:
         if ent is None:
             return
         ai, b = ent
+        if self.find_unused:
+            self._hooked.append(id(p))
         if self.cuda:
             # weight gradients are produced on the engine's side stream, BatchNorm / bias gradients on the main one:
             # the exchange has to wait for every stream that wrote into the bucket
@@ -254,25 +277,69 @@ class GradientAllReducer:
             else:
                 self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
 
+    def _local_flags(self):
+        """(flags, changed): one float per parameter, 1 where THIS rank produced a gradient in the step that just ran.
+        The per-parameter scan runs only when the step looked different from the previous one: the gradient hooks fired
+        for another parameter sequence, or a parameter whose gradients never come through a hook (plain torch autograd, or
+        unused) changed between having and not having a gradient."""
+        sig = (len(self._hooked), hash(tuple(self._hooked)))
+        if self._flags_host is not None and sig == self._sig and \
+                tuple(p.grad is not None for p in self._foreign) == self._foreign_flags:
+            return self._flags_host, False
+        flags, missing = [], False
+        hooked = set(self._hooked)
+        foreign = []
+        for arena in self.arenas:
+            for p in arena.params:
+                has = p.grad is not None
+                flags.append(1.0 if has else 0.0)
+                missing |= (not has) and p.requires_grad
+                if id(p) not in hooked:
+                    foreign.append(p)
+        self._sig, self._foreign = sig, foreign
+        self._foreign_flags = tuple(p.grad is not None for p in foreign)
+        self._any_missing = missing
+        changed = flags != self._flags_host
+        return flags, changed
+
+    def _poll_late_check(self):
+        """Verdict of the device-side comparison the previous step left behind (static_unused_pattern)."""
+        if self._late is None:
+            return
+        verdict, ev = self._late
+        self._late = None
+        if ev is not None and not ev.query():
+            # recorded a whole step ago: normally complete.  A launch thread more than one step ahead of the GPU waits here
+            # until the GPU has finished the PREVIOUS step's exchange — a full step of work is still queued behind that
+            ev.synchronize()
+        if int(verdict[0]) != 0:
+            self._used_host = None
+            raise RuntimeError(
+                'GradientAllReducer: the set of parameters used by OTHER ranks changed in the previous step while this '
+                "rank's own pattern stayed the same; the cached used-map was stale for that step.  Construct the reducer "
+                'with static_unused_pattern=False (TOK_DDP_UNUSED_STATIC=0) for models whose unused parameters vary from '
+                'step to step: the used-map is then read on the host in every step, as torch DDP does.')
+
     def finish_step(self):
         """Call after backward, before optimizer.step(): flush stragglers, exchange the module buffers (and, with
-        find_unused_parameters, the used-parameter map), join the comm stream."""
-        flags, any_missing = None, False
-        if self.find_unused:
-            # which parameters got a gradient on this rank (before the stragglers' slots are zero-filled)
-            flags = []
-            for arena in self.arenas:
-                for p in arena.params:
-                    has = p.grad is not None
-                    flags.append(1.0 if has else 0.0)
-                    any_missing |= (not has) and p.requires_grad
-        for ai, blist in enumerate(self.buckets):
-            for b in blist:
-                if b.work is None:
-                    if not self.find_unused:
-                        # a bucket nobody completed: either plain-autograd gradients waiting to be adopted (fine) or a
-                        # parameter without a gradient on this rank (the ranks would apply different updates)
-                        arena = self.arenas[ai]
+        find_unused_parameters, the used-parameter map), join the comm stream.  No host synchronisation in the steady
+        state: with find_unused_parameters the reduced used-map is read on the host only when this rank's own pattern
+        changed (see __init__)."""
+        flags, changed = None, False
+        try:
+            if self.find_unused:
+                self._poll_late_check()
+                # which parameters got a gradient on this rank (before the stragglers' slots are zero-filled)
+                flags, changed = self._local_flags()
+            else:
+                # a bucket nobody completed: either plain-autograd gradients waiting to be adopted (fine) or a parameter
+                # without a gradient on this rank (the ranks would apply different updates).  Every incomplete bucket is
+                # checked BEFORE the first straggler is launched: an error leaves no collective in flight on this rank.
+                for ai, blist in enumerate(self.buckets):
+                    arena = self.arenas[ai]
+                    for b in blist:
+                        if b.work is not None:
+                            continue
                         for pi in range(b.first, b.last + 1):
                             p = arena.params[pi]
                             if p.requires_grad and p.grad is None:
@@ -280,10 +347,16 @@ class GradientAllReducer:
                                     'GradientAllReducer: a parameter received no gradient in this step; pass '
                                     'find_unused_parameters=True (TOK_DDP_FIND_UNUSED=1) if parts of the model are unused '
                                     'on some ranks (torch DDP raises the same way)')
+        except Exception:
+            self._active = False
+            raise
+        for ai, blist in enumerate(self.buckets):
+            for b in blist:
+                if b.work is None:
                     self._launch(ai, b)
         used_work = None
         if self.find_unused and self.world > 1:
-            if flags != self._flags_host:      # uploaded only when the pattern changes (normally: once)
+            if changed or self._flags_host is None:      # uploaded only when the pattern changes (normally: once)
                 self._flags_dev.copy_(torch.tensor(flags, dtype=torch.float32))
                 self._flags_host = flags
             self._used.copy_(self._flags_dev)
@@ -311,17 +384,37 @@ class GradientAllReducer:
         self._buffer_work = []
         if used_work is not None:
             used_work.wait()
-            if any_missing:
+            if self._any_missing:
                 # a parameter unused on this rank but used on another one: every rank must apply the same (averaged)
-                # update, so the reduced slot becomes this rank's gradient too.  (Host read only on ranks that are
-                # missing a gradient; a parameter unused on EVERY rank keeps grad None, as under torch DDP.)
-                used = self._used.cpu()
-                k = 0
-                for arena in self.arenas:
-                    for pi, p in enumerate(arena.params):
-                        if p.grad is None and p.requires_grad and used[k] > 0:
-                            p.grad = arena.grad_view(pi)
-                        k += 1
+                # update, so the reduced slot becomes this rank's gradient too; a parameter unused on EVERY rank keeps
+                # grad None, as under torch DDP.  The host needs the reduced map for that decision: read (a blocking
+                # copy, what torch DDP does every step) when this rank's pattern changed, cached otherwise.
+                if changed or self._used_host is None or not self.static_unused:
+                    used = self._used.cpu()
+                    self._used_host = used
+                    self._used_ref_dev = self._used.clone()
+                    self._adopt, k = [], 0
+                    for arena in self.arenas:
+                        for pi, p in enumerate(arena.params):
+                            if flags[k] == 0.0 and p.requires_grad and used[k] > 0:
+                                self._adopt.append((arena, pi, p))
+                            k += 1
+                else:
+                    # steady state: compare on the device, on the slots this rank has no gradient for (the only ones the
+                    # host decision depends on); the verdict is polled by the next finish_step
+                    diff = ((self._used > 0) != (self._used_ref_dev > 0)) & (self._flags_dev == 0)
+                    if self._small.get('late') is None:
+                        v = torch.zeros(1, dtype=torch.int32)
+                        self._small['late'] = v.pin_memory() if self.cuda else v
+                        self._small['late_event'] = torch.cuda.Event() if self.cuda else None
+                    verdict, ev = self._small['late'], self._small['late_event']
+                    verdict.copy_(diff.any().to(torch.int32).reshape(1), non_blocking=True)
+                    if ev is not None:
+                        ev.record()
+                    self._late = (verdict, ev)
+                for arena, pi, p in self._adopt:
+                    if p.grad is None:
+                        p.grad = arena.grad_view(pi)
         self._active = False
 
     def params_checksum(self) -> torch.Tensor:
@@ -337,5 +430,12 @@ class GradientAllReducer:
         return torch.cat([lo, hi])
 
     def close(self):
+        """Detach from the engine's gradient hooks and from the module: a closed reducer must not receive the task's loss-mean
+        collectives (`BaseTask._mean_over_ranks_async` looks at `module._grad_reducer`)."""
+        self._active = False
         if self._on_grad in core.param_grad_hooks:
             core.param_grad_hooks.remove(self._on_grad)
+        m = self._module
+        if m is not None and getattr(m, '_grad_reducer', None) is self:
+            del m._grad_reducer
+        self._module = None

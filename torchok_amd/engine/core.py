@@ -353,6 +353,16 @@ _picked = {}          # device -> streams handed out by pick_stream
 _main_hint = {}       # device -> the stream regions are opened on (Region.input): what "beside the main stream" refers to
 
 
+def note_main_stream(device=None) -> None:
+    """Remember the CALLING stream as the main stream of `device` (unless one is known already).  GraphedTrainingStep calls
+    this before its warm-up steps, which run on a stream of their own."""
+    if not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if str(dev) not in _main_hint:
+        _main_hint[str(dev)] = torch.cuda.current_stream(dev)
+
+
 def _shares_queue(a: 'torch.cuda.Stream', b: 'torch.cuda.Stream') -> bool:
     e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     a.synchronize()
@@ -395,7 +405,10 @@ def _branch_stream(device, idx: int) -> 'torch.cuda.Stream':
     key = (device, idx)
     s = _branch_streams.get(key)
     if s is None:
-        s = _branch_streams[key] = pick_stream(device)
+        s = pick_stream(device)
+        if PICK_STREAMS and torch.cuda.is_current_stream_capturing():
+            return s     # an unprobed stream (no probing under capture): not remembered, the first eager use picks again
+        _branch_streams[key] = s
     return s
 
 
@@ -441,7 +454,10 @@ class _Branch:
 def _side_stream(device) -> 'torch.cuda.Stream':
     s = _side_streams.get(device)
     if s is None:
-        s = _side_streams[device] = pick_stream(device)
+        s = pick_stream(device)
+        if PICK_STREAMS and torch.cuda.is_current_stream_capturing():
+            return s     # see _branch_stream
+        _side_streams[device] = s
     return s
 
 
@@ -502,7 +518,9 @@ class Region:
     def input(self, x: torch.Tensor, c_pad_to: int = 8) -> TTensor:
         require_device(x)
         self.device = x.device
-        if x.is_cuda and self._tag == 0 and str(x.device) not in _main_hint:
+        if x.is_cuda and self._tag == 0 and str(x.device) not in _main_hint and not torch.cuda.is_current_stream_capturing():
+            # (a capture or its warm-up runs on a stream of its own: that one must not become "the main stream" the
+            # side / branch / comm streams are probed against for the rest of the process)
             _main_hint[str(x.device)] = cur_stream()
         need = self.grad_mode and x.requires_grad
         if x.dim() == 4:

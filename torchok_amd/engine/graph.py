@@ -39,6 +39,8 @@ class GraphedTrainingStep:
     def recapture(self):
         """(Re)record the step: a few eager steps on a side stream first (arena construction, momentum
         initialisation, pack tables, allocator warm-up), then the capture."""
+        from . import core
+        core.note_main_stream()     # the streams the engine probes are picked relative to the caller's stream, not the warm-up's
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

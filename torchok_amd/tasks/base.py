@@ -98,15 +98,16 @@ class BaseTask(nn.Module, ABC):
         if not tags:
             return tags, None, None, 1.0
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return tags, [outputs[t].detach() for t in tags], None, 1.0      # one rank: the values themselves, no kernels
+            # one rank: the mean over ranks is the value itself; a scalar costs no kernel, anything else is reduced to the
+            # scalar the multi-rank path (and the reference's `.mean()`, tasks/base.py:170) would log
+            return tags, [v if v.dim() == 0 else v.float().mean() for v in (outputs[t].detach() for t in tags)], None, 1.0
         vals = torch.stack([outputs[t].detach().float().mean() for t in tags])
-        if True:
-            red = getattr(self, '_grad_reducer', None)
-            if red is not None:
-                work, vals, scale = red.mean_small_async(vals)
-                return tags, vals, work, scale
-            dist.all_reduce(vals)
-            return tags, vals, None, 1.0 / dist.get_world_size()
+        red = getattr(self, '_grad_reducer', None)
+        if red is not None:
+            work, vals, scale = red.mean_small_async(vals)
+            return tags, vals, work, scale
+        dist.all_reduce(vals)
+        return tags, vals, None, 1.0 / dist.get_world_size()
 
     def _mean_over_ranks(self, outputs: Dict[str, Tensor]) -> Dict[str, Tensor]:
         tags, vals, work, scale = self._mean_over_ranks_async(outputs)
