@@ -539,10 +539,11 @@ int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgr
  * [timm 0.6.13] models/layers/mlp.py: Mlp.forward = fc2(GELU(fc1(x))), drop = 0, as SwinTransformerBlock / DaViT's blocks
  * call it (models/backbones/swin.py:18,238; davit.py:16,196).  x, y: bf16 [rows][c]; w1 = fc1 forward pack [hidden][c],
  * w2 = fc2 forward pack [c][hidden] (tok_pack_weight_fwd), b1 [hidden] / b2 [c] fp32.  The 4c-wide hidden tensor is never
- * read back: pre / act = NULL (inference) it is never stored; with pre / act [rows][hidden] given (training) the bf16
+ * read back: pre / act = NULL (inference) it is never stored; with pre / act [rows][hidden] given the bf16
  * pre-activation and activation rows are written for the backward GEMMs (tok_conv_dgrad_act, the two weight gradients)
- * while fc2 consumes them out of registers.  Rounding points (pre-activation and activation to bf16) and results are
- * those of tok_conv_fwd_act + tok_conv_fwd, bit for bit.
+ * while fc2 consumes them out of registers; with pre given and act = NULL (training on the recompute plan: tok_mlp_bwd_dx
+ * reads pre, tok_mlp_bwd_dw recomputes everything else) only the pre-activation rows are written.  Rounding points
+ * (pre-activation and activation to bf16) and results are those of tok_conv_fwd_act + tok_conv_fwd, bit for bit.
  * tok_mlp_serves: 1 when the geometry has a kernel (c in {96, 192, 384}, hidden = 4c), else the caller stays on the two
  * GEMM launches.                                                                                                         */
 int tok_mlp_serves(int64_t rows, int c, int hidden);
@@ -555,6 +556,19 @@ int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, 
  * those of tok_conv_dgrad_act + tok_conv_dgrad, bit for bit.                                                              */
 int tok_mlp_bwd_dx(const void* dy, const void* w2_dgrad, const void* pre, const void* w1_dgrad, void* dx, int accumulate,
                    void* dpre, int64_t rows, int c, int hidden, void* stream);
+/* All four parameter gradients of that Mlp from its INPUT x and its OUTPUT GRADIENT dy alone (csrc/mlp_dw.hip): pre, act,
+ * d(act) = dy W2 and d(pre) = d(act) GELU'(pre) are recomputed 32 tokens at a time in registers (same bf16 rounding points
+ * as the forward / tok_mlp_bwd_dx) and contracted with x / dy over the tokens on the spot:
+ *   dW1 [hidden][c] (+)= d(pre)^T x,  db1 [hidden] (+)= colsum d(pre),  dW2 [c][hidden] (+)= dy^T act,  db2 [c] (+)= colsum dy
+ * — the unfused weight-gradient GEMMs (tok_conv_wgrad_bias on (x, d(pre)) and (act, dy)) read two [rows][hidden] tensors
+ * that then have to be written first; this is the reference's `grad_checkpointing` trade (models/backbones/swin.py:75-78)
+ * applied inside one block.  w1 = fc1 forward pack [hidden][c], w2_dgrad = fc2 dgrad pack [hidden][c].  Token ranges
+ * run as independent workgroups whose fp32 partial slabs (workspace, tok_mlp_bwd_dw_ws_bytes) are folded in a fixed
+ * order: deterministic.  A NULL gradient pointer skips that parameter; acc_* != 0 adds to what the slot holds.        */
+size_t tok_mlp_bwd_dw_ws_bytes(int64_t rows, int c, int hidden);
+int tok_mlp_bwd_dw(const void* x, const void* dy, const void* w1, const float* b1, const void* w2_dgrad, float* dw1,
+                   int acc_w1, float* db1, int acc_b1, float* dw2, int acc_w2, float* db2, int acc_b2, void* workspace,
+                   size_t ws_bytes, int64_t rows, int c, int hidden, void* stream);
 
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:

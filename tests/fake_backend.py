@@ -170,7 +170,30 @@ class FakeTok:
         _t(y, (rows, c), BF16).copy_(o.permute(0, 2, 3, 1).to(BF16).reshape(rows, c))
         if pre is not None:
             _t(pre, (rows, hidden), BF16).copy_(p)
+        if act is not None:
             _t(act, (rows, hidden), BF16).copy_(h)
+        return 0
+
+    def tok_mlp_bwd_dw_ws_bytes(self, rows, c, hidden):
+        return 64
+
+    def tok_mlp_bwd_dw(self, x, dy, w1, b1, w2d, dw1, acc_w1, db1, acc_b1, dw2, acc_w2, db2, acc_b2, ws, ws_bytes, rows, c,
+                       hidden, st):
+        """fp32 restatement with the kernel's rounding points: pre, act, d(act), d(pre) rounded to bf16, fp32 sums."""
+        self.calls.append('mlp_bwd_dw')
+        xv, gv = _t(x, (rows, c), BF16).float(), _t(dy, (rows, c), BF16).float()
+        w1v, w2t = _t(w1, (hidden, c), BF16).float(), _t(w2d, (hidden, c), BF16).float()
+        pre = _bf(xv @ w1v.t() + _t(b1, (hidden,), torch.float32)).float()
+        act = _bf(F.gelu(pre)).float()
+        dact = _bf(gv @ w2t.t()).float()
+        d = 0.5 * (1 + torch.erf(pre * 0.7071067811865476)) + pre * 0.3989422804014327 * torch.exp(-0.5 * pre * pre)
+        dpre = _bf(dact * d).float()
+        for ptr_, acc, val, shape in ((dw1, acc_w1, dpre.t() @ xv, (hidden, c)), (db1, acc_b1, dpre.sum(0), (hidden,)),
+                                      (dw2, acc_w2, gv.t() @ act, (c, hidden)), (db2, acc_b2, gv.sum(0), (c,))):
+            if ptr_ is None:
+                continue
+            out = _t(ptr_, shape, torch.float32)
+            out.copy_(out + val if acc else val)
         return 0
 
     def tok_mlp_bwd_dx(self, dy, w2d, pre, w1d, dx, accumulate, dpre, rows, c, hidden, st):

@@ -138,6 +138,59 @@ def _rmsprop_case(dev, kw):
     assert ('grad_avg' in sd['state'][0]) == bool(kw.get('centered', False))
 
 
+@pytest.mark.parametrize('name,kw', [('SGD', dict(lr=0.05, momentum=0.9, weight_decay=1e-4)), ('AdamW', dict(lr=1e-3, weight_decay=0.05))])
+def test_cached_runs_follow_a_changing_gradient_pattern(fake_backend, name, kw):
+    """The optimizers answer "which runs of parameters have a gradient, with which state key" from the previous step while the
+    pattern of gradients repeats (no per-parameter walk: optim/optimizers.py _runs).  Seven steps against torch.optim fed the
+    same gradients: the whole arena (cached from step 2 on), then one parameter without a gradient for two steps (runs are
+    re-cut, that parameter's Adam step count stays behind), a foreign gradient tensor (adopted into the arena), and back."""
+    torch.manual_seed(5)
+    task, ref = _pair(optimizer=name, opt_params=kw)
+    opt = task.configure_optimizers()[0]['optimizer']
+    ropt = getattr(torch.optim, name)(ref.parameters(), **kw)
+    x, y = torch.randn(4, 3, 32, 32), torch.randint(0, 10, (4,))
+    rp = dict(ref.named_parameters())
+    names = [n for n, _ in task.named_parameters()]
+    skip, foreign = names[len(names) // 2], names[3]
+    walks = []
+    from torchok_amd.engine.arena import ParamArena
+    real_adopt = ParamArena.adopt_grad
+
+    def counting(self_, i):
+        walks.append(i)
+        return real_adopt(self_, i)
+    ParamArena.adopt_grad = counting
+    try:
+        per_step = []
+        for it in range(7):
+            out = task.training_step({'image': x, 'target': y}, it)
+            opt.zero_grad()
+            out['loss'].backward()
+            tp = dict(task.named_parameters())
+            if it in (3, 4):
+                tp[skip].grad = None
+            if it == 5:
+                tp[foreign].grad = tp[foreign].grad.detach().clone()          # a gradient tensor outside the arena
+            for n, p in tp.items():
+                rp[n].grad = None if p.grad is None else p.grad.detach().float().clone().contiguous()
+            walks.clear()
+            opt.step()
+            per_step.append(len(walks))
+            ropt.step()
+            for n, p in task.named_parameters():
+                assert rel_err(p, rp[n]) < 2e-5, (it, n)
+    finally:
+        ParamArena.adopt_grad = real_adopt
+    n = len(names)
+    # walk on the first step, on every change of the pattern (steps 3, 5, 6) and never in between (1, 2, 4)
+    assert per_step[0] == n and per_step[1] == 0 and per_step[2] == 0, per_step
+    assert per_step[3] == n and per_step[4] == 0 and per_step[5] == n and per_step[6] == n, per_step
+    if name == 'AdamW':
+        st = opt.state_dict()['state']
+        steps = sorted({int(v['step']) for v in st.values()})
+        assert steps == [5, 7], steps          # the skipped parameter missed two steps
+
+
 def test_frozen_parameters_get_no_grad_and_are_skipped(fake_backend):
     """FreezeUnfreeze-style freezing (reference callbacks/freeze_unfreeze.py): frozen params keep
     grad None, stay in the optimizer, and are not updated (torch semantics: grad None => skip)."""

@@ -1256,8 +1256,14 @@ def test_fused_mlp_equals_the_two_gemm_launches(libs, rows, c, save):
     xc, w1c, w2c, b1c, b2c = x[:n].cpu(), w1.cpu(), w2.cpu(), b1.cpu(), b2.cpu()
     assert fake.tok_mlp_fwd(P(xc), P(w1c), P(b1c), P(w2c), P(b2c), P(yh), None, None, n, c, h, None) == 0
     assert relerr(y1[:n].float(), yh.float()) < 1e-2
-    # only one of pre / act: refused
-    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), P(pre1), None, rows, c, h, st) != 0
+    # pre without act (the recompute plan of training): the pre-activation rows only, nothing else is touched
+    pre2 = torch.full((rows, h), 7.0, dtype=BF16, device='cuda')
+    act1.fill_(7.0)
+    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), P(pre2), None, rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(pre0, pre2) and bool((act1 == 7.0).all()) and bool((guard == 3.0).all())
+    # act without pre: refused
+    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y1), None, P(act1), rows, c, h, st) != 0
 
 
 @pytest.mark.parametrize('rows,c', [(1000, 96), (77, 192), (4133, 384), (70000, 96), (33000, 192), (16500, 384)])
@@ -1292,6 +1298,79 @@ def test_fused_mlp_backward_equals_the_two_dgrad_launches(libs, rows, c, acc):
     dyc, prec, w2c, w1c = dy[:n].cpu(), pre[:n].cpu(), w2d.cpu(), w1d.cpu()
     assert fake.tok_mlp_bwd_dx(P(dyc), P(w2c), P(prec), P(w1c), P(dxh), acc, None, n, c, h, None) == 0
     assert relerr(dx1[:n].float(), dxh.float()) < 1e-2
+
+
+@pytest.mark.parametrize('rows,c', [(1000, 96), (77, 192), (4133, 384), (70000, 96), (33000, 192), (16500, 384)])
+def test_mlp_parameter_gradients_by_recomputation(libs, rows, c):
+    """tok_mlp_bwd_dw: dW1, db1, dW2, db2 of the Mlp from x and dy alone (the hidden tensors are recomputed in registers).
+    Against the fp32 restatement on the same rounding points <= 1e-2 (north_star's bf16 bound; measured ~1e-3: a hidden
+    element whose bf16 rounding flips between two summation orders moves a whole product); against the UNFUSED device
+    launches (tok_mlp_fwd saving pre / act, tok_mlp_bwd_dx saving d(pre), tok_conv_wgrad_bias on them) <= 2e-3;
+    accumulate / overwrite / skipped slots; ragged row counts (partial last tile); bit-reproducible."""
+    lib, fake = libs
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: t_.data_ptr() if t_ is not None else None   # noqa: E731
+    h = 4 * c
+    x = rnd(rows, c).to(BF16).cuda()
+    dy = (rnd(rows, c, seed=7) * 0.5).to(BF16).cuda()
+    w1 = (rnd(h, c, seed=1) * c ** -0.5).to(BF16).cuda()            # fc1 forward pack [hidden][c]
+    w2 = (rnd(c, h, seed=2) * h ** -0.5).to(BF16).cuda()            # fc2 forward pack [c][hidden]
+    w2d = w2.t().contiguous()                                       # fc2 dgrad pack [hidden][c]
+    w1d = w1.t().contiguous()                                       # fc1 dgrad pack [c][hidden]
+    b1, b2 = (rnd(h, seed=3) * 0.3).cuda(), (rnd(c, seed=4) * 0.3).cuda()
+    ws_bytes = lib.tok_mlp_bwd_dw_ws_bytes(rows, c, h)
+    assert ws_bytes > 0 and lib.tok_mlp_bwd_dw_ws_bytes(rows, 100, 400) == 0
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device='cuda')
+    base = [rnd(h, c, seed=11).cuda(), rnd(h, seed=12).cuda(), rnd(c, h, seed=13).cuda(), rnd(c, seed=14).cuda()]
+
+    def run(acc):
+        outs = [b.clone() for b in base]
+        assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), acc, P(outs[1]), acc, P(outs[2]), acc, P(outs[3]),
+                                  acc, P(ws), ws_bytes, rows, c, h, st) == 0, lib.tok_last_error()
+        torch.cuda.synchronize()
+        return outs
+    got = run(0)
+    again = run(0)
+    for a_, b_ in zip(got, again):
+        assert torch.equal(a_, b_)                                  # fixed-order fold: deterministic
+    acc = run(1)
+    for a_, b_, base_ in zip(acc, got, base):
+        assert torch.allclose(a_, b_ + base_, rtol=1e-6, atol=1e-5)
+    # a skipped slot is not written, the others are unchanged by that
+    keep = base[1].clone()
+    outs = [b.clone() for b in base]
+    assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), 0, None, 0, P(outs[2]), 0, P(outs[3]), 0, P(ws),
+                              ws_bytes, rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], got[0]) and torch.equal(outs[2], got[2]) and torch.equal(outs[3], got[3]) and torch.equal(outs[1], keep)
+    # workspace too small: refused
+    assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), 0, None, 0, None, 0, None, 0, P(ws), 16, rows, c, h, st) != 0
+    # (a) the unfused launches on the tensors the fused forward / backward write
+    pre, act, dpre = (torch.empty(rows, h, dtype=BF16, device='cuda') for _ in range(3))
+    y, dx = (torch.empty(rows, c, dtype=BF16, device='cuda') for _ in range(2))
+    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y), P(pre), P(act), rows, c, h, st) == 0, lib.tok_last_error()
+    assert lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx), 0, P(dpre), rows, c, h, st) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    want = [dpre.float().t() @ x.float(), dpre.float().sum(0), dy.float().t() @ act.float(), dy.float().sum(0)]
+    names = ('dW1', 'db1', 'dW2', 'db2')
+    for nm, a_, w_ in zip(names, got, want):
+        assert relerr(a_, w_) < 2e-3, (nm, relerr(a_, w_))
+    # (b) the fp32 restatement (host)
+    n = min(rows, 4096)
+    xs, dys = x[:n].contiguous(), dy[:n].contiguous()
+    ws_n = torch.empty(lib.tok_mlp_bwd_dw_ws_bytes(n, c, h) // 4 + 16, dtype=torch.float32, device='cuda') \
+        if lib.tok_mlp_serves(n, c, h) else None
+    if ws_n is not None:
+        sub = [torch.empty_like(b) for b in base]
+        assert lib.tok_mlp_bwd_dw(P(xs), P(dys), P(w1), P(b1), P(w2d), P(sub[0]), 0, P(sub[1]), 0, P(sub[2]), 0, P(sub[3]), 0,
+                                  P(ws_n), ws_n.numel() * 4, n, c, h, st) == 0, lib.tok_last_error()
+        torch.cuda.synchronize()
+        host = [torch.zeros_like(b, device='cpu') for b in base]
+        xc, dyc, w1c, b1c, w2c = xs.cpu(), dys.cpu(), w1.cpu(), b1.cpu(), w2d.cpu()
+        assert fake.tok_mlp_bwd_dw(P(xc), P(dyc), P(w1c), P(b1c), P(w2c), P(host[0]), 0, P(host[1]), 0, P(host[2]), 0, P(host[3]), 0,
+                                   None, 0, n, c, h, None) == 0
+        for nm, a_, w_ in zip(names, sub, host):
+            assert relerr(a_, w_) < 1e-2, (nm, relerr(a_, w_))
 
 
 @pytest.mark.parametrize('n,h,w,c', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128), (4, 112, 112, 64)])

@@ -213,12 +213,17 @@ def test_fused_activation_epilogues_leave_training_bit_identical(monkeypatch):
 @pytest.mark.gpu
 def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
     """The whole Mlp from one launch (engine.transformer.FUSE_MLP, csrc/mlp_fused.hip) against fc1 + GELU and fc2 as two
-    launches: 5 AdamW steps on widths 96 / 192 / 384 (served) and 768 (not served), identical losses and parameters."""
-    from helpers import cls_config
+    launches: 5 AdamW steps on widths 96 / 192 / 384 (served) and 768 (not served).  The round-3 tape (saved pre / act rows,
+    unfused weight gradients) gives identical losses and parameters; the recompute plan (engine.transformer.MLP_RECOMPUTE:
+    parameter gradients from tok_mlp_bwd_dw) sums the same bf16 products over the tokens in another order: the first loss is
+    identical (same forward), the parameters after five steps agree to fp32-summation noise amplified by AdamW's
+    normalisation."""
+    from helpers import cls_config, rel_err
     from torchok_amd.engine import transformer as ET
     finals = []
-    for fuse in (True, False):
+    for fuse, recompute in ((True, False), (False, False), (True, True)):
         monkeypatch.setattr(ET, 'FUSE_MLP', fuse)
+        monkeypatch.setattr(ET, 'MLP_RECOMPUTE', recompute)
         cfg = cls_config('swinv2_custom', 5, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
                          backbone_params=dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0),
                          inputs_shape=(3, 64, 64))
@@ -240,6 +245,10 @@ def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
     assert finals[0][0] == finals[1][0]
     for n in finals[0][1]:
         assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+    assert finals[2][0][0] == finals[1][0][0]
+    assert max(abs(a - b) for a, b in zip(finals[2][0], finals[1][0])) < 2e-2
+    worst = max(rel_err(finals[2][1][n], finals[1][1][n]) for n in finals[1][1])
+    assert worst < 2e-2, worst
 
 
 def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_backend):
@@ -251,8 +260,9 @@ def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_b
     fake = fake_backend
     if True:
         res = []
-        for fuse in (True, False):
+        for fuse, recompute in ((True, False), (False, False), (True, True)):
             monkeypatch.setattr(ET, 'FUSE_MLP', fuse)
+            monkeypatch.setattr(ET, 'MLP_RECOMPUTE', recompute)
             torch.manual_seed(3)
             m = Mlp(96, 384)
             xt = torch.randn(40, 96).to(torch.bfloat16).requires_grad_(True)
@@ -263,6 +273,7 @@ def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_b
             assert ('mlp_fwd' in fake.calls) == fuse
             y.backward(gd)
             assert ('mlp_bwd_dx' in fake.calls) == fuse
+            assert ('mlp_bwd_dw' in fake.calls) == recompute      # the recompute plan: all four parameter gradients from one call
             res.append((y.detach().clone(), xt.grad.clone(), [p.grad.clone() for p in m.parameters()]))
             with torch.no_grad():
                 r2 = Region()
@@ -271,3 +282,7 @@ def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_b
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
         for a, b in zip(res[0][2], res[1][2]):
             assert torch.equal(a, b)
+        # recompute plan: same output and input gradient (same launches), parameter gradients by another summation
+        assert torch.equal(res[2][0], res[1][0]) and torch.equal(res[2][1], res[1][1])
+        for a, b in zip(res[2][2], res[1][2]):
+            assert a.shape == b.shape and float((a - b).norm() / (b.norm() + 1e-12)) < 1e-3

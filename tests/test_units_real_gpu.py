@@ -1,0 +1,145 @@
+"""Teacher-forced unit parity at the REAL widths of BASELINE.json's BatchNorm configs.
+
+Whole-step gradients of a BatchNorm network at full size are no gate: after ~50 layers of batch statistics and ReLU decisions
+on bf16 tensors ANY bf16 run — torch's own autocast included — sits 30-40 % from the fp32 gradient
+(profiles/*_parity_distances.json: hrnet_w48 512x1024 median 0.39 for HIP and 0.39 for autocast), so a bound relative to that
+yardstick passes almost anything.  Here every module is run ALONE on the oracle's own activations and output gradients
+(tests/test_units_gpu.py's harness), at the sizes the configs use:
+
+  C2 / C5   ResNet-50 bottlenecks at 224 px (batch 4): 56x56x64/256, 28x28x128/512, 14x14x256/1024, 7x7x512/2048 — stride-1
+            and stride-2 blocks, with and without the projection shortcut; both execution plans of the residual unit on the
+            large maps
+  C4        HRNet-W48 HighResolutionModules at 512x1024 (batch 1): stage 2 (48 / 96 channels at 128x256 / 64x128), stage 3
+            (+192 @ 32x64), stage 4 (+384 @ 16x32) — four BasicBlocks per branch and the all-to-all fuse layers
+            (1x1 conv-BN + nearest upsample, strided 3x3 chains, sum, ReLU)
+
+Gate per tensor (outputs, input gradients, every parameter gradient), relative L2:
+    HIP vs the bf16-autocast oracle <= 2e-2, or HIP no further from the fp32 oracle than 1.1 x the autocast oracle is (+2e-3).
+Both sides of the 'or' fail on a wrong kernel: a single module is 1-3 % from fp32 under bf16 storage, not 40 %.  The measured
+distances are recorded (helpers.record_distance -> profiles/r04_parity_distances.json)."""
+import copy
+
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle.hrnet_ref as H
+import oracle.torchok_ref as R
+from helpers import deterministic_state, record_distance, rel_err
+from test_units_gpu import _bf, _capture, _ours_map, _ref_unit, _round_weights_
+from torchok_amd.engine import functional as EF
+from torchok_amd.models.backbones import hrnet as PH
+from torchok_amd.models.backbones import resnet as PR
+
+pytestmark = pytest.mark.gpu
+PAIR_TOL = 2e-2
+
+
+def _gate(tag, ours, ref32, ref_ac):
+    worst = (0.0, '')
+
+    def one(what, o, r32, rac):
+        nonlocal worst
+        e, y, pair = rel_err(o, r32), rel_err(rac, r32), rel_err(o, rac)
+        record_distance(f'units_real/{tag}', what, hip_vs_autocast=pair, hip_vs_fp32=e, autocast_vs_fp32=y)
+        print(f'[real unit {tag}] {what:40s} HIP-vs-autocast {pair:.2e}   HIP-vs-fp32 {e:.2e}   autocast-vs-fp32 {y:.2e}')
+        if pair > worst[0]:
+            worst = (pair, what)
+        assert pair <= PAIR_TOL or e <= 1.1 * y + 2e-3, (tag, what, 'HIP vs autocast', pair, 'HIP vs fp32', e, 'autocast vs fp32', y)
+    for i, (o, r32, rac) in enumerate(zip(ours[0], ref32[0], ref_ac[0])):
+        one(f'out[{i}]', o, r32, rac.float())
+    for i, (o, r32, rac) in enumerate(zip(ours[1], ref32[1], ref_ac[1])):
+        if r32 is not None and o is not None:
+            one(f'd(input[{i}])', o, r32, rac.float())
+    for n, r32 in ref32[2].items():
+        if r32 is None or float(r32.norm()) < 1e-6 * max(1.0, float(r32.numel()) ** 0.5):
+            continue
+        one(f'd({n})', ours[2][n], r32, ref_ac[2][n].float())
+    return worst
+
+
+# ---- ResNet-50 @224 -----------------------------------------------------------------------------------------------------------
+R50_BLOCKS = ['layer1.0', 'layer1.2', 'layer2.0', 'layer2.3', 'layer3.0', 'layer3.5', 'layer4.0', 'layer4.2']
+
+
+@pytest.fixture(scope='module')
+def resnet50_224():
+    torch.manual_seed(0)
+    ref = R.ClassificationModel('resnet50', 1000, zero_init_last=False).train()
+    ref.load_state_dict(deterministic_state(ref.state_dict(), 41))
+    _round_weights_(ref)
+    g = torch.Generator().manual_seed(15)
+    x = _bf(torch.randn(4, 3, 224, 224, generator=g))
+    y = torch.randint(0, 1000, (4,), generator=g)
+
+    def run():
+        out = ref.forward_with_gt({'image': x, 'target': y})
+        nn.functional.cross_entropy(out['prediction'], y).backward()
+    return ref, _capture(ref, run, ['backbone.' + n for n in R50_BLOCKS])
+
+
+@pytest.mark.parametrize('plan', ['default', 'plain'])
+@pytest.mark.parametrize('name', R50_BLOCKS)
+def test_resnet50_bottleneck_at_224(resnet50_224, name, plan, monkeypatch):
+    """[timm] Bottleneck at the feature-map sizes of the 224-px recipe.  plan 'default': what the engine picks at this size
+    (the fused residual unit from 100 k rows up is a batch-256 decision; at batch 4 it is forced on for the 56 / 28 px blocks
+    so that the plan of the benchmark is the one tested); 'plain': conv / statistics / apply as separate launches."""
+    big = name.startswith('layer1') or name.startswith('layer2')
+    if plan == 'plain' and not big:
+        pytest.skip('layers 3-4 run the plain plan by default')
+    monkeypatch.setattr(EF, 'UNIT3_MIN_ROWS', (0 if big else 1 << 40) if plan == 'default' else 1 << 40)
+    ref, cap = resnet50_224
+    blk = dict(ref.backbone.named_modules())[name]
+    x, gout = _bf(cap['backbone.' + name][0]), _bf(cap['backbone.' + name][1])
+    r32, rac = _ref_unit(blk, x, gout), _ref_unit(blk, x, gout, autocast=True)
+    ds = None
+    if blk.downsample is not None:
+        ds = nn.Sequential(copy.deepcopy(blk.downsample[0]), copy.deepcopy(blk.downsample[1]))
+    ours_blk = PR.Bottleneck(blk.conv1.in_channels, blk.conv3.out_channels // 4, stride=blk.conv2.stride[0], downsample=ds)
+    ours_blk.load_state_dict(blk.state_dict())
+    ours_blk.cuda().train()
+    ours = _ours_map(lambda r, ins: ours_blk(ins[0]), x, gout, 'cuda', ours_blk)
+    _gate(f'resnet50@224 {name} ({plan})', ours, r32, rac)
+
+
+# ---- HRNet-W48 @512x1024 ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def hrnet_w48_full():
+    torch.manual_seed(0)
+    ref = H.SegmentationModel('hrnet_w48', 19).train()
+    ref.load_state_dict(deterministic_state(ref.state_dict(), 45))
+    _round_weights_(ref)
+    g = torch.Generator().manual_seed(17)
+    x = _bf(torch.randn(1, 3, 512, 1024, generator=g))
+    y = torch.randint(0, 19, (1, 512, 1024), generator=g)
+    y[:, :5] = 255
+
+    def run():
+        logits = ref.forward_with_gt({'image': x, 'target': y})['prediction']
+        nn.functional.cross_entropy(logits, y, ignore_index=255).backward()
+    return ref, _capture(ref, run, ['backbone.stage2.0', 'backbone.stage3.1', 'backbone.stage4.2'])
+
+
+@pytest.mark.parametrize('name,nb', [('backbone.stage2.0', 2), ('backbone.stage3.1', 3), ('backbone.stage4.2', 4)])
+def test_hrnet_w48_module_at_512x1024(hrnet_w48_full, name, nb):
+    """One whole [timm] HighResolutionModule of HRNet-W48 — nb branches of four BasicBlocks at 48 x 2^i channels, then the
+    all-to-all fuse — on the oracle's branch maps and the oracle's gradients of its outputs."""
+    ref, cap = hrnet_w48_full
+    mod = dict(ref.named_modules())[name]
+    xs = [_bf(t) for t in cap[name][0]]
+    with torch.no_grad():
+        shapes = [o.shape for o in copy.deepcopy(mod)([t.clone() for t in xs])]
+    # output gradients: the hook of _capture keeps the first output's; every output gets one at that scale
+    g = torch.Generator().manual_seed(19)
+    g0 = cap[name][1]
+    scale = float(g0.abs().mean()) if g0 is not None else 1e-4
+    gouts = [_bf(g0) if (i == 0 and g0 is not None) else _bf(torch.randn(s, generator=g) * scale) for i, s in enumerate(shapes)]
+    r32, rac = _ref_unit(mod, xs, gouts), _ref_unit(mod, xs, gouts, autocast=True)
+    chs = [t.shape[1] for t in xs]
+    assert chs == [48 * 2 ** i for i in range(nb)] and tuple(xs[0].shape[2:]) == (128, 256)
+    ours = PH.HighResolutionModule(nb, PR.BasicBlock, [4] * nb, list(chs), list(chs), 'SUM',
+                                   multi_scale_output=len(shapes) > 1)
+    ours.load_state_dict(mod.state_dict())
+    ours.cuda().train()
+    res = _ours_map(lambda r, ins: ours(list(ins)), xs, gouts, 'cuda', ours)
+    _gate(f'hrnet_w48@512x1024 {name}', res, r32, rac)

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(WAVES * 64, (mlp_min_blocks<C, NT, WAVES>())) void 
   const __amdgpu_buffer_rsrc_t w2srd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, a.w_bytes, 0x00020000);
   const bool hrows = SAVE || BWD;
   const __amdgpu_buffer_rsrc_t psrd = __builtin_amdgcn_make_buffer_rsrc((void*)(hrows ? a.pre : a.y), 0, hrows ? a.h_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc((void*)(SAVE ? a.act : a.y), 0, SAVE ? a.h_bytes : 0, 0x00020000);
+  // (forward, pre given without act: the activation rows go to a zero-length buffer — out-of-range stores are dropped by the
+  //  range check, no traffic — so that one instruction stream serves "save both" and "save the pre-activation only")
+  const bool arows = SAVE && a.act != nullptr;
+  const __amdgpu_buffer_rsrc_t asrd = __builtin_amdgcn_make_buffer_rsrc((void*)(arows ? a.act : a.y), 0, arows ? a.h_bytes : 0, 0x00020000);
 
   // ---- biases into LDS (read back as float4 per lane) -------------------------------------------------------------------
   if constexpr (!BWD) {
@@ -471,7 +474,8 @@ void launch_v(const MlpArgs& a, hipStream_t st) {
 template <int C, int HC, int NT, int WAVES, bool PF, int MODE, int RD = 3>
 void launch_m(const MlpArgs& a, hipStream_t st) {
   static_assert(RD >= 2 && RD <= 8, "lgkmcnt is a 4-bit counter: at most 14 fragment reads in flight");
-  if (a.act != nullptr) launch_v<C, HC, NT, WAVES, PF, MODE, true, RD>(a, st);
+  const bool save = MODE == 0 ? a.pre != nullptr : a.act != nullptr;
+  if (save) launch_v<C, HC, NT, WAVES, PF, MODE, true, RD>(a, st);
   else launch_v<C, HC, NT, WAVES, PF, MODE, false, RD>(a, st);
 }
 
@@ -518,7 +522,7 @@ extern "C" int tok_mlp_serves(int64_t rows, int c, int hidden) {
 extern "C" int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* y, void* pre,
                            void* act, int64_t rows, int c, int hidden, void* stream) {
   TOK_CHECK_ARG(x && w1 && b1 && w2 && b2 && y, "tok_mlp_fwd: null pointer");
-  TOK_CHECK_ARG((pre == nullptr) == (act == nullptr), "tok_mlp_fwd: pre and act come together");
+  TOK_CHECK_ARG(pre != nullptr || act == nullptr, "tok_mlp_fwd: act rows are saved together with the pre rows only");
   TOK_CHECK_ARG(tok_mlp_serves(rows, c, hidden), "tok_mlp_fwd: geometry (%lld, %d, %d) is not served (tok_mlp_serves)", (long long)rows, c,
                 hidden);
   MlpArgs a;

@@ -57,6 +57,7 @@ class ParamArena:
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
         self.state = [torch.zeros(off, dtype=torch.float32, device=dev) for _ in range(n_state)]
         self.index: Dict[int, int] = {}
+        self.gviews: List[torch.Tensor] = []      # the registered gradient slot of every parameter (identity = "lives in the arena")
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.params, self.offsets)):
                 view = torch.as_strided(self.master, p.shape, p.stride(), o)
@@ -67,7 +68,9 @@ class ParamArena:
                     p.grad = gview
                 p.data = view
                 core.register_grad_slot(p, gview)
+                self.gviews.append(gview)
                 self.index[id(p)] = i
+        self._want_ptrs = [self.master.data_ptr() + 4 * o for o in self.offsets]
 
     def span(self, i: int):
         p = self.params[i]
@@ -88,11 +91,24 @@ class ParamArena:
         p = self.params[i]
         return p.data_ptr() == self.master.data_ptr() + 4 * self.offsets[i]
 
+    def owns_all(self) -> bool:
+        """Every parameter's storage is still its arena slot (one pass of data_ptr() calls, no per-parameter Python frames:
+        the optimizers ask this every step — 0.55 ms per HRNet-W48 step through owns_data())."""
+        return [p.data_ptr() for p in self.params] == self._want_ptrs
+
+    def grad_flags(self):
+        """Per parameter: 0 no gradient, 1 the gradient IS the registered slot (what engine.core.commit_param_grad leaves
+        behind: the common case of a training step, recognised without a data_ptr() call), 2 some other tensor."""
+        return [0 if p.grad is None else (1 if p.grad is g else 2) for p, g in zip(self.params, self.gviews)]
+
     def adopt_grad(self, i: int) -> bool:
         """Make sure params[i].grad (if any) lives in the arena.  Returns False for grad None."""
         p = self.params[i]
-        if p.grad is None:
+        g = p.grad
+        if g is None:
             return False
+        if g is self.gviews[i]:
+            return True
         want = self.grad.data_ptr() + 4 * self.offsets[i]
         if p.grad.data_ptr() != want:
             gv = self.grad_view(i)
