@@ -234,21 +234,34 @@ def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
         opt = task.configure_optimizers()[0]['optimizer']
         g = torch.Generator().manual_seed(4)
         x, y = torch.randn(8, 3, 64, 64, generator=g).cuda(), torch.randint(0, 5, (8,), generator=g).cuda()
-        losses = []
+        losses, grads0 = [], None
         for it in range(5):
             out = task.training_step({'image': x, 'target': y}, it)
             opt.zero_grad()
             out['loss'].backward()
+            if it == 0:
+                grads0 = {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}
             opt.step()
             losses.append(float(out['loss'].detach()))
-        finals.append((losses, {n: p.detach().clone() for n, p in task.named_parameters()}))
+        finals.append((losses, {n: p.detach().clone() for n, p in task.named_parameters()}, grads0))
     assert finals[0][0] == finals[1][0]
     for n in finals[0][1]:
         assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+    # recompute plan, first step (same weights on both sides): same loss; every gradient outside the served Mlps bit for bit
+    # (same launches), the Mlp parameter gradients to summation order; then the loop stays close (AdamW's normalisation
+    # turns last-bit gradient differences of near-zero coordinates into lr-sized steps: later steps are only sanity-checked)
     assert finals[2][0][0] == finals[1][0][0]
-    assert max(abs(a - b) for a, b in zip(finals[2][0], finals[1][0])) < 2e-2
-    worst = max(rel_err(finals[2][1][n], finals[1][1][n]) for n in finals[1][1])
-    assert worst < 2e-2, worst
+    served = lambda n: '.mlp.fc' in n and not n.startswith('backbone.layers.3')     # noqa: E731  (stage 4, C = 768: not served)
+    n_mlp = 0
+    for n, gu in finals[1][2].items():
+        gr = finals[2][2][n]
+        if served(n):
+            n_mlp += 1
+            assert rel_err(gr, gu) < 2e-3, (n, rel_err(gr, gu))
+        else:
+            assert torch.equal(gr, gu), n
+    assert n_mlp == 4 * 6                        # fc1 / fc2 weight + bias of the six served blocks
+    assert abs(finals[2][0][-1] - finals[1][0][-1]) < 0.1 * abs(finals[1][0][-1]) + 0.05
 
 
 def test_fused_mlp_records_the_tape_of_the_separate_launches(monkeypatch, fake_backend):
