@@ -341,6 +341,21 @@ int tok_softmax_ce_smooth_bwd(const void* logits, const int64_t* target, const f
                               const float* gscale, int rows, int classes, int ld, int64_t ignore_index,
                               float label_smoothing, void* dlogits, void* stream);
 
+/* Pixel-wise cross entropy ON the bilinearly upsampled logits without the upsampled tensor: SegmentationHead.forward ends in
+ * F.interpolate(segm_logits, size=input.shape[2:], mode='bilinear') (models/heads/segmentation/base.py:31-41, align_corners
+ * None == False) and the segmentation recipes put CrossEntropyLoss on the result (losses/__init__.py:26).  low = the
+ * channel-last bf16 logits [n][hs][ws][ld] (ld = classes padded to 8, <= 32), target int64 [n][hd][wd].  Forward: every
+ * full-resolution pixel interpolates its logits from its 2x2 source footprint (ATen's source-index formula, the interpolated
+ * value rounded to bf16 exactly as tok_bilinear_fwd stores it), lse / row_loss [n*hd*wd] and the mean in loss[] as
+ * tok_softmax_ce_fwd.  Backward: d(low) (+)= adjoint of the interpolation applied to bf16(d upsampled logits), in gather form
+ * (deterministic) — the values tok_softmax_ce_bwd + tok_bilinear_bwd produce, without their 2 x [n][hd][wd][ld] tensors.   */
+int tok_upsample_ce_serves(int classes, int ld);
+int tok_upsample_ce_fwd(const void* low, int n, int hs, int ws, int classes, int ld, int hd, int wd, const int64_t* target,
+                        int64_t ignore_index, float* lse, float* row_loss, float* loss, void* stream);
+int tok_upsample_ce_bwd(const void* low, int n, int hs, int ws, int classes, int ld, int hd, int wd, const int64_t* target,
+                        int64_t ignore_index, const float* lse, const float* loss, const float* gscale, void* dlow,
+                        int accumulate, void* stream);
+
 /* DiceLoss (losses/segmentation/dice.py:86-188) on bf16 logits rows [rows][ld] (pixels of the channel-last logits).
  * mode 0 'multiclass': softmax + one_hot(target int64 [rows]); mode 1 'binary': sigmoid of column 0, target float32
  * [rows], classes = 1; mode 2 'multilabel': sigmoid per class, target float32 [rows][classes].  dims=(0, 2) statistics per class, `1 - dice` or `-log(dice)`, classes without true pixels

@@ -747,6 +747,38 @@ class FakeTok:
         o[1] = nv.float()
         return 0
 
+    # fused upsample + CE: the composition of the two restatements above (bf16-rounded interpolated logits, bf16-rounded
+    # d(upsampled logits)), which is what the kernels compute without materialising either tensor
+    def tok_upsample_ce_serves(self, classes, ld):
+        return int(classes > 0 and ld >= classes and ld % 8 == 0 and ld <= 32)
+
+    def _upsampled(self, low, n, hs, ws, classes, ld, hd, wd):
+        x = _t(low, (n, hs, ws, ld), BF16)[..., :classes].float().permute(0, 3, 1, 2)
+        y = F.interpolate(x, size=(hd, wd), mode='bilinear', align_corners=False)
+        up = torch.zeros(n * hd * wd, ld, dtype=BF16)
+        up[:, :classes] = _bf(y.permute(0, 2, 3, 1)).reshape(-1, classes)
+        return up
+
+    def tok_upsample_ce_fwd(self, low, n, hs, ws, classes, ld, hd, wd, target, ignore_index, lse, row_loss, loss, st):
+        self.calls.append('upsample_ce_fwd')
+        up = self._upsampled(low, n, hs, ws, classes, ld, hd, wd)
+        return self.tok_softmax_ce_smooth_fwd(up.data_ptr(), target, n * hd * wd, classes, ld, ignore_index, 0.0, lse, row_loss,
+                                              loss, st)
+
+    def tok_upsample_ce_bwd(self, low, n, hs, ws, classes, ld, hd, wd, target, ignore_index, lse, loss, gscale, dlow,
+                            accumulate, st):
+        self.calls.append('upsample_ce_bwd')
+        up = self._upsampled(low, n, hs, ws, classes, ld, hd, wd)
+        dup = torch.zeros(n * hd * wd, ld, dtype=BF16)
+        rc = self.tok_softmax_ce_smooth_bwd(up.data_ptr(), target, lse, loss, gscale, n * hd * wd, classes, ld, ignore_index, 0.0,
+                                            dup.data_ptr(), st)
+        calls = list(self.calls)
+        rc = rc or self.tok_bilinear_bwd(dup.data_ptr(), n, hd, wd, ld, 0, dlow, hs, ws, classes, ld, accumulate, st)
+        self.calls[:] = calls
+        if not accumulate:
+            _t(dlow, (n, hs, ws, ld), BF16)[..., classes:] = 0
+        return rc
+
     def tok_softmax_ce_bwd(self, logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, dlogits, st):
         return self.tok_softmax_ce_smooth_bwd(logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, 0.0,
                                               dlogits, st)

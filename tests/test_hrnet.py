@@ -245,3 +245,56 @@ def test_branch_streams_are_transparent(monkeypatch):
     assert losses[0] == losses[1]
     for n in finals[0]:
         assert torch.equal(finals[0][n], finals[1][n]), n
+
+
+def test_segmentation_head_hands_the_interpolation_to_its_consumer(dev):
+    """SegmentationHead (reference heads/segmentation/base.py:31-41) in training returns the (N, C, H, W) logits as an
+    UpsampledLogits: CrossEntropyLoss computes the loss from the low-resolution logits (tok_upsample_ce_*), every other
+    consumer gets the interpolated tensor on first touch — same values, same gradients either way; evaluation and the
+    one-class head return plain tensors."""
+    import torchok_amd as T
+    from torchok_amd.losses import cross_entropy as CE
+    torch.manual_seed(0)
+    head = T.HEADS.get('SegmentationHead')(in_channels=32, num_classes=19).to(dev)
+    img = torch.zeros(2, 3, 64, 96, device=dev)
+    feat = torch.randn(2, 32, 16, 24, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    tgt = torch.randint(0, 19, (2, 64, 96), generator=torch.Generator().manual_seed(1)).to(dev)
+    tgt[:, :3] = 255
+    ce = T.LOSSES.get('CrossEntropyLoss')(ignore_index=255)
+    res = {}
+    for fused in (True, False):
+        CE.FUSE_UPSAMPLE_CE = fused
+        try:
+            head.train()
+            head.zero_grad()
+            f = feat.clone().requires_grad_(True)
+            out = head([img, f])
+            assert isinstance(out, CE.UpsampledLogits) == fused
+            assert tuple(out.shape) == (2, 19, 64, 96) and out.dim() == 4 and out.dtype == torch.bfloat16
+            if fused:
+                assert out._full is None                      # metadata queries did not materialise anything
+            loss = ce(input=out, target=tgt)
+            if fused:
+                assert out._full is None                      # ... and neither did the loss
+            loss.backward()
+            res[fused] = (float(loss.detach()), f.grad.float().cpu(), head.classifier.weight.grad.float().cpu().clone())
+        finally:
+            CE.FUSE_UPSAMPLE_CE = True
+    assert abs(res[True][0] - res[False][0]) < 1e-5 * abs(res[False][0]) + 1e-6
+    assert rel_err(res[True][1], res[False][1]) < 2e-3 and rel_err(res[True][2], res[False][2]) < 2e-3
+    # any other consumer: the real tensor, with its autograd edge
+    f = feat.clone().requires_grad_(True)
+    out = head([img, f])
+    pred = out.argmax(1)
+    assert out._full is not None and tuple(pred.shape) == (2, 64, 96) and not isinstance(pred, CE.UpsampledLogits)
+    probs = out.float().softmax(1)
+    (probs[:, 0].mean() + ce(input=out, target=tgt)).backward()       # the loss takes the materialised tensor now
+    assert f.grad is not None and float(f.grad.float().abs().sum()) > 0
+    # evaluation / no_grad: plain tensors
+    head.eval()
+    with torch.no_grad():
+        out = head([img, feat])
+    assert type(out) is torch.Tensor and tuple(out.shape) == (2, 19, 64, 96)
+    one = T.HEADS.get('SegmentationHead')(in_channels=32, num_classes=1).to(dev).train()
+    out1 = one([img, feat.clone().requires_grad_(True)])
+    assert type(out1) is torch.Tensor and tuple(out1.shape) == (2, 64, 96)

@@ -1373,6 +1373,64 @@ def test_mlp_parameter_gradients_by_recomputation(libs, rows, c):
             assert relerr(a_, w_) < 1e-2, (nm, relerr(a_, w_))
 
 
+@pytest.mark.parametrize('n,hs,ws,classes,hd,wd', [(2, 32, 64, 19, 128, 256), (1, 16, 24, 3, 64, 96), (2, 9, 13, 21, 36, 52),
+                                                   (1, 8, 8, 8, 20, 28), (3, 128, 256, 19, 512, 1024)])
+def test_upsample_ce_equals_interpolate_then_cross_entropy(libs, n, hs, ws, classes, hd, wd):
+    """tok_upsample_ce_fwd / _bwd == tok_bilinear_fwd -> tok_softmax_ce_fwd and tok_softmax_ce_bwd -> tok_bilinear_bwd (the
+    launches it replaces, whose full-resolution logits and gradient it never writes): loss, per-pixel lse, d(low) — scale
+    factors 4, 2.5 and the HRNet-W48 head size; ignored pixels, a fresh and an accumulated gradient.  The interpolated value
+    and d(upsampled logits) are rounded to bf16 exactly where the unfused launches store them, so the results agree to
+    the contraction of one fp32 expression (measured: identical loss, d(low) <= 1e-3)."""
+    lib = libs[0]
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t_: t_.data_ptr() if t_ is not None else None   # noqa: E731
+    ld = (classes + 7) // 8 * 8
+    assert lib.tok_upsample_ce_serves(classes, ld) == 1 and lib.tok_upsample_ce_serves(40, 40) == 0
+    low = torch.zeros(n, hs, ws, ld, dtype=BF16, device='cuda')
+    low[..., :classes] = (rnd(n, hs, ws, classes, seed=1) * 2).to(BF16).cuda()
+    tgt = torch.randint(0, classes, (n, hd, wd), generator=torch.Generator().manual_seed(2)).cuda()
+    tgt[:, :2] = 255
+    tgt[:, :, -1] = 255
+    rows = n * hd * wd
+    gs = torch.tensor([0.7], device='cuda')
+    # unfused
+    up = torch.zeros(n, hd, wd, ld, dtype=BF16, device='cuda')
+    assert lib.tok_bilinear_fwd(P(low), n, hs, ws, ld, ld, P(up), hd, wd, ld, 0, st) == 0, lib.tok_last_error()
+    lse0, rl0 = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    loss0 = torch.zeros(_C.TOK_CE_LOSS_FLOATS, device='cuda')
+    assert lib.tok_softmax_ce_fwd(P(up), P(tgt), rows, classes, ld, 255, P(lse0), P(rl0), P(loss0), st) == 0
+    dup = torch.empty_like(up)
+    assert lib.tok_softmax_ce_bwd(P(up), P(tgt), P(lse0), P(loss0), P(gs), rows, classes, ld, 255, P(dup), st) == 0
+    base = torch.zeros(n, hs, ws, ld, dtype=BF16, device='cuda')
+    base[..., :classes] = (rnd(n, hs, ws, classes, seed=3) * 1e-3).to(BF16).cuda()
+    d0, d0a = torch.zeros_like(low), base.clone()
+    assert lib.tok_bilinear_bwd(P(dup), n, hd, wd, ld, 0, P(d0), hs, ws, ld, ld, 0, st) == 0
+    assert lib.tok_bilinear_bwd(P(dup), n, hd, wd, ld, 0, P(d0a), hs, ws, ld, ld, 1, st) == 0
+    # fused
+    lse1, rl1 = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    loss1 = torch.zeros(_C.TOK_CE_LOSS_FLOATS, device='cuda')
+    assert lib.tok_upsample_ce_fwd(P(low), n, hs, ws, classes, ld, hd, wd, P(tgt), 255, P(lse1), P(rl1), P(loss1), st) == 0, \
+        lib.tok_last_error()
+    d1, d1a = torch.full_like(low, 9.0), base.clone()
+    assert lib.tok_upsample_ce_bwd(P(low), n, hs, ws, classes, ld, hd, wd, P(tgt), 255, P(lse1), P(loss1), P(gs), P(d1), 0, st) == 0, \
+        lib.tok_last_error()
+    assert lib.tok_upsample_ce_bwd(P(low), n, hs, ws, classes, ld, hd, wd, P(tgt), 255, P(lse1), P(loss1), P(gs), P(d1a), 1, st) == 0
+    torch.cuda.synchronize()
+    assert float(loss1[1]) == float(loss0[1]) == float((tgt != 255).sum())
+    assert abs(float(loss1[0]) - float(loss0[0])) <= 1e-6 * abs(float(loss0[0]))
+    assert float((lse1 - lse0).abs().max()) <= 1e-5 * float(lse0.abs().max())
+    assert relerr(d1[..., :classes].float(), d0[..., :classes].float()) < 1e-3
+    assert relerr(d1a[..., :classes].float(), d0a[..., :classes].float()) < 1e-3
+    assert bool((d1[..., classes:] == 0).all())                       # padding channels of a fresh gradient are zeroed
+    # against torch in fp32 on the same bf16 low-resolution logits
+    lowf = low[..., :classes].float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(torch.nn.functional.interpolate(lowf, size=(hd, wd), mode='bilinear', align_corners=False),
+                                            tgt, ignore_index=255)
+    (ref * 0.7).backward()
+    assert abs(float(loss1[0]) - float(ref)) < 3e-3 * abs(float(ref))
+    assert relerr(d1[..., :classes].float().permute(0, 3, 1, 2), lowf.grad) < 1e-2
+
+
 @pytest.mark.parametrize('n,h,w,c', [(2, 16, 16, 64), (1, 15, 17, 8), (3, 7, 9, 128), (4, 112, 112, 64)])
 def test_fused_stem_pool_equals_the_unfused_chain(libs, n, h, w, c):
     """tok_bn_relu_maxpool_fwd == tok_bn_act_fwd + tok_maxpool3x3s2_fwd; tok_bn_pool_bwd_reduce / _apply ==

@@ -109,6 +109,9 @@ PROTOTYPES = {
     'tok_softmax_ce_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, _P, _P]),
     'tok_softmax_ce_smooth_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P, _P, _P]),
     'tok_softmax_ce_smooth_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_float, _P, _P]),
+    'tok_upsample_ce_serves': (c_int, [c_int, c_int]),
+    'tok_upsample_ce_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P, _P, _P]),
+    'tok_upsample_ce_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P, _P, _P, c_int, _P]),
     'tok_dice_rows': (c_int, [c_int64]),
     'tok_dice_fwd': (c_int, [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_int, _P, c_int, _P, _P, _P, _P]),
     'tok_dice_bwd': (c_int, [_P, _P, _P, _P, c_int64, c_int, c_int, c_int, _P, _P]),

@@ -404,6 +404,214 @@ extern "C" int tok_softmax_ce_bwd(const void* logits, const int64_t* target, con
   return tok_softmax_ce_smooth_bwd(logits, target, lse, loss, gscale, rows, classes, ld, ignore_index, 0.f, dlogits, stream);
 }
 
+// ---- pixel-wise cross entropy on bilinearly upsampled logits, without the upsampled tensor -------------------------------------
+// SegmentationHead.forward (/root/reference/torchok/models/heads/segmentation/base.py:31-41) ends in
+// F.interpolate(segm_logits, size=input.shape[2:], mode='bilinear') and the recipe's loss is CrossEntropyLoss on the result
+// (examples/configs/segmentation_*.yaml): at HRNet-W48 / 512x1024 / batch 24 the (B, 19 -> 24, 512, 1024) bf16 tensor is
+// 604 MB, written by tok_bilinear_fwd, read by the loss, and its gradient written and read once more by tok_bilinear_bwd.
+// Here every full-resolution pixel evaluates its 2x2 footprint of the LOW-resolution logits on the fly (same source-index
+// formula and the same bf16 rounding of the interpolated value as tok_bilinear_fwd: the loss is the unfused one), and the
+// backward is the adjoint in gather form (tok_bilinear_bwd's walk): a low-resolution pixel visits the full-resolution pixels
+// whose footprint contains it, recomputes their softmax from the saved log-sum-exp and sums weight * bf16(d logits) —
+// deterministic, no atomics, nothing full-resolution in HBM except lse / row_loss (4 bytes per pixel each).
+namespace {
+// ATen area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false) — as in resample.hip
+__device__ __forceinline__ void up_src_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float s = scale * ((float)dst + 0.5f) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i0 = i0 > in_size - 1 ? in_size - 1 : i0;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+struct UpArgs {
+  int n, hs, ws, classes, ld, hd, wd;
+  float sh, sw;     // in / out
+};
+
+// interpolated, bf16-rounded logits of full-resolution pixel (b, y, x): v[0 .. 8 NV)
+template <int NV>
+__device__ __forceinline__ void up_logits(const bf16* __restrict__ low, const UpArgs& a, int b, int y, int x, float* v) {
+  int y0, y1, x0, x1;
+  float ly, lx;
+  up_src_index(a.sh, y, a.hs, y0, y1, ly);
+  up_src_index(a.sw, x, a.ws, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const bf16* base = low + (size_t)b * a.hs * a.ws * a.ld;
+  const bf16* p00 = base + ((size_t)y0 * a.ws + x0) * a.ld;
+  const bf16* p01 = base + ((size_t)y0 * a.ws + x1) * a.ld;
+  const bf16* p10 = base + ((size_t)y1 * a.ws + x0) * a.ld;
+  const bf16* p11 = base + ((size_t)y1 * a.ws + x1) * a.ld;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bf16x8 v00 = ldg16(p00 + i * 8), v01 = ldg16(p01 + i * 8), v10 = ldg16(p10 + i * 8), v11 = ldg16(p11 + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[i * 8 + e] = bf2f(f2bf(hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]))));
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void upce_fwd_kernel(const bf16* __restrict__ low, const int64_t* __restrict__ target, UpArgs a,
+                                                       int64_t ignore_index, float* __restrict__ lse,
+                                                       float* __restrict__ row_loss) {
+  const size_t total = (size_t)a.n * a.hd * a.wd;
+  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
+    const int x = (int)(pix % a.wd);
+    const size_t t2 = pix / a.wd;
+    const int y = (int)(t2 % a.hd);
+    const int b = (int)(t2 / a.hd);
+    float v[8 * NV];
+    up_logits<NV>(low, a, b, y, x, v);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8 * NV; ++c) mx = fmaxf(mx, c < a.classes ? v[c] : -INFINITY);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8 * NV; ++c) s += (c < a.classes) ? expf(v[c] - mx) : 0.f;
+    const float l = mx + logf(s);
+    lse[pix] = l;
+    const int64_t t = target[pix];
+    float rl = 0.f;
+    if (ce_row_valid(t, ignore_index, a.classes)) {
+      float zt = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8 * NV; ++c) zt = (c == (int)t) ? v[c] : zt;
+      rl = l - zt;
+    }
+    row_loss[pix] = rl;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void upce_bwd_kernel(const bf16* __restrict__ low, const int64_t* __restrict__ target, UpArgs a,
+                                                       int64_t ignore_index, const float* __restrict__ lse,
+                                                       const float* __restrict__ loss, const float* __restrict__ gscale,
+                                                       bf16* dlow, int accumulate) {
+  const size_t total = (size_t)a.n * a.hs * a.ws;
+  const float rh = 1.f / a.sh, rw = 1.f / a.sw;
+  const float g = (gscale ? gscale[0] : 1.f) / loss[1];
+  for (size_t pix = (size_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (size_t)gridDim.x * 256) {
+    const int xs = (int)(pix % a.ws);
+    const size_t t2 = pix / a.ws;
+    const int ys = (int)(t2 % a.hs);
+    const int b = (int)(t2 / a.hs);
+    // full-resolution rows / columns whose source coordinate lies in (ys - 1, ys + 1), widened by one for rounding;
+    // source row 0 also owns the clamp (tok_bilinear_bwd's window)
+    int yd0 = ys == 0 ? 0 : (int)floorf(((float)ys - 0.5f) * rh - 0.5f) - 1;
+    int yd1 = (int)ceilf(((float)ys + 1.5f) * rh - 0.5f) + 1;
+    int xd0 = xs == 0 ? 0 : (int)floorf(((float)xs - 0.5f) * rw - 0.5f) - 1;
+    int xd1 = (int)ceilf(((float)xs + 1.5f) * rw - 0.5f) + 1;
+    yd0 = yd0 < 0 ? 0 : yd0;  xd0 = xd0 < 0 ? 0 : xd0;
+    yd1 = yd1 > a.hd - 1 ? a.hd - 1 : yd1;  xd1 = xd1 > a.wd - 1 ? a.wd - 1 : xd1;
+    float acc[8 * NV];
+#pragma unroll
+    for (int c = 0; c < 8 * NV; ++c) acc[c] = 0.f;
+    for (int yd = yd0; yd <= yd1; ++yd) {
+      int y0, y1; float ly;
+      up_src_index(a.sh, yd, a.hs, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int xd = xd0; xd <= xd1; ++xd) {
+        int x0, x1; float lx;
+        up_src_index(a.sw, xd, a.ws, x0, x1, lx);
+        const float wx = (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f);
+        if (wx == 0.f) continue;
+        const size_t dp = ((size_t)b * a.hd + yd) * a.wd + xd;
+        const int64_t t = target[dp];
+        if (!ce_row_valid(t, ignore_index, a.classes)) continue;
+        float v[8 * NV];
+        up_logits<NV>(low, a, b, yd, xd, v);
+        const float l = lse[dp];
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int c = 0; c < 8 * NV; ++c) {
+          // d(upsampled logits), rounded to bf16 as the unfused tok_softmax_ce_bwd stores it
+          const float w = c < a.classes ? bf2f(f2bf((expf(v[c] - l) - (c == (int)t ? 1.f : 0.f)) * g)) : 0.f;
+          acc[c] = fmaf(wgt, w, acc[c]);
+        }
+      }
+    }
+    bf16* d = dlow + pix * a.ld;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      bf16x8 o;
+      if (accumulate) {
+        const bf16x8 prev = ldg16(d + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[i * 8 + e] + bf2f(prev[e]));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[i * 8 + e]);
+      }
+      stg16(d + i * 8, o);
+    }
+  }
+}
+
+bool fill_up(UpArgs& a, int n, int hs, int ws, int classes, int ld, int hd, int wd) {
+  if (n <= 0 || hs <= 0 || ws <= 0 || hd <= 0 || wd <= 0 || classes <= 0 || ld < classes || (ld & 7) || ld > 32) return false;
+  if ((long long)n * hd * wd >= (1ll << 31)) return false;
+  a.n = n; a.hs = hs; a.ws = ws; a.classes = classes; a.ld = ld; a.hd = hd; a.wd = wd;
+  a.sh = (float)hs / (float)hd; a.sw = (float)ws / (float)wd;
+  return true;
+}
+int up_blocks(size_t work) {
+  const size_t b = (work + 255) / 256;
+  return (int)(b > 65536 ? 65536 : b);
+}
+}  // namespace
+
+extern "C" int tok_upsample_ce_serves(int classes, int ld) { return classes > 0 && ld >= classes && (ld & 7) == 0 && ld <= 32; }
+
+extern "C" int tok_upsample_ce_fwd(const void* low, int n, int hs, int ws, int classes, int ld, int hd, int wd,
+                                   const int64_t* target, int64_t ignore_index, float* lse, float* row_loss, float* loss,
+                                   void* stream) {
+  UpArgs a;
+  TOK_CHECK_ARG(low && target && lse && row_loss && loss && fill_up(a, n, hs, ws, classes, ld, hd, wd),
+                "tok_upsample_ce_fwd: bad args (row pitch a multiple of 8 up to 32 channels, n*hd*wd < 2^31)");
+  TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(low) & 15) == 0 && (reinterpret_cast<uintptr_t>(loss) & 7) == 0,
+                "tok_upsample_ce_fwd: low must be 16-byte, loss 8-byte aligned");
+  hipStream_t st = tok_stream(stream);
+  const int rows = n * hd * wd;
+  const int grid = up_blocks((size_t)rows);
+  switch (ld >> 3) {
+    case 1: hipLaunchKernelGGL(upce_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, row_loss); break;
+    case 2: hipLaunchKernelGGL(upce_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, row_loss); break;
+    case 3: hipLaunchKernelGGL(upce_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, row_loss); break;
+    default: hipLaunchKernelGGL(upce_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, row_loss); break;
+  }
+  TOK_CHECK_LAUNCH("tok_upsample_ce_fwd");
+  double* part = reinterpret_cast<double*>(loss + 2);
+  const int nparts = rows < 4096 ? 1 : (tok_cdiv(rows, 4096) < CE_PARTS ? tok_cdiv(rows, 4096) : CE_PARTS);
+  const int chunk = tok_cdiv(rows, nparts);
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(nparts), dim3(256), 0, st, row_loss, target, rows, ignore_index, classes, chunk, part);
+  TOK_CHECK_LAUNCH("tok_upsample_ce_fwd(partial)");
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, st, part, nparts, loss);
+  TOK_CHECK_LAUNCH("tok_upsample_ce_fwd(mean)");
+  return TOK_OK;
+}
+
+extern "C" int tok_upsample_ce_bwd(const void* low, int n, int hs, int ws, int classes, int ld, int hd, int wd,
+                                   const int64_t* target, int64_t ignore_index, const float* lse, const float* loss,
+                                   const float* gscale, void* dlow, int accumulate, void* stream) {
+  UpArgs a;
+  TOK_CHECK_ARG(low && target && lse && loss && dlow && fill_up(a, n, hs, ws, classes, ld, hd, wd), "tok_upsample_ce_bwd: bad args");
+  TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(low) & 15) == 0 && (reinterpret_cast<uintptr_t>(dlow) & 15) == 0,
+                "tok_upsample_ce_bwd: low / dlow must be 16-byte aligned");
+  hipStream_t st = tok_stream(stream);
+  const int grid = up_blocks((size_t)n * hs * ws);
+  switch (ld >> 3) {
+    case 1: hipLaunchKernelGGL(upce_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, loss, gscale, (bf16*)dlow, accumulate); break;
+    case 2: hipLaunchKernelGGL(upce_bwd_kernel<2>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, loss, gscale, (bf16*)dlow, accumulate); break;
+    case 3: hipLaunchKernelGGL(upce_bwd_kernel<3>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, loss, gscale, (bf16*)dlow, accumulate); break;
+    default: hipLaunchKernelGGL(upce_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, loss, gscale, (bf16*)dlow, accumulate); break;
+  }
+  TOK_CHECK_LAUNCH("tok_upsample_ce_bwd");
+  return TOK_OK;
+}
+
 namespace {
 // BCEWithLogitsLoss with an ignore value (losses/classification/binary_cross_entropy.py:50-59): elements whose target
 // equals `ignore` are dropped, the rest take  (1 - t) x - log_sigmoid(x)  in fp32 (ATen's formula), mean or sum.

@@ -82,6 +82,123 @@ class _SoftmaxCE(torch.autograd.Function):
         return d, None, None, None
 
 
+class UpsampledLogits(torch.Tensor):
+    """What SegmentationHead returns in training: the (N, C, H, W) result of `F.interpolate(low, size, mode='bilinear')`
+    (reference heads/segmentation/base.py:37) WITHOUT having computed it.  CrossEntropyLoss recognises the object and runs the
+    fused kernels on the low-resolution logits (tok_upsample_ce_fwd / _bwd: the full-resolution tensor and its gradient —
+    2 x 604 MB per HRNet-W48 step at 512x1024, batch 24 — are never written).  Anything else that touches it (a metric, a
+    Dice loss, user code) gets the real tensor: every torch function applied to it first materialises the interpolation
+    through the engine's bilinear unit (with its autograd edge to the low-resolution logits) — metadata queries (shape, dtype,
+    device, dim, size, requires_grad) excepted."""
+
+    @staticmethod
+    def __new__(cls, low: Tensor, size):
+        n, c = low.shape[:2]
+        r = torch.Tensor._make_wrapper_subclass(cls, (n, c, int(size[0]), int(size[1])), dtype=low.dtype, device=low.device,
+                                                requires_grad=False)
+        r._low, r._size, r._full = low, (int(size[0]), int(size[1])), None
+        return r
+
+    def __init__(self, low: Tensor, size):
+        pass
+
+    def materialize(self) -> Tensor:
+        if self._full is None:
+            from .. import engine
+            from ..engine import resample as ER
+            with engine.region() as r:
+                self._full = r.output(ER.bilinear_resize(r, r.input(self._low), self._size))
+        return self._full
+
+    _META = {'dim', 'size', 'stride', '__get__', 'numel', 'is_floating_point', 'is_contiguous', 'data_ptr', '__len__',
+             'ndimension', 'nelement', 'element_size', 'is_complex', 'get_device', '__repr__', '__str__', '__format__'}
+
+    def __repr__(self, *, tensor_contents=None):
+        return f'UpsampledLogits(low={tuple(self._low.shape)}, size={self._size}, materialized={self._full is not None})'
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if getattr(func, '__name__', '') in cls._META:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+
+        def real(a):
+            if isinstance(a, UpsampledLogits):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            return a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # reached only by code that bypasses __torch_function__ (C++ callers): same answer, the real tensor
+        def real(a):
+            if isinstance(a, UpsampledLogits):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            return a
+        return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
+class _UpsampleCE(torch.autograd.Function):
+    """CrossEntropyLoss(F.interpolate(low, size, 'bilinear'), target) from the low-resolution logits (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, low: Tensor, target: Tensor, size, ignore_index: int):
+        require_device(low)
+        n, classes, hs, ws = low.shape
+        hd, wd = size
+        zp = low.detach().permute(0, 2, 3, 1)
+        ld = zp.stride(2)
+        if not (zp.dtype == BF16 and zp.stride(3) == 1 and ld >= classes and ld % 8 == 0 and zp.stride(1) == ws * ld
+                and zp.stride(0) == hs * ws * ld and zp.data_ptr() % 16 == 0):
+            ld = pad8(classes)
+            buf = torch.zeros((n, hs, ws, ld), dtype=BF16, device=low.device)
+            buf[..., :classes] = zp
+            zp = buf[..., :classes]
+        z = torch.as_strided(zp, (n, hs, ws, ld), (hs * ws * ld, ws * ld, ld, 1))
+        if target.dtype != torch.int64 or not target.is_contiguous():
+            target = target.to(torch.int64).contiguous()
+        dev = z.device
+        rows = n * hd * wd
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(rows, dtype=torch.float32, device=dev)
+        loss = torch.empty(_C.TOK_CE_LOSS_FLOATS, dtype=torch.float32, device=dev)
+        _C.check(_C.lib().tok_upsample_ce_fwd(ptr(z), n, hs, ws, classes, ld, hd, wd, ptr(target), ignore_index, ptr(lse),
+                                              ptr(row_loss), ptr(loss), stream_ptr()), 'tok_upsample_ce_fwd')
+        ctx.z, ctx.target, ctx.lse, ctx.loss, ctx.ignore_index = z, target, lse, loss, ignore_index
+        ctx.geom = (n, hs, ws, classes, ld, hd, wd)
+        ctx.in_dtype = low.dtype
+        n_valid = loss[1]
+        ctx.mark_non_differentiable(n_valid)
+        return loss[0], n_valid
+
+    @staticmethod
+    def backward(ctx, g, _unused=None):
+        n, hs, ws, classes, ld, hd, wd = ctx.geom
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        d = torch.empty((n, hs, ws, ld), dtype=BF16, device=ctx.z.device)
+        _C.check(_C.lib().tok_upsample_ce_bwd(ptr(ctx.z), n, hs, ws, classes, ld, hd, wd, ptr(ctx.target), ctx.ignore_index,
+                                              ptr(ctx.lse), ptr(ctx.loss), ptr(gs), ptr(d), 0, stream_ptr()),
+                 'tok_upsample_ce_bwd')
+        ctx.z = ctx.target = ctx.lse = ctx.loss = None
+        if ld == pad8(classes) != classes:
+            mark_padded(d)
+        d = d[..., :classes].permute(0, 3, 1, 2)
+        if ctx.in_dtype != BF16:
+            d = d.to(ctx.in_dtype)
+        return d, None, None, None
+
+
+# TOK_FUSE_UPSAMPLE_CE=0: SegmentationHead returns the interpolated tensor itself (the round-3 path)
+FUSE_UPSAMPLE_CE = os.environ.get('TOK_FUSE_UPSAMPLE_CE', '1') == '1'
+
+
 @LOSSES.register_class
 class CrossEntropyLoss(nn.Module):
     def __init__(self, weight=None, size_average=None, ignore_index: int = -100, reduce=None,
@@ -94,6 +211,14 @@ class CrossEntropyLoss(nn.Module):
         self.ignore_index, self.label_smoothing, self.reduction = ignore_index, label_smoothing, reduction
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
+        if isinstance(input, UpsampledLogits):
+            low, size = input._low, input._size
+            ld = low.permute(0, 2, 3, 1).stride(2) if low.dim() == 4 else 0
+            if (self.label_smoothing == 0.0 and input._full is None and target.shape == (low.shape[0],) + size
+                    and _C.lib().tok_upsample_ce_serves(low.shape[1], max(ld, pad8(low.shape[1])))):
+                loss, n_valid = _UpsampleCE.apply(low, target, size, self.ignore_index)
+                return loss if self.reduction == 'mean' else loss * n_valid
+            input = input.materialize()
         if input.dim() not in (2, 4):
             raise NotImplementedError('torchok_amd CrossEntropyLoss: (N, C) or (N, C, H, W) logits')
         if input.dim() == 4 and target.shape != (input.shape[0],) + tuple(input.shape[2:]):

@@ -3,6 +3,7 @@
 -> squeeze for one class."""
 from typing import List
 
+import torch
 import torch.nn as nn
 from torch import Tensor
 
@@ -10,6 +11,7 @@ from ... import engine
 from ...constructor import HEADS
 from ...engine import functional as EF
 from ...engine import resample as ER
+from ...losses import cross_entropy as CE
 from ..base import BaseModel
 
 
@@ -24,11 +26,18 @@ class SegmentationHead(BaseModel):
 
     def forward(self, x: List[Tensor]) -> Tensor:
         input_image, features = x
+        size = tuple(input_image.shape[2:])
+        # training, more than one class: the interpolation is handed to whoever consumes the logits — CrossEntropyLoss fuses
+        # it into its kernels (losses/cross_entropy.py: UpsampledLogits), any other consumer materialises it on first touch
+        lazy = (self.do_interpolate and self.num_classes > 1 and self.training and torch.is_grad_enabled()
+                and CE.FUSE_UPSAMPLE_CE)
         with engine.region() as r:
             logits = EF.conv_bn_act(r, r.input(features), self.classifier, None, False, None)
-            if self.do_interpolate:
-                logits = ER.bilinear_resize(r, logits, tuple(input_image.shape[2:]))
+            if self.do_interpolate and not lazy:
+                logits = ER.bilinear_resize(r, logits, size)
             segm_logits = r.output(logits)
+        if lazy:
+            return CE.UpsampledLogits(segm_logits, size)
         if self.num_classes == 1:
             segm_logits = segm_logits[:, 0]
         return segm_logits
