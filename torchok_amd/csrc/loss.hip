@@ -1,6 +1,7 @@
 // Fused softmax cross-entropy (mean reduction, ignore_index), bf16 logits, fp32 math.
 // One wavefront per row: lane-strided max / sum-exp with 64-lane butterflies, no LDS.
 #include "tok_common.h"
+#include <stdlib.h>
 #include <math.h>
 
 namespace {
@@ -469,8 +470,8 @@ __global__ __launch_bounds__(256) void upce_fwd_kernel(const bf16* __restrict__ 
     for (int c = 0; c < 8 * NV; ++c) mx = fmaxf(mx, c < a.classes ? v[c] : -INFINITY);
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8 * NV; ++c) s += (c < a.classes) ? expf(v[c] - mx) : 0.f;
-    const float l = mx + logf(s);
+    for (int c = 0; c < 8 * NV; ++c) s += (c < a.classes) ? __expf(v[c] - mx) : 0.f;
+    const float l = mx + __logf(s);
     lse[pix] = l;
     const int64_t t = target[pix];
     float rl = 0.f;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void upce_bwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 8 * NV; ++c) {
           // d(upsampled logits), rounded to bf16 as the unfused tok_softmax_ce_bwd stores it
-          const float w = c < a.classes ? bf2f(f2bf((expf(v[c] - l) - (c == (int)t ? 1.f : 0.f)) * g)) : 0.f;
+          const float w = c < a.classes ? bf2f(f2bf((__expf(v[c] - l) - (c == (int)t ? 1.f : 0.f)) * g)) : 0.f;
           acc[c] = fmaf(wgt, w, acc[c]);
         }
       }
@@ -548,6 +549,126 @@ __global__ __launch_bounds__(256) void upce_bwd_kernel(const bf16* __restrict__ 
       stg16(d + i * 8, o);
     }
   }
+}
+
+// The same adjoint with every full-resolution pixel evaluated ONCE per block instead of once per low-resolution pixel it
+// touches (4x for a scale of 4: the gather kernel above spends its time in 19 expf per visit): a block owns UT x UT
+// low-resolution pixels, stages bf16(d upsampled logits) of the full-resolution window that can touch them in LDS (phase 1),
+// then every (low-resolution pixel, 8-channel group) walks its footprint with tok_bilinear_bwd's exact index / weight
+// arithmetic, reading LDS (phase 2).  Window = the union of the per-pixel windows of the gather kernel, at most UWIN x UWIN.
+constexpr int UT = 8, UWIN = 40, UPP = 12;     // tile edge, window edge, window of ONE source pixel (2 r + 4 at r <= 4)
+
+__device__ __forceinline__ void up_window(float r, int s, int n_dst, int& d0, int& d1) {
+  d0 = s == 0 ? 0 : (int)floorf(((float)s - 0.5f) * r - 0.5f) - 1;
+  d1 = (int)ceilf(((float)s + 1.5f) * r - 0.5f) + 1;
+  d0 = d0 < 0 ? 0 : d0;
+  d1 = d1 > n_dst - 1 ? n_dst - 1 : d1;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void upce_bwd_tiled_kernel(const bf16* __restrict__ low, const int64_t* __restrict__ target,
+                                                             UpArgs a, int64_t ignore_index, const float* __restrict__ lse,
+                                                             const float* __restrict__ loss, const float* __restrict__ gscale,
+                                                             bf16* dlow, int accumulate, int tiles_y, int tiles_x) {
+  extern __shared__ __attribute__((aligned(16))) char up_smem[];
+  bf16* win = reinterpret_cast<bf16*>(up_smem);                 // [wh][ww][8 NV]
+  const int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  const int t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y;
+  const int b = t2 / tiles_y;
+  const int ys0 = ty * UT, xs0 = tx * UT;
+  const int ys1 = min(a.hs, ys0 + UT) - 1, xs1 = min(a.ws, xs0 + UT) - 1;
+  const float rh = 1.f / a.sh, rw = 1.f / a.sw;
+  int wy0, wy1, wx0, wx1, tmp0, tmp1;
+  up_window(rh, ys0, a.hd, wy0, tmp1);
+  up_window(rh, ys1, a.hd, tmp0, wy1);
+  up_window(rw, xs0, a.wd, wx0, tmp1);
+  up_window(rw, xs1, a.wd, tmp0, wx1);
+  const int wh = wy1 - wy0 + 1, ww = wx1 - wx0 + 1;             // <= UWIN (checked by the launcher for the scale)
+  const float g = (gscale ? gscale[0] : 1.f) / loss[1];
+  // ---- phase 1: bf16(d upsampled logits) of the window ----------------------------------------------------------------------
+  for (int i = threadIdx.x; i < wh * ww; i += 256) {
+    const int yd = wy0 + i / ww, xd = wx0 + i % ww;
+    const size_t dp = ((size_t)b * a.hd + yd) * a.wd + xd;
+    const int64_t t = target[dp];
+    bf16* o = win + (size_t)i * (8 * NV);
+    if (!ce_row_valid(t, ignore_index, a.classes)) {
+#pragma unroll
+      for (int v8 = 0; v8 < NV; ++v8) *reinterpret_cast<bf16x8*>(o + v8 * 8) = zero8();
+      continue;
+    }
+    float v[8 * NV];
+    up_logits<NV>(low, a, b, yd, xd, v);
+    const float l = lse[dp];
+#pragma unroll
+    for (int v8 = 0; v8 < NV; ++v8) {
+      bf16x8 q;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = v8 * 8 + e;
+        q[e] = f2bf(c < a.classes ? (__expf(v[c] - l) - (c == (int)t ? 1.f : 0.f)) * g : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(o + v8 * 8) = q;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the adjoint of the interpolation, one (low-resolution pixel, 8-channel group) per thread ------------------------
+  for (int i = threadIdx.x; i < UT * UT * NV; i += 256) {
+    const int v8 = i % NV;
+    const int p = i / NV;
+    const int ys = ys0 + p / UT, xs = xs0 + p % UT;
+    if (ys > ys1 || xs > xs1) continue;
+    int yd0, yd1, xd0, xd1;
+    up_window(rh, ys, a.hd, yd0, yd1);
+    up_window(rw, xs, a.wd, xd0, xd1);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    // the column weights of this pixel once (the window of one source pixel is at most UPP wide at the scales the tiled
+    // kernel serves), then rows x columns of LDS reads
+    float wxs[UPP];
+#pragma unroll
+    for (int j = 0; j < UPP; ++j) {
+      const int xd = xd0 + j;
+      int x0, x1; float lx;
+      up_src_index(a.sw, xd <= xd1 ? xd : xd1, a.ws, x0, x1, lx);
+      wxs[j] = xd <= xd1 ? (x0 == xs ? 1.f - lx : 0.f) + (x1 == xs ? lx : 0.f) : 0.f;
+    }
+    for (int yd = yd0; yd <= yd1; ++yd) {
+      int y0, y1; float ly;
+      up_src_index(a.sh, yd, a.hs, y0, y1, ly);
+      const float wy = (y0 == ys ? 1.f - ly : 0.f) + (y1 == ys ? ly : 0.f);
+      if (wy == 0.f) continue;
+      const bf16* rowp = win + ((size_t)(yd - wy0) * ww + (xd0 - wx0)) * (8 * NV) + v8 * 8;
+#pragma unroll
+      for (int j = 0; j < UPP; ++j) {
+        if (wxs[j] == 0.f) continue;
+        const bf16x8 q = *reinterpret_cast<const bf16x8*>(rowp + (size_t)j * (8 * NV));
+        const float wgt = wy * wxs[j];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, bf2f(q[e]), acc[e]);
+      }
+    }
+    bf16* d = dlow + (((size_t)b * a.hs + ys) * a.ws + xs) * a.ld + v8 * 8;
+    bf16x8 o;
+    if (accumulate) {
+      const bf16x8 prev = ldg16(d);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e] + bf2f(prev[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    }
+    stg16(d, o);
+  }
+}
+
+// window of UT source pixels at destination/source ratio r: (UT - 1) r between first and last pixel + (2 r + 4) per pixel
+bool up_tiled_ok(const UpArgs& a) {
+  static const int flag = [] { const char* e = getenv("TOK_UPCE_TILED"); return (int)(e ? atoi(e) : 1); }();
+  const float r = fmaxf(1.f / a.sh, 1.f / a.sw);
+  return flag && (int)ceilf((UT + 1) * r) + 4 <= UWIN;
 }
 
 bool fill_up(UpArgs& a, int n, int hs, int ws, int classes, int ld, int hd, int wd) {
@@ -601,6 +722,31 @@ extern "C" int tok_upsample_ce_bwd(const void* low, int n, int hs, int ws, int c
   TOK_CHECK_ARG((reinterpret_cast<uintptr_t>(low) & 15) == 0 && (reinterpret_cast<uintptr_t>(dlow) & 15) == 0,
                 "tok_upsample_ce_bwd: low / dlow must be 16-byte aligned");
   hipStream_t st = tok_stream(stream);
+  if (up_tiled_ok(a)) {
+    const int tiles_y = tok_cdiv(hs, UT), tiles_x = tok_cdiv(ws, UT);
+    const int tgrid = n * tiles_y * tiles_x;
+    const int smem = UWIN * UWIN * ld * 2;
+#define TOK_UPCE_TILED(NV)                                                                                                          \
+    {                                                                                                                               \
+      static const bool attr_set = [] {                                                                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&upce_bwd_tiled_kernel<NV>),                                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, UWIN * UWIN * NV * 16);                               \
+        return true;                                                                                                                \
+      }();                                                                                                                          \
+      (void)attr_set;                                                                                                               \
+      hipLaunchKernelGGL(upce_bwd_tiled_kernel<NV>, dim3(tgrid), dim3(256), smem, st, (const bf16*)low, target, a, ignore_index,    \
+                         lse, loss, gscale, (bf16*)dlow, accumulate, tiles_y, tiles_x);                                             \
+    }
+    switch (ld >> 3) {
+      case 1: TOK_UPCE_TILED(1) break;
+      case 2: TOK_UPCE_TILED(2) break;
+      case 3: TOK_UPCE_TILED(3) break;
+      default: TOK_UPCE_TILED(4) break;
+    }
+#undef TOK_UPCE_TILED
+    TOK_CHECK_LAUNCH("tok_upsample_ce_bwd(tiled)");
+    return TOK_OK;
+  }
   const int grid = up_blocks((size_t)n * hs * ws);
   switch (ld >> 3) {
     case 1: hipLaunchKernelGGL(upce_bwd_kernel<1>, dim3(grid), dim3(256), 0, st, (const bf16*)low, target, a, ignore_index, lse, loss, gscale, (bf16*)dlow, accumulate); break;
