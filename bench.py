@@ -462,6 +462,10 @@ def main():
                        'parallelism': f'dp{world}', 'launch_mode': 'hipGraph replay' if use_graph else 'eager'},
             'roofline': roofline,
         }
+        try:      # fp32 elements the optimizer kernel walks (padded arena): what tools/pmc_traffic.py calibrates the counters on
+            line['config']['arena_elements'] = int(sum(a.total for a in opt._arenas if a is not None))
+        except Exception:
+            pass
         if roofline is not None:
             # (a constant read from the committed PMC pass of this workload, like `traffic`: counters cannot be collected
             #  from inside the timed process)

@@ -11,12 +11,14 @@ db=$(ls $out/raw/${tag}_kt/*results.db 2>/dev/null | head -1)
 if [ -n "$db" ]; then
   { echo "# rocprofv3 --kernel-trace --stats of bench.py $* --steps 6 --warmup 3; tools/prof_summary.py"; python tools/prof_summary.py $db 9; } > $out/${tag}_kernel_stats.txt
   { echo "# one training step out of the same trace; tools/timeline.py"; python tools/timeline.py $db; } > $out/${tag}_timeline.txt 2>&1
+  { echo "# where the main queue idles in that step; tools/gaps.py"; python tools/gaps.py $db --min-us 8 --top 30; } > $out/${tag}_gaps.txt 2>&1
 fi
 timeout 500 rocprofv3 --pmc FETCH_SIZE -d $out/raw/${tag}_pf -o p -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/raw/${tag}_pf.log 2>&1
 timeout 500 rocprofv3 --pmc WRITE_SIZE -d $out/raw/${tag}_pw -o p -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/raw/${tag}_pw.log 2>&1
 f=$(ls $out/raw/${tag}_pf/*results.db 2>/dev/null | head -1); w=$(ls $out/raw/${tag}_pw/*results.db 2>/dev/null | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then
-  { echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py $* --steps 2 --warmup 1; tools/pmc_traffic.py"; python tools/pmc_traffic.py $f $w 3 $out/${tag}_pmc_traffic.json; } > $out/${tag}_pmc_traffic.txt 2>&1
+  ae=$(python -c "import json,sys; print(json.load(open(sys.argv[1]))['config'].get('arena_elements', 0))" $out/${tag}_bench.json 2>/dev/null || echo 0)
+  { echo "# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py $* --steps 2 --warmup 1; tools/pmc_traffic.py (calibration: optimizer kernel over $ae fp32 arena elements)"; python tools/pmc_traffic.py $f $w 3 $out/${tag}_pmc_traffic.json $ae; } > $out/${tag}_pmc_traffic.txt 2>&1
 fi
 timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/raw/${tag}_pm -o p -- python bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $out/raw/${tag}_pm.log 2>&1
 m=$(ls $out/raw/${tag}_pm/*results.db 2>/dev/null | head -1)

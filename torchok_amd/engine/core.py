@@ -401,7 +401,14 @@ def pick_stream(device, main: Optional['torch.cuda.Stream'] = None) -> 'torch.cu
     return best
 
 
+# TOK_BRANCH_MAP="0,1,2,2": branch index -> stream slot (experiment: HRNet's four branches + the side stream are five streams on
+# four hardware queues; folding two of the small branches onto one stream gives every stream a queue of its own)
+_BRANCH_MAP = [int(v) for v in os.environ['TOK_BRANCH_MAP'].split(',')] if os.environ.get('TOK_BRANCH_MAP') else None
+
+
 def _branch_stream(device, idx: int) -> 'torch.cuda.Stream':
+    if _BRANCH_MAP is not None and idx < len(_BRANCH_MAP):
+        idx = _BRANCH_MAP[idx]
     key = (device, idx)
     s = _branch_streams.get(key)
     if s is None:
