@@ -78,3 +78,8 @@ bool conv_win_serves(const ConvArgs& a);
 int conv_win_grid(int gridM, int gridN);
 void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN);
 int conv_win_launch(ConvArgs& a, hipStream_t st);            // fills a.gridM / a.gridN / a.stat_rows itself
+
+// gemm256.hip: pointwise layers with a deep reduction and a mid-sized pixel count on 256 x 256 tiles (8 waves)
+bool gemm256_serves(const ConvArgs& a);                      // geometry / mode test (pure function of the arguments)
+int gemm256_rows(const ConvArgs& a);                         // statistics rows = pixel tiles
+int gemm256_launch(ConvArgs& a, hipStream_t st);             // fills a.gridM / a.gridN / a.stat_rows itself

@@ -954,6 +954,7 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
       conv_win_tiles(g, &gm, &gn);
       return conv_win_grid(gm, gn) / gn;
     }
+    if (gemm256_serves(g)) return gemm256_rows(g);
     if (bn_tile == 128 && conv_ring_serves(g, false))
       return conv_ring_grid(tok_cdiv(g.M, 256), tok_cdiv(d->k, 128)) / tok_cdiv(d->k, 128);
   }
@@ -1026,6 +1027,13 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   if (!c4 && ep == nullptr && conv_win_serves(a)) {
     // 3x3 / stride 1 / padding 1: shared input window in LDS (conv_win.hip)
     rc = conv_win_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH("tok_conv_fwd");
+    return TOK_OK;
+  }
+  if (!c4 && ep == nullptr && gemm256_serves(a)) {
+    // deep-K pointwise layers with a mid-sized pixel count: 256 x 256 tiles, eight waves (gemm256.hip)
+    rc = gemm256_launch(a, st);
     if (rc) return rc;
     TOK_CHECK_LAUNCH("tok_conv_fwd");
     return TOK_OK;
@@ -1129,6 +1137,12 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
   }
+  if (d->stride == 1 && gemm256_serves(a)) {
+    rc = gemm256_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH(who);
+    return TOK_OK;
+  }
   if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false)) {
     a.gridM = tok_cdiv(a.M, 256);
     a.gridN = tok_cdiv(d->c, 128);
@@ -1177,6 +1191,7 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
     conv_win_tiles(a, &gm, &gn);
     return conv_win_grid(gm, gn) / gn;
   }
+  if (d->stride == 1 && gemm256_serves(a)) return gemm256_rows(a);
   if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false))
     return conv_ring_grid(tok_cdiv(a.M, 256), tok_cdiv(d->c, 128)) / tok_cdiv(d->c, 128);
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c))
