@@ -8,7 +8,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 SHAPES = [(50176, 1024, 256), (50176, 256, 1024), (50176, 512, 1024), (12544, 2048, 512), (12544, 512, 2048), (12544, 1024, 2048),
-          (50176, 384, 1152), (50176, 384, 384), (12544, 768, 2304), (12544, 768, 768), (12544, 768, 3072), (12544, 3072, 768), (5000, 512, 520)]
+          (50176, 384, 1152), (50176, 384, 384), (12544, 768, 2304), (12544, 768, 768), (12544, 768, 3072), (12544, 3072, 768), (12544, 2304, 768), (5000, 512, 520), (786432, 720, 720),
+          (200704, 712, 512)]
 
 
 def run(tag):
@@ -56,7 +57,7 @@ def run(tag):
         fl = 2.0 * m * k * n
         print(f'[{tag}] M={m} K={k} N={n}: fwd+stats {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF/s)  dgrad {td:6.1f} us ({fl / td / 1e6:5.0f} TF/s)  rows {rows}/{rows_d}', flush=True)
         out[(m, k, n)] = dict(y=y.float().cpu(), s=stats.sum(1).cpu(), dx=dx.float().cpu(), dxa=dxa.float().cpu(), dxs=dxs.float().cpu(),
-                              p=part.sum(1).cpu(), ref_y=(x.float() @ w.float().t()).cpu() if m * n < 3e8 else None)
+                              p=part.sum(1).cpu(), ref_y=(x.float() @ w.float().t()).cpu() if m * n < 1.2e8 else None)
     torch.save(out, f'/tmp/g256_{tag}.pt')
 
 
@@ -64,7 +65,7 @@ if __name__ == '__main__':
     if len(sys.argv) > 1:
         run(sys.argv[1])
         sys.exit(0)
-    for tag, v in (('new', '1'), ('old', '0')):
+    for tag, v in (('new', '2'), ('old', '0')):
         subprocess.run([sys.executable, __file__, tag], env=dict(os.environ, TOK_GEMM256=v), check=True)
     a, b = torch.load('/tmp/g256_new.pt'), torch.load('/tmp/g256_old.pt')
 

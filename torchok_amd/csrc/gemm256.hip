@@ -65,19 +65,21 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   const int mt = id / a.gridN, nt = id - mt * a.gridN;
   const int m0 = mt * GT, n0 = nt * GT;
   const int KD = a.Ktot;                                   // reduction length = row pitch of both operands (elements)
-  const int KT = KD / GK;
+  const int KT = (KD + GK - 1) / GK;               // (KD % 8 == 0: a 16-byte chunk is inside or outside the row)
 
   const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
   // ---- stage DMA: block bid = j * 8 + wave; blocks 0 .. 31 weight rows, 32 .. 63 pixel rows, 8 rows of 128 bytes each ----------
   uint32_t voff[NI];
+  int kq[NI];              // first reduction element of this lane's 16-byte chunk inside a stage (K tail: chunks past K are zeros)
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
     const int bid = j * 8 + wave;
     const int tb = bid & 31;
     const int row = tb * 8 + (lane >> 3);
     const int q = (lane & 7) ^ ((row & 3) | (((row >> 3) & 1) << 2));
+    kq[j] = q * 8;
     const bool isw = bid < 32;
     const int grow = (isw ? n0 : m0) + row;
     const bool ok = grow < (isw ? a.K : a.M);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int bid = j * 8 + wave;
-      uint32_t off = (live && voff[j] != 0xFFFFFFF0u) ? voff[j] + (uint32_t)(kt * (GK * 2)) : 0xFFFFFFF0u;
+      uint32_t off = (live && voff[j] != 0xFFFFFFF0u && kt * GK + kq[j] < KD) ? voff[j] + (uint32_t)(kt * (GK * 2)) : 0xFFFFFFF0u;
       asm volatile("" : "+v"(off));
       lds_void* dst = (lds_void*)(smem + buf * STAGE_B + bid * 1024);
       if (bid < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrd, dst, 16, off, 0, 0, 0);
@@ -229,21 +231,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   }
 }
 
-// TOK_GEMM256=1 turns the kernel on.  OFF by default — measured in round 4 against conv_igemm.hip's 128 x 128 kernel, per call in
+// TOK_GEMM256: 0 off, 1 (default) the layers listed in gemm256_serves, 2 every layer the kernel can run.  Measured in round 4 against conv_igemm.hip's 128 x 128 kernel, per call in
 // isolation (tools/ubench/g256_check.py; results bit-identical): in its K loop a stage costs 1.49 us here against 1.69 us for the
 // same work there (57 % of the MFMA rate), but a 256 x 256 tile carries ~11 us of fixed cost (first stage, 128-KB output tile,
 // one workgroup per CU: nothing overlaps prologue and epilogue) and the layers have 0.6-4 tiles per CU: +10-14 % on
 // M = 12 544, N >= 2304 or K = 3072 (SwinV2-T stage 4: 0.13 ms per step), -5..-60 % on K <= 512 or fewer than 150 tiles.
 int g256_flag() {
-  static const int v = [] { const char* e = getenv("TOK_GEMM256"); return (int)(e ? atoi(e) : 0); }();
+  static const int v = [] { const char* e = getenv("TOK_GEMM256"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
 int g256_min_k() {
   static const int v = [] { const char* e = getenv("TOK_GEMM256_MIN_K"); return (int)(e ? atoi(e) : 256); }();
-  return v;
-}
-long long g256_max_rows() {
-  static const long long v = [] { const char* e = getenv("TOK_GEMM256_MAX_ROWS"); return e ? atoll(e) : 60000ll; }();
   return v;
 }
 int g256_min_tiles() {
@@ -255,17 +253,22 @@ int g256_min_tiles() {
 
 // geometry / mode test: a pure function of the arguments, so that the statistics-row queries agree with the launch
 bool gemm256_serves(const ConvArgs& a) {
-  if (!g256_flag()) return false;
+  const int flag = g256_flag();
+  if (!flag) return false;
   if (!(a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.C != 4)) return false;
   if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.mask_store || a.sub != nullptr || a.fin_mode != 0) return false;
-  if (a.Ktot % GK != 0 || a.Ktot < g256_min_k() || a.K % 8 != 0 || a.K < 192) return false;
-  if (a.M < 4096 || a.M > g256_max_rows()) return false;      // the long-M layers are streaming problems: ring kernels
+  if (a.Ktot % 8 != 0 || a.K % 8 != 0 || a.K < 192 || a.M < 4096) return false;
   const long long tiles = (long long)tok_cdiv(a.M, GT) * tok_cdiv(a.K, GT);
-  if (tiles < g256_min_tiles()) return false;
   // a ragged last channel tile wastes its empty part: at most a quarter of the work
   const int nt = tok_cdiv(a.K, GT);
   if ((long long)nt * GT * 3 > (long long)a.K * 4) return false;
-  return true;
+  if (tiles < g256_min_tiles()) return false;
+  if (flag >= 2) return a.Ktot >= g256_min_k();      // TOK_GEMM256=2: every layer the kernel can run (tests, A/B)
+  // Default rule, decided on the STEP (same-box A/B, round 4): every pointwise layer with a reduction of 384 or more and at least
+  // 96 tiles.  In isolation the kernel only wins on the deepest / widest layers (see g256_flag); inside a step, where every kernel
+  // runs 1.3-1.8x slower than alone, its lower LDS and L2 -> LDS traffic per MFMA pays more widely: SwinV2-T 20.71 -> 20.33 ms,
+  // DaViT-T 22.07 -> 21.84, HRNet-W48 76.54 -> 76.13, ResNet-50 18.36 -> 18.22 (reduction >= 256: 18.24; >= 1024: 18.28).
+  return a.Ktot >= 384;
 }
 
 int gemm256_rows(const ConvArgs& a) { return tok_cdiv(a.M, GT); }
