@@ -1718,3 +1718,29 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_default_kernels():
         v = dict(re.findall(r'(y|s|dx|dxa|dxs|p) ([0-9.e+-]+)', l.split('new vs old')[1].split('y-vs-fp32')[0]))
         assert float(v['y']) == 0.0 and float(v['dx']) == 0.0 and float(v['dxa']) == 0.0 and float(v['dxs']) == 0.0, l
         assert float(v['s']) < 1e-5 and float(v['p']) < 1e-5, l
+
+
+def test_wgrad_256_tile_kernel_matches_the_128_tile_plan():
+    """conv_wgrad_ring8_kernel<256, 256> (eight waves; serves pointwise layers over >= 200 k pixels by default, every eligible layer
+    with TOK_WGRAD_256=2) against the 128 x 128 ring plan: dW, accumulated dW and the bias column sums agree to fp32 summation
+    order (different split-M partition), and with the fp32 product where the host can form it.  Subprocess arms: the knob is
+    read once per process (tools/ubench/wgrad256_check.py)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ubench', 'wgrad256_check.py')], capture_output=True, text=True,
+                         timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('M,Ktot,k=')]
+    assert len(lines) >= 12, out.stdout[-2000:]
+    ws_new = re.findall(r'\[new\].*workspace\s+([0-9.]+) MB', out.stdout)
+    ws_old = re.findall(r'\[old\].*workspace\s+([0-9.]+) MB', out.stdout)
+    assert ws_new and ws_new != ws_old              # other split-M plans: the two arms ran different kernels
+    for l in lines:
+        v = dict(re.findall(r'(dw|db|dwa) ([0-9.e+-]+)', l.split('new vs old')[1].split('db-vs-fp32')[0]))
+        assert float(v['dw']) < 5e-6 and float(v['db']) < 5e-6 and float(v['dwa']) < 5e-6, l
+        m = re.search(r'dW-vs-fp32 new ([0-9.e+-]+)', l)
+        if m:
+            assert float(m.group(1)) < 1e-5, l

@@ -509,6 +509,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(WgradArgs a) {
 }
 
 
+// ---- 256 x 256 tiles, eight waves (pointwise layers with wide outputs AND deep filters) ------------------------------------------
+// What bounds conv_wgrad_ring_kernel<128, 128> on the transformer and late-ResNet layers is the L2 -> LDS staging path: a
+// 128 x 128 tile stages (128 + 128) x 2 bytes per reduction row for 128 x 128 MACs, and every (n, k) tile of a layer stages ALL
+// M rows of its two operand slices again — SwinV2-T stage-3 fc2 (384 x 1536 weights, 50 176 tokens): 36 tiles x 25.7 MB =
+// 925 MB through a path that sustains ~10 TB/s chip-wide = the 93 us the launch takes (2.0 TB/s of HBM, MFMA util 0.23:
+// "neither bound", profiles/r03_*).  A 256 x 256 tile stages half the bytes per MAC.  Same ring (three 32-row stages, counted
+// vmcnt + raw barrier, transpose reads from row-major tiles) on 512 threads: waves 2 (n) x 4 (k), a wave owns 128 x 64 of the
+// tile = 32 accumulator blocks, 24 transpose reads per 32 MFMAs.  One workgroup per CU (96 KB of LDS, ~200 registers); the
+// split-M partial tiles are 256 KB each, so the plan aims at one workgroup per CU (256 slabs) — twice the partial-sum bytes of
+// the 128 x 128 plan, against half the staged bytes.
+template <int TN, int TK>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_ring8_kernel(WgradArgs a) {
+  constexpr int MS = 32, NST = 3, NTHR = 512;
+  constexpr int CN = TN / 8, CK = TK / 8;
+  constexpr int RPY = NTHR / CN, RPX = NTHR / CK;
+  constexpr int YP = MS / RPY, XP = MS / RPX;
+  static_assert(YP >= 1 && XP >= 1 && MS % RPY == 0 && MS % RPX == 0, "tile too narrow for 512 threads");
+  constexpr int LOADS = YP + XP;
+  constexpr int YS = TN * 2, XS = TK * 2;
+  constexpr int YBYTES = MS * YS, XBYTES = MS * XS, STAGE = YBYTES + XBYTES;
+  constexpr int SWY = (CN / 2 - 1) < (RPY - 1) ? (CN / 2 - 1) : (RPY - 1);
+  constexpr int SWX = (CK / 2 - 1) < (RPX - 1) ? (CK / 2 - 1) : (RPX - 1);
+  constexpr int NT = TN / 32, KTL = TK / 64;       // 16-wide blocks per wave: TN / 2 rows of n, TK / 4 columns of k
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wn2 = wv & 1, wk4 = wv >> 1;
+
+  const int ntile = a.tilesN * a.tilesK;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / a.tilesK;
+  const int tk = t - tn * a.tilesK;
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + MS - 1) / MS;
+
+  const int ycol = tid % CN, yrow = tid / CN;
+  const int xcol = tid % CK, xrow = tid / CK;
+  const int ylog = ycol ^ ((yrow & SWY) << 1);
+  const int xlog = xcol ^ ((xrow & SWX) << 1);
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int yn = tn * TN + ylog * 8;
+  const bool yn_ok = yn < a.K;
+  const int kc0 = tk * TK + xlog * 8;              // pointwise: the k column IS the input channel
+  const bool k_ok = kc0 < a.C;
+  int xm[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) xm[i] = mstart + xrow + i * RPX;
+  int ym = mstart + yrow;
+
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+  auto issue = [&](int dbuf) {
+    char* Ydst = smem + dbuf * STAGE + wave_u * 1024;
+    char* Xdst = smem + dbuf * STAGE + YBYTES + wave_u * 1024;
+#pragma unroll
+    for (int i = 0; i < YP; ++i) {
+      const int m = ym + i * RPY;
+      uint32_t off = (yn_ok && m < mend) ? (uint32_t)(m * a.K + yn) * 2u : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(Ydst + i * RPY * YS), 16, off, 0, 0, 0);
+    }
+    ym += MS;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      uint32_t off = (k_ok && xm[i] < mend) ? (uint32_t)(xm[i] * a.C + kc0) * 2u : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(Xdst + i * RPX * XS), 16, off, 0, 0, 0);
+      xm[i] += MS;
+    }
+  };
+
+  const int g = lane >> 4, li = lane & 15;
+  const int rrow = 4 * g + (li >> 2);
+  const int yswz = ((rrow & SWY) << 1) << 4, xswz = ((rrow & SWX) << 1) << 4;
+  auto ycolb = [&](int i) { return ((wn2 * (TN / 2) + i * 16 + (li & 3) * 4) * 2) ^ yswz; };
+  auto xcolb = [&](int j) { return ((wk4 * (TK / 4) + j * 16 + (li & 3) * 4) * 2) ^ xswz; };
+
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = a.cs != nullptr && tk == 0 && wk4 == 0;     // wave-uniform: bias gradient = dy^T 1 (see the ring kernel)
+  f32x4 csacc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) csacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16 one_b = (bf16)1.0f;
+  const bf16x8 ones = {one_b, one_b, one_b, one_b, one_b, one_b, one_b, one_b};
+
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
+  issue(0);
+  issue(1);
+  int cur = 0, nxt = 2;
+  for (int st = 0; st < steps; ++st) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(nxt);
+    const uint32_t Yb = lds_base + cur * STAGE;
+    const uint32_t Xb = Yb + YBYTES;
+    u32x2 ya[NT][2], xb[KTL][2];
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      xb[j][0] = tr_read_asm(Xb + rrow * XS + xcolb(j));
+      xb[j][1] = tr_read_asm(Xb + (rrow + 16) * XS + xcolb(j));
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      ya[i][0] = tr_read_asm(Yb + rrow * YS + ycolb(i));
+      ya[i][1] = tr_read_asm(Yb + (rrow + 16) * YS + ycolb(i));
+    }
+    // (24 transpose reads: the 4-bit lgkmcnt counter cannot count them all; the first 8 — every x fragment — are waited for
+    //  together with the first half of the dy fragments, then the rest)
+    bf16x8 af[NT], bfr[KTL];
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+    for (int i = 0; i < NT / 2; ++i) {
+      af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+      for (int j = 0; j < KTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = NT / 2; i < NT; ++i) {
+      af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+      for (int j = 0; j < KTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) csacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, csacc[i], 0, 0, 0);
+    }
+    cur = cur == NST - 1 ? 0 : cur + 1;
+    nxt = nxt == NST - 1 ? 0 : nxt + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (do_cs && li == 0) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
+        if (n < a.cs_cols) a.cs[(size_t)split * a.cs_stride + n] = csacc[i][r];
+      }
+  }
+  float* out = a.ws + (size_t)split * a.ws_stride;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      const int kcol = tk * TK + wk4 * (TK / 4) + j * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + wn2 * (TN / 2) + i * 16 + g * 4 + r;
+        if (n < a.K && kcol < a.Ktot) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+
 // ---- tap-stationary 3x3 variant --------------------------------------------------------------------------------------------
 // The two kernels above treat the nine taps as independent column tiles: every (tap, channel) tile stages the SAME dy rows
 // again, decomposes the SAME output pixels into (image, p, q) again, and a barrier round covers 16 MFMAs per wave — on the 3x3
@@ -1042,6 +1214,17 @@ Plan make_plan(const tok_conv_desc* d) {
     if (d->k <= 64) { p.TN = 64; p.TK = Ktot >= 256 ? 256 : (Ktot >= 128 ? 128 : 64); }
     else if (Ktot <= 64) { p.TK = 64; p.TN = d->k >= 256 ? 256 : 128; }
     else { p.TN = 128; p.TK = 128; }
+    // wide outputs AND deep filters over very many pixels: 256 x 256 tiles on eight waves (conv_wgrad_ring8_kernel: half the staged
+    // bytes per MAC) where the ragged edge tiles waste at most a third of the work.  Measured per call (tools/ubench/
+    // wgrad256_check.py, same dW to fp32 summation order): HRNet-W48's 720 x 720 neck convolution over 786 432 pixels 1829 ->
+    // 1479 us; on the 12 544 ... 50 176-pixel layers of ResNet-50 / SwinV2-T the 128 x 128 plan wins (99 vs 152 us at
+    // 384 x 1536: twice the partial-slab bytes, one workgroup per CU, a barrier per 32 MFMAs) — hence the pixel threshold.
+    // TOK_WGRAD_256=0 keeps the 128 x 128 plan everywhere, =2 lowers the threshold to 8192 pixels (A/B, tests).
+    static const int big = [] { const char* e = getenv("TOK_WGRAD_256"); return (int)(e ? atoi(e) : 1); }();
+    if (big && d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->k >= 256 && Ktot >= 256 && M >= (big >= 2 ? 8192 : 200000) &&
+        (long long)tok_cdiv(d->k, 256) * tok_cdiv(Ktot, 256) * 65536 * 2 <= (long long)d->k * Ktot * 3) {
+      p.TN = 256; p.TK = 256;
+    }
     p.tilesN = tok_cdiv(d->k, p.TN);
     p.tilesK = tok_cdiv(Ktot, p.TK);
     const int tiles = p.tilesN * p.tilesK;
@@ -1250,7 +1433,17 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
       hipLaunchKernelGGL((conv_wgrad_taps_kernel<0>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
     }
   } else if (p.ring) {
-    if (p.TN == 64 && p.TK == 64) launch_ring<64, 64>(a, st);
+    if (p.TN == 256 && p.TK == 256) {
+      constexpr int smem8 = 3 * 32 * (256 + 256) * 2;
+      static const bool attr8 = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ring8_kernel<256, 256>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem8);
+        return true;
+      }();
+      (void)attr8;
+      hipLaunchKernelGGL((conv_wgrad_ring8_kernel<256, 256>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(512), smem8, st, a);
+    }
+    else if (p.TN == 64 && p.TK == 64) launch_ring<64, 64>(a, st);
     else if (p.TN == 64 && p.TK == 128) launch_ring<64, 128>(a, st);
     else if (p.TN == 64 && p.TK == 256) launch_ring<64, 256>(a, st);
     else if (p.TN == 128 && p.TK == 64) launch_ring<128, 64>(a, st);
