@@ -245,7 +245,7 @@ int g256_min_k() {
   return v;
 }
 int g256_min_tiles() {
-  static const int v = [] { const char* e = getenv("TOK_GEMM256_MIN_TILES"); return (int)(e ? atoi(e) : 96); }();
+  static const int v = [] { const char* e = getenv("TOK_GEMM256_MIN_TILES"); return (int)(e ? atoi(e) : 128); }();
   return v;
 }
 
@@ -265,7 +265,7 @@ bool gemm256_serves(const ConvArgs& a) {
   if (tiles < g256_min_tiles()) return false;
   if (flag >= 2) return a.Ktot >= g256_min_k();      // TOK_GEMM256=2: every layer the kernel can run (tests, A/B)
   // Default rule, decided on the STEP (same-box A/B, round 4): every pointwise layer with a reduction of 384 or more and at least
-  // 96 tiles.  In isolation the kernel only wins on the deepest / widest layers (see g256_flag); inside a step, where every kernel
+  // 128 tiles (half a tile per CU: the 98-tile 2048 -> 512 layer of ResNet-50's last stage takes 55 us here against 35 us).  In isolation the kernel only wins on the deepest / widest layers (see g256_flag); inside a step, where every kernel
   // runs 1.3-1.8x slower than alone, its lower LDS and L2 -> LDS traffic per MFMA pays more widely: SwinV2-T 20.71 -> 20.33 ms,
   // DaViT-T 22.07 -> 21.84, HRNet-W48 76.54 -> 76.13, ResNet-50 18.36 -> 18.22 (reduction >= 256: 18.24; >= 1024: 18.28).
   return a.Ktot >= 384;
