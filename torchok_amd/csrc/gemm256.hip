@@ -61,9 +61,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   const int r = lane & 15, g = lane >> 4;
   const int wn = wave & 1, wm = wave >> 1;
 
-  const int id = tok_xcd_remap(blockIdx.x, gridDim.x);     // the channel tiles of one pixel tile share an XCD's L2
-  const int mt = id / a.gridN, nt = id - mt * a.gridN;
-  const int m0 = mt * GT, n0 = nt * GT;
+  const int ntiles = a.gridM * a.gridN;
   const int KD = a.Ktot;                                   // reduction length = row pitch of both operands (elements)
   const int KT = (KD + GK - 1) / GK;               // (KD % 8 == 0: a 16-byte chunk is inside or outside the row)
 
@@ -75,16 +73,24 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   int kq[NI];              // first reduction element of this lane's 16-byte chunk inside a stage (K tail: chunks past K are zeros)
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int bid = j * 8 + wave;
-    const int tb = bid & 31;
-    const int row = tb * 8 + (lane >> 3);
-    const int q = (lane & 7) ^ ((row & 3) | (((row >> 3) & 1) << 2));
-    kq[j] = q * 8;
-    const bool isw = bid < 32;
-    const int grow = (isw ? n0 : m0) + row;
-    const bool ok = grow < (isw ? a.K : a.M);
-    voff[j] = ok ? (uint32_t)(((long long)grow * KD + q * 8) * 2) : 0xFFFFFFF0u;
+    const int row = ((j * 8 + wave) & 31) * 8 + (lane >> 3);
+    kq[j] = ((lane & 7) ^ ((row & 3) | (((row >> 3) & 1) << 2))) * 8;
   }
+  // a workgroup walks tiles id, id + grid, ...; consecutive ids share a pixel tile (the channel tiles of one pixel tile on one XCD's L2)
+  auto setup = [&](int id, int& m0, int& n0) {
+    const int mt = id / a.gridN, nt = id - mt * a.gridN;
+    m0 = mt * GT;
+    n0 = nt * GT;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int bid = j * 8 + wave;
+      const int row = (bid & 31) * 8 + (lane >> 3);
+      const bool isw = bid < 32;
+      const int grow = (isw ? n0 : m0) + row;
+      const bool ok = grow < (isw ? a.K : a.M);
+      voff[j] = ok ? (uint32_t)(((long long)grow * KD + kq[j]) * 2) : 0xFFFFFFF0u;
+    }
+  };
   auto issue = [&](int kt, int buf, bool live) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -111,6 +117,18 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
     b_ch[kk] = (((uint32_t)(4 * kk + g)) ^ swx) << 4;
   }
 
+  // Persistent walk over the tiles.  Per tile, one barrier per K stage: wait for this wave's share of stage kt, barrier (everyone's
+  // share landed, nobody reads the other buffer any more), request stage kt + 1 into the other buffer, then two 32-deep steps of
+  // 12 fragment reads + 32 MFMAs; the two waves of a SIMD interleave their read and MFMA phases.  The first stage of the NEXT tile is
+  // requested before the epilogue of this one (its buffer is free since the barrier of the last stage: KT >= 2), so a tile's
+  // ~2 us of first-stage latency hide behind the previous tile's stores.  (Measured and not kept: fragment reads one step ahead
+  // of the MFMAs on a second register set with the DMA two stages ahead — 255 registers, 3-7 % slower on every shape.)
+  int tile = tok_xcd_remap(blockIdx.x, gridDim.x);
+  int m0, n0;
+  setup(tile, m0, n0);
+  int base = 0;
+  issue(0, base, tile < ntiles);
+  while (tile < ntiles) {
   f32x4 acc[4][2][4];
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -118,14 +136,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb) acc[p][b][mb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // One barrier per K stage: wait for this wave's share of stage kt, barrier (everyone's share landed, nobody reads the other
-  // buffer any more), request stage kt + 1 into the other buffer, then two 32-deep steps of 12 fragment reads + 32 MFMAs.  The two
-  // waves of a SIMD interleave their read and MFMA phases.  (Measured and not kept: fragment reads one step ahead of the MFMAs on
-  // a second register set with the DMA two stages ahead — 255 registers, 3-7 % SLOWER on every shape.)
-  issue(0, 0, KT > 0);
   for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
+    const int buf = (base + kt) & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(kt + 1, buf ^ 1, kt + 1 < KT);
@@ -151,7 +163,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
                                                                     __builtin_bit_cast(bf16x8, bfr[mb]), acc[p][b][mb], 0, 0, 0);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // next tile's first stage (the last stage's barrier freed the other buffer), then this tile's epilogue
+  const int cm0 = m0, cn0 = n0, cmt = m0 / GT;
+  const int next = tile + gridDim.x;
+  base = (base + KT) & 1;
+  if (next < ntiles) {
+    setup(next, m0, n0);
+    issue(0, base, true);
+  }
 
   // ---- epilogue: lane (r, g) holds channels n0 + wn*128 + 32 p + 8 g .. + 8 of pixel m0 + wm*64 + 16 mb + r ---------------------
   float s1[4][8], s2[4][8];
@@ -163,14 +182,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    const int n8 = n0 + wn * 128 + 32 * p + 8 * g;
+    const int n8 = cn0 + wn * 128 + 32 * p + 8 * g;
     const bool nok = n8 + 8 <= a.K;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = (a.bias != nullptr && nok) ? a.bias[n8 + e] : 0.f;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-      const int pix = m0 + wm * 64 + 16 * mb + r;
+      const int pix = cm0 + wm * 64 + 16 * mb + r;
       if (pix < a.M && nok) {
         const size_t off = (size_t)pix * a.K + n8;
         float v[8];
@@ -208,9 +227,9 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
     }
   }
   if constexpr (MODE != 0) {
-    // one partial row per pixel tile: 16 pixel-lanes folded by DPP, the four pixel-waves of a channel range through LDS
-    __syncthreads();                                   // the tile buffers are dead
-    float* red = reinterpret_cast<float*>(smem);       // [2][4 wm][256 n]
+    // one partial row per pixel tile: 16 pixel-lanes folded by DPP, the four pixel-waves of a channel range through LDS (a region
+    // behind the two stages: the next tile's first stage may be landing in them)
+    float* red = reinterpret_cast<float*>(smem + 2 * STAGE_B);       // [2][4 wm][256 n]
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -222,20 +241,21 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
           red[(1 * 4 + wm) * GT + nl] = t2;
         }
       }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     const int which = tid >> 8, c = tid & 255;
     const float t = red[(which * 4 + 0) * GT + c] + red[(which * 4 + 1) * GT + c] + red[(which * 4 + 2) * GT + c] +
                     red[(which * 4 + 3) * GT + c];
-    const int n = n0 + c;
-    if (n < a.K) a.stats[((size_t)which * a.stat_rows + mt) * a.K + n] = t;
+    const int n = cn0 + c;
+    if (n < a.K) a.stats[((size_t)which * a.stat_rows + cmt) * a.K + n] = t;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // red is free again before the next tile's epilogue writes it
   }
+  tile = next;
+  }   // tiles
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-// TOK_GEMM256: 0 off, 1 (default) the layers listed in gemm256_serves, 2 every layer the kernel can run.  Measured in round 4 against conv_igemm.hip's 128 x 128 kernel, per call in
-// isolation (tools/ubench/g256_check.py; results bit-identical): in its K loop a stage costs 1.49 us here against 1.69 us for the
-// same work there (57 % of the MFMA rate), but a 256 x 256 tile carries ~11 us of fixed cost (first stage, 128-KB output tile,
-// one workgroup per CU: nothing overlaps prologue and epilogue) and the layers have 0.6-4 tiles per CU: +10-14 % on
-// M = 12 544, N >= 2304 or K = 3072 (SwinV2-T stage 4: 0.13 ms per step), -5..-60 % on K <= 512 or fewer than 150 tiles.
 int g256_flag() {
   static const int v = [] { const char* e = getenv("TOK_GEMM256"); return (int)(e ? atoi(e) : 1); }();
   return v;
@@ -274,7 +294,7 @@ bool gemm256_serves(const ConvArgs& a) {
 int gemm256_rows(const ConvArgs& a) { return tok_cdiv(a.M, GT); }
 
 int gemm256_launch(ConvArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * STAGE_B;
+  constexpr int smem = 2 * STAGE_B + 2 * 4 * GT * 4;
   static const bool attr_set = [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -285,7 +305,8 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
   a.gridM = tok_cdiv(a.M, GT);
   a.gridN = tok_cdiv(a.K, GT);
   a.stat_rows = a.gridM;
-  const int grid = a.gridM * a.gridN;
+  const int tiles = a.gridM * a.gridN;
+  const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU, walking tiles
   if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
   else if (a.bn_y == nullptr) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(grid), dim3(512), smem, st, a);
   else hipLaunchKernelGGL(gemm256_kernel<2>, dim3(grid), dim3(512), smem, st, a);
