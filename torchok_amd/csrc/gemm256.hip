@@ -277,7 +277,9 @@ bool gemm256_serves(const ConvArgs& a) {
   if (!flag) return false;
   if (!(a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.C != 4)) return false;
   if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.mask_store || a.sub != nullptr || a.fin_mode != 0) return false;
-  if (a.Ktot % 8 != 0 || a.K % 8 != 0 || a.K < 192 || a.M < 4096) return false;
+  if (a.Ktot % 8 != 0 || a.K % 8 != 0 || a.Ktot <= GK) return false;      // (two stages at least: the next-tile prefetch relies on it)
+  if (flag >= 3) return true;                   // TOK_GEMM256=3: every layer the kernel can run at all (stress runs of the test suite)
+  if (a.K < 192 || a.M < 4096) return false;
   const long long tiles = (long long)tok_cdiv(a.M, GT) * tok_cdiv(a.K, GT);
   // a ragged last channel tile wastes its empty part: at most a quarter of the work
   const int nt = tok_cdiv(a.K, GT);
