@@ -1698,8 +1698,8 @@ def test_bn3_bwd_prepare(libs, p, k):
 
 def test_gemm256_tile_kernel_is_bit_identical_to_the_default_kernels():
     """csrc/gemm256.hip (256 x 256 tiles, eight waves; off by default, TOK_GEMM256=1) against the kernels that serve the same
-    pointwise layers by default: forward + batch statistics, data gradient fresh / accumulated / with BatchNorm-backward sums on
-    ResNet-50 layer-3/4 and SwinV2-T stage-3/4 shapes.  The knob is read once per process, so the two arms run as subprocesses
+    pointwise layers by default: forward + batch statistics, data gradient fresh / accumulated / with BatchNorm-backward sums / with the ReLU-masked
+    store on ResNet-50 layer-3/4 and SwinV2-T stage-3/4 shapes.  The knob is read once per process, so the two arms run as subprocesses
     (tools/ubench/g256_check.py) and the comparison is parsed from its report: outputs bit-identical, statistics to fp32 summation order."""
     import os
     import re
@@ -1715,9 +1715,9 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_default_kernels():
     rows_old = re.findall(r'\[old\].*rows (\d+)/(\d+)', out.stdout)
     assert rows_new and rows_new != rows_old          # the two arms really ran different kernels (other statistics rows)
     for l in lines:
-        v = dict(re.findall(r'(y|s|dx|dxa|dxs|p) ([0-9.e+-]+)', l.split('new vs old')[1].split('y-vs-fp32')[0]))
-        assert float(v['y']) == 0.0 and float(v['dx']) == 0.0 and float(v['dxa']) == 0.0 and float(v['dxs']) == 0.0, l
-        assert float(v['s']) < 1e-5 and float(v['p']) < 1e-5, l
+        v = dict(re.findall(r'\b(y|s|dxa|dxs|dxm|dx|pm|p) ([0-9.e+-]+)', l.split('new vs old')[1].split('y-vs-fp32')[0]))
+        assert all(float(v[n]) == 0.0 for n in ('y', 'dx', 'dxa', 'dxs', 'dxm')), l
+        assert float(v['s']) < 1e-5 and float(v['p']) < 1e-5 and float(v['pm']) < 1e-5, l
 
 
 def test_wgrad_256_tile_kernel_matches_the_128_tile_plan():

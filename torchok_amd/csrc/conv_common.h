@@ -80,6 +80,8 @@ void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN);
 int conv_win_launch(ConvArgs& a, hipStream_t st);            // fills a.gridM / a.gridN / a.stat_rows itself
 
 // gemm256.hip: pointwise layers with a deep reduction and a mid-sized pixel count on 256 x 256 tiles (8 waves)
-bool gemm256_serves(const ConvArgs& a);                      // geometry / mode test (pure function of the arguments)
-int gemm256_rows(const ConvArgs& a);                         // statistics rows = pixel tiles
+bool gemm256_geometry(const ConvArgs& a);                    // does the kernel own this layer (pure function of the geometry)
+bool gemm256_modes(const ConvArgs& a);                       // ... and carry this epilogue mode
+bool gemm256_serves(const ConvArgs& a);                      // both
+int gemm256_rows(const ConvArgs& a);                         // statistics rows = pixel tiles, rounded up to a multiple of 8 (pad rows are zero)
 int gemm256_launch(ConvArgs& a, hipStream_t st);             // fills a.gridM / a.gridN / a.stat_rows itself

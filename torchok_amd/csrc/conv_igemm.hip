@@ -847,6 +847,12 @@ static bool pw_serves(int bn_tile, long long rows, int c_red, int n_out) {
   return pw_ring_enabled() && bn_tile == 64 && rows >= pw_min_rows() && c_red % 8 == 0 && n_out % 64 == 0;
 }
 
+// 256 x 256 tiles (gemm256.hip) — decided on the GEOMETRY alone, and behind the pointwise ring, so that the statistics-row
+// queries (which know the descriptor, not the epilogue mode) and every launch agree on who owns a layer
+static bool g256_owns(const ConvArgs& a, int bn_tile) {
+  return gemm256_geometry(a) && !pw_serves(bn_tile, a.M, a.Ktot, a.K);
+}
+
 template <int BM, int BN, int IN_DIV, bool C4>
 int launch(ConvArgs& a, hipStream_t st) {
   if constexpr (IN_DIV == 1 && !C4) {
@@ -954,7 +960,7 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
       conv_win_tiles(g, &gm, &gn);
       return conv_win_grid(gm, gn) / gn;
     }
-    if (gemm256_serves(g)) return gemm256_rows(g);
+    if (g256_owns(g, bn_tile)) return gemm256_rows(g);
     if (bn_tile == 128 && conv_ring_serves(g, false))
       return conv_ring_grid(tok_cdiv(g.M, 256), tok_cdiv(d->k, 128)) / tok_cdiv(d->k, 128);
   }
@@ -1031,13 +1037,16 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
     TOK_CHECK_LAUNCH("tok_conv_fwd");
     return TOK_OK;
   }
-  if (!c4 && ep == nullptr && gemm256_serves(a)) {
+  const bool g256 = !c4 && g256_owns(a, bn_pick);
+  if (g256 && gemm256_modes(a)) {
     // deep-K pointwise layers with a mid-sized pixel count: 256 x 256 tiles, eight waves (gemm256.hip)
     rc = gemm256_launch(a, st);
     if (rc) return rc;
     TOK_CHECK_LAUNCH("tok_conv_fwd");
     return TOK_OK;
   }
+  // (a mode gemm256 does not carry that still writes statistics rows: this file's kernel on gemm256's row count — a multiple of 8)
+  if (g256 && a.stats != nullptr && a.fin_mode == 0) a.force_grid = gemm256_rows(a) * tok_cdiv(d->k, ep != nullptr ? 64 : bn_pick);
   if (!c4 && ep == nullptr && bn_pick == 128 && conv_ring_serves(a, false)) {
     // deep-K layers: 256 x 128 tiles on the three-stage DMA ring (conv_ring.hip)
     a.gridM = tok_cdiv(a.M, 256);
@@ -1137,7 +1146,8 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
   }
-  if (d->stride == 1 && gemm256_serves(a)) {
+  const bool g256 = d->stride == 1 && g256_owns(a, pl.bn_tile);
+  if (g256 && gemm256_modes(a)) {
     rc = gemm256_launch(a, st);
     if (rc) return rc;
     TOK_CHECK_LAUNCH(who);
@@ -1151,6 +1161,7 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
   }
+  if (g256 && a.stats != nullptr && a.fin_mode == 0) a.force_grid = gemm256_rows(a) * pl.gridN;   // (see conv_fwd_impl)
   if (a.fin_mode != 0) {
     const int rows_q = tok_conv_dgrad_stat_rows(d);
     if (rows_q > 0 && rows_q * pl.gridN < plan_grid(pl.bn_tile, pl.gridM, pl.gridN)) a.force_grid = rows_q * pl.gridN;
@@ -1191,7 +1202,7 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
     conv_win_tiles(a, &gm, &gn);
     return conv_win_grid(gm, gn) / gn;
   }
-  if (d->stride == 1 && gemm256_serves(a)) return gemm256_rows(a);
+  if (d->stride == 1 && g256_owns(a, pl.bn_tile)) return gemm256_rows(a);
   if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false))
     return conv_ring_grid(tok_cdiv(a.M, 256), tok_cdiv(d->c, 128)) / tok_cdiv(d->c, 128);
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c))

@@ -50,7 +50,8 @@ __device__ __forceinline__ float row16_sum_f(float v) {
   return v;
 }
 
-// MODE 0: plain (bias, accumulate); 1: + batch statistics of the stored output; 2: + BatchNorm-backward sums (bn_y, bn_mask)
+// MODE 0: plain (bias, accumulate); 1: + batch statistics of the stored output; 2: + BatchNorm-backward sums (bn_y, bn_mask);
+// 3: dz = relu_mask ? dx : 0 is what gets stored, and sum(dz) goes to the statistics rows (tok_conv_dgrad_maskstore)
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,6 +204,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
+        if constexpr (MODE == 3) {
+          const unsigned bits = (unsigned)a.bn_mask[off >> 3];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
+            s1[p][e] += bf2f(o[e]);
+          }
+        }
         stg16(a.y + off, o);
         if constexpr (MODE == 1) {
           // batch statistics of the bf16 output as stored (what bn_act_fwd normalises; conv_igemm.hip's rounding point)
@@ -248,6 +257,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
                     red[(which * 4 + 3) * GT + c];
     const int n = cn0 + c;
     if (n < a.K) a.stats[((size_t)which * a.stat_rows + cmt) * a.K + n] = t;
+    if (cmt == a.gridM - 1 && n < a.K)                  // the pad rows behind the last pixel tile
+      for (int rr = a.gridM; rr < a.stat_rows; ++rr) a.stats[((size_t)which * a.stat_rows + rr) * a.K + n] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // red is free again before the next tile's epilogue writes it
   }
@@ -271,12 +282,20 @@ int g256_min_tiles() {
 
 }  // namespace
 
-// geometry / mode test: a pure function of the arguments, so that the statistics-row queries agree with the launch
-bool gemm256_serves(const ConvArgs& a) {
+// Two tests.  GEOMETRY (a pure function of the layer) is what the statistics-row queries see — they know the descriptor, not the
+// epilogue mode — so every mode that writes statistics rows must be served whenever the geometry is (plain, BatchNorm forward /
+// backward sums, mask-store: all here); the modes below carry no rows (or, fused finalize, fold their own) and fall back freely.
+bool gemm256_modes(const ConvArgs& a) {
+  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
+  if (a.mask_store && (a.bn_mask == nullptr || a.stats == nullptr)) return false;
+  return true;
+}
+bool gemm256_serves(const ConvArgs& a) { return gemm256_geometry(a) && gemm256_modes(a); }
+
+bool gemm256_geometry(const ConvArgs& a) {
   const int flag = g256_flag();
   if (!flag) return false;
   if (!(a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && a.C != 4)) return false;
-  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.mask_store || a.sub != nullptr || a.fin_mode != 0) return false;
   if (a.Ktot % 8 != 0 || a.K % 8 != 0 || a.Ktot <= GK) return false;      // (two stages at least: the next-tile prefetch relies on it)
   if (flag >= 3) return true;                   // TOK_GEMM256=3: every layer the kernel can run at all (stress runs of the test suite)
   if (a.K < 192 || a.M < 4096) return false;
@@ -293,7 +312,8 @@ bool gemm256_serves(const ConvArgs& a) {
   return a.Ktot >= 384;
 }
 
-int gemm256_rows(const ConvArgs& a) { return tok_cdiv(a.M, GT); }
+// (a multiple of 8: conv_igemm.hip's kernels, which take over for the modes this one does not carry, run grids of 8 * gridN)
+int gemm256_rows(const ConvArgs& a) { return (tok_cdiv(a.M, GT) + 7) / 8 * 8; }
 
 int gemm256_launch(ConvArgs& a, hipStream_t st) {
   constexpr int smem = 2 * STAGE_B + 2 * 4 * GT * 4;
@@ -301,15 +321,17 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     return true;
   }();
   (void)attr_set;
   a.gridM = tok_cdiv(a.M, GT);
   a.gridN = tok_cdiv(a.K, GT);
-  a.stat_rows = a.gridM;
+  a.stat_rows = gemm256_rows(a);
   const int tiles = a.gridM * a.gridN;
   const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU, walking tiles
-  if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
+  if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
+  else if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
   else if (a.bn_y == nullptr) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(grid), dim3(512), smem, st, a);
   else hipLaunchKernelGGL(gemm256_kernel<2>, dim3(grid), dim3(512), smem, st, a);
   return 0;
