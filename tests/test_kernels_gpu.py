@@ -1715,8 +1715,8 @@ def test_gemm256_tile_kernel_is_bit_identical_to_the_default_kernels():
     rows_old = re.findall(r'\[old\].*rows (\d+)/(\d+)', out.stdout)
     assert rows_new and rows_new != rows_old          # the two arms really ran different kernels (other statistics rows)
     for l in lines:
-        v = dict(re.findall(r'\b(y|s|dxa|dxs|dxm|dx|pm|p) ([0-9.e+-]+)', l.split('new vs old')[1].split('y-vs-fp32')[0]))
-        assert all(float(v[n]) == 0.0 for n in ('y', 'dx', 'dxa', 'dxs', 'dxm')), l
+        v = dict(re.findall(r'\b(yact|ya|y|s|dxa|dxs|dxm|dxg|dx|pm|p) ([0-9.e+-]+)', l.split('new vs old')[1].split('y-vs-fp32')[0]))
+        assert all(float(v[n]) == 0.0 for n in ('y', 'dx', 'dxa', 'dxs', 'dxm', 'ya', 'yact', 'dxg')), l
         assert float(v['s']) < 1e-5 and float(v['p']) < 1e-5 and float(v['pm']) < 1e-5, l
 
 

@@ -53,14 +53,19 @@ def run(tag):
         mask = torch.randint(0, 256, (m, k // 8), device='cuda', generator=g, dtype=torch.uint8)
         dxs = torch.empty(m, k, dtype=BF, device='cuda')
         assert lib.tok_conv_dgrad_bnstats(d, P(dy), P(wd), P(dxs), 0, P(bny), P(mask), P(part), st) == 0, lib.tok_last_error()
+        bias = torch.randn(n, device='cuda', generator=g)
+        ya, yact = torch.empty(m, n, dtype=BF, device='cuda'), torch.empty(m, n, dtype=BF, device='cuda')     # fc1 + GELU
+        tfa = timeit(lambda: lib.tok_conv_fwd_act(d, P(x), P(w), P(bias), P(ya), P(yact), 1, st), 5)
+        dxg = torch.empty(m, k, dtype=BF, device='cuda')                                                       # fc2's dgrad * GELU'
+        tda = timeit(lambda: lib.tok_conv_dgrad_act(d, P(dy), P(wd), P(bny), 1, P(dxg), st), 5)
         partm = torch.zeros(2, rows_d, k, device='cuda')
         dxm = base.clone()                            # mask-store on top of an accumulated gradient (the residual unit's use)
         assert lib.tok_conv_dgrad_maskstore(d, P(dy), P(wd), P(dxm), 1, P(mask), P(partm), st) == 0, lib.tok_last_error()
         torch.cuda.synchronize()
         fl = 2.0 * m * k * n
-        print(f'[{tag}] M={m} K={k} N={n}: fwd+stats {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF/s)  dgrad {td:6.1f} us ({fl / td / 1e6:5.0f} TF/s)  rows {rows}/{rows_d}', flush=True)
+        print(f'[{tag}] M={m} K={k} N={n}: fwd+stats {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF/s)  dgrad {td:6.1f} us ({fl / td / 1e6:5.0f} TF/s)  fwd+gelu {tfa:6.1f} us  dgrad*gelu' {tda:6.1f} us  rows {rows}/{rows_d}', flush=True)
         out[(m, k, n)] = dict(y=y.float().cpu(), s=stats.sum(1).cpu(), dx=dx.float().cpu(), dxa=dxa.float().cpu(), dxs=dxs.float().cpu(),
-                              p=part.sum(1).cpu(), dxm=dxm.float().cpu(), pm=partm.sum(1).cpu(), ref_y=(x.float() @ w.float().t()).cpu() if m * n < 1.2e8 else None)
+                              p=part.sum(1).cpu(), dxm=dxm.float().cpu(), pm=partm.sum(1).cpu(), ya=ya.float().cpu(), yact=yact.float().cpu(), dxg=dxg.float().cpu(), ref_y=(x.float() @ w.float().t()).cpu() if m * n < 1.2e8 else None)
     torch.save(out, f'/tmp/g256_{tag}.pt')
 
 
@@ -76,6 +81,6 @@ if __name__ == '__main__':
         return float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30))
     for key in a:
         ra, rb = a[key], b[key]
-        line = ' '.join(f'{nm} {rel(ra[nm], rb[nm]):.1e}' for nm in ('y', 's', 'dx', 'dxa', 'dxs', 'p', 'dxm', 'pm'))
+        line = ' '.join(f'{nm} {rel(ra[nm], rb[nm]):.1e}' for nm in ('y', 's', 'dx', 'dxa', 'dxs', 'p', 'dxm', 'pm', 'ya', 'yact', 'dxg'))
         ref = f" y-vs-fp32 new {rel(ra['y'], ra['ref_y']):.1e} old {rel(rb['y'], rb['ref_y']):.1e}" if ra['ref_y'] is not None else ''
         print(f'M,K,N={key}: new vs old  {line}{ref}')

@@ -51,7 +51,8 @@ __device__ __forceinline__ float row16_sum_f(float v) {
 }
 
 // MODE 0: plain (bias, accumulate); 1: + batch statistics of the stored output; 2: + BatchNorm-backward sums (bn_y, bn_mask);
-// 3: dz = relu_mask ? dx : 0 is what gets stored, and sum(dz) goes to the statistics rows (tok_conv_dgrad_maskstore)
+// 3: dz = relu_mask ? dx : 0 is what gets stored, and sum(dz) goes to the statistics rows (tok_conv_dgrad_maskstore);
+// 4: fused activation (tok_conv_fwd_act's second output / tok_conv_dgrad_act's derivative factor), no statistics
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,6 +213,28 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
             s1[p][e] += bf2f(o[e]);
           }
         }
+        if constexpr (MODE == 4) {
+          // fused activation, conv_igemm.hip's arithmetic on the bf16-rounded GEMM result (bit-identical to the unfused launches):
+          // backward, o *= act'(act_x); forward, a second output y2 = act(o)
+          if (a.act_x != nullptr) {
+            const bf16x8 hx = ldg16(a.act_x + off);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = bf2f(hx[e]);
+              const float dd = a.act == 0 ? (f > 0.f ? 1.f : 0.f) : gelu_d(f);
+              o[e] = f2bf(bf2f(o[e]) * dd);
+            }
+          }
+          if (a.y2 != nullptr) {
+            bf16x8 o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = bf2f(o[e]);
+              o2[e] = f2bf(a.act == 0 ? fmaxf(f, 0.f) : gelu_f(f));
+            }
+            stg16(a.y2 + off, o2);
+          }
+        }
         stg16(a.y + off, o);
         if constexpr (MODE == 1) {
           // batch statistics of the bf16 output as stored (what bn_act_fwd normalises; conv_igemm.hip's rounding point)
@@ -284,10 +307,14 @@ int g256_min_tiles() {
 
 // Two tests.  GEOMETRY (a pure function of the layer) is what the statistics-row queries see — they know the descriptor, not the
 // epilogue mode — so every mode that writes statistics rows must be served whenever the geometry is (plain, BatchNorm forward /
-// backward sums, mask-store: all here); the modes below carry no rows (or, fused finalize, fold their own) and fall back freely.
+// backward sums, mask-store: all here; fused activation has no rows); the modes below carry no rows (or, fused finalize, fold their own) and fall back freely.
 bool gemm256_modes(const ConvArgs& a) {
-  if (a.y2 != nullptr || a.act_x != nullptr || a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
+  if (a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
   if (a.mask_store && (a.bn_mask == nullptr || a.stats == nullptr)) return false;
+  if (a.y2 != nullptr || a.act_x != nullptr) {
+    static const int act_on = [] { const char* e = getenv("TOK_GEMM256_ACT"); return (int)(e ? atoi(e) : 1); }();   // TOK_GEMM256_ACT=0: fused-activation layers stay on conv_igemm.hip (A/B)
+    if (!act_on || a.stats != nullptr || a.mask_store) return false;
+  }
   return true;
 }
 bool gemm256_serves(const ConvArgs& a) { return gemm256_geometry(a) && gemm256_modes(a); }
@@ -322,6 +349,7 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     return true;
   }();
   (void)attr_set;
@@ -330,7 +358,8 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
   a.stat_rows = gemm256_rows(a);
   const int tiles = a.gridM * a.gridN;
   const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU, walking tiles
-  if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
+  if (a.y2 != nullptr || a.act_x != nullptr) hipLaunchKernelGGL(gemm256_kernel<4>, dim3(grid), dim3(512), smem, st, a);
+  else if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
   else if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
   else if (a.bn_y == nullptr) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(grid), dim3(512), smem, st, a);
   else hipLaunchKernelGGL(gemm256_kernel<2>, dim3(grid), dim3(512), smem, st, a);

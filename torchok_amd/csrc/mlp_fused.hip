@@ -504,6 +504,10 @@ int mlp_min_rows() {   // below this the serial chain of hidden chunks of one ti
   static const int v = [] { const char* e = getenv("TOK_MLP_MIN_ROWS"); return (int)(e ? atoi(e) : 32768); }();
   return v;
 }
+int mlp_max_c() {   // TOK_MLP_MAX_C=<c>: widths above c stay on the two GEMM launches (A/B switch per stage)
+  static const int v = [] { const char* e = getenv("TOK_MLP_MAX_C"); return (int)(e ? atoi(e) : 384); }();
+  return v;
+}
 int mlp_flag() {   // TOK_MLP_FUSED=0: the MLP stays on the two GEMM launches (A/B switch)
   static const int v = [] { const char* e = getenv("TOK_MLP_FUSED"); return (int)(e ? atoi(e) : 1); }();
   return v;
@@ -513,7 +517,7 @@ int mlp_flag() {   // TOK_MLP_FUSED=0: the MLP stays on the two GEMM launches (A
 
 extern "C" int tok_mlp_serves(int64_t rows, int c, int hidden) {
   if (!mlp_flag()) return 0;
-  if (!(c == 96 || c == 192 || c == 384)) return 0;
+  if (!(c == 96 || c == 192 || c == 384) || c > mlp_max_c()) return 0;
   if (hidden != 4 * c) return 0;
   if (rows < mlp_min_rows() || rows <= 0 || rows * (long long)hidden * 2 >= (1ll << 32)) return 0;
   return 1;
