@@ -63,7 +63,7 @@ def run(tag):
         assert lib.tok_conv_dgrad_maskstore(d, P(dy), P(wd), P(dxm), 1, P(mask), P(partm), st) == 0, lib.tok_last_error()
         torch.cuda.synchronize()
         fl = 2.0 * m * k * n
-        print(f'[{tag}] M={m} K={k} N={n}: fwd+stats {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF/s)  dgrad {td:6.1f} us ({fl / td / 1e6:5.0f} TF/s)  fwd+gelu {tfa:6.1f} us  dgrad*gelu' {tda:6.1f} us  rows {rows}/{rows_d}', flush=True)
+        print(f'[{tag}] M={m} K={k} N={n}: fwd+stats {tf:6.1f} us ({fl / tf / 1e6:5.0f} TF/s)  dgrad {td:6.1f} us ({fl / td / 1e6:5.0f} TF/s)  fwd+gelu {tfa:6.1f} us  dgrad*dgelu {tda:6.1f} us  rows {rows}/{rows_d}', flush=True)
         out[(m, k, n)] = dict(y=y.float().cpu(), s=stats.sum(1).cpu(), dx=dx.float().cpu(), dxa=dxa.float().cpu(), dxs=dxs.float().cpu(),
                               p=part.sum(1).cpu(), dxm=dxm.float().cpu(), pm=partm.sum(1).cpu(), ya=ya.float().cpu(), yact=yact.float().cpu(), dxg=dxg.float().cpu(), ref_y=(x.float() @ w.float().t()).cpu() if m * n < 1.2e8 else None)
     torch.save(out, f'/tmp/g256_{tag}.pt')

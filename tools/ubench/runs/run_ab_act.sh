@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out/ab_act
-( timeout 900 python tools/ubench/g256_check.py ) > gpurun_out/ab_act/g256_check.txt 2>&1; echo "g256_check rc=$?"
+echo skip check
 SW="--backbone swinv2_custom --steps 30 --warmup 10 --no-cpu-baseline --no-secondary"
 for rep in 1 2; do
 for cfg in "base:TOK_GEMM256_ACT=0" "act:TOK_GEMM256_ACT=1" "s3unfused:TOK_MLP_MAX_C=192" "s23unfused:TOK_MLP_MAX_C=96" ; do
@@ -24,5 +24,5 @@ try:
 except Exception as e: print('davit ${name} failed', e)
 PY
 done
-grep "M,K,N" gpurun_out/ab_act/g256_check.txt | head -20
-grep "\[new\]" gpurun_out/ab_act/g256_check.txt | head -20
+
+

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
 
   // ---- epilogue: lane (r, g) holds channels n0 + wn*128 + 32 p + 8 g .. + 8 of pixel m0 + wm*64 + 16 mb + r ---------------------
   float s1[4][8], s2[4][8];
-  if constexpr (MODE != 0) {
+  if constexpr (MODE >= 1 && MODE <= 3) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
       }
     }
   }
-  if constexpr (MODE != 0) {
+  if constexpr (MODE >= 1 && MODE <= 3) {
     // one partial row per pixel tile: 16 pixel-lanes folded by DPP, the four pixel-waves of a channel range through LDS (a region
     // behind the two stages: the next tile's first stage may be landing in them)
     float* red = reinterpret_cast<float*>(smem + 2 * STAGE_B);       // [2][4 wm][256 n]
@@ -312,7 +312,7 @@ bool gemm256_modes(const ConvArgs& a) {
   if (a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
   if (a.mask_store && (a.bn_mask == nullptr || a.stats == nullptr)) return false;
   if (a.y2 != nullptr || a.act_x != nullptr) {
-    static const int act_on = [] { const char* e = getenv("TOK_GEMM256_ACT"); return (int)(e ? atoi(e) : 1); }();   // TOK_GEMM256_ACT=0: fused-activation layers stay on conv_igemm.hip (A/B)
+    static const int act_on = [] { const char* e = getenv("TOK_GEMM256_ACT"); return (int)(e ? atoi(e) : 0); }();   // TOK_GEMM256_ACT=1: fused-activation layers too (bit-identical; per call 105 vs 122 us on SwinV2-T stage 4 fc1, but the STEP is 0.06 ms slower with it — SwinV2-T 20.41 vs 20.35, DaViT-T 21.71 vs 21.53 — so off by default)
     if (!act_on || a.stats != nullptr || a.mask_store) return false;
   }
   return true;
