@@ -74,7 +74,7 @@ if __name__ == '__main__':
         run(sys.argv[1])
         sys.exit(0)
     for tag, v in (('new', '2'), ('old', '0')):
-        subprocess.run([sys.executable, __file__, tag], env=dict(os.environ, TOK_GEMM256=v), check=True)
+        subprocess.run([sys.executable, __file__, tag], env=dict(os.environ, TOK_GEMM256=v, TOK_GEMM256_ACT='1'), check=True)    # (fused activation on the 256 tiles is off by default: switched on for the comparison)
     a, b = torch.load('/tmp/g256_new.pt'), torch.load('/tmp/g256_old.pt')
 
     def rel(u, v):
