@@ -584,6 +584,12 @@ size_t tok_mlp_bwd_dw_ws_bytes(int64_t rows, int c, int hidden);
 int tok_mlp_bwd_dw(const void* x, const void* dy, const void* w1, const float* b1, const void* w2_dgrad, float* dw1,
                    int acc_w1, float* db1, int acc_b1, float* dw2, int acc_w2, float* db2, int acc_b2, void* workspace,
                    size_t ws_bytes, int64_t rows, int c, int hidden, void* stream);
+/* 1 when the library was compiled with -DTOK_BUILD_EXPERIMENTS (__graft_entry__.build() under TOK_BUILD_EXPERIMENTS=1): the
+ * measured-negative kernels — tok_mlp_bwd_dw (csrc/mlp_dw.hip), the 256 x 128 ring convolution (csrc/conv_ring.hip,
+ * TOK_CONV_RING=1) and the fused-activation mode of the 256 x 256 tile kernel (TOK_GEMM256_ACT=1) — are then present.  The
+ * default library does not contain them: tok_mlp_bwd_dw_ws_bytes answers 0 and tok_mlp_bwd_dw fails with an error string.
+ * No reference counterpart (a build property).                                                                          */
+int tok_built_with_experiments(void);
 
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:

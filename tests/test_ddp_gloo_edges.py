@@ -38,14 +38,15 @@ def _worker(rank, world, port, tmp):
     u = torch.nn.Parameter(torch.tensor([3.0]))           # used nowhere
     params = list(task.parameters()) + [q, r, u]
     opt = T.OPTIMIZERS.get('SGD')(params, lr=0.1, momentum=0.9)
-    red = GradientAllReducer(opt, bucket_bytes=4 << 20, module=task, find_unused_parameters=True)
+    red = GradientAllReducer(opt, bucket_bytes=4 << 20, module=task, find_unused_parameters=True,
+                             static_unused_pattern=True)      # the opt-in: host read only when the local pattern changes
     g = torch.Generator().manual_seed(200 + rank)
     x, y = torch.randn(4, 3, 32, 32, generator=g), torch.randint(0, 10, (4,), generator=g)
 
-    def step(i, reducer):
+    def step(i, reducer, use_r=True):
         out = task.training_step({'image': x, 'target': y}, i)
         loss = out['loss'] + (q * torch.tensor([1.0 + rank, 2.0])).sum()
-        if rank == 1:
+        if rank == 1 and use_r:
             loss = loss + 4.0 * r.sum()
         opt.zero_grad()
         reducer.begin_step()
@@ -96,21 +97,37 @@ def _worker(rank, world, port, tmp):
     dist.all_gather(both, flat)
     assert torch.equal(both[0], both[1])
     # a change on the OTHER rank that this rank cannot see (rank 1 stops using `r`; rank 0 never had a gradient for it) is
-    # caught by the device-side comparison and reported by the next finish_step on the rank whose cache was stale; rank 1
-    # saw its own pattern change and re-read the map
-    out = task.training_step({'image': x, 'target': y}, 20)
-    loss = out['loss'] + (q * torch.tensor([1.0 + rank, 2.0])).sum()
-    opt.zero_grad()
-    red.begin_step()
-    loss.backward()
-    red.finish_step()
-    if rank == 0:
-        with pytest.raises(RuntimeError, match='static_unused_pattern'):
-            red._poll_late_check()
-    else:
+    # caught by the device-side comparison on rank 0; the verdict is MAX-reduced over the ranks, so BOTH ranks raise in the
+    # next finish_step — together, before either launches a collective (with a per-rank verdict rank 0 raised
+    # while rank 1 waited inside all_reduce)
+    step(20, red, use_r=False)
+    with pytest.raises(RuntimeError, match='static_unused_pattern'):
         red._poll_late_check()
-        assert r.grad is None          # unused everywhere now
     dist.barrier()
+    red.close()
+
+    # the DEFAULT (static_unused_pattern=False, torch DDP's per-step host read) follows a pattern that changes on the other
+    # rank only: no error, `r` gets the averaged update while rank 1 uses it and grad None on both ranks once it does not
+    snap_dyn = [p.detach().clone() for p in params]
+    dyn = GradientAllReducer(opt, bucket_bytes=4 << 20, broadcast_params=False, find_unused_parameters=True)
+    assert dyn.static_unused is False
+    for i, use_r in enumerate((True, False, True, False, False)):
+        step(30 + i, dyn, use_r=use_r)
+        if use_r:
+            assert r.grad is not None and torch.allclose(r.grad, torch.tensor([2.0])), (rank, i)
+        else:
+            assert r.grad is None, (rank, i)
+        assert u.grad is None
+        opt.step()
+        flat = torch.cat([p.detach().flatten() for p in params])
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), i
+    dyn.close()
+    with torch.no_grad():
+        for p, sn in zip(params, snap_dyn):
+            p.copy_(sn)
+    red = GradientAllReducer(opt, bucket_bytes=4 << 20, module=task, find_unused_parameters=True)
 
     # bf16 buckets: same step from the same state, compared with the fp32 exchange
     red.close()

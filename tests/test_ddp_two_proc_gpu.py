@@ -4,7 +4,10 @@ constructor/runner.py:18, and BaseTask.on_train_batch_end, tasks/base.py:163-173
 RCCL needs two devices, but torch's gloo backend all-reduces device tensors (staged through the host), so two processes
 that share `cuda:0` exercise everything of the N > 1 path except the wire: the HIP kernels, gradients arriving from the
 engine's side stream, the bucket events, the comm stream, the flat buffer broadcast, the asynchronous loss mean and — for
-the transformer backbone — `find_unused_parameters` with its cached used-map.  Checked per model:
+the transformer backbone — `find_unused_parameters` with its cached used-map (`static_unused_pattern=True`).  Cases: ResNet-18
+(BatchNorm, strict mode, fp32 payload), a small SwinV2, ResNet-18 with the bf16 gradient payload (`grad_dtype='bf16'`), and
+the HRNet segmentation task, whose backward writes into the buckets from the branch streams (the case the reducer's
+per-bucket stream list exists for).  Checked per model:
 
  * the exchanged gradient equals the mean of the two ranks' local gradients (local BatchNorm statistics),
  * after three shared `train_step`s parameters AND buffers are bit-identical on both ranks,
@@ -71,8 +74,12 @@ def _worker(rank, world, port, tmp):
     dev = 'cuda:0'
 
     def build(backbone, seed, optimizer, opt_params, **bk):
-        cfg = cls_config(backbone, 10, optimizer=optimizer, opt_params=opt_params, backbone_params=bk or None,
-                         inputs_shape=(3, 64, 64))
+        if backbone.startswith('hrnet'):
+            from test_hrnet import seg_config
+            cfg = seg_config(backbone, classes=5, size=64)
+        else:
+            cfg = cls_config(backbone, 10, optimizer=optimizer, opt_params=opt_params, backbone_params=bk or None,
+                             inputs_shape=(3, 64, 64))
         task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params)
         sd = deterministic_state({k: v for k, v in task.state_dict().items() if not k.startswith('input_tensors')},
                                  seed + 100 * rank)
@@ -80,18 +87,24 @@ def _worker(rank, world, port, tmp):
         return task.to(dev).train()
 
     cases = [
-        ('resnet18', dict(), 'SGD', {'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4}, False),
+        ('resnet18', dict(), 'SGD', {'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4}, False, 'fp32'),
         ('swinv2_custom', dict(img_size=64, window_size=4, depths=[2, 2, 2, 2], drop_path_rate=0.0), 'AdamW',
-         {'lr': 1e-3, 'weight_decay': 0.05}, True),
+         {'lr': 1e-3, 'weight_decay': 0.05}, True, 'fp32'),
+        ('resnet18', dict(), 'SGD', {'lr': 0.05, 'momentum': 0.9, 'weight_decay': 1e-4}, False, 'bf16'),
+        ('hrnet_w18_small', dict(), 'SGD', {}, False, 'fp32'),
     ]
-    for backbone, bk, oname, oparams, find_unused in cases:
+    for backbone, bk, oname, oparams, find_unused, payload in cases:
         task = build(backbone, 3, oname, oparams, **bk)
         opt = task.configure_optimizers()[0]['optimizer']
-        red = GradientAllReducer(opt, bucket_bytes=1 << 20, module=task, find_unused_parameters=find_unused)
-        assert task._grad_reducer is red
+        red = GradientAllReducer(opt, bucket_bytes=1 << 20, module=task, find_unused_parameters=find_unused,
+                                 static_unused_pattern=True if find_unused else None, grad_dtype=payload)
+        assert task._grad_reducer is red and red.bf16 == (payload == 'bf16')
         g = torch.Generator().manual_seed(50 + rank)
         x = torch.randn(16, 3, 64, 64, generator=g).to(dev)
-        y = torch.randint(0, 10, (16,), generator=g).to(dev)
+        if backbone.startswith('hrnet'):
+            y = torch.randint(0, 5, (16, 64, 64), generator=g).to(dev)
+        else:
+            y = torch.randint(0, 10, (16,), generator=g).to(dev)
         batch = {'image': x, 'target': y}
 
         # (1) mean gradient == mean of the two local gradients
@@ -112,8 +125,12 @@ def _worker(rank, world, port, tmp):
         if find_unused:
             assert not all(with_grad)                  # the per-stage feature norms of a transformer backbone
         got = torch.cat([p.grad.flatten() for p in task.parameters() if p.grad is not None])
-        assert float((got - want).norm() / want.norm()) < 1e-5, backbone
+        # fp32 payload: the mean itself; bf16 payload: each bucket is narrowed before the exchange (torch's bf16_compress_hook)
+        assert float((got - want).norm() / want.norm()) < (1e-5 if payload == 'fp32' else 2 ** -7), (backbone, payload)
         assert len(red.buckets[0]) > 1                 # several buckets: launched from the gradient hooks during backward
+        # gradients reach a bucket from more than one stream (weight gradients on the side stream, BatchNorm / bias gradients
+        # on the main one, HRNet's branches on theirs): the exchange waited for each of them
+        assert max(len(b.streams) for b in red.buckets[0]) >= 2, (backbone, [len(b.streams) for b in red.buckets[0]])
         opt.zero_grad(set_to_none=True)
 
         # (2) three steps of the shared train_step; no host synchronisation inside finish_step once the pattern is known

@@ -79,3 +79,64 @@ def test_shipped_recipe_loss_pair(dev):
     assert abs(float(out['loss'].detach()) - 0.5 * (float(ce.detach()) + float(dice.detach()))) < 2e-2
     out['loss'].backward()
     assert all(p.grad is not None for p in task.head.parameters())
+
+
+@pytest.mark.parametrize('losses', ['ce+dice', 'dice', 'bce'])
+def test_lazy_upsampled_logits_keep_every_loss_gradient(dev, losses, monkeypatch):
+    """SegmentationHead returns a storage-less UpsampledLogits in training; `Function.apply` of Dice / BCE /
+    regression saw a tensor without grad_fn and their gradient was silently dropped (CE + Dice trained on CE only).  The lazy
+    path must give the gradients of the materialised path (TOK_FUSE_UPSAMPLE_CE=0) for the head AND the backbone."""
+    from test_hrnet import seg_config
+    from torchok_amd.losses import cross_entropy as CE
+    classes = 3
+    x = torch.randn(2, 3, 64, 64).to(dev)
+    y = torch.randint(0, classes, (2, 64, 64)).to(dev)
+
+    def run(lazy):
+        monkeypatch.setattr(CE, 'FUSE_UPSAMPLE_CE', lazy)
+        torch.manual_seed(3)
+        cfg = seg_config('hrnet_w18_small', classes=classes, size=64)
+        spec = type(cfg.joint_loss.losses[0])
+        if losses == 'ce+dice':
+            cfg.joint_loss.losses[0].params = {}
+            cfg.joint_loss.losses.append(spec(name='DiceLoss', params={'mode': 'multiclass'},
+                                              mapping={'input': 'prediction', 'target': 'target'}))
+        elif losses == 'dice':
+            cfg.joint_loss.losses[:] = [spec(name='DiceLoss', params={'mode': 'multiclass'},
+                                             mapping={'input': 'prediction', 'target': 'target'})]
+        else:
+            cfg.joint_loss.losses[:] = [spec(name='BCEWithLogitsLoss', params={},
+                                             mapping={'input': 'prediction', 'target': 'target'})]
+        task = T.TASKS.get(cfg.task.name)(cfg, **cfg.task.params).to(dev).train()
+        tgt = y if losses != 'bce' else torch.nn.functional.one_hot(y, classes).permute(0, 3, 1, 2).float()
+        out = task.training_step({'image': x, 'target': tgt}, 0)
+        if lazy:
+            pred = task.forward_with_gt({'image': x, 'target': tgt})['prediction']
+            assert isinstance(pred, CE.UpsampledLogits)
+        assert out['loss'].grad_fn is not None
+        out['loss'].backward()
+        return float(out['loss'].detach()), {n: p.grad.detach().float().clone() for n, p in task.named_parameters()
+                                            if p.grad is not None}
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0 - l1) < 2e-3 * max(1.0, abs(l0))
+    assert g0.keys() == g1.keys() and len(g0) > 50
+    for n in ('head.classifier.weight', 'head.classifier.bias'):
+        assert float(g1[n].abs().max()) > 0
+        assert rel_err(g1[n], g0[n]) < 2e-2, (n, rel_err(g1[n], g0[n]))
+    stem = next(n for n in g0 if n.startswith('backbone.conv1'))
+    assert rel_err(g1[stem], g0[stem]) < 6e-2, rel_err(g1[stem], g0[stem])
+
+
+def test_upsampled_logits_expose_no_fake_memory(dev):
+    """data_ptr / stride / is_contiguous / .data of the wrapper answer from the REAL tensor (the wrapper
+    has no storage); shape / dtype / device queries do not materialise."""
+    from torchok_amd.losses.cross_entropy import UpsampledLogits
+    low = torch.randn(2, 8, 4, 4).to(dev).to(torch.bfloat16)
+    u = UpsampledLogits(low, (16, 16))
+    assert tuple(u.shape) == (2, 8, 16, 16) and u.dtype == low.dtype and u.dim() == 4 and u.numel() == 2 * 8 * 256
+    assert u.device == low.device and u._full is None
+    full = u.materialize()
+    assert u.data_ptr() == full.data_ptr() != 0
+    assert u.stride() == full.stride() and u.is_contiguous() == full.is_contiguous()
+    assert u.data.data_ptr() == full.data_ptr()

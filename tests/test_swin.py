@@ -220,8 +220,12 @@ def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
     normalisation."""
     from helpers import cls_config, rel_err
     from torchok_amd.engine import transformer as ET
+    from torchok_amd import _C
     finals = []
-    for fuse, recompute in ((True, False), (False, False), (True, True)):
+    plans = ((True, False), (False, False), (True, True))
+    if not _C.lib().tok_built_with_experiments():
+        plans = plans[:2]       # the recompute plan's kernel (csrc/mlp_dw.hip) is not in the default library
+    for fuse, recompute in plans:
         monkeypatch.setattr(ET, 'FUSE_MLP', fuse)
         monkeypatch.setattr(ET, 'MLP_RECOMPUTE', recompute)
         cfg = cls_config('swinv2_custom', 5, optimizer='AdamW', opt_params={'lr': 1e-3, 'weight_decay': 0.05},
@@ -247,6 +251,8 @@ def test_fused_mlp_leaves_training_bit_identical(monkeypatch):
     assert finals[0][0] == finals[1][0]
     for n in finals[0][1]:
         assert torch.equal(finals[0][1][n], finals[1][1][n]), n
+    if len(finals) < 3:
+        return
     # recompute plan, first step (same weights on both sides): same loss; every gradient outside the served Mlps bit for bit
     # (same launches), the Mlp parameter gradients to summation order; then the loop stays close (AdamW's normalisation
     # turns last-bit gradient differences of near-zero coordinates into lr-sized steps: later steps are only sanity-checked)

@@ -167,6 +167,7 @@ PROTOTYPES = {
     'tok_mlp_bwd_dw_ws_bytes': (c_size_t, [c_int64, c_int, c_int]),
     'tok_mlp_bwd_dw': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_size_t, c_int64, c_int,
                                c_int, _P]),
+    'tok_built_with_experiments': (c_int, []),
     'tok_chan_gram': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     'tok_chan_apply': (c_int, [_P, c_int, _P, c_int, c_float, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_scale_rows_add': (c_int, [_P, _P, _P, c_int, _P, c_int, c_int64, c_int, _P]),

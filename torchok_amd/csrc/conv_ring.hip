@@ -25,6 +25,8 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifdef TOK_BUILD_EXPERIMENTS   // measured neutral on the step: not in the default library
+
 namespace {
 
 constexpr int RBM = 256, RBN = 128, RBK = 32, RNST = 3;
@@ -432,3 +434,14 @@ int conv_ring_launch(ConvArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((conv_ring_kernel<false>), dim3(grid), dim3(256), smem, st, a);
   return 0;
 }
+
+#else   // default build: the kernel is not compiled; nothing is ever served by it
+
+bool conv_ring_serves(const ConvArgs&, bool) { return false; }
+int conv_ring_grid(int, int) { return 0; }
+int conv_ring_launch(ConvArgs&, hipStream_t) {
+  tok_set_error("conv_ring: not built (compile with TOK_BUILD_EXPERIMENTS=1)");
+  return TOK_ERR_INVALID;
+}
+
+#endif

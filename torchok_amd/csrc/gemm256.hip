@@ -312,6 +312,9 @@ bool gemm256_modes(const ConvArgs& a) {
   if (a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
   if (a.mask_store && (a.bn_mask == nullptr || a.stats == nullptr)) return false;
   if (a.y2 != nullptr || a.act_x != nullptr) {
+#ifndef TOK_BUILD_EXPERIMENTS
+    return false;      // gemm256_kernel<4> (fused activation) is an experiment: step 0.06 ms slower with it
+#endif
     static const int act_on = [] { const char* e = getenv("TOK_GEMM256_ACT"); return (int)(e ? atoi(e) : 0); }();   // TOK_GEMM256_ACT=1: fused-activation layers too (bit-identical; per call 105 vs 122 us on SwinV2-T stage 4 fc1, but the STEP is 0.06 ms slower with it — SwinV2-T 20.41 vs 20.35, DaViT-T 21.71 vs 21.53 — so off by default)
     if (!act_on || a.stats != nullptr || a.mask_store) return false;
   }
@@ -349,7 +352,9 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+#ifdef TOK_BUILD_EXPERIMENTS
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+#endif
     return true;
   }();
   (void)attr_set;
@@ -358,8 +363,11 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
   a.stat_rows = gemm256_rows(a);
   const int tiles = a.gridM * a.gridN;
   const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU, walking tiles
+#ifdef TOK_BUILD_EXPERIMENTS
   if (a.y2 != nullptr || a.act_x != nullptr) hipLaunchKernelGGL(gemm256_kernel<4>, dim3(grid), dim3(512), smem, st, a);
-  else if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
+  else
+#endif
+  if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
   else if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
   else if (a.bn_y == nullptr) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(grid), dim3(512), smem, st, a);
   else hipLaunchKernelGGL(gemm256_kernel<2>, dim3(grid), dim3(512), smem, st, a);

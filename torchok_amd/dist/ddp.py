@@ -82,19 +82,23 @@ class GradientAllReducer:
         of the ranks that used it; when False (default) a parameter without a gradient at `finish_step` is an error, as
         under torch DDP, and the step carries no extra collective and no per-parameter Python scan.
 
-        `static_unused_pattern` (default True; `TOK_DDP_UNUSED_STATIC=0` turns it off): torch DDP reads the reduced used-map
-        on the host in every step (a blocking device-to-host copy in its `finalize_backward`).  Here the host reads it only
-        in a step where THIS rank's own pattern of missing gradients changed (normally: the first step); afterwards the
-        cached answer is used and the reduced map of every step is compared with it ON THE DEVICE, the one-byte verdict
-        travelling to pinned memory behind an event that the next `finish_step` polls.  A change on another rank that this
-        rank could not see (its own pattern stayed the same) is therefore detected one step late and raises."""
+        `static_unused_pattern` (default False = torch DDP's behaviour: the reduced used-map is read on the host in every
+        step, a blocking device-to-host copy like the one in its `finalize_backward`; correct for models whose unused
+        parameters vary from step to step).  True (`TOK_DDP_UNUSED_STATIC=1`) is an opt-in for models whose pattern is fixed
+        (SwinV2's per-stage norms under a classification loss): the host reads the map only in a step where THIS rank's own
+        pattern of missing gradients changed (normally: the first step); afterwards the cached answer is used and the reduced
+        map of every step is compared with it ON THE DEVICE, the verdict is MAX-reduced over the ranks (one more tiny
+        collective per step, issued by every rank in every step) and travels to pinned memory behind an event that the next
+        `finish_step` polls.  A change on another rank that this rank could not see is therefore detected one step late —
+        by EVERY rank in the same `finish_step`, before any of them launches a collective (with a per-rank
+        verdict one rank raised while its peers sat in all_reduce until the RCCL timeout)."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         if find_unused_parameters is None:
             find_unused_parameters = os.environ.get('TOK_DDP_FIND_UNUSED', '0') == '1'
         self.find_unused = bool(find_unused_parameters)
         if static_unused_pattern is None:
-            static_unused_pattern = os.environ.get('TOK_DDP_UNUSED_STATIC', '1') != '0'
+            static_unused_pattern = os.environ.get('TOK_DDP_UNUSED_STATIC', '0') == '1'
         self.static_unused = bool(static_unused_pattern)
         self.group = process_group
         self.world = dist.get_world_size(process_group)
@@ -312,13 +316,14 @@ class GradientAllReducer:
             # recorded a whole step ago: normally complete.  A launch thread more than one step ahead of the GPU waits here
             # until the GPU has finished the PREVIOUS step's exchange — a full step of work is still queued behind that
             ev.synchronize()
-        if int(verdict[0]) != 0:
+        if float(verdict[0]) != 0:
             self._used_host = None
             raise RuntimeError(
-                'GradientAllReducer: the set of parameters used by OTHER ranks changed in the previous step while this '
-                "rank's own pattern stayed the same; the cached used-map was stale for that step.  Construct the reducer "
-                'with static_unused_pattern=False (TOK_DDP_UNUSED_STATIC=0) for models whose unused parameters vary from '
-                'step to step: the used-map is then read on the host in every step, as torch DDP does.')
+                'GradientAllReducer: the set of parameters used by some ranks changed in the previous step while the pattern '
+                'of a rank that missed them stayed the same; its cached used-map was stale for that step (every rank raises '
+                'here together).  static_unused_pattern=True (TOK_DDP_UNUSED_STATIC=1) is for models whose unused parameters '
+                'are the same in every step; leave it False otherwise: the used-map is then read on the host in every step, '
+                'as torch DDP does.')
 
     def finish_step(self):
         """Call after backward, before optimizer.step(): flush stragglers, exchange the module buffers (and, with
@@ -382,6 +387,7 @@ class GradientAllReducer:
         for w in self._buffer_work:
             w.wait()
         self._buffer_work = []
+        late_flag = None
         if used_work is not None:
             used_work.wait()
             if self._any_missing:
@@ -401,20 +407,31 @@ class GradientAllReducer:
                             k += 1
                 else:
                     # steady state: compare on the device, on the slots this rank has no gradient for (the only ones the
-                    # host decision depends on); the verdict is polled by the next finish_step
-                    diff = ((self._used > 0) != (self._used_ref_dev > 0)) & (self._flags_dev == 0)
-                    if self._small.get('late') is None:
-                        v = torch.zeros(1, dtype=torch.int32)
-                        self._small['late'] = v.pin_memory() if self.cuda else v
-                        self._small['late_event'] = torch.cuda.Event() if self.cuda else None
-                    verdict, ev = self._small['late'], self._small['late_event']
-                    verdict.copy_(diff.any().to(torch.int32).reshape(1), non_blocking=True)
-                    if ev is not None:
-                        ev.record()
-                    self._late = (verdict, ev)
+                    # host decision depends on)
+                    late_flag = (((self._used > 0) != (self._used_ref_dev > 0)) & (self._flags_dev == 0)).any()
                 for arena, pi, p in self._adopt:
                     if p.grad is None:
                         p.grad = arena.grad_view(pi)
+            if self.static_unused:
+                # the verdict is collective: every rank contributes in every step (0 from a rank that just read the map on the
+                # host or misses nothing), so that a stale cache on ONE rank makes ALL ranks raise in the same finish_step.  On
+                # RCCL the current stream waits for the collective, the host does not.
+                v = self._small.get('late_dev')
+                if v is None:
+                    v = self._small['late_dev'] = torch.zeros(1, dtype=torch.float32, device=self._used.device)
+                    host = torch.zeros(1, dtype=torch.float32)
+                    self._small['late'] = host.pin_memory() if self.cuda else host
+                    self._small['late_event'] = torch.cuda.Event() if self.cuda else None
+                if late_flag is None:
+                    v.zero_()
+                else:
+                    v.copy_(late_flag.to(torch.float32).reshape(1))
+                dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+                verdict, ev = self._small['late'], self._small['late_event']
+                verdict.copy_(v, non_blocking=True)
+                if ev is not None:
+                    ev.record()
+                self._late = (verdict, ev)
         self._active = False
 
     def params_checksum(self) -> torch.Tensor:

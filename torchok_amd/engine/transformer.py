@@ -309,6 +309,9 @@ class _MlpNode(Node):
 
         def param_grads():
             ws_bytes = int(lib.tok_mlp_bwd_dw_ws_bytes(m, c, hid))
+            if ws_bytes == 0 and not lib.tok_built_with_experiments():
+                raise RuntimeError('TOK_MLP_RECOMPUTE=1 needs a library built with TOK_BUILD_EXPERIMENTS=1 '
+                                   '(csrc/mlp_dw.hip is not part of the default libtok_gfx950.so)')
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
             tg = [param_grad_target(p) if p.requires_grad else (None, 0) for p in params]
             a = [ptr(t[0]) if t[0] is not None else None for t in tg]

@@ -28,7 +28,12 @@ class JointLoss(Module):
         total_loss = None
         tagged = {}
         for loss_module, mapping, tag, weight in zip(self.losses, self.mappings, self.tags, self.weights):
-            loss = loss_module(**self._parse_match_csv(mapping, **kwargs))
+            args = self._parse_match_csv(mapping, **kwargs)
+            if not getattr(loss_module, 'consumes_lazy_logits', False):
+                # SegmentationHead's lazy upsampling (losses/cross_entropy.py: UpsampledLogits) is understood by CrossEntropyLoss
+                # only; every other loss module (ours or a user's) gets the real tensor with its autograd edge
+                args = {k: (v.materialize() if hasattr(v, 'materialize') and hasattr(v, '_low') else v) for k, v in args.items()}
+            loss = loss_module(**args)
             # `0. + loss * weight` of the reference; x*1.0 and 0.+x are exact, so skip those launches
             term = loss if weight == 1.0 else loss * weight
             total_loss = term if total_loss is None else total_loss + term

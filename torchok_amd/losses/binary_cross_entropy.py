@@ -7,6 +7,7 @@ from torch import Tensor, nn
 
 from .. import _C
 from ..constructor import LOSSES
+from .cross_entropy import materialized
 from ..engine.core import BF16, mark_padded, pad8, ptr, require_device, stream_ptr
 
 
@@ -62,6 +63,7 @@ class BCEWithLogitsLoss(nn.Module):
         self.ignore_index = ignore_index
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
+        input = materialized(input)   # an UpsampledLogits would hide the autograd edge from Function.apply
         if tuple(input.shape) != tuple(target.shape):
             raise ValueError(f'BCEWithLogitsLoss: input {tuple(input.shape)} and target {tuple(target.shape)} differ')
         return _BCELogits.apply(input, target, float(self.ignore_index), self.reduction == 'mean')

@@ -110,8 +110,14 @@ class UpsampledLogits(torch.Tensor):
                 self._full = r.output(ER.bilinear_resize(r, r.input(self._low), self._size))
         return self._full
 
-    _META = {'dim', 'size', 'stride', '__get__', 'numel', 'is_floating_point', 'is_contiguous', 'data_ptr', '__len__',
-             'ndimension', 'nelement', 'element_size', 'is_complex', 'get_device', '__repr__', '__str__', '__format__'}
+    # what the storage-less wrapper may answer itself: shape / dtype / device queries only.  Anything that exposes memory
+    # (data_ptr, stride, is_contiguous, .data, .grad ...) materialises first: the wrapper has no storage, its strides describe
+    # a contiguous NCHW tensor while the real one is channels-last with a padded pitch.
+    _META = {'dim', 'size', 'numel', 'is_floating_point', '__len__', 'ndimension', 'nelement', 'element_size', 'is_complex',
+             'get_device', '__repr__', '__str__', '__format__'}
+    _META_PROPS = {'shape', 'dtype', 'device', 'ndim', 'requires_grad', 'is_cuda', 'is_cpu', 'layout', 'names', 'is_leaf',
+                   'grad_fn', 'is_sparse', 'is_quantized', 'is_meta', 'is_mkldnn', 'is_nested', 'is_sparse_csr', 'is_xpu',
+                   'is_mps', 'is_xla', 'is_vulkan', 'is_ipu', 'is_maia', 'is_mtia', 'output_nr', '_version', 'name'}
 
     def __repr__(self, *, tensor_contents=None):
         return f'UpsampledLogits(low={tuple(self._low.shape)}, size={self._size}, materialized={self._full is not None})'
@@ -119,7 +125,9 @@ class UpsampledLogits(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if getattr(func, '__name__', '') in cls._META:
+        name = getattr(func, '__name__', '')
+        if name in cls._META or (name == '__get__' and
+                                 getattr(getattr(func, '__self__', None), '__name__', None) in cls._META_PROPS):
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
 
@@ -143,6 +151,13 @@ class UpsampledLogits(torch.Tensor):
                 return type(a)(real(v) for v in a)
             return a
         return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+
+def materialized(x):
+    """The real tensor behind an UpsampledLogits (anything else is returned as is).  `torch.autograd.Function.apply` does not
+    go through `__torch_function__`: it would see the wrapper (no grad_fn, requires_grad False) and return a loss that is cut
+    off from the head — every loss that calls a Function on its `input` passes it through here first."""
+    return x.materialize() if isinstance(x, UpsampledLogits) else x
 
 
 class _UpsampleCE(torch.autograd.Function):
@@ -201,6 +216,8 @@ FUSE_UPSAMPLE_CE = os.environ.get('TOK_FUSE_UPSAMPLE_CE', '1') == '1'
 
 @LOSSES.register_class
 class CrossEntropyLoss(nn.Module):
+    consumes_lazy_logits = True     # JointLoss hands the UpsampledLogits through instead of materialising it
+
     def __init__(self, weight=None, size_average=None, ignore_index: int = -100, reduce=None,
                  reduction: str = 'mean', label_smoothing: float = 0.0):
         super().__init__()

@@ -8,6 +8,7 @@ from torch import Tensor, nn
 
 from .. import _C
 from ..constructor import LOSSES
+from .cross_entropy import materialized
 from ..engine.core import BF16, mark_padded, pad8, ptr, require_device, stream_ptr
 
 BINARY_MODE, MULTICLASS_MODE, MULTILABEL_MODE = 'binary', 'multiclass', 'multilabel'
@@ -105,6 +106,7 @@ class DiceLoss(nn.Module):
         self.from_logits, self.smooth, self.eps, self.log_loss = from_logits, smooth, eps, log_loss
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
+        input = materialized(input)   # an UpsampledLogits would hide the autograd edge from Function.apply
         if self.mode in (BINARY_MODE, MULTILABEL_MODE) and input.shape != target.shape:
             raise ValueError(f"Shapes of input {input.shape} and target {target.shape} tensors don't match!")
         if self.mode == MULTICLASS_MODE and input[:, 0].shape != target.shape:

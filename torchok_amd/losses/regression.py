@@ -5,6 +5,7 @@ from torch import Tensor, nn
 
 from .. import _C
 from ..constructor import LOSSES
+from .cross_entropy import materialized
 from ..engine.core import BF16, ptr, require_device, stream_ptr
 
 
@@ -42,6 +43,7 @@ class _RegressionLoss(nn.Module):
         self.reduction, self.knee = reduction, knee
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
+        input = materialized(input)   # an UpsampledLogits would hide the autograd edge from Function.apply
         if tuple(input.shape) != tuple(target.shape):
             raise ValueError(f'{type(self).__name__}: input {tuple(input.shape)} and target {tuple(target.shape)} differ '
                              f'(broadcasting is not built)')
