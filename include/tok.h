@@ -294,6 +294,35 @@ int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* mask,
                      const float* scale, const float* shift, const float* coef, int relu,
                      void* dy, void* dshortcut, int dshortcut_accumulate,
                      int64_t m, int c, void* stream);
+/* EXPERIMENT (library built with TOK_BUILD_EXPERIMENTS=1; the default library answers tok_bn_fused_apply_ok = 0): measured
+ * slower than the two launches it replaces, profiles/r05_bn_fold_probe.txt.
+ * The finalize folded into the apply pass (round 5; csrc/bn.hip "finalize folded into the apply pass"): ONE launch for
+ * tok_bn_finalize -> tok_bn_act_fwd(_colsum) resp. tok_bn_bwd_finalize -> tok_bn_bwd_apply — F.batch_norm's statistics step
+ * and its element-wise step as the reference runs them back to back (modules/bricks/convbnact.py:48-53, [timm] Bottleneck
+ * bn1..bn3 via backbones/resnet.py:12-14).  The first blocks of the apply grid fold the partial rows (same order of additions
+ * as the stand-alone finalize: every output is bit-identical to the two-launch form), publish scale / shift (coef) with
+ * device-scope stores and signal a counter that every block polls before it consumes; all blocks request their first rows
+ * before they wait.  `sync`: a scratch slot of TOK_PHASE_SLOT_BYTES bytes shared only by launches of ONE stream — int32 [0]:
+ * arrival counter, never reset by a kernel: `sync_target` is the value it reaches when the producers of THIS launch have
+ * signalled = its value before the launch + tok_bn_fused_producers(c) (the caller keeps the running total; wrap-safe);
+ * [2] != 0 afterwards means a wait gave up (results invalid); from byte 256 on: the published vectors, one 128-byte line per
+ * producer block (written once per launch by exactly one block and read only after the signal, so consumers fetch them
+ * through their L2 with ordinary loads).  Not for hipGraph capture (a replay would repeat the targets).  Served: c <= 2048 (ask tok_bn_fused_apply_ok; with_colsum:
+ * the grid of tok_bn_act_fwd_colsum_rows must hold the producers).  tok_bn_bwd_finalize_apply carries the completion event of
+ * tok_next_launch_event like tok_bn_bwd_apply.                                                                              */
+#define TOK_PHASE_SLOT_BYTES (256 + 32768)
+int tok_bn_fused_apply_ok(int64_t m, int c, int with_colsum);
+int tok_bn_fused_producers(int c);
+int tok_bn_finalize_act_fwd(const float* stats, int rows, int64_t count, int c, int c_real, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                            float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
+                            const void* y, const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m,
+                            float* colsum_partial, int32_t* sync, int32_t sync_target, void* stream);
+int tok_bn_bwd_finalize_apply(const float* partial, int rows, int64_t m, int c, int c_real, const float* gamma,
+                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef,
+                              int accumulate, int dzy_form, const void* dout, const void* y, const uint8_t* mask,
+                              const float* scale, const float* shift, int relu, void* dy, void* dshortcut,
+                              int dshortcut_accumulate, int32_t* sync, int32_t sync_target, void* stream);
 
 /* ---- pooling ----------------------------------------------------------------------------
  * aten::max_pool2d(3, stride 2, pad 1) at resnet.py:510; adaptive avg pool + flatten at

@@ -532,6 +532,34 @@ class FakeTok:
     def tok_bn_act_fwd_colsum_rows(self, m, c):
         return 3
 
+    def tok_bn_fused_producers(self, c):
+        return (c + 15) // 16 if c >= 512 else (c + 3) // 4
+
+    def tok_bn_fused_apply_ok(self, m, c, with_colsum):
+        return 1 if c <= 2048 else 0
+
+    def tok_bn_finalize_act_fwd(self, stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd, scale,
+                                shift, y, shortcut, relu, out, mask, m, colsum_partial, sync, sync_target, st):
+        rc = self.tok_bn_finalize(stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd, scale, shift,
+                                  st)
+        if rc:
+            return rc
+        if colsum_partial is not None:
+            rc = self.tok_bn_act_fwd_colsum(y, scale, shift, shortcut, relu, out, mask, m, cp, colsum_partial, st)
+        else:
+            rc = self.tok_bn_act_fwd(y, scale, shift, shortcut, relu, out, mask, m, cp, st)
+        self.calls[-1] = 'bn_finalize_act_fwd'
+        return rc
+
+    def tok_bn_bwd_finalize_apply(self, partial, rows, m, cp, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, dout,
+                                  y, mask, scale, shift, relu, dy, dshortcut, ds_acc, sync, sync_target, st):
+        rc = self.tok_bn_bwd_finalize(partial, rows, m, cp, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, st)
+        if rc:
+            return rc
+        rc = self.tok_bn_bwd_apply(dout, y, mask, scale, shift, coef, relu, dy, dshortcut, ds_acc, m, cp, st)
+        self.calls[-1] = 'bn_bwd_finalize_apply'
+        return rc
+
     def tok_bn_act_fwd_colsum(self, y, scale, shift, shortcut, relu, out, mask, m, c, partial, st):
         rc = self.tok_bn_act_fwd(y, scale, shift, shortcut, relu, out, mask, m, c, st)
         self.calls[-1] = 'bn_act_fwd_colsum'

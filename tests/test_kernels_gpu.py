@@ -1747,3 +1747,91 @@ def test_wgrad_256_tile_kernel_matches_the_128_tile_plan():
         m = re.search(r'dW-vs-fp32 new ([0-9.e+-]+)', l)
         if m:
             assert float(m.group(1)) < 1e-5, l
+
+
+@pytest.mark.parametrize('m,c,cr', [(1000, 64, 64), (50176, 256, 256), (300, 2048, 2048), (777, 48, 48), (12544, 1024, 1024),
+                                    (40, 512, 512), (4096, 24, 18), (200704, 128, 128)])
+@pytest.mark.parametrize('relu,with_sc', [(1, 0), (1, 1), (0, 0)])
+def test_bn_finalize_folded_into_apply_is_bit_identical(libs, m, c, cr, relu, with_sc):
+    """Round 5: tok_bn_finalize_act_fwd / tok_bn_bwd_finalize_apply (the first blocks of the apply grid fold the partial rows,
+    publish with device-scope stores, every block polls a counter) against the two-launch form: every output bit for bit —
+    statistics vectors, running statistics, out, ReLU bits, column-sum rows, dgamma / dbeta (+ accumulate), coefficients, dy,
+    dshortcut.  Several launches per case on ONE sync slot (its arrival counter only grows; the caller passes each launch its target), grids smaller than the number of
+    producer blocks (m = 40), padded channels (24 / 18), no wait may give up."""
+    lib, _ = libs
+    if not lib.tok_built_with_experiments():
+        assert lib.tok_bn_fused_apply_ok(m, c, 0) == 0
+        pytest.skip('the folded launches are compiled only with TOK_BUILD_EXPERIMENTS=1 (measured slower, profiles/r05_bn_fold_probe.txt)')
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    dev = lambda t: t.to(DEV)   # noqa: E731
+    assert lib.tok_bn_fused_apply_ok(m, c, 0) == 1 and lib.tok_bn_fused_apply_ok(m, 4096, 0) == 0
+    y = dev((rnd(m, c) * 1.5 + 0.3).to(BF16))
+    rows = 37
+    stats = dev(rnd(2, rows, c, seed=5).abs() * m / rows)
+    gamma, beta = dev(rnd(cr, seed=1) * 0.5 + 1), dev(rnd(cr, seed=2) * 0.2)
+    sc = dev(rnd(m, c, seed=9).to(BF16)) if with_sc else None
+    sync = torch.zeros((256 + 32768) // 4, dtype=torch.int32, device=DEV)      # TOK_PHASE_SLOT_BYTES
+    total = [0]                   # running value of the slot's arrival counter (the kernels never reset it)
+    want_cs = bool(lib.tok_bn_fused_apply_ok(m, c, 1)) and not with_sc
+    cs_rows = lib.tok_bn_act_fwd_colsum_rows(m, c)
+
+    stats_b = dev(rnd(2, rows, c, seed=6).abs() * m / rows * 3.0)      # a second layer's statistics through the same slot
+
+    def fwd(fused, stats=stats):
+        rm, rv, nbt = dev(rnd(cr, seed=3)), dev(rnd(cr, seed=4).abs() + 0.5), dev(torch.tensor([7]))
+        vec = torch.full((4, c), 7.0, device=DEV)
+        out = torch.zeros(m, c, dtype=BF16, device=DEV)
+        mask = torch.zeros(m, c // 8, dtype=torch.uint8, device=DEV)
+        cs = torch.zeros(cs_rows, c, device=DEV) if want_cs else None
+        fin = (P(stats), rows, m, c, cr, P(gamma), P(beta), P(rm), P(rv), P(nbt), 0.1, 1e-5, P(vec[2]), P(vec[3]), P(vec[0]),
+               P(vec[1]))
+        if fused:
+            total[0] += lib.tok_bn_fused_producers(c)
+            assert lib.tok_bn_finalize_act_fwd(*fin, P(y), P(sc), relu, P(out), P(mask), m, P(cs), P(sync), total[0], st) == 0, \
+                lib.tok_last_error()
+        else:
+            assert lib.tok_bn_finalize(*fin, st) == 0
+            if want_cs:
+                assert lib.tok_bn_act_fwd_colsum(P(y), P(vec[0]), P(vec[1]), P(sc), relu, P(out), P(mask), m, c, P(cs), st) == 0
+            else:
+                assert lib.tok_bn_act_fwd(P(y), P(vec[0]), P(vec[1]), P(sc), relu, P(out), P(mask), m, c, st) == 0
+        torch.cuda.synchronize()
+        return [vec, rm, rv, nbt, out, mask] + ([cs] if want_cs else [])
+    ref, ref_b = fwd(False), fwd(False, stats_b)
+    assert not torch.equal(ref[4], ref_b[4])
+    for _ in range(3):
+        for want, st_ in ((ref, stats), (ref_b, stats_b)):      # alternating: a stale published line of the previous launch would show
+            got = fwd(True, st_)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b)
+            assert sync.tolist()[:3] == [total[0], 0, 0]
+    vec = ref[0]
+    mask = ref[5] if (relu and with_sc) else None
+    dout = dev(rnd(m, c, seed=11).to(BF16))
+    rows_b = lib.tok_bn_bwd_rows(m, c)
+    part = torch.zeros(2, rows_b, c, device=DEV)
+    assert lib.tok_bn_bwd_reduce(P(dout), P(y), P(mask), P(vec[0]), P(vec[1]), P(vec[2]), P(vec[3]), relu, m, c, P(part), st) == 0
+
+    def bwd(fused, acc, dzy):
+        dg, db = torch.full((cr,), 0.5, device=DEV), torch.full((cr,), -0.25, device=DEV)
+        coef = torch.full((3, c), 3.0, device=DEV)
+        dy = torch.zeros(m, c, dtype=BF16, device=DEV)
+        ds = dev(rnd(m, c, seed=13).to(BF16)) if with_sc else None
+        fin = (P(part), rows_b, m, c, cr, P(gamma), P(vec[2]), P(vec[3]), P(dg), P(db), P(coef), acc, dzy)
+        app = (P(dout), P(y), P(mask), P(vec[0]), P(vec[1]))
+        if fused:
+            total[0] += lib.tok_bn_fused_producers(c)
+            assert lib.tok_bn_bwd_finalize_apply(*fin, *app, relu, P(dy), P(ds), acc, P(sync), total[0], st) == 0, \
+                lib.tok_last_error()
+        else:
+            assert lib.tok_bn_bwd_finalize(*fin, st) == 0
+            assert lib.tok_bn_bwd_apply(*app, P(coef), relu, P(dy), P(ds), acc, m, c, st) == 0
+        torch.cuda.synchronize()
+        return [dg, db, coef, dy] + ([ds] if with_sc else [])
+    for acc, dzy in ((0, 0), (1, 1)):
+        ref_b = bwd(False, acc, dzy)
+        for _ in range(2):
+            for a, b in zip(bwd(True, acc, dzy), ref_b):
+                assert torch.equal(a, b)
+            assert sync.tolist()[:3] == [total[0], 0, 0]

@@ -82,6 +82,12 @@ PROTOTYPES = {
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
     'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
+    'tok_bn_fused_apply_ok': (c_int, [c_int64, c_int, c_int]),
+    'tok_bn_fused_producers': (c_int, [c_int]),
+    'tok_bn_finalize_act_fwd': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P,
+                                        _P, _P, c_int, _P, _P, c_int64, _P, _P, c_int, _P]),
+    'tok_bn_bwd_finalize_apply': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P,
+                                          _P, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
     'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_avgpool2x2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -1105,6 +1105,22 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // `extra` (may be null): the floats [slab, slab + extra_pad) of every split are a second, short vector (the bias-gradient
 // partials of tok_conv_wgrad_bias) reduced by the same launch into extra[0 .. extra_n) (+= if extra_acc); stride = floats
 // between splits (slab + extra_pad, or slab).
+template <int U>
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ ws, size_t stride, size_t i, int row, int splitM, float4& t) {
+  for (int sp = row; sp < splitM; sp += 16 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int su = sp + 16 * u;
+      v[u] = reinterpret_cast<const float4*>(ws + (size_t)(su < splitM ? su : splitM - 1) * stride)[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (sp + 16 * u < splitM) { t.x += v[u].x; t.y += v[u].y; t.z += v[u].z; t.w += v[u].w; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 int splitM, size_t slab, int accumulate, size_t stride,
                                                                 float* __restrict__ extra, int extra_n, int extra_pad,
@@ -1117,9 +1133,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
     const size_t i = base + col;
     float4 t = {0.f, 0.f, 0.f, 0.f};
     if (i < n4) {
-#pragma unroll 4
-      for (int sp = row; sp < splitM; sp += 16) {
-        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)sp * stride)[i];
+      // up to eight slabs per thread in flight (round 5: a 512-way split was eight dependent rounds of four loads) — but only
+      // as many as the thread has: the loads are unconditional.  Additions in slab order whatever the unroll.
+      if (splitM > 64) reduce_slabs<8>(ws, stride, i, row, splitM, t);
+      else if (splitM > 32) reduce_slabs<4>(ws, stride, i, row, splitM, t);
+      else if (splitM > 16) reduce_slabs<2>(ws, stride, i, row, splitM, t);
+      else if (row < splitM) {
+        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)row * stride)[i];
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
       }
     }
@@ -1369,6 +1389,7 @@ namespace {
 int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw, int k_real, int c_real, void* ws, size_t ws_bytes,
                int accumulate, float* dbias, int bias_accumulate, void* stream) {
   TOK_CHECK_ARG(d && x && dy && dw && ws, "tok_conv_wgrad: null pointer");
+  if (tok_dbg_skip(16)) return TOK_OK;
   TOK_CHECK_ARG(d->k % 8 == 0 && (d->c % 8 == 0 || d->c == 4), "tok_conv_wgrad: bad channel padding");
   TOK_CHECK_ARG(k_real <= d->k && c_real <= d->c, "tok_conv_wgrad: real dims exceed padded dims");
   TOK_CHECK_ARG(d->c == 4 ? d->s_pad == 8 : d->s_pad == d->s, "tok_conv_wgrad: bad s_pad");
@@ -1465,6 +1486,7 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   }
   if (direct) return TOK_OK;
   if (flat) {
+    if (tok_dbg_skip(2)) return TOK_OK;
     const size_t slab = (size_t)d->k * d->r * d->s * d->c;
     const size_t nb = (slab / 4 + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_flat_kernel, dim3((int)(nb < 4096 ? nb : 4096)), dim3(256), 0, st,

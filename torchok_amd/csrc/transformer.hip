@@ -292,6 +292,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16* __restrict__ do
 
 // dst[col] (+)= sum_r src[r][col], fixed order, fp64 accumulation.  blockIdx.y = 1: the second (src, dst, accumulate) of a pair
 // launch (LayerNorm's d(gamma) and d(beta) rows in one launch: 48 small launches less per SwinV2-T step)
+template <int U>
+__device__ __forceinline__ void colsum_rows(const float* __restrict__ s0, int64_t rows, int cols, int rl, double& a) {
+  for (int64_t r = rl; r < rows; r += 16 * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r + 16 * u;
+      v[u] = s0[(ru < rows ? ru : rows - 1) * cols];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) a += r + 16 * u < rows ? (double)v[u] : 0.0;
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ src, int64_t rows, int cols,
                                                          float* dst, int accumulate, const float* __restrict__ src1,
                                                          float* dst1, int accumulate1) {
@@ -302,16 +316,11 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
   double a = 0.0;
   if (col < cols) {
     const float* s0 = src + col;
-    for (int64_t r = rl; r < rows; r += 128) {   // 8 loads in flight, additions in row order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int64_t ru = r + 16 * u;
-        v[u] = s0[(ru < rows ? ru : rows - 1) * cols];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) a += r + 16 * u < rows ? (double)v[u] : 0.0;
-    }
+    // as many loads in flight per lane as it has rows, up to 32; additions in row order (round 5: with 8 in flight the 1024
+    // partial rows of an activation pass were eight dependent L2-miss rounds, 6 us on the forward chain of every fused
+    // residual unit; the loads are unconditional, so short folds keep the 8-wide form)
+    if (rows > 128) colsum_rows<32>(s0, rows, cols, rl, a);
+    else colsum_rows<8>(s0, rows, cols, rl, a);
   }
   red[threadIdx.x] = a;
   __syncthreads();
@@ -1204,6 +1213,7 @@ extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* m
 
 extern "C" int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream) {
   TOK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "tok_colsum_f32: bad args");
+  if (tok_dbg_skip(4)) return TOK_OK;
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(256), 0, tok_stream(stream), src, rows, cols, dst,
                      accumulate, (const float*)nullptr, (float*)nullptr, 0);
   TOK_CHECK_LAUNCH("tok_colsum_f32");

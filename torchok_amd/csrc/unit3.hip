@@ -175,11 +175,22 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_block_kernel(
   const double inv_m = 1.0 / (double)count;
   const double zp = (double)zsum[p] * inv_m;
   const int q0 = sl * qper;
-#pragma unroll 4
-  for (int q = q0; q < q0 + qper; ++q) {
-    const float wq = round_bf16(wk[q]), z = Z[(size_t)q * P + p];
-    acc = fmaf(wq, z, acc);
-    accc += (double)wq * ((double)z - (double)zsum[q] * zp);
+  // the slice's loads 16 at a time (round 5: four at a time made P = 128 a chain of sixteen L2 round trips), same order of sums
+  for (int qb = q0; qb < q0 + qper; qb += 16) {
+    float wv[16], zv[16], sv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int q = qb + u < q0 + qper ? qb + u : q0 + qper - 1;
+      wv[u] = wk[q]; zv[u] = Z[(size_t)q * P + p]; sv[u] = zsum[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (qb + u < q0 + qper) {
+        const float wq = round_bf16(wv[u]);
+        acc = fmaf(wq, zv[u], acc);
+        accc += (double)wq * ((double)zv[u] - (double)sv[u] * zp);
+      }
+    }
   }
   red[tid] = acc;
   cred[tid] = accc;
@@ -228,18 +239,30 @@ __global__ __launch_bounds__(256) void bn_gram_finalize_block_kernel(
 // r — thread (slice, p) sums a slice of the reduction for column p (W rows read coalesced, At[k][r] is a broadcast), slices
 // folded through LDS in slice order.  Replaces the tiled product + its split-reduce launch (two dependent launches of
 // latency on the backward chain of every fused unit).
-__global__ __launch_bounds__(256) void bn3_wb_block_kernel(const float* __restrict__ At, const float* __restrict__ w, int P, int K,
-                                                           bf16* __restrict__ wb, float* __restrict__ cvec) {
-  __shared__ float red[256];
+// (round 5: 1024 threads — four times the slices, each a quarter as long, 16 loads in flight: the reduction over K = 4P channels
+//  was a chain of 8 ... 32 L2 round trips on the backward chain of every fused unit)
+__global__ __launch_bounds__(1024) void bn3_wb_block_kernel(const float* __restrict__ At, const float* __restrict__ w, int P, int K,
+                                                            bf16* __restrict__ wb, float* __restrict__ cvec) {
+  __shared__ float red[1024];
   const int r = blockIdx.x;                 // 0 .. P: row of [Wb ; c]
   const int tid = threadIdx.x;
   const int p = tid % P, sl = tid / P;
-  const int slices = 256 / P;
+  const int slices = 1024 / P;
   const int kper = (K + slices - 1) / slices;
   const int k0 = sl * kper, k1 = min(K, k0 + kper);
   float acc = 0.f;
-#pragma unroll 8
-  for (int k = k0; k < k1; ++k) acc = fmaf(At[(size_t)k * (P + 1) + r], round_bf16(w[(size_t)k * P + p]), acc);
+  for (int kb = k0; kb < k1; kb += 16) {
+    float av[16], wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int k = kb + u < k1 ? kb + u : k1 - 1;
+      av[u] = At[(size_t)k * (P + 1) + r];
+      wv[u] = w[(size_t)k * P + p];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (kb + u < k1) acc = fmaf(av[u], round_bf16(wv[u]), acc);
+  }
   red[tid] = acc;
   __syncthreads();
   if (sl == 0) {
@@ -298,22 +321,40 @@ __global__ __launch_bounds__(256) void relu_mask_reduce_kernel(const bf16* dout,
 //   dW_k = c1 G_k + c2 T_k + c3 colsum(z)        (T = W Z, kept from the forward pass)
 //   Wa[p][k] = bf16(c1_k w_kp)  (dgrad pack layout [P][K]: transposed through LDS, 32-byte segments)
 //   At[k][0..P) = c2_k w_kp,  At[k][P] = c3_k      (left operand of launch 2)
+template <int U>
+__device__ __forceinline__ void fold_partial(const float* __restrict__ partial, int rows, int K, int k, int lane, double& a1) {
+  for (int rb = lane; rb < rows; rb += 64 * U) {
+    float pv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + 64 * u;
+      pv[u] = partial[(size_t)(r < rows ? r : rows - 1) * K + k];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) a1 += rb + 64 * u < rows ? (double)pv[u] : 0.0;
+  }
+}
+
 constexpr int PR_CH = 16;
-__global__ __launch_bounds__(256) void bn3_prepare_rows_kernel(
+// (round 5: one WAVE per channel — 1024 threads — instead of a wave walking four channels one after the other, and the
+//  partial rows / G row requested up front: the kernel is a dependent chain of L2 round trips, 15 us on the backward chain of
+//  every fused unit before)
+__global__ __launch_bounds__(1024) void bn3_prepare_rows_kernel(
     const float* __restrict__ G, const float* __restrict__ w, const float* __restrict__ T, const float* __restrict__ zsum,
     const float* __restrict__ partial, int rows, int64_t count, int P, int K, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, float* dgamma, float* dbeta, int param_accumulate,
     float* __restrict__ coef, float* dw, int dw_accumulate, bf16* __restrict__ wa, float* __restrict__ At) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* wl = reinterpret_cast<float*>(smem_raw);        // [PR_CH][P] c1-scaled bf16-rounded filter rows (for the Wa transpose)
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
   const int k0 = blockIdx.x * PR_CH;
-  for (int cc = 0; cc < PR_CH / 4; ++cc) {
-    const int c = wv * (PR_CH / 4) + cc;
-    const int k = k0 + c;
-    if (k >= K) continue;
+  const int k = k0 + c;
+  if (k < K) {
     double a1 = 0.0, a2 = 0.0;
-    for (int r = lane; r < rows; r += 64) a1 += (double)partial[(size_t)r * K + k];
+    // additions in row order; as many rows per lane in flight as the lane has (unconditional loads), up to 16
+    if (rows <= 256) fold_partial<4>(partial, rows, K, k, lane, a1);
+    else if (rows <= 512) fold_partial<8>(partial, rows, K, k, lane, a1);
+    else fold_partial<16>(partial, rows, K, k, lane, a1);
     for (int p = lane; p < P; p += 64) a2 += (double)G[(size_t)k * P + p] * (double)round_bf16(w[(size_t)k * P + p]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -345,7 +386,7 @@ __global__ __launch_bounds__(256) void bn3_prepare_rows_kernel(
   }
   __syncthreads();
   // Wa[p][k0 .. k0 + 16): one 32-byte segment per p
-  for (int i = tid; i < P * (PR_CH / 8); i += 256) {
+  for (int i = tid; i < P * (PR_CH / 8); i += 1024) {
     const int p = i / (PR_CH / 8), h = i % (PR_CH / 8);
     if (k0 + h * 8 + 8 <= K) {
       bf16x8 o;
@@ -401,6 +442,7 @@ extern "C" int tok_bn_gram_finalize(const float* Z, const float* zsum, const flo
   TOK_CHECK_ARG(Z && zsum && w && gamma && beta && mean && rstd && scale && shift && wz, "tok_bn_gram_finalize: null pointer");
   TOK_CHECK_ARG(count > 0 && p > 0 && k > 0, "tok_bn_gram_finalize: bad sizes");
   TOK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "tok_bn_gram_finalize: running stats go together");
+  if (tok_dbg_skip(4)) return TOK_OK;
   hipStream_t st = tok_stream(stream);
   // wz = W_bf16 Z  (k x p): kept by the caller for tok_bn3_bwd_prepare
   if (p == 64 || p == 128 || p == 256) {
@@ -440,6 +482,7 @@ extern "C" int tok_bn3_bwd_prepare(const float* G, const float* w, const float* 
   TOK_CHECK_ARG(G && w && wz && zsum && partial && gamma && mean && rstd && coef && dw && wa && wb && cvec && ws,
                 "tok_bn3_bwd_prepare: null pointer");
   TOK_CHECK_ARG(rows > 0 && count > 0 && p > 0 && p <= 2048 && k > 0 && k % 8 == 0, "tok_bn3_bwd_prepare: bad sizes");
+  if (tok_dbg_skip(4)) return TOK_OK;
   hipStream_t st = tok_stream(stream);
   const size_t smem = (size_t)PR_CH * p * sizeof(float);
   static const bool attr_set = [&] {
@@ -450,12 +493,12 @@ extern "C" int tok_bn3_bwd_prepare(const float* G, const float* w, const float* 
   (void)attr_set;
   float* At = ws;                                   // [k][p + 1]
   float* parts = ws + (size_t)k * (p + 1);          // split-reduction partials of the (p + 1) x p product
-  hipLaunchKernelGGL(bn3_prepare_rows_kernel, dim3(tok_cdiv(k, PR_CH)), dim3(256), smem, st, G, w, wz, zsum, partial, rows, count,
+  hipLaunchKernelGGL(bn3_prepare_rows_kernel, dim3(tok_cdiv(k, PR_CH)), dim3(1024), smem, st, G, w, wz, zsum, partial, rows, count,
                      p, k, gamma, mean, rstd, dgamma, dbeta, param_accumulate, coef, dw, dw_accumulate, (bf16*)wa, At);
   TOK_CHECK_LAUNCH("tok_bn3_bwd_prepare(rows)");
   // [wb ; cvec] = At^T W_bf16   ((p + 1) x p, reduction over k)
   if (p == 64 || p == 128 || p == 256) {
-    hipLaunchKernelGGL(bn3_wb_block_kernel, dim3(p + 1), dim3(256), 0, st, (const float*)At, w, p, k, (bf16*)wb, cvec);
+    hipLaunchKernelGGL(bn3_wb_block_kernel, dim3(p + 1), dim3(1024), 0, st, (const float*)At, w, p, k, (bf16*)wb, cvec);
     TOK_CHECK_LAUNCH("tok_bn3_bwd_prepare(wb)");
     return TOK_OK;
   }
