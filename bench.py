@@ -173,16 +173,25 @@ def secondary_block(budget_s: float = 20.0, warmup: int = 3, steps: int = 10):
     from torchok_amd.engine.step import train_step
     plans = [
         ('swinv2_t_224_bs256_adamw', lambda: build_swin_task(1000, 224), 256, (3, 224, 224), 1000, False,
-         ('mfma', ALG_FLOPS_PER_IMG[('swinv2_custom', 224)], MFMA_PEAK_BF16)),
+         ('mfma', ALG_FLOPS_PER_IMG[('swinv2_custom', 224)], MFMA_PEAK_BF16),
+         'BASELINE config 3: SwinV2-T (embed 96, depths 2-2-6-2, window 7, drop_path 0.1) + ClassificationTask(Pooling, '
+         'ClassificationHead 1000) + CrossEntropyLoss + AdamW, synthetic 3x224x224 bf16, batch 256 on one GPU (the per-rank '
+         'shape of its DDP runs)'),
         ('hrnet_w48_seg_512x1024_bs24', lambda: build_seg_task('hrnet_w48', 19, 512, 1024), 24, (3, 512, 1024), 19, True,
-         ('hbm', ALG_BYTES_SEG[('hrnet_w48', 512, 1024)], HBM_PEAK)),
+         ('hbm', ALG_BYTES_SEG[('hrnet_w48', 512, 1024)], HBM_PEAK),
+         'BASELINE config 4: HRNet-W48 + HRNetSegmentationNeck + SegmentationHead(19) + SegmentationTask + CrossEntropyLoss + '
+         'SGD, synthetic 3x512x1024 bf16 (Cityscapes shape), batch 24 on one GPU (the per-rank shape of the 8-GPU run)'),
         ('resnet50_arcface11318_bs128', lambda: build_c5_task('arcface'), 128, (3, 224, 224), 11318, False,
-         ('hbm', ALG_BYTES_C5['arcface'], HBM_PEAK)),
+         ('hbm', ALG_BYTES_C5['arcface'], HBM_PEAK),
+         'BASELINE config 5 at its PER-RANK shape (global batch 1024 over 8 GPUs = 128 per rank; pure data parallelism, so the '
+         'rank sees exactly this): ResNet-50 + PoolingLinear(512) + ArcFaceHead(11318) + CrossEntropyLoss + SGD, 3x224x224 bf16'),
         ('resnet50_contrastive_bs128', lambda: build_c5_task('contrastive'), 128, (3, 224, 224), 11318, False,
-         ('hbm', ALG_BYTES_C5['contrastive'], HBM_PEAK)),
+         ('hbm', ALG_BYTES_C5['contrastive'], HBM_PEAK),
+         'config 5 recipe variant at its per-rank shape (128 of 1024): ResNet-50 + PoolingLinear + LinearHead + ContrastiveLoss '
+         '(PairwiseLearnTask) + SGD, 3x224x224 bf16'),
     ]
     out, t_start = {}, time.perf_counter()
-    for name, build, bsz, shape, classes, seg, (bound, per_img, peak) in plans:
+    for name, build, bsz, shape, classes, seg, (bound, per_img, peak), workload in plans:
         if time.perf_counter() - t_start > budget_s:
             out[name] = {'skipped': f'secondary budget of {budget_s:.0f} s spent'}
             continue
@@ -203,7 +212,8 @@ def secondary_block(budget_s: float = 20.0, warmup: int = 3, steps: int = 10):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / steps
             ach = per_img * bsz / (ms * 1e-3)
-            out[name] = {'ms_per_step': round(ms, 3), 'images_per_sec': round(bsz / ms * 1e3, 1), 'bound': bound,
+            out[name] = {'workload': workload, 'ms_per_step': round(ms, 3), 'images_per_sec': round(bsz / ms * 1e3, 1),
+                         'bound': bound,
                          'frac': round(ach / peak, 4),
                          'algorithmic_per_img': f'{per_img / 1e9:.2f} GFLOP' if bound == 'mfma' else f'{per_img / 1e6:.1f} MB',
                          'batch': bsz, 'steps': steps, 'warmup': warmup,
@@ -230,6 +240,28 @@ def _usable_cores() -> int:
     except Exception:
         pass
     return max(1, min(n, 64))
+
+
+def _pin_rank(local_rank: int, local_world: int):
+    """N > 1: one launch thread per rank.  Each rank's process keeps to a disjoint slice of the cores it was given
+    (`os.sched_setaffinity`) and runs torch's host-side ops on ONE thread: eight ranks x (launch thread + autograd thread +
+    RCCL proxy) on a host whose cgroup may hand the job 16 cores must not also start eight intra-op pools of 16 threads
+    each (profiles/r05_host_contention.txt).  Returns a short description for the bench line."""
+    torch.set_num_threads(1)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass                                    # already started: harmless
+    if not hasattr(os, 'sched_getaffinity') or local_world <= 1:
+        return {'host_threads_per_rank': 1}
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // local_world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {'host_threads_per_rank': 1}
+    return {'host_threads_per_rank': 1, 'cpu_affinity': f'{len(mine)} of {len(cores)} cores ({mine[0]}..{mine[-1]})'}
 
 
 def _cpu_model() -> str:
@@ -343,6 +375,12 @@ def main():
     # TOK_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL group, bucketed gradient all-reduce, barriers) with one
     # rank — the way to exercise it on a 1-GPU box; the numbers it prints include the reducer's overhead
     dist_on = world > 1 or os.environ.get('TOK_BENCH_FORCE_DIST') == '1'
+    host_pin = None
+    if world > 1:
+        # before RCCL starts its proxy threads (they inherit the mask); the env defaults cover libraries that read them lazily
+        os.environ.setdefault('OMP_NUM_THREADS', '1')
+        os.environ.setdefault('MKL_NUM_THREADS', '1')
+        host_pin = _pin_rank(local_rank, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
@@ -368,7 +406,9 @@ def main():
         # (the transformer backbones keep per-stage feature norms that a classification forward never runs: torch DDP needs
         # find_unused_parameters=True for them as well, reference swin.py:129-148)
         reducer = GradientAllReducer(opt, module=task,     # + DDP's rank-0 buffer broadcast (one flat collective per dtype)
-                                     find_unused_parameters=True if swin else None)
+                                     find_unused_parameters=True if swin else None,
+                                     # the unused set of these backbones is the same in every step: no per-step host read
+                                     static_unused_pattern=True if swin else None)
 
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
     image = torch.randn(args.batch, 3, args.res, width, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
@@ -477,6 +517,8 @@ def main():
             roofline['mfma_util_committed_profile'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
         if dist_on:
             line['config']['rccl_ranks'] = dist.get_world_size()
+            if host_pin is not None:
+                line['config']['host'] = host_pin
             line['ranks_in_sync'] = in_sync
             line['config']['per_step_collectives'] = 'gradient buckets + buffer broadcast + loss mean (async, comm stream)'
             line['config']['grad_exchange'] = f"bucketed all-reduce(AVG), {'bf16' if reducer.bf16 else 'fp32'} payload, " \

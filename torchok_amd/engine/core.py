@@ -377,17 +377,21 @@ def _shares_queue(a: 'torch.cuda.Stream', b: 'torch.cuda.Stream') -> bool:
     return e0.elapsed_time(eb) > 0.5 * e0.elapsed_time(ea)
 
 
+# TOK_STREAM_PRIO=-1: the picked (side / branch / comm) streams are created with HIGH priority (experiment, round 5)
+_STREAM_PRIO = int(os.environ.get('TOK_STREAM_PRIO', '0'))
+
+
 def pick_stream(device, main: Optional['torch.cuda.Stream'] = None) -> 'torch.cuda.Stream':
     """A new stream for work that is meant to run BESIDE the calling (main) stream and beside the streams picked before."""
     if (not PICK_STREAMS or torch.cuda.is_current_stream_capturing()):
-        return torch.cuda.Stream(device=device)
+        return torch.cuda.Stream(device=device, priority=_STREAM_PRIO)
     with torch.cuda.device(device):
         if main is None:
             main = _main_hint.get(str(device)) or torch.cuda.current_stream()
         others = _picked.setdefault(str(device), [])
         best, best_cost = None, None
         for _ in range(8):
-            c = torch.cuda.Stream(device=device)
+            c = torch.cuda.Stream(device=device, priority=_STREAM_PRIO)
             cost = 100 * int(_shares_queue(main, c))
             if cost < 100:
                 # when sharing cannot be avoided (five streams on four queues: HRNet's three branch streams + the side
