@@ -35,6 +35,13 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// TOK_WIN_PROBE=<mask> (probe builds only, tools/ubench/win_probe.sh; results invalid, timing only):
+//   1 no window-fragment LDS reads after the first tap of a chunk   2 no weight-fragment LDS reads after the first tap
+//   4 no block barrier   8 no DMA (weights + window)   16 no MFMAs   32 no epilogue
+#ifndef TOK_WIN_PROBE
+#define TOK_WIN_PROBE 0
+#endif
+
 namespace {
 
 constexpr int WBK = 32;
@@ -181,18 +188,30 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     bot_mask = __builtin_amdgcn_readfirstlane(bm);
   };
 
+#if TOK_WIN_PROBE & 3
+  u32x4 pwf[4] = {}, paf[MT] = {};
+#endif
   // one stage: tap (R, S) of the current chunk out of weight slot SLOT
   auto compute = [&](auto tapc, auto slotc) {
     constexpr int TAP = decltype(tapc)::value, SLOT = decltype(slotc)::value;
     constexpr int R = TAP / 3, S = TAP % 3;
+#if TOK_WIN_PROBE & 3
+    u32x4 (&wf)[4] = pwf;
+    u32x4 (&af)[MT] = paf;
+#else
     u32x4 wf[4], af[MT];
+#endif
+    if (!(TOK_WIN_PROBE & 2) || TAP == 0) {
     wf[0] = wlds16<SLOT * W_STAGE + 0 * 64>(wfrag);
     wf[1] = wlds16<SLOT * W_STAGE + 4 * 64>(wfrag);
     wf[2] = wlds16<SLOT * W_STAGE + 32 * 64>(wfrag);
     wf[3] = wlds16<SLOT * W_STAGE + 36 * 64>(wfrag);
+    }
 #define TOK_AF(mt) af[mt] = wlds16<(((mt) / SEGS + R) * WW + ((mt) % SEGS) * 16 + S) * 64>(afrag)
+    if (!(TOK_WIN_PROBE & 1) || TAP == 0) {
     TOK_AF(0); TOK_AF(1); TOK_AF(2); TOK_AF(3);
     if constexpr (MT == 8) { TOK_AF(4); TOK_AF(5); TOK_AF(6); TOK_AF(7); }
+    }
 #undef TOK_AF
     const uint32_t skip = R == 0 ? top_mask : (R == 2 ? bot_mask : 0u);
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MT / 2) : "memory");      // weights + the first half of the pixel tiles
@@ -200,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
     for (int mt = 0; mt < MT / 2; ++mt) {
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
+      if (TOK_WIN_PROBE & 16) { if (mt == 0) acc[0][0][0] += __builtin_bit_cast(f32x4, af[0])[0] + __builtin_bit_cast(f32x4, wf[0])[0]; continue; }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
     for (int mt = MT / 2; mt < MT; ++mt) {
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
+      if (TOK_WIN_PROBE & 16) { if (mt == MT / 2) acc[0][0][1] += __builtin_bit_cast(f32x4, af[MT - 1])[0] + __builtin_bit_cast(f32x4, wf[3])[0]; continue; }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
@@ -352,19 +373,19 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     {                                                                                                                           \
       /* newer than this stage's data: what the previous stage issued (the weight rows + a window piece at taps 0..6) */          \
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((TAP == 0 || TAP == 8) ? WROWS : WROWS + 1) : "memory");                  \
-      __builtin_amdgcn_s_barrier();                                                                                             \
+      if (!(TOK_WIN_PROBE & 4)) __builtin_amdgcn_s_barrier();                                                                   \
       /* weights of stage + 2: taps 2..8 of this chunk, taps 0, 1 of the next one */                                            \
-      if (TAP + 2 < 9) issue_weights((TAP + 2) % 3, ccC, TAP + 2, true);                                                        \
-      else issue_weights((TAP + 2) % 3, ccN, TAP + 2 - 9, liveN);                                                               \
+      if (TAP + 2 < 9) issue_weights((TAP + 2) % 3, ccC, TAP + 2, !(TOK_WIN_PROBE & 8));                                        \
+      else issue_weights((TAP + 2) % 3, ccN, TAP + 2 - 9, liveN && !(TOK_WIN_PROBE & 8));                                       \
       /* one piece of the next chunk's window into the other buffer (its last reader finished before this barrier) */          \
-      if (TAP < 7) issue_window(TAP, ccN, wb ^ 1);                                                                              \
+      if (TAP < 7) issue_window(TAP, (TOK_WIN_PROBE & 8) ? (1 << 20) : ccN, wb ^ 1);                                            \
       compute(std::integral_constant<int, TAP>{}, std::integral_constant<int, TAP % 3>{});                                      \
     }
     TOK_STAGE(0) TOK_STAGE(1) TOK_STAGE(2) TOK_STAGE(3) TOK_STAGE(4) TOK_STAGE(5) TOK_STAGE(6) TOK_STAGE(7) TOK_STAGE(8)
 #undef TOK_STAGE
 
     if (new_tile) {
-      epilogue();
+      if (!(TOK_WIN_PROBE & 32) || ch + 1 == nchunks) epilogue();
       zero_acc();
       if (liveN) setup_compute(itN);
     }
