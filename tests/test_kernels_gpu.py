@@ -136,6 +136,38 @@ def test_conv_fwd_stem_c4(libs):
     assert relerr(dv[id(y)].float(), y.float()) < 4e-3
 
 
+@pytest.mark.parametrize('n,h,w,k', [(4, 70, 72, 64), (3, 64, 96, 32), (2, 224, 224, 64)])
+def test_conv_fwd_stem_on_the_shared_window(libs, n, h, w, k):
+    """csrc/stem.hip (round 5): the 7x7 / stride 2 / padding 3 stem of a 4-channel-padded image on a shared input window —
+    served for even widths from 16 tiles up; ragged tile edges (35 x 36 outputs), fewer than 64 output channels, the real
+    224 x 224 geometry.  Output and BatchNorm partial sums against the fp32 restatement; the sums are those of the STORED values."""
+    lib, fake = libs
+    d = _desc(n, h, w, 4, k, 7, 2, 3, s_pad=8)
+    x = rnd(n, h, w, 4).to(BF16)
+    x[..., 3] = 0
+    wt = rnd(k, 7, 8, 4, scale=0.08).to(BF16)
+    wt[:, :, 7, :] = 0
+    wt[..., 3] = 0
+    y = torch.zeros(n, d.p, d.q, k, dtype=BF16)
+    rows = lib.tok_conv_fwd_stat_rows(ctypes.byref(d))
+    stats = torch.full((2, rows, k), 7.0)
+    stats_h = torch.zeros(2 * fake.tok_conv_fwd_stat_rows(d) * k)
+    yd, sd = y.to(DEV), stats.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tok_conv_fwd(ctypes.byref(d), x.to(DEV).data_ptr(), wt.to(DEV).data_ptr(), None, yd.data_ptr(), sd.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert fake.tok_conv_fwd(d, x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), stats_h.data_ptr(), None) == 0
+    assert relerr(yd.float(), y.float()) < 4e-3
+    f = yd.float().reshape(-1, k)
+    assert relerr(sd[0].sum(0), f.sum(0)) < 1e-4 or float((sd[0].sum(0).cpu() - f.sum(0).cpu()).abs().max()) < 2e-2
+    assert relerr(sd[1].sum(0), (f * f).sum(0)) < 1e-4
+    # bit-reproducible, and without statistics the same output
+    y2 = torch.zeros_like(yd)
+    assert lib.tok_conv_fwd(ctypes.byref(d), x.to(DEV).data_ptr(), wt.to(DEV).data_ptr(), None, y2.data_ptr(), None, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y2, yd)
+
+
 @pytest.mark.parametrize('case', [c for c in CONV_CASES if c[3] % 8 == 0])
 @pytest.mark.parametrize('accumulate', [0, 1])
 def test_conv_dgrad(libs, case, accumulate):

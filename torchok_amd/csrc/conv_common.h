@@ -85,3 +85,7 @@ bool gemm256_modes(const ConvArgs& a);                       // ... and carry th
 bool gemm256_serves(const ConvArgs& a);                      // both
 int gemm256_rows(const ConvArgs& a);                         // statistics rows = pixel tiles, rounded up to a multiple of 8 (pad rows are zero)
 int gemm256_launch(ConvArgs& a, hipStream_t st);             // fills a.gridM / a.gridN / a.stat_rows itself
+
+// stem.hip: the 7x7 / stride 2 stem convolution of a 4-channel-padded image on a shared input window
+bool stem_win_serves(const ConvArgs& a);
+int stem_win_launch(ConvArgs& a, int stat_rows, hipStream_t st);   // stat_rows: rows of a.stats as sized by tok_conv_fwd_stat_rows

@@ -1030,6 +1030,13 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   const bool c4 = d->c == 4;
   int rc;
   const int bn_pick = pick_bn(d->k, a.Ktot, a.gridM, d->h == 1 && d->w == 1);
+  if (c4 && ep == nullptr && stem_win_serves(a)) {
+    // the 7x7 / stride 2 stem on a shared input window (stem.hip); statistics rows as tok_conv_fwd_stat_rows sized them
+    rc = stem_win_launch(a, tok_conv_fwd_stat_rows(d), st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH("tok_conv_fwd");
+    return TOK_OK;
+  }
   if (!c4 && ep == nullptr && conv_win_serves(a)) {
     // 3x3 / stride 1 / padding 1: shared input window in LDS (conv_win.hip)
     rc = conv_win_launch(a, st);
