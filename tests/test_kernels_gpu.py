@@ -256,6 +256,31 @@ def test_conv_wgrad_stem_c4(libs):
     assert relerr(dv[id(dw)], dw) < 2e-3
 
 
+@pytest.mark.parametrize('n,h,w,k', [(4, 70, 72, 64), (3, 64, 96, 32), (2, 224, 224, 64)])
+@pytest.mark.parametrize('acc', [0, 1])
+def test_conv_wgrad_stem_on_the_shared_window(libs, n, h, w, k, acc):
+    """csrc/stem.hip (round 5): the stem's weight gradient with both MFMA operands read by transpose reads — dy from an LDS
+    tile, the patches straight out of the staged input window.  Even widths, ragged tiles, fewer than 64 filters, the real
+    geometry; overwrite / accumulate; against the fp32 restatement, and bit-reproducible."""
+    lib, fake = libs
+    d = _desc(n, h, w, 4, k, 7, 2, 3, s_pad=8)
+    x = rnd(n, h, w, 4).to(BF16)
+    x[..., 3] = 0
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    dw = rnd(k, 7, 7, 3, seed=3)
+    wsb = lib.tok_conv_wgrad_ws_bytes(ctypes.byref(d))
+    ws = torch.zeros(max(wsb // 4, 16))
+    dv = both(libs, 'tok_conv_wgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                 f(x), f(dy), f(dw), k, 3, f(ws), wsb, acc, None])
+    assert relerr(dv[id(dw)], dw) < 2e-3
+    dw2 = rnd(k, 7, 7, 3, seed=3).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tok_conv_wgrad(ctypes.byref(d), dv[id(x)].data_ptr(), dv[id(dy)].data_ptr(), dw2.data_ptr(), k, 3,
+                              dv[id(ws)].data_ptr(), wsb, acc, st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dv[id(dw)])
+
+
 def test_pack_weights(libs):
     k, r, s, c = 10, 3, 3, 3
     src = rnd(k, r, s, c)

@@ -89,3 +89,5 @@ int gemm256_launch(ConvArgs& a, hipStream_t st);             // fills a.gridM / 
 // stem.hip: the 7x7 / stride 2 stem convolution of a 4-channel-padded image on a shared input window
 bool stem_win_serves(const ConvArgs& a);
 int stem_win_launch(ConvArgs& a, int stat_rows, hipStream_t st);   // stat_rows: rows of a.stats as sized by tok_conv_fwd_stat_rows
+bool stem_wgrad_serves(const tok_conv_desc* d);
+int stem_wgrad_launch(const tok_conv_desc* d, const void* x, const void* dy, float* ws, int slabs, hipStream_t st);

@@ -15,6 +15,7 @@
 // kernel sums the partials in a fixed order (deterministic — no atomics) and un-pads into the
 // fp32 master-gradient layout [k][r][s][c].
 #include "tok_common.h"
+#include "conv_common.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1428,6 +1429,10 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   }
   hipStream_t st = tok_stream(stream);
   const bool c4 = d->c == 4;
+  if (c4 && dbias == nullptr && stem_wgrad_serves(d)) {
+    // the 7x7 / stride 2 stem: transpose reads straight from a shared input window (stem.hip); one slab per workgroup
+    stem_wgrad_launch(d, x, dy, a.ws, p.splitM, st);
+  } else
   if (p.taps) {
     constexpr int smem = 3 * 10 * 32 * 128;
     static const bool attr_set = [&] {

@@ -194,6 +194,163 @@ __global__ __launch_bounds__(256, 2) void stem_win_kernel(ConvArgs a, StemGeo ge
   }
 }
 
+// ---- the stem's weight gradient on the same window ----------------------------------------------------------------------------
+// dW[k][r][s][c] = sum over output pixels of dy[pix][k] * x[2 oy + r - 3][2 ox + s - 3][c]: both MFMA operands have the reduction
+// (pixels) along their rows, so both are read with ds_read_b64_tr_b16 — dy from a row-major [128 pixels][64 channels] LDS tile
+// (LDS-DMA, XOR-swizzled 16-byte chunks like conv_wgrad.hip's), and the patch matrix [pixel][r][slot][c] is never built: a
+// transpose read takes one address per lane, and element (pixel (oy, ox), r, slot, c) is the window pixel (2 oy + r, 2 ox + slot)
+// (even-aligned window, padding tap in front: slot = tap + 1, as in the forward).  conv_wgrad_kernel's C4 path gathers the same
+// patches with two 8-byte global loads per 16-byte chunk and an address computation per row: 241 us for the 256 x 224 x 224 batch,
+// the last launch of the backward pass with the main stream idle behind it.  Tile = 8 x 16 output pixels (four 32-pixel MFMA
+// steps), window 21 x 40 pixels (6.6 KB) + dy tile 16 KB, two buffers; 2 x 2 waves: 32 of the 64 filters x 7 of the 14
+// sixteen-column blocks (7 rows x 2 halves of a filter row) each, 56 accumulator registers.  One [k][224] slab per workgroup
+// (column = r * 32 + tap * 4 + c: the layout wgrad_reduce_kernel folds), as many workgroups as the plan has slabs.
+constexpr int SG_TH = 8, SG_TW = 16;
+constexpr int SG_WROWS = 2 * SG_TH + 5;                 // 21
+constexpr int SG_WPIECES = SG_WROWS * (ST_WP / 2);      // 420
+constexpr int SG_WBUF = 2 * 256 * 16;                   // 8 KB
+constexpr int SG_YBUF = 128 * 128;                      // 16 KB
+constexpr int SG_STAGE = SG_WBUF + SG_YBUF;
+
+__device__ __forceinline__ u32x2 st_tr_read(uint32_t lds_addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr));
+  return v;
+}
+
+struct StemWg {
+  const bf16* x;
+  const bf16* dy;
+  float* ws;
+  int H, W, P, Q, K;
+  int TX, TY;
+  FastDiv fd_tpi, fd_tx;
+  int tiles;
+  uint32_t x_bytes, dy_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_wgrad_kernel(StemWg a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) void lds_void;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn2 = wv & 1, wk2 = wv >> 1;
+  const int g = lane >> 4, li = lane & 15;
+  const int rrow = 4 * g + (li >> 2);
+
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+
+  auto issue = [&](int tile, int buf) {
+    const bool live = tile < a.tiles;
+    const uint32_t img = fdiv((uint32_t)tile, a.fd_tpi);
+    const int rem = tile - (int)img * (a.TX * a.TY);
+    const int ty = (int)fdiv((uint32_t)rem, a.fd_tx);
+    const int tx = rem - ty * a.TX;
+    const int oy0 = ty * SG_TH, ox0 = tx * SG_TW;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 4;
+    char* base = smem + buf * SG_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pi = (j * 4 + wave_u) * 64 + lane;
+      const int wr = pi / (ST_WP / 2), cp = pi - wr * (ST_WP / 2);
+      const int iy = iy0 + wr, ix = ix0 + 2 * cp;
+      const bool ok = live && pi < SG_WPIECES && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      uint32_t off = ok ? (uint32_t)((((int)img * a.H + iy) * a.W + ix) * 8) : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(base + (j * 4 + wave_u) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = (j * 4 + wave_u) * 64 + lane;           // LDS piece: pixel row y = q / 8, slot q % 8
+      const int y = q >> 3, slot = q & 7;
+      const int chunk = slot ^ ((y & 3) << 1);              // logical 8-channel chunk kept in that slot (conflict-free transpose reads)
+      const int oy = oy0 + (y >> 4), ox = ox0 + (y & 15);
+      const bool ok = live && oy < a.P && ox < a.Q && chunk * 8 < a.K;
+      uint32_t off = ok ? (uint32_t)(((((int)img * a.P + oy) * a.Q + ox) * a.K + chunk * 8) * 2) : 0xFFFFFFF0u;
+      asm volatile("" : "+v"(off));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)(base + SG_WBUF + (j * 4 + wave_u) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[2][7];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // lane-constant parts of the fragment addresses
+  const uint32_t yswz = (uint32_t)(((rrow & 3) << 1) << 4);
+  uint32_t ycol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) ycol[i] = (uint32_t)((((wn2 * 2 + i) * 16 + (li & 3) * 4) * 2)) ^ yswz;
+  // window: pixel (2 oy_l + r, 2 ox_l + slot), ox_l = rrow, slot = (J & 1) * 4 + (li & 3), J = wk2 * 7 + j, r = J >> 1
+  uint32_t wcol[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int J = wk2 * 7 + j;
+    wcol[j] = (uint32_t)((((J >> 1) * ST_WP) + 2 * rrow + (J & 1) * 4 + (li & 3)) * 8);
+  }
+
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  issue(tile, 0);
+  int buf = 0;
+  for (; tile < a.tiles; tile += G) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(tile + G, buf ^ 1);
+    const uint32_t Wl = lds_base + (uint32_t)(buf * SG_STAGE), Yl = Wl + SG_WBUF;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      u32x2 ya[2][2], xb[7][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ya[i][0] = st_tr_read(Yl + (uint32_t)((st * 32 + rrow) * 128) + ycol[i]);
+        ya[i][1] = st_tr_read(Yl + (uint32_t)((st * 32 + rrow + 16) * 128) + ycol[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        xb[j][0] = st_tr_read(Wl + (uint32_t)((2 * (2 * st) * ST_WP) * 8) + wcol[j]);
+        xb[j][1] = st_tr_read(Wl + (uint32_t)((2 * (2 * st + 1) * ST_WP) * 8) + wcol[j]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // D[n][col]: lane holds filters (wn2 * 2 + i) * 16 + g * 4 + reg, column li of block J = (r, slot = (J & 1) * 4 + (li >> 2), c = li & 3)
+  float* out = a.ws + (size_t)blockIdx.x * a.K * 224;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int J = wk2 * 7 + j;
+      const int slot = (J & 1) * 4 + (li >> 2);
+      const int kcol = (J >> 1) * 32 + (slot - 1) * 4 + (li & 3);      // tap = slot - 1 (slot 0 is the padding tap in front)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wn2 * 2 + i) * 16 + g * 4 + r;
+        if (n < a.K && slot >= 1) out[(size_t)n * 224 + kcol] = acc[i][j][r];
+      }
+    }
+}
+
 int stem_flag() {   // TOK_STEM_WIN=0: the stem stays on conv_igemm's C4 path (A/B switch)
   static const int v = [] { const char* e = getenv("TOK_STEM_WIN"); return (int)(e ? atoi(e) : 1); }();
   return v;
@@ -222,5 +379,28 @@ int stem_win_launch(ConvArgs& a, int stat_rows, hipStream_t st) {
   if (a.stats != nullptr && grid > stat_rows) grid = stat_rows;
   constexpr int smem = 2 * ST_BUF;
   hipLaunchKernelGGL(stem_win_kernel, dim3(grid), dim3(256), smem, st, a, g);
+  return 0;
+}
+
+bool stem_wgrad_serves(const tok_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("TOK_STEM_WGRAD"); return (int)(e ? atoi(e) : 1); }();   // TOK_STEM_WGRAD=0: conv_wgrad_kernel's C4 path (A/B switch)
+  if (!on || !stem_flag()) return false;
+  if (!(d->c == 4 && d->r == 7 && d->s == 7 && d->s_pad == 8 && d->stride == 2 && d->pad == 3)) return false;
+  if (d->k % 8 != 0 || d->k > 64 || d->w % 2 != 0) return false;
+  return (long long)d->n * tok_cdiv(d->p, SG_TH) * tok_cdiv(d->q, SG_TW) >= 16;
+}
+
+// one [k][224] fp32 slab per workgroup into ws (slab stride k * 224), `slabs` workgroups
+int stem_wgrad_launch(const tok_conv_desc* d, const void* x, const void* dy, float* ws, int slabs, hipStream_t st) {
+  StemWg a;
+  a.x = (const bf16*)x; a.dy = (const bf16*)dy; a.ws = ws;
+  a.H = d->h; a.W = d->w; a.P = d->p; a.Q = d->q; a.K = d->k;
+  a.TX = tok_cdiv(d->q, SG_TW); a.TY = tok_cdiv(d->p, SG_TH);
+  a.fd_tpi = make_fastdiv((uint32_t)(a.TX * a.TY));
+  a.fd_tx = make_fastdiv((uint32_t)a.TX);
+  a.tiles = d->n * a.TX * a.TY;
+  a.x_bytes = (uint32_t)((unsigned long long)d->n * d->h * d->w * 8);
+  a.dy_bytes = (uint32_t)((unsigned long long)d->n * d->p * d->q * d->k * 2);
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(slabs), dim3(256), 2 * SG_STAGE, st, a);
   return 0;
 }
