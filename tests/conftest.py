@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 # the shell to override.  Kernels that are not in the default library (conv_ring.hip, mlp_dw.hip: TOK_BUILD_EXPERIMENTS=1)
 # are exercised by `TOK_BUILD_EXPERIMENTS=1 python __graft_entry__.py && TOK_CONV_RING=1 pytest -m gpu` (the stress run).
 os.environ.setdefault('TOK_CONV_WIN_MIN_TILES', '1')
+os.environ.setdefault('TOK_CONV_S2D_MIN_TILES', '1')
 os.environ.setdefault('TOK_MLP_MIN_ROWS', '1')          # the fused MLP serves the small test shapes too
 if os.environ.get('TOK_CONV_RING') == '1':              # stress run on an experiments build: small shapes reach the ring kernel
     os.environ.setdefault('TOK_CONV_RING_MIN_TILES', '1')

@@ -181,6 +181,48 @@ def test_conv_dgrad(libs, case, accumulate):
     assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
 
 
+S2D_CASES = [(3, 56, 56, 128, 128, 3, 2, 1),    # 28 x 28 class maps: 32-wide tiles, 128 channels
+             (5, 28, 28, 256, 256, 3, 2, 1),    # 14 x 14: 16-wide tiles, rows of several images in one tile
+             (1, 64, 256, 48, 48, 3, 2, 1),     # wide map walked in x-tiles, 64-channel tiles, 48 = 32 + a 16-channel tail
+             (2, 32, 128, 96, 192, 3, 2, 1),    # 96 of 128 output channels
+             (3, 36, 44, 64, 40, 3, 2, 1)]      # ragged: 18 x 22 class maps, 40 gathered channels
+
+
+@pytest.mark.parametrize('case', S2D_CASES)
+@pytest.mark.parametrize('mode', ['plain', 'accumulate', 'bnstats', 'bnstats_mask'])
+def test_conv_dgrad_stride2_on_the_shared_window(libs, case, mode):
+    """conv_s2d.hip: the four parity classes of a stride-2 data gradient on one window of dY, every epilogue it serves,
+    against the restatement (tests/fake_backend.py)."""
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    lib, fake = libs
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    wd = rnd(c, r, r, k, scale=(r * r * k) ** -0.5).to(BF16)
+    dx = rnd(n, h, w, c, seed=5).to(BF16)
+    if mode in ('plain', 'accumulate'):
+        dv = both(libs, 'tok_conv_dgrad', lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d,
+                                                     f(dy), f(wd), f(dx), int(mode == 'accumulate'), None])
+        assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
+        return
+    with_mask = mode == 'bnstats_mask'
+    bn_y = rnd(n, h, w, c, seed=6).to(BF16)
+    mask = torch.randint(0, 256, (n * h * w, c // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    rows = lib.tok_conv_dgrad_stat_rows(ctypes.byref(d))
+    assert rows > 0
+    part_d = torch.full((2, rows, c), 7.0)          # every row must be written
+    part_h = torch.zeros(2, 2, c)
+    dv = both(libs, 'tok_conv_dgrad_bnstats',
+              lambda f: [ctypes.byref(d) if f.__name__ == 'to_dev' else d, f(dy), f(wd), f(dx), 0, f(bn_y),
+                         f(mask) if with_mask else None, f(part_d) if f.__name__ == 'to_dev' else f(part_h), None])
+    assert relerr(dv[id(dx)].float(), dx.float()) < 5e-3
+    g = dv[id(dx)].float().cpu().reshape(-1, c)
+    bits = ((mask.long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(-1, c).float() if with_mask else 1.0
+    dz = g * bits
+    got = dv[id(part_d)].cpu().sum(1)
+    assert relerr(got[0], dz.sum(0)) < 4e-3
+    assert relerr(got[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 4e-3
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_wgrad(libs, case):
     n, h, w, c, k, r, stride, pad = case

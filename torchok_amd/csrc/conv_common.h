@@ -78,6 +78,11 @@ bool conv_win_serves(const ConvArgs& a);
 int conv_win_grid(int gridM, int gridN);
 void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN);
 int conv_win_launch(ConvArgs& a, hipStream_t st);            // fills a.gridM / a.gridN / a.stat_rows itself
+// conv_s2d.hip: data gradient of 3x3 / stride 2 / padding 1 layers on a shared dY window (`a` as dgrad_fill leaves it)
+bool conv_s2d_serves(const ConvArgs& a, int stride, int pad);
+int conv_s2d_grid(int gridM, int gridN);
+void conv_s2d_tiles(const ConvArgs& a, int* gridM, int* gridN);
+int conv_s2d_launch(ConvArgs& a, hipStream_t st);            // fills a.gridM / a.gridN / a.stat_rows itself
 
 // gemm256.hip: pointwise layers with a deep reduction and a mid-sized pixel count on 256 x 256 tiles (8 waves)
 bool gemm256_geometry(const ConvArgs& a);                    // does the kernel own this layer (pure function of the geometry)

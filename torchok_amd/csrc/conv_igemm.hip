@@ -1153,6 +1153,12 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
   }
+  if (d->stride == 2 && conv_s2d_serves(a, d->stride, d->pad)) {
+    rc = conv_s2d_launch(a, st);
+    if (rc) return rc;
+    TOK_CHECK_LAUNCH(who);
+    return TOK_OK;
+  }
   const bool g256 = d->stride == 1 && g256_owns(a, pl.bn_tile);
   if (g256 && gemm256_modes(a)) {
     rc = gemm256_launch(a, st);
@@ -1208,6 +1214,11 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
     int gm, gn;
     conv_win_tiles(a, &gm, &gn);
     return conv_win_grid(gm, gn) / gn;
+  }
+  if (d->stride == 2 && conv_s2d_serves(a, d->stride, d->pad)) {
+    int gm, gn;
+    conv_s2d_tiles(a, &gm, &gn);
+    return conv_s2d_grid(gm, gn) / gn;
   }
   if (d->stride == 1 && g256_owns(a, pl.bn_tile)) return gemm256_rows(a);
   if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false))
