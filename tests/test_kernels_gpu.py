@@ -82,7 +82,8 @@ CONV_CASES = [
     # shared-window 3x3 kernel (conv_win.hip; served with TOK_CONV_WIN_MIN_TILES=1 at these sizes, see the module fixture)
     (5, 14, 14, 256, 256, 3, 1, 1),    # 16-column tiles, a tile spans two images (flattened rows)
     (3, 28, 28, 128, 128, 3, 1, 1),    # 32-column tiles, 28 of 32 columns used
-    (1, 40, 72, 96, 96, 3, 1, 1),      # 64-column tiles, two x-tiles (the second ragged), 96 of 128 channels
+    (1, 40, 72, 96, 96, 3, 1, 1),      # 64-column tiles, two x-tiles (the second ragged), one 96-channel tile
+    (2, 16, 32, 192, 192, 3, 1, 1),    # two 96-channel tiles
     (2, 56, 56, 64, 128, 3, 1, 1),
     (5, 13, 15, 40, 136, 3, 1, 1),     # C = 40: second chunk a quarter full; K = 136: second channel tile ragged
     (2, 56, 56, 64, 64, 3, 1, 1),      # 64-channel form of the window kernel (4 x 1 waves): ResNet stage 1
@@ -184,7 +185,8 @@ def test_conv_dgrad(libs, case, accumulate):
 S2D_CASES = [(3, 56, 56, 128, 128, 3, 2, 1),    # 28 x 28 class maps: 32-wide tiles, 128 channels
              (5, 28, 28, 256, 256, 3, 2, 1),    # 14 x 14: 16-wide tiles, rows of several images in one tile
              (1, 64, 256, 48, 48, 3, 2, 1),     # wide map walked in x-tiles, 64-channel tiles, 48 = 32 + a 16-channel tail
-             (2, 32, 128, 96, 192, 3, 2, 1),    # 96 of 128 output channels
+             (2, 32, 128, 96, 192, 3, 2, 1),    # one 96-channel tile
+             (2, 32, 64, 192, 192, 3, 2, 1),    # two 96-channel tiles
              (3, 36, 44, 64, 40, 3, 2, 1)]      # ragged: 18 x 22 class maps, 40 gathered channels
 
 
@@ -525,7 +527,8 @@ def test_optimizers_match_torch(libs):
 
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 256, 64, 1, 1, 0),
                                   (3, 14, 14, 64, 256, 1, 2, 0), (2, 17, 19, 64, 128, 3, 2, 1),
-                                  (1, 7, 7, 512, 512, 3, 1, 1)])
+                                  (1, 7, 7, 512, 512, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
+                                  (2, 16, 32, 192, 192, 3, 1, 1)])
 @pytest.mark.parametrize('with_mask', [0, 1])
 def test_conv_dgrad_bnstats(libs, case, with_mask):
     """dgrad whose epilogue also reduces sum(dz), sum(dz*y) of the unit that produced x."""

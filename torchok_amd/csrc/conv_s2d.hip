@@ -30,7 +30,8 @@ namespace {
 constexpr int WBK = 32;
 constexpr int NPJ = 6;                            // 1-KB window pieces per thread
 constexpr int S2_BUF = NPJ * 4 * 1024;            // 24 KB >= (TH + 1)(TW + 1) pixels x 64 B for every TW
-constexpr int s2_smem(int bn) { return 3 * bn * WBK * 2 + 2 * S2_BUF; }   // 72 KB (128 channels) / 60 KB (64)
+constexpr int s2_wrows(int bn) { return bn == 64 ? 64 : 128; }              // weight rows of a ring slot (96-channel tiles keep 128-row slots)
+constexpr int s2_smem(int bn) { return 3 * s2_wrows(bn) * WBK * 2 + 2 * S2_BUF; }   // 72 KB (128 / 96 channels) / 60 KB (64)
 
 __device__ __forceinline__ int win_f(int q) { return (0x78 >> ((q & 3) << 1)) & 3; }   // {0, 2, 3, 1}
 
@@ -53,9 +54,11 @@ __device__ __forceinline__ int s2_ntaps(int cls) { return (1 + (cls >> 1)) * (1 
 
 template <int TW, int WBN>
 __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo) {
-  constexpr int W_STAGE = WBN * WBK * 2;          // one tap's weight tile: 8 / 4 KB
-  constexpr int WGN = WBN / 64, WGM = 4 / WGN;
-  constexpr int WROWS = WBN / 64;                 // weight DMA instructions per thread and stage
+  constexpr int W_STAGE = s2_wrows(WBN) * WBK * 2;   // one tap's weight slot: 8 / 4 KB
+  constexpr int WGN = WBN == 128 ? 2 : 1, WGM = 4 / WGN;   // wave layouts as conv_win.hip: 2 x 2 (128), 4 x 1 (64, 96)
+  constexpr int WCH = WBN / WGN;                  // channels of a wave: 64 / 96
+  constexpr int NH = WCH / 32;                    // 32-channel halves of a wave
+  constexpr int WROWS = W_STAGE / 4096;           // weight DMA instructions per thread and stage
   constexpr int TH = 256 / TW;
   constexpr int WW = TW + 1;                      // window pitch in pixels
   constexpr int WIN_PX = (TH + 1) * WW;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   };
   // weight tile of (chunk cc, tap) into ring slot `slot`
   const int wrow_off0 = (n0 + lrow) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
-  const bool wrow_ok0 = n0 + lrow < a.K, wrow_ok1 = n0 + lrow + 64 < a.K;
+  const bool wrow_ok0 = n0 + lrow < a.K, wrow_ok1 = lrow + 64 < WBN && n0 + lrow + 64 < a.K;
   auto issue_weights = [&](int slot, int cc, int tap, bool live) {
     const int kch = cc * WBK + kcW * 8;
     const bool kok = live && kch < a.C;
@@ -135,16 +138,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   // ---- fragment addressing ---------------------------------------------------------------------------------------------
   const int sl = lane >> 4;
   const int li = lane & 15;
-  const int wrow0 = wn * 64 + (li >> 2) * 8 + (li & 3);
+  const int wrow0 = wn * WCH + (li >> 2) * 8 + (li & 3);
   const uint32_t wfrag = lds_base + (uint32_t)(wrow0 * 64 + ((sl ^ win_f(li >> 2)) << 4));   // + slot * W_STAGE + row imm
   // window: pixel (wave's first row + row + dR) * WW + seg * 16 + li + dS, chunk sl
   uint32_t afrag = lds_base + WIN0 + (uint32_t)((wm * WROWS_PER_WAVE * WW + li) * 64 + sl * 16);   // window buffer 0
 
   float s1r = 0.f, s2r = 0.f;
-  f32x4 acc[4][MT];
+  float s1q = 0.f, s2q = 0.f;                     // third half (NH == 3): lanes li < 8
+  f32x4 acc[2 * NH][MT];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 2 * NH; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
@@ -174,13 +178,17 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
 
   // one stage: the tap with window shift (dR, dS) of the current chunk out of weight slot `slot`
   auto compute = [&](int dR, int dS, int slot) {
-    u32x4 wf[4], af[MT];
+    u32x4 wf[2 * NH], af[MT];
     const uint32_t wa = wfrag + (uint32_t)(slot * W_STAGE);
     const uint32_t aa = afrag + (uint32_t)((dR * WW + dS) * 64);
     wf[0] = wlds16<0 * 64>(wa);
     wf[1] = wlds16<4 * 64>(wa);
     wf[2] = wlds16<32 * 64>(wa);
     wf[3] = wlds16<36 * 64>(wa);
+    if constexpr (NH == 3) {
+      wf[4] = wlds16<64 * 64>(wa);
+      wf[5] = wlds16<68 * 64>(wa);
+    }
 #define TOK_AF(mt) af[mt] = wlds16<(((mt) / SEGS) * WW + ((mt) % SEGS) * 16) * 64>(aa)
     TOK_AF(0); TOK_AF(1); TOK_AF(2); TOK_AF(3);
     if constexpr (MT == 8) { TOK_AF(4); TOK_AF(5); TOK_AF(6); TOK_AF(7); }
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     for (int mt = 0; mt < MT / 2; ++mt) {
       if ((skip >> (mt / SEGS)) & 1u) continue;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 2 * NH; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     for (int mt = MT / 2; mt < MT; ++mt) {
       if ((skip >> (mt / SEGS)) & 1u) continue;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 2 * NH; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -212,10 +220,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   // epilogue of the tile being computed: lane (sl, li) holds channels nb + {0..7}, nb + 32 + {0..7} of pixel
   // (gyC + wave row + mt / SEGS, gxC + (mt % SEGS) * 16 + li) of the class map
   auto epilogue = [&]() {
-    const int nb = n0 + wn * 64 + sl * 8;
+    const int nb = n0 + wn * WCH + sl * 8;
     if (a.bias != nullptr) {
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
+      for (int c = 0; c < NH * 8; ++c) {
         const int n = nb + (c >> 3) * 32 + (c & 7);
         const float bv = n < a.K ? a.bias[n] : 0.f;
 #pragma unroll
@@ -225,23 +233,24 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     const bool want_old = a.accumulate != 0;
     const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
     const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
-    float s1[16], s2[16];
+    float s1[NH * 8 + (NH == 3 ? 8 : 0)], s2[NH * 8 + (NH == 3 ? 8 : 0)];   // (NH == 3: padded to two butterflies of 16)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    for (int c = 0; c < NH * 8 + (NH == 3 ? 8 : 0); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    constexpr int GQ = NH == 3 ? 1 : 2;             // fragments whose epilogue operands are in flight together
 #pragma unroll
-    for (int g = 0; g < MT; g += 2) {
-      bf16x8 pre_old[2][2], pre_y[2][2];
-      unsigned pre_bits[2][2];
-      size_t pix[2];
-      bool pok[2];
+    for (int g = 0; g < MT; g += GQ) {
+      bf16x8 pre_old[GQ][NH], pre_y[GQ][NH];
+      unsigned pre_bits[GQ][NH];
+      size_t pix[GQ];
+      bool pok[GQ];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < GQ; ++q) {
         const int mt = g + q;
         const int gy = gyC + wm * WROWS_PER_WAVE + mt / SEGS, gx = gxC + (mt % SEGS) * 16 + li;
         pok[q] = gy < geo.BH && gx < a.W;
         pix[q] = (size_t)(2 * gy + pyC) * a.Q + 2 * gx + pxC;     // dX pixel of class pixel (gy, gx)
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NH; ++half) {
           const bool ok = pok[q] && nb + half * 32 + 8 <= a.K;
           const size_t eoff = pix[q] * a.K + nb + half * 32;
           pre_old[q][half] = (ok && want_old) ? ldg16(a.y + eoff) : zero8();
@@ -250,12 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
         }
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < GQ; ++q) {
         const int mt = g + q;
         if (!pok[q]) continue;
         bf16* yp = a.y + pix[q] * a.K + nb;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < NH; ++half) {
           if (nb + half * 32 + 8 > a.K) continue;
           float v[8];
 #pragma unroll
@@ -299,22 +308,26 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     }
     if (a.stats != nullptr) {
 #pragma unroll
-      for (int step = 0; step < 4; ++step) {
-        const int off = 8 >> step;
-        const int cnt = 8 >> step;
-        const bool up = (li & off) != 0;
+      for (int base = 0; base < (NH == 3 ? 32 : 16); base += 16) {
 #pragma unroll
-        for (int j = 0; j < cnt; ++j) {
-          const float send1 = up ? s1[j] : s1[j + cnt];
-          const float send2 = up ? s2[j] : s2[j + cnt];
-          const float keep1 = up ? s1[j + cnt] : s1[j];
-          const float keep2 = up ? s2[j + cnt] : s2[j];
-          s1[j] = keep1 + __shfl_xor(send1, off, 64);
-          s2[j] = keep2 + __shfl_xor(send2, off, 64);
+        for (int step = 0; step < 4; ++step) {
+          const int off = 8 >> step;
+          const int cnt = 8 >> step;
+          const bool up = (li & off) != 0;
+#pragma unroll
+          for (int j = 0; j < cnt; ++j) {
+            const float send1 = up ? s1[base + j] : s1[base + j + cnt];
+            const float send2 = up ? s2[base + j] : s2[base + j + cnt];
+            const float keep1 = up ? s1[base + j + cnt] : s1[base + j];
+            const float keep2 = up ? s2[base + j + cnt] : s2[base + j];
+            s1[base + j] = keep1 + __shfl_xor(send1, off, 64);
+            s2[base + j] = keep2 + __shfl_xor(send2, off, 64);
+          }
         }
       }
       s1r += s1[0];
       s2r += s2[0];
+      if constexpr (NH == 3) { s1q += s1[16]; s2q += s2[16]; }
     }
   };
 
@@ -392,9 +405,13 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   if (a.stats != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
-    const int nl = wn * 64 + (li >> 3) * 32 + sl * 8 + (li & 7);
+    const int nl = wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
     red[(0 * WGM + wm) * WBN + nl] = s1r;
     red[(1 * WGM + wm) * WBN + nl] = s2r;
+    if (NH == 3 && li < 8) {
+      red[(0 * WGM + wm) * WBN + nl + 64] = s1q;
+      red[(1 * WGM + wm) * WBN + nl + 64] = s2q;
+    }
     __syncthreads();
     if (tid < 2 * WBN) {
       const int which = tid / WBN;
@@ -419,7 +436,11 @@ int s2d_min_tiles() {
 }
 
 int pick_tw(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
-int pick_wbn(int K) { return K <= 64 ? 64 : 128; }
+int s2d_96() {      // TOK_CONV_WIN_96=0: layers of 96 / 192 channels stay on 128-wide tiles (A/B switch shared with conv_win.hip)
+  static const int v = [] { const char* e = getenv("TOK_CONV_WIN_96"); return (int)(e ? atoi(e) : 1); }();
+  return v;
+}
+int pick_wbn(int K) { return K <= 64 ? 64 : ((K == 96 || K == 192) && s2d_96() ? 96 : 128); }
 
 template <int TW, int BN>
 void launch_variant(const ConvArgs& a, const S2Geo& g, int grid, hipStream_t st) {
@@ -481,6 +502,10 @@ int conv_s2d_launch(ConvArgs& a, hipStream_t st) {
     if (tw == 16) launch_variant<16, 128>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 128>(a, g, grid, st);
     else launch_variant<64, 128>(a, g, grid, st);
+  } else if (bn == 96) {
+    if (tw == 16) launch_variant<16, 96>(a, g, grid, st);
+    else if (tw == 32) launch_variant<32, 96>(a, g, grid, st);
+    else launch_variant<64, 96>(a, g, grid, st);
   } else {
     if (tw == 16) launch_variant<16, 64>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 64>(a, g, grid, st);
