@@ -528,7 +528,7 @@ def test_optimizers_match_torch(libs):
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 256, 64, 1, 1, 0),
                                   (3, 14, 14, 64, 256, 1, 2, 0), (2, 17, 19, 64, 128, 3, 2, 1),
                                   (1, 7, 7, 512, 512, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
-                                  (2, 16, 32, 192, 192, 3, 1, 1)])
+                                  (2, 16, 32, 192, 192, 3, 1, 1), (2, 20, 36, 48, 48, 3, 1, 1)])
 @pytest.mark.parametrize('with_mask', [0, 1])
 def test_conv_dgrad_bnstats(libs, case, with_mask):
     """dgrad whose epilogue also reduces sum(dz), sum(dz*y) of the unit that produced x."""

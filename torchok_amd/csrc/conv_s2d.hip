@@ -30,7 +30,7 @@ namespace {
 constexpr int WBK = 32;
 constexpr int NPJ = 6;                            // 1-KB window pieces per thread
 constexpr int S2_BUF = NPJ * 4 * 1024;            // 24 KB >= (TH + 1)(TW + 1) pixels x 64 B for every TW
-constexpr int s2_wrows(int bn) { return bn == 64 ? 64 : 128; }              // weight rows of a ring slot (96-channel tiles keep 128-row slots)
+constexpr int s2_wrows(int bn) { return bn <= 64 ? 64 : 128; }              // weight rows of a ring slot (96-channel tiles keep 128-row slots)
 constexpr int s2_smem(int bn) { return 3 * s2_wrows(bn) * WBK * 2 + 2 * S2_BUF; }   // 72 KB (128 / 96 channels) / 60 KB (64)
 
 __device__ __forceinline__ int win_f(int q) { return (0x78 >> ((q & 3) << 1)) & 3; }   // {0, 2, 3, 1}
@@ -58,6 +58,9 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   constexpr int WGN = WBN == 128 ? 2 : 1, WGM = 4 / WGN;   // wave layouts as conv_win.hip: 2 x 2 (128), 4 x 1 (64, 96)
   constexpr int WCH = WBN / WGN;                  // channels of a wave: 64 / 96
   constexpr int NH = WCH / 32;                    // 32-channel halves of a wave
+  constexpr bool QT = WCH % 32 != 0;              // + a 16-channel quarter (48-channel tiles, see conv_win.hip)
+  constexpr int NTL = WCH / 16;                   // MFMA tiles of a wave along the channels
+  static_assert(!QT || (NH == 1 && WGN == 1), "the quarter tile is written for 48-channel waves");
   constexpr int WROWS = W_STAGE / 4096;           // weight DMA instructions per thread and stage
   constexpr int TH = 256 / TW;
   constexpr int WW = TW + 1;                      // window pitch in pixels
@@ -120,8 +123,11 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
                                              0);
   };
   // weight tile of (chunk cc, tap) into ring slot `slot`
-  const int wrow_off0 = (n0 + lrow) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
-  const bool wrow_ok0 = n0 + lrow < a.K, wrow_ok1 = lrow + 64 < WBN && n0 + lrow + 64 < a.K;
+  // channel (of this tile) that goes to LDS row lrow: the row itself, but for the quarter's rows 32 + 8 g + j <- 32 + 4 g + j
+  const int wsrc0 = (QT && lrow >= 32) ? 32 + ((lrow - 32) >> 3) * 4 + (lrow & 3) : lrow;
+  const bool wuse0 = !(QT && lrow >= 32 && (lrow & 4));
+  const int wrow_off0 = (n0 + wsrc0) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
+  const bool wrow_ok0 = wuse0 && wsrc0 < WBN && n0 + wsrc0 < a.K, wrow_ok1 = lrow + 64 < WBN && n0 + lrow + 64 < a.K;
   auto issue_weights = [&](int slot, int cc, int tap, bool live) {
     const int kch = cc * WBK + kcW * 8;
     const bool kok = live && kch < a.C;
@@ -145,10 +151,10 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
 
   float s1r = 0.f, s2r = 0.f;
   float s1q = 0.f, s2q = 0.f;                     // third half (NH == 3): lanes li < 8
-  f32x4 acc[2 * NH][MT];
+  f32x4 acc[NTL][MT];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2 * NH; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
@@ -178,13 +184,13 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
 
   // one stage: the tap with window shift (dR, dS) of the current chunk out of weight slot `slot`
   auto compute = [&](int dR, int dS, int slot) {
-    u32x4 wf[2 * NH], af[MT];
+    u32x4 wf[NTL], af[MT];
     const uint32_t wa = wfrag + (uint32_t)(slot * W_STAGE);
     const uint32_t aa = afrag + (uint32_t)((dR * WW + dS) * 64);
     wf[0] = wlds16<0 * 64>(wa);
     wf[1] = wlds16<4 * 64>(wa);
     wf[2] = wlds16<32 * 64>(wa);
-    wf[3] = wlds16<36 * 64>(wa);
+    if constexpr (NTL >= 4) wf[3] = wlds16<36 * 64>(wa);
     if constexpr (NH == 3) {
       wf[4] = wlds16<64 * 64>(wa);
       wf[5] = wlds16<68 * 64>(wa);
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     for (int mt = 0; mt < MT / 2; ++mt) {
       if ((skip >> (mt / SEGS)) & 1u) continue;
 #pragma unroll
-      for (int t = 0; t < 2 * NH; ++t)
+      for (int t = 0; t < NTL; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
     for (int mt = MT / 2; mt < MT; ++mt) {
       if ((skip >> (mt / SEGS)) & 1u) continue;
 #pragma unroll
-      for (int t = 0; t < 2 * NH; ++t)
+      for (int t = 0; t < NTL; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -229,13 +235,23 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
       }
+      if constexpr (QT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int n = n0 + NH * 32 + sl * 4 + c;
+          const float bv = n < a.K ? a.bias[n] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[2 * NH][mt][c] += bv;
+        }
+      }
     }
     const bool want_old = a.accumulate != 0;
     const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
     const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
-    float s1[NH * 8 + (NH == 3 ? 8 : 0)], s2[NH * 8 + (NH == 3 ? 8 : 0)];   // (NH == 3: padded to two butterflies of 16)
+    constexpr int SN = NH == 3 ? 32 : 16;           // butterflies of 16: [halves x 8][quarter x 4][padding]
+    float s1[SN], s2[SN];
 #pragma unroll
-    for (int c = 0; c < NH * 8 + (NH == 3 ? 8 : 0); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    for (int c = 0; c < SN; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     constexpr int GQ = NH == 3 ? 1 : 2;             // fragments whose epilogue operands are in flight together
 #pragma unroll
     for (int g = 0; g < MT; g += GQ) {
@@ -300,6 +316,51 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
                 const float r = bf2f(o[e]);
                 s1[half * 8 + e] += r;
                 s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
+              }
+            }
+          }
+        }
+        if constexpr (QT) {
+          // the quarter: channels nq + {0..3} of this pixel (8 bytes; the mask byte covers two lanes' channels)
+          const int nq = n0 + NH * 32 + sl * 4;
+          if (nq + 4 <= a.K) {
+            const size_t eo = pix[q] * a.K + nq;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[2 * NH][mt][e];
+            if (a.accumulate) {
+              const bf16x4 old = *reinterpret_cast<const bf16x4*>(a.y + eo);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            const unsigned bits = want_bits ? ((unsigned)a.bn_mask[eo >> 3] >> (unsigned)(eo & 4)) & 0xfu : 0xfu;
+            if (a.mask_store) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
+                s1[NH * 8 + e] += bf2f(o[e]);
+              }
+            }
+            *reinterpret_cast<bf16x4*>(a.y + eo) = o;
+            if (a.stats != nullptr && !a.mask_store) {
+              if (a.bn_y != nullptr) {
+                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(a.bn_y + eo);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
+                  s1[NH * 8 + e] += dz;
+                  s2[NH * 8 + e] = fmaf(dz, bf2f(yv[e]), s2[NH * 8 + e]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float r = bf2f(o[e]);
+                  s1[NH * 8 + e] += r;
+                  s2[NH * 8 + e] = fmaf(r, r, s2[NH * 8 + e]);
+                }
               }
             }
           }
@@ -405,9 +466,12 @@ __global__ __launch_bounds__(256, 2) void conv_s2d_kernel(ConvArgs a, S2Geo geo)
   if (a.stats != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
-    const int nl = wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
-    red[(0 * WGM + wm) * WBN + nl] = s1r;
-    red[(1 * WGM + wm) * WBN + nl] = s2r;
+    // lane li of the butterfly holds sum index li: halves as [half][8], the quarter's four channels at 8..11
+    const int nl = QT ? (li < 8 ? sl * 8 + li : 32 + sl * 4 + (li & 3)) : wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
+    if (!QT || li < 12) {
+      red[(0 * WGM + wm) * WBN + nl] = s1r;
+      red[(1 * WGM + wm) * WBN + nl] = s2r;
+    }
     if (NH == 3 && li < 8) {
       red[(0 * WGM + wm) * WBN + nl + 64] = s1q;
       red[(1 * WGM + wm) * WBN + nl + 64] = s2q;
@@ -440,7 +504,10 @@ int s2d_96() {      // TOK_CONV_WIN_96=0: layers of 96 / 192 channels stay on 12
   static const int v = [] { const char* e = getenv("TOK_CONV_WIN_96"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
-int pick_wbn(int K) { return K <= 64 ? 64 : ((K == 96 || K == 192) && s2d_96() ? 96 : 128); }
+int pick_wbn(int K) {
+  if (K == 48 && s2d_96()) return 48;
+  return K <= 64 ? 64 : ((K == 96 || K == 192) && s2d_96() ? 96 : 128);
+}
 
 template <int TW, int BN>
 void launch_variant(const ConvArgs& a, const S2Geo& g, int grid, hipStream_t st) {
@@ -506,6 +573,10 @@ int conv_s2d_launch(ConvArgs& a, hipStream_t st) {
     if (tw == 16) launch_variant<16, 96>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 96>(a, g, grid, st);
     else launch_variant<64, 96>(a, g, grid, st);
+  } else if (bn == 48) {
+    if (tw == 16) launch_variant<16, 48>(a, g, grid, st);
+    else if (tw == 32) launch_variant<32, 48>(a, g, grid, st);
+    else launch_variant<64, 48>(a, g, grid, st);
   } else {
     if (tw == 16) launch_variant<16, 64>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 64>(a, g, grid, st);

@@ -47,7 +47,7 @@ namespace {
 constexpr int WBK = 32;
 constexpr int WIN_PIECES = 28;                    // 1-KB DMA pieces per window buffer (4 waves x 7 slots)
 constexpr int WIN_BUF = WIN_PIECES * 1024;        // 28 KB >= (TH + 2)(TW + 2) pixels x 64 B for every TW
-constexpr int win_wrows(int bn) { return bn == 64 ? 64 : 128; }             // weight rows of a ring slot (96-channel tiles keep 128-row slots)
+constexpr int win_wrows(int bn) { return bn <= 64 ? 64 : 128; }             // weight rows of a ring slot (96-channel tiles keep 128-row slots)
 constexpr int win_smem(int bn) { return 3 * win_wrows(bn) * WBK * 2 + 2 * WIN_BUF; }   // 80 KB (128 / 96 channels) / 68 KB (64)
 
 __device__ __forceinline__ int win_f(int q) { return (0x78 >> ((q & 3) << 1)) & 3; }   // {0, 2, 3, 1}
@@ -68,13 +68,18 @@ struct WinGeo {
 // BN = 128: 2 (pixel rows) x 2 (64 channels) waves of 128 pixels x 64 channels; BN = 64 (layers of <= 64 output channels: the
 // high-resolution HRNet branches, ResNet's first stage): 4 x 1 waves of 64 pixels x 64 channels; BN = 96 (layers of 96 / 192
 // channels, HRNet-W48's second and third branch: 128-wide tiles would run a quarter of their MFMAs on padding): 4 x 1 waves of
-// 64 pixels x 96 channels = three 32-channel halves per wave.
+// 64 pixels x 96 channels = three 32-channel halves per wave; BN = 48 (HRNet-W48's first branch): 4 x 1 waves of 64 pixels x
+// 48 channels = one half + one QUARTER (a single 16-row MFMA tile whose LDS rows 32 + 8 g + j hold channels 32 + 4 g + j, so
+// that a lane's four accumulator rows are four consecutive channels: 8-byte stores, half a mask byte).
 template <int TW, int WBN>
 __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo) {
   constexpr int W_STAGE = win_wrows(WBN) * WBK * 2;   // one tap's weight slot: 8 / 4 KB
   constexpr int WGN = WBN == 128 ? 2 : 1, WGM = 4 / WGN;
   constexpr int WCH = WBN / WGN;                  // channels of a wave: 64 / 96
   constexpr int NH = WCH / 32;                    // 32-channel halves of a wave (two 16-row MFMA tiles each)
+  constexpr bool QT = WCH % 32 != 0;              // + a 16-channel quarter
+  constexpr int NTL = WCH / 16;                   // MFMA tiles of a wave along the channels
+  static_assert(!QT || (NH == 1 && WGN == 1), "the quarter tile is written for 48-channel waves");
   constexpr int WROWS = W_STAGE / 4096;           // weight DMA instructions per thread and stage
   constexpr int TH = 256 / TW;
   constexpr int WW = TW + 2;                      // window pitch in pixels
@@ -140,8 +145,11 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
                                              0);
   };
   // weight tile of (chunk cc, tap) into ring slot `slot`
-  const int wrow_off0 = (n0 + lrow) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
-  const bool wrow_ok0 = n0 + lrow < a.K, wrow_ok1 = lrow + 64 < WBN && n0 + lrow + 64 < a.K;
+  // channel (of this tile) that goes to LDS row lrow: the row itself, but for the quarter's rows (see above)
+  const int wsrc0 = (QT && lrow >= 32) ? 32 + ((lrow - 32) >> 3) * 4 + (lrow & 3) : lrow;
+  const bool wuse0 = !(QT && lrow >= 32 && (lrow & 4));
+  const int wrow_off0 = (n0 + wsrc0) * a.Ktot * 2, wrow_off1 = (n0 + lrow + 64) * a.Ktot * 2;
+  const bool wrow_ok0 = wuse0 && wsrc0 < WBN && n0 + wsrc0 < a.K, wrow_ok1 = lrow + 64 < WBN && n0 + lrow + 64 < a.K;
   auto issue_weights = [&](int slot, int cc, int tap, bool live) {
     const int kch = cc * WBK + kcW * 8;
     const bool kok = live && kch < a.C;
@@ -165,10 +173,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 
   float s1r = 0.f, s2r = 0.f;
   float s1q = 0.f, s2q = 0.f;                     // third half (NH == 3): lanes li < 8
-  f32x4 acc[2 * NH][MT];
+  f32x4 acc[NTL][MT];
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int t = 0; t < 2 * NH; ++t)
+    for (int t = 0; t < NTL; ++t)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
@@ -195,23 +203,23 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   };
 
 #if TOK_WIN_PROBE & 3
-  u32x4 pwf[2 * NH] = {}, paf[MT] = {};
+  u32x4 pwf[NTL] = {}, paf[MT] = {};
 #endif
   // one stage: tap (R, S) of the current chunk out of weight slot SLOT
   auto compute = [&](auto tapc, auto slotc) {
     constexpr int TAP = decltype(tapc)::value, SLOT = decltype(slotc)::value;
     constexpr int R = TAP / 3, S = TAP % 3;
 #if TOK_WIN_PROBE & 3
-    u32x4 (&wf)[2 * NH] = pwf;
+    u32x4 (&wf)[NTL] = pwf;
     u32x4 (&af)[MT] = paf;
 #else
-    u32x4 wf[2 * NH], af[MT];
+    u32x4 wf[NTL], af[MT];
 #endif
     if (!(TOK_WIN_PROBE & 2) || TAP == 0) {
     wf[0] = wlds16<SLOT * W_STAGE + 0 * 64>(wfrag);
     wf[1] = wlds16<SLOT * W_STAGE + 4 * 64>(wfrag);
     wf[2] = wlds16<SLOT * W_STAGE + 32 * 64>(wfrag);
-    wf[3] = wlds16<SLOT * W_STAGE + 36 * 64>(wfrag);
+    if constexpr (NTL >= 4) wf[3] = wlds16<SLOT * W_STAGE + 36 * 64>(wfrag);
     if constexpr (NH == 3) {
       wf[4] = wlds16<SLOT * W_STAGE + 64 * 64>(wfrag);
       wf[5] = wlds16<SLOT * W_STAGE + 68 * 64>(wfrag);
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
       if (TOK_WIN_PROBE & 16) { if (mt == 0) acc[0][0][0] += __builtin_bit_cast(f32x4, af[0])[0] + __builtin_bit_cast(f32x4, wf[0])[0]; continue; }
 #pragma unroll
-      for (int t = 0; t < 2 * NH; ++t)
+      for (int t = 0; t < NTL; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -241,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
     for (int mt = MT / 2; mt < MT; ++mt) {
       if (R != 1 && ((skip >> (mt / SEGS)) & 1u)) continue;
-      if (TOK_WIN_PROBE & 16) { if (mt == MT / 2) acc[0][0][1] += __builtin_bit_cast(f32x4, af[MT - 1])[0] + __builtin_bit_cast(f32x4, wf[2 * NH - 1])[0]; continue; }
+      if (TOK_WIN_PROBE & 16) { if (mt == MT / 2) acc[0][0][1] += __builtin_bit_cast(f32x4, af[MT - 1])[0] + __builtin_bit_cast(f32x4, wf[NTL - 1])[0]; continue; }
 #pragma unroll
-      for (int t = 0; t < 2 * NH; ++t)
+      for (int t = 0; t < NTL; ++t)
         acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[t]), __builtin_bit_cast(bf16x8, af[mt]),
                                                              acc[t][mt], 0, 0, 0);
     }
@@ -261,13 +269,23 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
       }
+      if constexpr (QT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int n = n0 + NH * 32 + sl * 4 + c;
+          const float bv = n < a.K ? a.bias[n] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[2 * NH][mt][c] += bv;
+        }
+      }
     }
     const bool want_old = a.accumulate != 0;
     const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
     const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
-    float s1[NH * 8 + (NH == 3 ? 8 : 0)], s2[NH * 8 + (NH == 3 ? 8 : 0)];   // (NH == 3: padded to two butterflies of 16)
+    constexpr int SN = NH == 3 ? 32 : 16;           // butterflies of 16: [halves x 8][quarter x 4][padding]
+    float s1[SN], s2[SN];
 #pragma unroll
-    for (int c = 0; c < NH * 8 + (NH == 3 ? 8 : 0); ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    for (int c = 0; c < SN; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
     constexpr int GQ = NH == 3 ? 1 : 2;             // fragments whose epilogue operands are in flight together
 #pragma unroll
     for (int g = 0; g < MT; g += GQ) {
@@ -332,6 +350,51 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
                 const float r = bf2f(o[e]);
                 s1[half * 8 + e] += r;
                 s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
+              }
+            }
+          }
+        }
+        if constexpr (QT) {
+          // the quarter: channels nq + {0..3} of this pixel (8 bytes; the mask byte covers two lanes' channels)
+          const int nq = n0 + NH * 32 + sl * 4;
+          if (nq + 4 <= a.K) {
+            const size_t eo = pix[q] * a.K + nq;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[2 * NH][mt][e];
+            if (a.accumulate) {
+              const bf16x4 old = *reinterpret_cast<const bf16x4*>(a.y + eo);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
+            const unsigned bits = want_bits ? ((unsigned)a.bn_mask[eo >> 3] >> (unsigned)(eo & 4)) & 0xfu : 0xfu;
+            if (a.mask_store) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
+                s1[NH * 8 + e] += bf2f(o[e]);
+              }
+            }
+            *reinterpret_cast<bf16x4*>(a.y + eo) = o;
+            if (a.stats != nullptr && !a.mask_store) {
+              if (a.bn_y != nullptr) {
+                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(a.bn_y + eo);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
+                  s1[NH * 8 + e] += dz;
+                  s2[NH * 8 + e] = fmaf(dz, bf2f(yv[e]), s2[NH * 8 + e]);
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float r = bf2f(o[e]);
+                  s1[NH * 8 + e] += r;
+                  s2[NH * 8 + e] = fmaf(r, r, s2[NH * 8 + e]);
+                }
               }
             }
           }
@@ -415,9 +478,12 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   if (a.stats != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
-    const int nl = wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
-    red[(0 * WGM + wm) * WBN + nl] = s1r;
-    red[(1 * WGM + wm) * WBN + nl] = s2r;
+    // lane li of the butterfly holds sum index li: halves as [half][8], the quarter's four channels at 8..11
+    const int nl = QT ? (li < 8 ? sl * 8 + li : 32 + sl * 4 + (li & 3)) : wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
+    if (!QT || li < 12) {
+      red[(0 * WGM + wm) * WBN + nl] = s1r;
+      red[(1 * WGM + wm) * WBN + nl] = s2r;
+    }
     if (NH == 3 && li < 8) {
       red[(0 * WGM + wm) * WBN + nl + 64] = s1q;
       red[(1 * WGM + wm) * WBN + nl + 64] = s2q;
@@ -446,11 +512,14 @@ int win_min_tiles() {
 }
 
 int pick_tw(int W) { return W <= 16 ? 16 : (W <= 32 ? 32 : 64); }
-int win_96() {      // TOK_CONV_WIN_96=0: layers of 96 / 192 channels stay on 128-wide tiles (A/B switch)
+int win_96() {      // TOK_CONV_WIN_96=0: layers of 48 / 96 / 192 channels stay on 64- / 128-wide tiles (A/B switch)
   static const int v = [] { const char* e = getenv("TOK_CONV_WIN_96"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
-int pick_wbn(int K) { return K <= 64 ? 64 : ((K == 96 || K == 192) && win_96() ? 96 : 128); }
+int pick_wbn(int K) {
+  if (K == 48 && win_96()) return 48;
+  return K <= 64 ? 64 : ((K == 96 || K == 192) && win_96() ? 96 : 128);
+}
 
 template <int TW, int BN>
 void launch_variant(const ConvArgs& a, const WinGeo& g, int grid, hipStream_t st) {
@@ -516,6 +585,10 @@ int conv_win_launch(ConvArgs& a, hipStream_t st) {
     if (tw == 16) launch_variant<16, 96>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 96>(a, g, grid, st);
     else launch_variant<64, 96>(a, g, grid, st);
+  } else if (bn == 48) {
+    if (tw == 16) launch_variant<16, 48>(a, g, grid, st);
+    else if (tw == 32) launch_variant<32, 48>(a, g, grid, st);
+    else launch_variant<64, 48>(a, g, grid, st);
   } else {
     if (tw == 16) launch_variant<16, 64>(a, g, grid, st);
     else if (tw == 32) launch_variant<32, 64>(a, g, grid, st);
