@@ -861,9 +861,10 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_taps_kernel(WgradArgs a) {
 // CT = 16-channel tiles per side of the workgroup tile: 4 -> 64 x 64 channels (four compute waves, nine column tiles each, taps
 // straddle waves), 3 -> 48 x 48 (HRNet's 48 / 96-wide branches: three compute waves, one filter row each; the fourth wave only
 // stages).  Rows keep the 128-byte pitch; the 48-wide form leaves the last two 16-byte slots of a row unfetched.
-template <int CT>
+// NST = stages of the ring (NST - 1 in flight ahead of the one being read): 4 x 20 KB = 80 KB, two workgroups per CU.
+template <int CT, int NST>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
-  constexpr int MS = 32, NST = 3, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
+  constexpr int MS = 32, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
   constexpr int WIN = MS + 2;                    // pixels per filter-row window
   constexpr int YT = MS * 128;                   // dy tile: 4 KB
   constexpr int XT = 128 * 128;                  // x region: room for 4 DMA instructions (128 rows), 3 * 34 = 102 used
@@ -903,7 +904,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
     const int R = row + 32 * j;
     const int win = R / WIN;
     xlive[j] = cx_ok && R < 3 * WIN;
+#if defined(TOK_WGWIN_PROBE) && (TOK_WGWIN_PROBE & 1)
+    xdelta[j] = -1 + (R - win * WIN);            // probe (timing only): the three filter-row windows alias the centre row
+#else
     xdelta[j] = (win - 1) * a.W - 1 + (R - win * WIN);
+#endif
   }
   const int total_pix = a.M;                     // stride 1, "same" padding: input pixels == output pixels
 
@@ -938,11 +943,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   const int rrow = 4 * g + (li >> 2);
   const uint32_t ysw = (uint32_t)(((rrow & 3) << 1) << 4);
   const uint32_t cq = (uint32_t)((li & 3) * 8);          // byte offset of this lane's 4 columns inside a 16-column tile
-  // zero line behind the ring (128 bytes): target of the transpose reads of invalid (pixel, tap) pairs
+  // zero line = row 127 of the stage's own x region: rows 102..127 take out-of-range DMA offsets (xlive false), i.e. zeros,
+  // with every stage; target of the transpose reads of invalid (pixel, tap) pairs
   typedef __attribute__((address_space(3))) char lds_char;
   const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
-  const uint32_t zero_line = lds_base + NST * STAGE;
-  if (tid < 8) *reinterpret_cast<u32x4*>(smem + NST * STAGE + tid * 16) = (u32x4){0u, 0u, 0u, 0u};
 
   // the whole stage loop is instantiated once per wave index (tap / tile numbers become literals); every copy executes the
   // same barriers, so the four waves of a workgroup may sit in different copies
@@ -965,12 +969,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  issue(1);
-  int cur = 0, nxt = 2;
+#pragma unroll
+  for (int s_ = 0; s_ < NST - 1; ++s_) issue(s_);
+  int cur = 0, nxt = NST - 1;
   int mrd = mstart + rrow;                        // output pixel of this lane's first reduction row in the stage being read
   for (int st = 0; st < steps; ++st) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(LOADS) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * LOADS) : "memory");
     __builtin_amdgcn_s_barrier();
     issue(nxt);
     if constexpr (W0 < 0) {      // staging-only wave: its DMA share is issued, nothing to multiply
@@ -996,6 +1000,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
     mrd += MS;
     const uint32_t Yb = lds_base + cur * STAGE + (uint32_t)(rrow * 128);
     const uint32_t Xb = lds_base + cur * STAGE + YT;
+    const uint32_t zero_line = Xb + 127 * 128;
     u32x2 ya[NT][2], xb[KTL][2];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -1444,17 +1449,24 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
     const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W &&
                       (unsigned long long)a.M * a.C * 2 < 0xFFFFFFF0ull && taps_enabled() != 2;
     if (same) {
-      constexpr int smem_w = 3 * (32 * 128 + 128 * 128) + 128;
+      static const int nst = [] { const char* e = getenv("TOK_WGRAD_WIN_NST"); return e ? atoi(e) : 3; }();   // 4: A/B switch (measured neutral)
+      const int smem_w = (nst == 3 ? 3 : 4) * (32 * 128 + 128 * 128);
       static const bool attr_w = [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  smem_w);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
         return true;
       }();   // once per process (thread-safe function-local static)
       (void)attr_w;
-      if (p.TN == 48) hipLaunchKernelGGL(conv_wgrad_win_kernel<3>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
-      else hipLaunchKernelGGL(conv_wgrad_win_kernel<4>, dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem_w, st, a);
+      const dim3 gw(a.tilesN * a.tilesK * a.splitM);
+      if (nst == 3) {
+        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3>), gw, dim3(256), smem_w, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_win_kernel<4, 3>), gw, dim3(256), smem_w, st, a);
+      } else {
+        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 4>), gw, dim3(256), smem_w, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_win_kernel<4, 4>), gw, dim3(256), smem_w, st, a);
+      }
     } else {
       hipLaunchKernelGGL((conv_wgrad_taps_kernel<0>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
     }
