@@ -443,15 +443,20 @@ def main():
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
+    host_done = []
     for i in range(args.steps):
         loss = step(args.warmup + i)
         evs[i + 1].record()
+        host_done.append(time.perf_counter())
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    # how far the launch thread runs ahead of the GPU: evs[0] was recorded on an idle device at host time t0, so step i's
+    # kernels finish at about t0 + elapsed(evs[0], evs[i + 1]); the host finished enqueuing that step at host_done[i]
+    host_lead_ms = [evs[0].elapsed_time(evs[i + 1]) - (host_done[i] - t0) * 1e3 for i in range(args.steps)]
     final_loss = float(loss.detach())
     in_sync = replicas_in_sync(reducer)      # N > 1: every rank must hold bit-identical parameters after the run
     if dist_on:
@@ -488,6 +493,7 @@ def main():
             'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'step_p50_ms': round(statistics.median(step_ms), 3),
+            'host_lead_ms': {'min': round(min(host_lead_ms), 2), 'p50': round(statistics.median(host_lead_ms), 2)},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16',
             'data': 'synthetic', 'final_loss': round(final_loss, 4),
             'config': {'workload': (f'{args.backbone} + SegmentationTask(HRNetSegmentationNeck, SegmentationHead '

@@ -173,6 +173,17 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 
   float s1r = 0.f, s2r = 0.f;
   float s1q = 0.f, s2q = 0.f;                     // third half (NH == 3): lanes li < 8
+  // narrow tiles have the registers to keep the per-lane BatchNorm sums across the tiles of a workgroup: one transposing
+  // butterfly per kernel instead of one per tile (~500 of a 48-channel tile's ~4000 cycles).  TOK_S1 / TOK_S2 name the slot
+  // either way (PST is a constant: the other array is never touched and takes no registers).
+  constexpr bool PST = WBN <= 64;
+  float ps1[16], ps2[16];
+  if constexpr (PST) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { ps1[c] = 0.f; ps2[c] = 0.f; }
+  }
+#define TOK_S1(i) (PST ? ps1[(i) & 15] : s1[i])
+#define TOK_S2(i) (PST ? ps2[(i) & 15] : s2[i])
   f32x4 acc[NTL][MT];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -284,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
     const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
     constexpr int SN = NH == 3 ? 32 : 16;           // butterflies of 16: [halves x 8][quarter x 4][padding]
     float s1[SN], s2[SN];
+    if constexpr (!PST) {
 #pragma unroll
-    for (int c = 0; c < SN; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+      for (int c = 0; c < SN; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
+    }
     constexpr int GQ = NH == 3 ? 1 : 2;             // fragments whose epilogue operands are in flight together
 #pragma unroll
     for (int g = 0; g < MT; g += GQ) {
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
-              s1[half * 8 + e] += bf2f(o[e]);
+              TOK_S1(half * 8 + e) += bf2f(o[e]);
             }
           }
           stg16(yp + half * 32, o);
@@ -341,15 +354,15 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
-                s1[half * 8 + e] += dz;
-                s2[half * 8 + e] = fmaf(dz, bf2f(pre_y[q][half][e]), s2[half * 8 + e]);
+                TOK_S1(half * 8 + e) += dz;
+                TOK_S2(half * 8 + e) = fmaf(dz, bf2f(pre_y[q][half][e]), TOK_S2(half * 8 + e));
               }
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float r = bf2f(o[e]);
-                s1[half * 8 + e] += r;
-                s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
+                TOK_S1(half * 8 + e) += r;
+                TOK_S2(half * 8 + e) = fmaf(r, r, TOK_S2(half * 8 + e));
               }
             }
           }
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
                 if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
-                s1[NH * 8 + e] += bf2f(o[e]);
+                TOK_S1(NH * 8 + e) += bf2f(o[e]);
               }
             }
             *reinterpret_cast<bf16x4*>(a.y + eo) = o;
@@ -385,15 +398,15 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
-                  s1[NH * 8 + e] += dz;
-                  s2[NH * 8 + e] = fmaf(dz, bf2f(yv[e]), s2[NH * 8 + e]);
+                  TOK_S1(NH * 8 + e) += dz;
+                  TOK_S2(NH * 8 + e) = fmaf(dz, bf2f(yv[e]), TOK_S2(NH * 8 + e));
                 }
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   const float r = bf2f(o[e]);
-                  s1[NH * 8 + e] += r;
-                  s2[NH * 8 + e] = fmaf(r, r, s2[NH * 8 + e]);
+                  TOK_S1(NH * 8 + e) += r;
+                  TOK_S2(NH * 8 + e) = fmaf(r, r, TOK_S2(NH * 8 + e));
                 }
               }
             }
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
         }
       }
     }
-    if (a.stats != nullptr) {
+    if (!PST && a.stats != nullptr) {
 #pragma unroll
       for (int base = 0; base < (NH == 3 ? 32 : 16); base += 16) {
 #pragma unroll
@@ -411,18 +424,18 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
           const bool up = (li & off) != 0;
 #pragma unroll
           for (int j = 0; j < cnt; ++j) {
-            const float send1 = up ? s1[base + j] : s1[base + j + cnt];
-            const float send2 = up ? s2[base + j] : s2[base + j + cnt];
-            const float keep1 = up ? s1[base + j + cnt] : s1[base + j];
-            const float keep2 = up ? s2[base + j + cnt] : s2[base + j];
-            s1[base + j] = keep1 + __shfl_xor(send1, off, 64);
-            s2[base + j] = keep2 + __shfl_xor(send2, off, 64);
+            const float send1 = up ? TOK_S1(base + j) : TOK_S1(base + j + cnt);
+            const float send2 = up ? TOK_S2(base + j) : TOK_S2(base + j + cnt);
+            const float keep1 = up ? TOK_S1(base + j + cnt) : TOK_S1(base + j);
+            const float keep2 = up ? TOK_S2(base + j + cnt) : TOK_S2(base + j);
+            TOK_S1(base + j) = keep1 + __shfl_xor(send1, off, 64);
+            TOK_S2(base + j) = keep2 + __shfl_xor(send2, off, 64);
           }
         }
       }
-      s1r += s1[0];
-      s2r += s2[0];
-      if constexpr (NH == 3) { s1q += s1[16]; s2q += s2[16]; }
+      s1r += TOK_S1(0);
+      s2r += TOK_S2(0);
+      if constexpr (NH == 3) { s1q += TOK_S1(16); s2q += TOK_S2(16); }
     }
   };
 
@@ -474,7 +487,28 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+#undef TOK_S1
+#undef TOK_S2
   // ---- BatchNorm partial sums -> one row per workgroup --------------------------------------------------------------------
+  if (PST && a.stats != nullptr) {                 // the one butterfly of the narrow tiles
+#pragma unroll
+    for (int step = 0; step < 4; ++step) {
+      const int off = 8 >> step;
+      const int cnt = 8 >> step;
+      const bool up = (li & off) != 0;
+#pragma unroll
+      for (int j = 0; j < cnt; ++j) {
+        const float send1 = up ? ps1[j] : ps1[j + cnt];
+        const float send2 = up ? ps2[j] : ps2[j + cnt];
+        const float keep1 = up ? ps1[j + cnt] : ps1[j];
+        const float keep2 = up ? ps2[j + cnt] : ps2[j];
+        ps1[j] = keep1 + __shfl_xor(send1, off, 64);
+        ps2[j] = keep2 + __shfl_xor(send2, off, 64);
+      }
+    }
+    s1r = ps1[0];
+    s2r = ps2[0];
+  }
   if (a.stats != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
