@@ -225,6 +225,43 @@ def test_conv_dgrad_stride2_on_the_shared_window(libs, case, mode):
     assert relerr(got[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 4e-3
 
 
+@pytest.mark.parametrize('case', S2D_CASES + [(2, 20, 36, 48, 48, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
+                                              (2, 16, 32, 192, 192, 3, 1, 1), (2, 16, 32, 64, 64, 3, 1, 1)])
+@pytest.mark.parametrize('mode', ['maskstore', 'bias_sums'])
+def test_conv_dgrad_window_kernels_mask_store_and_bias(libs, case, mode):
+    """The remaining epilogues of the window kernels (conv_win.hip / conv_s2d.hip) on every channel-tile form (48 = half +
+    quarter, 64, 96 = three halves, 128): the masked store with its one sum, and bias + accumulate + BatchNorm-backward sums."""
+    n, h, w, c, k, r, stride, pad = case
+    d = _desc(*case)
+    lib, fake = libs
+    dy = rnd(n, d.p, d.q, k).to(BF16)
+    wd = rnd(c, r, r, k, scale=(r * r * k) ** -0.5).to(BF16)
+    dx = rnd(n, h, w, c, seed=5).to(BF16)
+    mask = torch.randint(0, 256, (n * h * w, c // 8), dtype=torch.uint8, generator=torch.Generator().manual_seed(7))
+    bits = ((mask.long().unsqueeze(-1) >> torch.arange(8)) & 1).reshape(-1, c).float()
+    rows = lib.tok_conv_dgrad_stat_rows(ctypes.byref(d))
+    part_d = torch.full((2, rows, c), 7.0)
+    part_h = torch.zeros(2, 2, c)
+    dref = lambda f: ctypes.byref(d) if f.__name__ == 'to_dev' else d        # noqa: E731
+    pref = lambda f: f(part_d) if f.__name__ == 'to_dev' else f(part_h)      # noqa: E731
+    if mode == 'maskstore':
+        dv = both(libs, 'tok_conv_dgrad_maskstore', lambda f: [dref(f), f(dy), f(wd), f(dx), 1, f(mask), pref(f), None])
+        got = dv[id(dx)].float().cpu().reshape(-1, c)
+        assert relerr(got, dx.float().reshape(-1, c)) < 5e-3
+        assert float((got * (1 - bits)).abs().max()) == 0.0                  # masked positions are stored as zeros
+        assert relerr(dv[id(part_d)].cpu()[0].sum(0), got.sum(0)) < 4e-3
+        return
+    bias = rnd(c, seed=11)
+    bn_y = rnd(n, h, w, c, seed=6).to(BF16)
+    dv = both(libs, 'tok_conv_dgrad_bias', lambda f: [dref(f), f(dy), f(wd), f(bias), f(dx), 1, f(bn_y), f(mask), pref(f), None])
+    got = dv[id(dx)].float().cpu().reshape(-1, c)
+    assert relerr(got, dx.float().reshape(-1, c)) < 5e-3
+    dz = got * bits
+    sums = dv[id(part_d)].cpu().sum(1)
+    assert relerr(sums[0], dz.sum(0)) < 4e-3
+    assert relerr(sums[1], (dz * bn_y.float().reshape(-1, c)).sum(0)) < 4e-3
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_wgrad(libs, case):
     n, h, w, c, k, r, stride, pad = case
