@@ -183,8 +183,9 @@ extern "C" int tok_scale_rows_add(const void* a, const void* b, const float* row
 // NHWC bf16, weights fp32 [C][3][3] (the master itself: 9 values per channel), thread = (pixel, 8 channels).
 namespace {
 
+template <bool FLIP>   // FLIP: the data gradient (correlation -> convolution)
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, bf16* out, int accumulate, int flip,
+                                                        const float* __restrict__ bias, bf16* out, int accumulate,
                                                         int N, int H, int W, int C, int ld) {
   const int cg_total = ld >> 3;
   const size_t total = (size_t)N * H * W * cg_total;
@@ -199,23 +200,39 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const bf16* __restrict__
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int c = cg * 8 + e;
-      acc[e] = (bias != nullptr && c < C) ? bias[c] : 0.f;
+      const float bv = bias != nullptr ? bias[c < C ? c : C - 1] : 0.f;   // unconditional (clamped) load, padding lanes stay 0
+      acc[e] = c < C ? bv : 0.f;
     }
+    // nine unconditional loads at clamped coordinates (a load inside a branch is fenced with s_waitcnt vmcnt(0) by hipcc: nine
+    // dependent round trips per element); a tap outside the image multiplies a zero, which leaves the sum bit-identical
+    bf16x8 v[9];
+    bool tap_ok[9];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int hh = hq + r - 1;
-      if ((unsigned)hh >= (unsigned)H) continue;
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const int ww = wq + s - 1;
-        if ((unsigned)ww >= (unsigned)W) continue;
-        const bf16x8 v = ldg16(x + (((size_t)n * H + hh) * W + ww) * ld + cg * 8);
-        const int tap = flip ? (2 - r) * 3 + (2 - s) : r * 3 + s;      // flip: the data gradient (correlation -> convolution)
+        const int hh = hq + r - 1, ww = wq + s - 1;
+        tap_ok[r * 3 + s] = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+        const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh), wc = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+        v[r * 3 + s] = ldg16(x + (((size_t)n * H + hc) * W + wc) * ld + cg * 8);
+      }
+    float wt[8][9];                                // the 8 channels' filters: 24 more loads in the same batch
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = cg * 8 + e;
-          if (c < C) acc[e] = fmaf(bf2f(v[e]), w[c * 9 + tap], acc[e]);
-        }
+    for (int e = 0; e < 8; ++e) {
+      const int c = cg * 8 + e;
+      const float* wc_ = w + (size_t)(c < C ? c : C - 1) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[e][t] = wc_[t];
+    }
+    __builtin_amdgcn_sched_barrier(0);             // (keeps the loads in flight together: the scheduler sank each to its use)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cg * 8 + e;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float wv = FLIP ? wt[e][8 - t] : wt[e][t];
+        const float xv = tap_ok[t] ? bf2f(v[t][e]) : 0.f;
+        if (c < C) acc[e] = fmaf(xv, wv, acc[e]);
       }
     }
     const size_t off = (((size_t)n * H + hq) * W + wq) * ld + cg * 8;
@@ -285,8 +302,10 @@ extern "C" int tok_dwconv3x3(const void* x, const float* w, const float* bias, v
   const size_t total = (size_t)n * h * wd * (ld >> 3);
   size_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(dwconv3x3_kernel, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)x, w, bias,
-                     (bf16*)out, accumulate, flip, n, h, wd, c, ld);
+  if (flip) hipLaunchKernelGGL(dwconv3x3_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)x, w,
+                               bias, (bf16*)out, accumulate, n, h, wd, c, ld);
+  else hipLaunchKernelGGL(dwconv3x3_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, tok_stream(stream), (const bf16*)x, w,
+                          bias, (bf16*)out, accumulate, n, h, wd, c, ld);
   TOK_CHECK_LAUNCH("tok_dwconv3x3");
   return TOK_OK;
 }
