@@ -84,6 +84,7 @@ CONV_CASES = [
     (3, 28, 28, 128, 128, 3, 1, 1),    # 32-column tiles, 28 of 32 columns used
     (1, 40, 72, 96, 96, 3, 1, 1),      # 64-column tiles, two x-tiles (the second ragged), one 96-channel tile
     (2, 16, 32, 192, 192, 3, 1, 1),    # two 96-channel tiles
+    (1, 16, 32, 384, 384, 3, 1, 1),    # few pixel tiles: four 96-channel tiles instead of three 128-channel ones
     (2, 56, 56, 64, 128, 3, 1, 1),
     (5, 13, 15, 40, 136, 3, 1, 1),     # C = 40: second chunk a quarter full; K = 136: second channel tile ragged
     (2, 56, 56, 64, 64, 3, 1, 1),      # 64-channel form of the window kernel (4 x 1 waves): ResNet stage 1
@@ -565,7 +566,8 @@ def test_optimizers_match_torch(libs):
 @pytest.mark.parametrize('case', [(2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 256, 64, 1, 1, 0),
                                   (3, 14, 14, 64, 256, 1, 2, 0), (2, 17, 19, 64, 128, 3, 2, 1),
                                   (1, 7, 7, 512, 512, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
-                                  (2, 16, 32, 192, 192, 3, 1, 1), (2, 20, 36, 48, 48, 3, 1, 1)])
+                                  (2, 16, 32, 192, 192, 3, 1, 1), (2, 20, 36, 48, 48, 3, 1, 1),
+                                  (1, 16, 32, 384, 384, 3, 1, 1)])
 @pytest.mark.parametrize('with_mask', [0, 1])
 def test_conv_dgrad_bnstats(libs, case, with_mask):
     """dgrad whose epilogue also reduces sum(dz), sum(dz*y) of the unit that produced x."""

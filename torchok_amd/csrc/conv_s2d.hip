@@ -538,9 +538,16 @@ int s2d_96() {      // TOK_CONV_WIN_96=0: layers of 96 / 192 channels stay on 12
   static const int v = [] { const char* e = getenv("TOK_CONV_WIN_96"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
-int pick_wbn(int K) {
-  if (K == 48 && s2d_96()) return 48;
-  return K <= 64 ? 64 : ((K == 96 || K == 192) && s2d_96() ? 96 : 128);
+// channel tile of a layer of K output channels whose map gives `ptiles` pixel tiles: the widest form that does not pad (48 / 96 /
+// 192 -> 48 / 96), and 96 instead of 128 where both divide K but 128-wide tiles would leave CUs without a workgroup (HRNet-W48's
+// 384-channel branch at 16 x 32: 48 pixel tiles x 3 = 144 workgroups on 256 CUs; x 4 = 192 shorter ones)
+int pick_wbn(int K, long long ptiles) {
+  if (!s2d_96()) return K <= 64 ? 64 : 128;
+  if (K == 48) return 48;
+  if (K <= 64) return 64;
+  if (K % 96 == 0 && K % 128 != 0) return 96;
+  if (K % 96 == 0 && ptiles * (K / 128) <= 256 && ptiles * (K / 96) <= 512) return 96;
+  return 128;
 }
 
 template <int TW, int BN>
@@ -583,20 +590,22 @@ int conv_s2d_grid(int gridM, int gridN) {
 
 // gridM = 4 classes x row groups x x-tiles (class fastest), gridN = channel tiles
 void conv_s2d_tiles(const ConvArgs& a, int* gridM, int* gridN) {
-  const int tw = pick_tw(a.W), th = 256 / tw, bn = pick_wbn(a.K);
+  const int tw = pick_tw(a.W), th = 256 / tw;
   const long long bh = (long long)(a.M / (a.P * a.Q)) * a.H;
   *gridM = (int)(4 * ((bh + th - 1) / th) * ((a.W + tw - 1) / tw));
+  const int bn = pick_wbn(a.K, *gridM);
   *gridN = (a.K + bn - 1) / bn;
 }
 
 int conv_s2d_launch(ConvArgs& a, hipStream_t st) {
-  const int tw = pick_tw(a.W), bn = pick_wbn(a.K);
+  const int tw = pick_tw(a.W);
   S2Geo g;
   g.BH = (a.M / (a.P * a.Q)) * a.H;
   g.XT = (a.W + tw - 1) / tw;
   g.fd_xt = make_fastdiv(g.XT);
   g.fd_h = make_fastdiv(a.H);
   conv_s2d_tiles(a, &a.gridM, &a.gridN);
+  const int bn = pick_wbn(a.K, a.gridM);
   const int grid = conv_s2d_grid(a.gridM, a.gridN);
   a.stat_rows = grid / a.gridN;
   if (bn == 128) {

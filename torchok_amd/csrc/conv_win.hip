@@ -550,9 +550,16 @@ int win_96() {      // TOK_CONV_WIN_96=0: layers of 48 / 96 / 192 channels stay 
   static const int v = [] { const char* e = getenv("TOK_CONV_WIN_96"); return (int)(e ? atoi(e) : 1); }();
   return v;
 }
-int pick_wbn(int K) {
-  if (K == 48 && win_96()) return 48;
-  return K <= 64 ? 64 : ((K == 96 || K == 192) && win_96() ? 96 : 128);
+// channel tile of a layer of K output channels whose map gives `ptiles` pixel tiles: the widest form that does not pad (48 / 96 /
+// 192 -> 48 / 96), and 96 instead of 128 where both divide K but 128-wide tiles would leave CUs without a workgroup (HRNet-W48's
+// 384-channel branch at 16 x 32: 48 pixel tiles x 3 = 144 workgroups on 256 CUs; x 4 = 192 shorter ones)
+int pick_wbn(int K, long long ptiles) {
+  if (!win_96()) return K <= 64 ? 64 : 128;
+  if (K == 48) return 48;
+  if (K <= 64) return 64;
+  if (K % 96 == 0 && K % 128 != 0) return 96;
+  if (K % 96 == 0 && ptiles * (K / 128) <= 256 && ptiles * (K / 96) <= 512) return 96;
+  return 128;
 }
 
 template <int TW, int BN>
@@ -595,20 +602,22 @@ int conv_win_grid(int gridM, int gridN) {
 
 // tile counts of a layer: gridM = row groups x x-tiles, gridN = channel tiles (128 wide; 64 for layers of <= 64 channels)
 void conv_win_tiles(const ConvArgs& a, int* gridM, int* gridN) {
-  const int tw = pick_tw(a.W), th = 256 / tw, bn = pick_wbn(a.K);
+  const int tw = pick_tw(a.W), th = 256 / tw;
   const long long bh = (long long)(a.M / (a.H * a.W)) * a.H;
   *gridM = (int)(((bh + th - 1) / th) * ((a.W + tw - 1) / tw));
+  const int bn = pick_wbn(a.K, *gridM);
   *gridN = (a.K + bn - 1) / bn;
 }
 
 int conv_win_launch(ConvArgs& a, hipStream_t st) {
-  const int tw = pick_tw(a.W), bn = pick_wbn(a.K);
+  const int tw = pick_tw(a.W);
   WinGeo g;
   g.BH = (a.M / (a.H * a.W)) * a.H;
   g.XT = (a.W + tw - 1) / tw;
   g.fd_xt = make_fastdiv(g.XT);
   g.fd_h = make_fastdiv(a.H);
   conv_win_tiles(a, &a.gridM, &a.gridN);
+  const int bn = pick_wbn(a.K, a.gridM);
   const int grid = conv_win_grid(a.gridM, a.gridN);
   a.stat_rows = grid / a.gridN;
   if (bn == 128) {
