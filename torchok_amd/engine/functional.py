@@ -130,6 +130,16 @@ WGRAD_SIDE_STREAM = os.environ.get('TOK_WGRAD_SIDE', '1') == '1'
 WGRAD_AFTER_DGRAD = os.environ.get('TOK_WGRAD_AFTER_DGRAD', '0') == '1'   # measured: 22.0 vs 21.1 ms/step — the later start costs more
 WGRAD_SIDE_MAX_ROWS = int(os.environ.get('TOK_WGRAD_SIDE_MAX_ROWS', '100000'))
 WGRAD_SIDE_WHICH = os.environ.get('TOK_WGRAD_SIDE_WHICH', '3x3')   # measured (ResNet-50, unit-3 fusion on): all 21.58, 3x3 21.45 ms/step
+# long-M pointwise weight gradients stay on the main stream when they are HBM-bound like the chain they would fight (ResNet-50: 51-102
+# MACs per operand element), and go to the side stream when they are MFMA-bound (HRNet-W48's 720 -> 720 neck convolution over 786 432
+# pixels: 360): HRNet-W48 70.65 -> 69.83 ms/step, ResNet-50 / SwinV2-T unchanged (profiles/r05_side_stream_resweep.txt)
+WGRAD_SIDE_MIN_INTENSITY = float(os.environ.get('TOK_WGRAD_SIDE_MIN_INTENSITY', '128'))
+
+
+def _pointwise_wgrad_is_mfma_bound(k, c) -> bool:
+    return (k * c) / float(k + c) >= WGRAD_SIDE_MIN_INTENSITY
+
+
 FUSE_BN_FINALIZE = os.environ.get('TOK_FUSE_BN_FINALIZE', '0') == '1'    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
 
@@ -355,7 +365,8 @@ class _ConvBnActNode(Node):
         else:
             r, s = conv.weight.shape[2], conv.weight.shape[3]
         side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
-                   (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')))
+                   (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
+                   _pointwise_wgrad_is_mfma_bound(conv.weight.shape[0], conv.weight.shape[1]))
         return bool(WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
                     and not torch.cuda.is_current_stream_capturing())
 
@@ -480,7 +491,8 @@ class _ConvBnActNode(Node):
             # LDS/MFMA-bound (3x3) and short-M weight gradients complement the HBM-bound main chain; the long-M pointwise ones
             # are HBM-bound themselves and only fight it for bandwidth
             side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
-                       (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')))
+                       (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
+                       (r * s == 1 and _pointwise_wgrad_is_mfma_bound(k, c)))
             if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
                     and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
