@@ -862,7 +862,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_taps_kernel(WgradArgs a) {
 // straddle waves), 3 -> 48 x 48 (HRNet's 48 / 96-wide branches: three compute waves, one filter row each; the fourth wave only
 // stages).  Rows keep the 128-byte pitch; the 48-wide form leaves the last two 16-byte slots of a row unfetched.
 // NST = stages of the ring (NST - 1 in flight ahead of the one being read): 4 x 20 KB = 80 KB, two workgroups per CU.
-template <int CT, int NST>
+// KTL = column tiles (tap, 16 channels) per compute wave: 9 (CT = 4: 36 tiles on four waves; CT = 3: 27 tiles on three waves, the
+// fourth only stages) or 7 (CT = 3: 27 tiles on FOUR waves, 7 + 7 + 7 + 6: a quarter less MFMA / transpose-read chain per barrier).
+template <int CT, int NST, int KTLP = 9>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   constexpr int MS = 32, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
   constexpr int WIN = MS + 2;                    // pixels per filter-row window
@@ -870,7 +872,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   constexpr int XT = 128 * 128;                  // x region: room for 4 DMA instructions (128 rows), 3 * 34 = 102 used
   constexpr int STAGE = YT + XT;                 // 20 KB
   constexpr int LOADS = 1 + 4;
-  constexpr int NT = CT, KTL = 9;
+  constexpr int NT = CT, KTL = KTLP;
+  constexpr int NTILES = TAPS * CT;                // column tiles of the workgroup tile
+  constexpr int NCW = (NTILES + KTL - 1) / KTL;    // compute waves
+  static_assert(NCW <= 4 && KTL >= 5, "wave split");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < KTL; ++j) {
-        const int J = W0 * KTL + j;
+        const int J = W0 * KTL + j < NTILES ? W0 * KTL + j : NTILES - 1;     // (a ragged last wave repeats its last tile; never stored)
         const int k = J / CT - T0;
         const uint32_t cb = ((uint32_t)((J % CT) * 32) + cq) ^ tsw[k];       // stays inside 128 bytes: fine for the zero line too
         xb[j][0] = tr_read_asm(tb[k][0] + cb);
@@ -1043,6 +1048,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 5; j < KTL; ++j) {
+      if (W0 * KTL + j >= NTILES) continue;
       const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
@@ -1058,6 +1064,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < KTL; ++j) {
     const int J = W0 * KTL + j;
+    if (J >= NTILES) continue;
     const int cin = ct * TC + (J % CT) * 16 + li;
     const int kcol = (J / CT) * a.C + cin;
 #pragma unroll
@@ -1074,8 +1081,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   if (wv == 0) run(std::integral_constant<int, 0>{});
   else if (wv == 1) run(std::integral_constant<int, 1>{});
   else if (wv == 2) run(std::integral_constant<int, 2>{});
-  else if (CT == 4) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, -1>{});       // staging-only wave (48-wide tiles)
+  else if (NCW == 4) run(std::integral_constant<int, 3>{});
+  else run(std::integral_constant<int, -1>{});       // staging-only wave (48-wide tiles on three compute waves)
 }
 
 // dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
@@ -1456,12 +1463,15 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
         return true;
       }();   // once per process (thread-safe function-local static)
       (void)attr_w;
       const dim3 gw(a.tilesN * a.tilesK * a.splitM);
       if (nst == 3) {
-        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3>), gw, dim3(256), smem_w, st, a);
+        static const int w48 = [] { const char* e = getenv("TOK_WGRAD_WIN48_WAVES"); return e ? atoi(e) : 4; }();   // 3: A/B switch
+        if (p.TN == 48 && w48 == 4) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3, 7>), gw, dim3(256), smem_w, st, a);
+        else if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3>), gw, dim3(256), smem_w, st, a);
         else hipLaunchKernelGGL((conv_wgrad_win_kernel<4, 3>), gw, dim3(256), smem_w, st, a);
       } else {
         if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 4>), gw, dim3(256), smem_w, st, a);
