@@ -171,19 +171,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   // window: pixel (wave's first row + row + r) * WW + seg * 16 + li + s, chunk sl; everything but the lane part is an immediate
   uint32_t afrag = lds_base + WIN0 + (uint32_t)((wm * WROWS_PER_WAVE * WW + li) * 64 + sl * 16);   // window buffer 0
 
-  float s1r = 0.f, s2r = 0.f;
-  float s1q = 0.f, s2q = 0.f;                     // third half (NH == 3): lanes li < 8
-  // narrow tiles have the registers to keep the per-lane BatchNorm sums across the tiles of a workgroup: one transposing
-  // butterfly per kernel instead of one per tile (~500 of a 48-channel tile's ~4000 cycles).  TOK_S1 / TOK_S2 name the slot
-  // either way (PST is a constant: the other array is never touched and takes no registers).
-  constexpr bool PST = WBN <= 64;
-  float ps1[16], ps2[16];
-  if constexpr (PST) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) { ps1[c] = 0.f; ps2[c] = 0.f; }
-  }
-#define TOK_S1(i) (PST ? ps1[(i) & 15] : s1[i])
-#define TOK_S2(i) (PST ? ps2[(i) & 15] : s2[i])
+#define TOK_WIN_PIXEL(gy, gx) ((size_t)(gy) * a.W + (gx))
+#define TOK_WIN_EPI_PART 1
+#include "conv_win_epilogue.inc"
+#undef TOK_WIN_EPI_PART
   f32x4 acc[NTL][MT];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -270,174 +261,9 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
 
   // epilogue of the tile being computed: lane (sl, li) holds channels nb + {0..7}, nb + 32 + {0..7} of pixel
   // (gyC + wave row + mt / SEGS, gxC + (mt % SEGS) * 16 + li)
-  auto epilogue = [&]() {
-    const int nb = n0 + wn * WCH + sl * 8;
-    if (a.bias != nullptr) {
-#pragma unroll
-      for (int c = 0; c < NH * 8; ++c) {
-        const int n = nb + (c >> 3) * 32 + (c & 7);
-        const float bv = n < a.K ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[c >> 2][mt][c & 3] += bv;
-      }
-      if constexpr (QT) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int n = n0 + NH * 32 + sl * 4 + c;
-          const float bv = n < a.K ? a.bias[n] : 0.f;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) acc[2 * NH][mt][c] += bv;
-        }
-      }
-    }
-    const bool want_old = a.accumulate != 0;
-    const bool want_y = a.stats != nullptr && !a.mask_store && a.bn_y != nullptr;
-    const bool want_bits = a.bn_mask != nullptr && (a.mask_store || want_y);
-    constexpr int SN = NH == 3 ? 32 : 16;           // butterflies of 16: [halves x 8][quarter x 4][padding]
-    float s1[SN], s2[SN];
-    if constexpr (!PST) {
-#pragma unroll
-      for (int c = 0; c < SN; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-    }
-    constexpr int GQ = NH == 3 ? 1 : 2;             // fragments whose epilogue operands are in flight together
-#pragma unroll
-    for (int g = 0; g < MT; g += GQ) {
-      bf16x8 pre_old[GQ][NH], pre_y[GQ][NH];
-      unsigned pre_bits[GQ][NH];
-      size_t pix[GQ];
-      bool pok[GQ];
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) {
-        const int mt = g + q;
-        const int gy = gyC + wm * WROWS_PER_WAVE + mt / SEGS, gx = gxC + (mt % SEGS) * 16 + li;
-        pok[q] = gy < geo.BH && gx < a.W;
-        pix[q] = (size_t)gy * a.W + gx;
-#pragma unroll
-        for (int half = 0; half < NH; ++half) {
-          const bool ok = pok[q] && nb + half * 32 + 8 <= a.K;
-          const size_t eoff = pix[q] * a.K + nb + half * 32;
-          pre_old[q][half] = (ok && want_old) ? ldg16(a.y + eoff) : zero8();
-          pre_y[q][half] = (ok && want_y) ? ldg16(a.bn_y + eoff) : zero8();
-          pre_bits[q][half] = (ok && want_bits) ? (unsigned)a.bn_mask[eoff >> 3] : 0xffu;
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) {
-        const int mt = g + q;
-        if (!pok[q]) continue;
-        bf16* yp = a.y + pix[q] * a.K + nb;
-#pragma unroll
-        for (int half = 0; half < NH; ++half) {
-          if (nb + half * 32 + 8 > a.K) continue;
-          float v[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = acc[half * 2 + (e >> 2)][mt][e & 3];
-          if (a.accumulate) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bf2f(pre_old[q][half][e]);
-          }
-          bf16x8 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = f2bf(v[e]);
-          if (a.mask_store) {
-            const unsigned bits = pre_bits[q][half];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
-              TOK_S1(half * 8 + e) += bf2f(o[e]);
-            }
-          }
-          stg16(yp + half * 32, o);
-          if (a.stats != nullptr && !a.mask_store) {
-            if (a.bn_y != nullptr) {
-              const unsigned bits = pre_bits[q][half];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
-                TOK_S1(half * 8 + e) += dz;
-                TOK_S2(half * 8 + e) = fmaf(dz, bf2f(pre_y[q][half][e]), TOK_S2(half * 8 + e));
-              }
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                const float r = bf2f(o[e]);
-                TOK_S1(half * 8 + e) += r;
-                TOK_S2(half * 8 + e) = fmaf(r, r, TOK_S2(half * 8 + e));
-              }
-            }
-          }
-        }
-        if constexpr (QT) {
-          // the quarter: channels nq + {0..3} of this pixel (8 bytes; the mask byte covers two lanes' channels)
-          const int nq = n0 + NH * 32 + sl * 4;
-          if (nq + 4 <= a.K) {
-            const size_t eo = pix[q] * a.K + nq;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[2 * NH][mt][e];
-            if (a.accumulate) {
-              const bf16x4 old = *reinterpret_cast<const bf16x4*>(a.y + eo);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += bf2f(old[e]);
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = f2bf(v[e]);
-            const unsigned bits = want_bits ? ((unsigned)a.bn_mask[eo >> 3] >> (unsigned)(eo & 4)) & 0xfu : 0xfu;
-            if (a.mask_store) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                if (!((bits >> e) & 1u)) o[e] = (bf16)0.f;
-                TOK_S1(NH * 8 + e) += bf2f(o[e]);
-              }
-            }
-            *reinterpret_cast<bf16x4*>(a.y + eo) = o;
-            if (a.stats != nullptr && !a.mask_store) {
-              if (a.bn_y != nullptr) {
-                const bf16x4 yv = *reinterpret_cast<const bf16x4*>(a.bn_y + eo);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float dz = ((bits >> e) & 1u) ? bf2f(o[e]) : 0.f;
-                  TOK_S1(NH * 8 + e) += dz;
-                  TOK_S2(NH * 8 + e) = fmaf(dz, bf2f(yv[e]), TOK_S2(NH * 8 + e));
-                }
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const float r = bf2f(o[e]);
-                  TOK_S1(NH * 8 + e) += r;
-                  TOK_S2(NH * 8 + e) = fmaf(r, r, TOK_S2(NH * 8 + e));
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    if (!PST && a.stats != nullptr) {
-#pragma unroll
-      for (int base = 0; base < (NH == 3 ? 32 : 16); base += 16) {
-#pragma unroll
-        for (int step = 0; step < 4; ++step) {
-          const int off = 8 >> step;
-          const int cnt = 8 >> step;
-          const bool up = (li & off) != 0;
-#pragma unroll
-          for (int j = 0; j < cnt; ++j) {
-            const float send1 = up ? TOK_S1(base + j) : TOK_S1(base + j + cnt);
-            const float send2 = up ? TOK_S2(base + j) : TOK_S2(base + j + cnt);
-            const float keep1 = up ? TOK_S1(base + j + cnt) : TOK_S1(base + j);
-            const float keep2 = up ? TOK_S2(base + j + cnt) : TOK_S2(base + j);
-            TOK_S1(base + j) = keep1 + __shfl_xor(send1, off, 64);
-            TOK_S2(base + j) = keep2 + __shfl_xor(send2, off, 64);
-          }
-        }
-      }
-      s1r += TOK_S1(0);
-      s2r += TOK_S2(0);
-      if constexpr (NH == 3) { s1q += TOK_S1(16); s2q += TOK_S2(16); }
-    }
-  };
+#define TOK_WIN_EPI_PART 2
+#include "conv_win_epilogue.inc"
+#undef TOK_WIN_EPI_PART
 
   // ---- prologue: window of the first chunk (buffer 0), weight stages of its taps 0 and 1 ------------------------------------
   setup_window(it0);
@@ -487,53 +313,10 @@ __global__ __launch_bounds__(256, 2) void conv_win_kernel(ConvArgs a, WinGeo geo
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
-#undef TOK_S1
-#undef TOK_S2
-  // ---- BatchNorm partial sums -> one row per workgroup --------------------------------------------------------------------
-  if (PST && a.stats != nullptr) {                 // the one butterfly of the narrow tiles
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      const int off = 8 >> step;
-      const int cnt = 8 >> step;
-      const bool up = (li & off) != 0;
-#pragma unroll
-      for (int j = 0; j < cnt; ++j) {
-        const float send1 = up ? ps1[j] : ps1[j + cnt];
-        const float send2 = up ? ps2[j] : ps2[j + cnt];
-        const float keep1 = up ? ps1[j + cnt] : ps1[j];
-        const float keep2 = up ? ps2[j + cnt] : ps2[j];
-        ps1[j] = keep1 + __shfl_xor(send1, off, 64);
-        ps2[j] = keep2 + __shfl_xor(send2, off, 64);
-      }
-    }
-    s1r = ps1[0];
-    s2r = ps2[0];
-  }
-  if (a.stats != nullptr) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);     // [2][WGM][WBN]: the rings are drained
-    // lane li of the butterfly holds sum index li: halves as [half][8], the quarter's four channels at 8..11
-    const int nl = QT ? (li < 8 ? sl * 8 + li : 32 + sl * 4 + (li & 3)) : wn * WCH + (li >> 3) * 32 + sl * 8 + (li & 7);
-    if (!QT || li < 12) {
-      red[(0 * WGM + wm) * WBN + nl] = s1r;
-      red[(1 * WGM + wm) * WBN + nl] = s2r;
-    }
-    if (NH == 3 && li < 8) {
-      red[(0 * WGM + wm) * WBN + nl + 64] = s1q;
-      red[(1 * WGM + wm) * WBN + nl + 64] = s2q;
-    }
-    __syncthreads();
-    if (tid < 2 * WBN) {
-      const int which = tid / WBN;
-      const int c = tid - which * WBN;
-      float t = 0.f;
-#pragma unroll
-      for (int w_ = 0; w_ < WGM; ++w_) t += red[(which * WGM + w_) * WBN + c];
-      const int row = xcd * S8 + jm;
-      const int n = n0 + c;
-      if (n < a.K) a.stats[((size_t)which * a.stat_rows + row) * a.K + n] = t;
-    }
-  }
+#define TOK_WIN_EPI_PART 3
+#include "conv_win_epilogue.inc"
+#undef TOK_WIN_EPI_PART
+#undef TOK_WIN_PIXEL
 }
 
 int win_flag() {   // TOK_CONV_WIN=0: 3x3 layers stay on the implicit-GEMM kernels (A/B switch)
