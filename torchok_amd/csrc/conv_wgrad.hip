@@ -33,6 +33,7 @@ struct WgradArgs {
   float* cs;     // ring kernel, may be null: column sums of dy over this split's rows (bias-gradient partials); split s at
                  // cs + s * cs_stride — with the flat reduce the row sits right behind the split's dW slab (one reduce launch)
   int cs_cols;   // unpadded output channel count
+  int adv_q, adv_p;   // pipelined window kernel: 32 % Q and (32 / Q) % P — how a pixel's (row, column) moves per 32-pixel stage
   size_t cs_stride, ws_stride;   // floats between consecutive splits of cs / of the dW partial slabs
 };
 
@@ -1085,6 +1086,260 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
   else run(std::integral_constant<int, -1>{});       // staging-only wave (48-wide tiles on three compute waves)
 }
 
+
+// ---- the window kernel, software-pipelined inside the wave (round 6) -------------------------------------------------------------
+// conv_wgrad_win_kernel runs one wave per SIMD at the step's split target (256 workgroups), and its stage is a serial chain:
+// barrier -> five DMA issues -> border masks -> 26 transpose reads -> lgkmcnt -> 36 MFMAs (576 of the stage's ~1700 cycles;
+// profiles/r05_layer_tables.txt: 411-644 TF/s).  Nothing overlaps the MFMA phase because the fragments it multiplies are the
+// ones it just waited for.  Here the fragments of stage st + 1 are read WHILE stage st is multiplied from registers: the x
+// fragment of column tile j is re-read in place right after the NT MFMAs that consumed it, only the dy fragments (used by every
+// MFMA of the stage) need a second register set (the stage body is instantiated twice, roles swapped).  The five DMA issues of
+// the stage that refills the just-freed slot ride behind the first five column tiles, the read bases of stage st + 2 (border
+// handling) are formed behind the last ones.  And the stage's VALU count — what a single wave per SIMD cannot hide — is cut:
+//  * DMA offsets are running sums (one add per piece and stage); rows past the tensor fall to the buffer range check, rows
+//    past the split's chunk are fetched and multiplied by the zero line (their reduction rows are invalid for every tap);
+//  * the (row, column) of a lane's two reduction rows are advanced by 32 pixels with one wrap each (a.adv_q = 32 % Q,
+//    a.adv_p = (32 / Q) % P from the host) instead of two magic-number divisions per stage;
+//  * a wave tests only the border conditions of ITS three taps (compile-time tap numbers), not a 9-bit mask.
+// Ring, stage layout, border handling, summation order per accumulator (stage order) and hence every output bit equal
+// conv_wgrad_win_kernel's.
+template <int CT, int NST, int KTLP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_winp_kernel(WgradArgs a) {
+  constexpr int MS = 32, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
+  constexpr int WIN = MS + 2;
+  constexpr int YT = MS * 128;
+  constexpr int XT = 128 * 128;
+  constexpr int STAGE = YT + XT;
+  constexpr int LOADS = 1 + 4;
+  constexpr int NT = CT, KTL = KTLP;
+  constexpr int NTILES = TAPS * CT;
+  constexpr int NCW = (NTILES + KTL - 1) / KTL;
+  static_assert(NCW == 4 && KTL >= 7 && NST >= 3, "four compute waves");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int tilesC = a.tilesK;
+  const int ntile = a.tilesN * tilesC;
+  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
+  const int split = id / ntile;
+  const int t = id - split * ntile;
+  const int tn = t / tilesC;
+  const int ct = t - tn * tilesC;
+
+  const int mstart = split * a.mchunk;
+  const int mend = min(a.M, mstart + a.mchunk);
+  const int steps = (mend - mstart + MS - 1) / MS;
+
+  const int row = tid >> 3, cc = tid & 7;
+  const int clog = cc ^ ((row & 3) << 1);
+  const int yn = tn * TN + clog * 8;
+  const bool yn_ok = yn < a.K && clog * 8 < TN;
+  const int cx = ct * TC + clog * 8;
+  const bool cx_ok = cx < a.C && clog * 8 < TC;
+  // running byte offsets of this thread's five DMA pieces (0: dy row, 1..4: x window rows R = row + 32 j).  A piece the thread
+  // never fetches (padding columns, rows 102..127 = the zero lines) starts at 2^31 + 2^30: the host serves this kernel only
+  // for tensors below 2^30 bytes, so such an offset stays past the buffer range check while it advances with the others
+  // (uniform increments: no per-piece increment registers in a loop that runs at the 256-register limit)
+  uint32_t doff[LOADS];
+  const uint32_t dinc_y = (uint32_t)(MS * a.K) * 2u;
+  const uint32_t dinc_x = (uint32_t)(MS * a.C) * 2u;
+  doff[0] = yn_ok ? (uint32_t)((mstart + row) * a.K + yn) * 2u : 0xC0000000u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int R = row + 32 * j;
+    const int win = R / WIN;
+    const bool live = cx_ok && R < 3 * WIN;
+    const int pix = mstart + (win - 1) * a.W - 1 + (R - win * WIN);      // may be negative: wraps past the range check
+    doff[1 + j] = live ? (uint32_t)(pix * a.C + cx) * 2u : 0xC0000000u;
+  }
+
+  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  typedef __attribute__((address_space(3))) void lds_void;
+
+  // piece `pc` of the next stage to fetch into ring slot `slot`
+  auto issue_piece = [&](int slot, int pc) {
+    char* base = smem + slot * STAGE + wv * 1024;
+    if (pc == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)base, 16, doff[0], 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(base + YT + (pc - 1) * 4096), 16, doff[pc], 0, 0, 0);
+    doff[pc] += pc == 0 ? dinc_y : dinc_x;
+  };
+
+  const int rrow = 4 * (lane >> 4) + ((lane & 15) >> 2);
+  const uint32_t cq = (uint32_t)((lane & 3) * 8);
+  typedef __attribute__((address_space(3))) char lds_char;
+  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;     // 0: the kernel has no static LDS (128-byte rows are XORed below)
+  // LDS byte address of this lane's transpose read = (row base | lane's 8-byte column quarter | row swizzle) ^ (32 * tile):
+  // the swizzle of a 128-byte row (its 16-byte chunks XOR ((row & 3) << 1)) moves 32-byte tiles as wholes
+  const uint32_t yrc = (uint32_t)(rrow * 128) | cq | (uint32_t)(((rrow & 3) << 1) << 4);
+
+  // (row, column) of this lane's two reduction rows and the index of the first, one stage BEHIND the stage whose read bases
+  // are formed next (the body advances them first)
+  int pp[2], qq[2], mm0 = mstart + rrow;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t mc = (uint32_t)min(mm0 + 16 * h, a.M - 1);
+    const uint32_t b = magic_div(mc, a.pq_mul, a.pq_shift);
+    const uint32_t rem = mc - b * (uint32_t)a.PQ;
+    const uint32_t p0 = magic_div(rem, a.q_mul, a.q_shift);
+    pp[h] = (int)p0; qq[h] = (int)(rem - p0 * (uint32_t)a.Q);
+  }
+  const int mend16 = mend - 16;
+
+  auto run = [&](auto WVC) {
+  constexpr int W0 = decltype(WVC)::value;
+  constexpr int T0 = (W0 * KTL) / CT;
+  // tap index (0..2, relative to T0) of the wave's column tile j, and the last tile that reads tap k's bases
+  auto tap_of = [](int j) constexpr { return (W0 * KTL + j) / CT - T0; };
+  auto last_j = [&](int k) constexpr { int l = -1; for (int j = 0; j < KTL && W0 * KTL + j < NTILES; ++j) if (tap_of(j) == k) l = j; return l; };
+  // per tap: lane part of the read address inside a stage's x region (row of the tap's window | column quarter | swizzle)
+  uint32_t xrc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int tap = T0 + k < TAPS ? T0 + k : TAPS - 1;
+    const int kr = tap / 3, ks = tap - kr * 3;
+    const int R = kr * WIN + ks + rrow;
+    xrc[k] = (uint32_t)(R * 128) | cq | (uint32_t)(((R & 3) << 1) << 4);
+  }
+  f32x4 acc[NT][KTL];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // the two (half) read bases of tap k for the stage at (pp, qq, mm0) in ring slot `slot`: the tap's row of the window, or the
+  // slot's zero line where the lane's reduction row is outside the image for that tap / past the chunk
+  auto bases_tap = [&](int slot, int k, uint32_t (&tb)[3][2]) {
+    const uint32_t Xb = lds_base + slot * STAGE + YT;
+    const uint32_t zero_line = Xb + 127 * 128;
+    const int tap = T0 + k < TAPS ? T0 + k : TAPS - 1;
+    const int kr = tap / 3, ks = tap - kr * 3;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bool ok = h == 0 ? mm0 < mend : mm0 < mend16;
+      if (kr == 0) ok = ok && pp[h] >= 1;
+      if (kr == 2) ok = ok && pp[h] <= a.H - 2;
+      if (ks == 0) ok = ok && qq[h] >= 1;
+      if (ks == 2) ok = ok && qq[h] <= a.W - 2;
+      tb[k][h] = ok ? xrc[k] + (Xb + (uint32_t)(h * 16 * 128)) : zero_line;
+    }
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int q = qq[h] + a.adv_q;
+      const bool wq = q >= a.Q;
+      q -= wq ? a.Q : 0;
+      int p = pp[h] + a.adv_p + (wq ? 1 : 0);
+      p -= p >= a.P ? a.P : 0;
+      qq[h] = q; pp[h] = p;
+    }
+    mm0 += MS;
+  };
+  auto read_y = [&](int slot, int i, u32x2 (&ya)[NT][2]) {
+    const uint32_t ad = (yrc + (lds_base + slot * STAGE)) ^ (uint32_t)(i * 32);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i][0]) : "v"(ad));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(ya[i][1]) : "v"(ad));
+  };
+  // (a tile past the wave's share is NOT read: the result of an asm read nobody consumes is a dead register to the compiler,
+  //  which hands it to another value while the LDS data is still on its way — seen as sporadically zeroed read bases)
+  auto read_x = [&](const uint32_t (&tb)[3][2], int j, u32x2 (&xb)[KTL][2]) {
+    if (W0 * KTL + j >= NTILES) return;
+    const int J = W0 * KTL + j;
+    const int k = J / CT - T0;
+    const uint32_t tl = (uint32_t)((J % CT) * 32);
+    xb[j][0] = tr_read_asm(tb[k][0] ^ tl);
+    xb[j][1] = tr_read_asm(tb[k][1] ^ tl);
+  };
+
+  u32x2 yA[NT][2], yB[NT][2], xb[KTL][2];
+  uint32_t tb[3][2];
+
+  // prologue: the whole ring in flight, fragments of stage 0 into registers, read bases of stage 1
+#pragma unroll
+  for (int s_ = 0; s_ < NST; ++s_)
+#pragma unroll
+    for (int pc = 0; pc < LOADS; ++pc) issue_piece(s_, pc);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 1) * LOADS) : "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bases_tap(0, k, tb);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) read_y(0, i, yA);
+#pragma unroll
+  for (int j = 0; j < KTL; ++j) read_x(tb, j, xb);
+  advance();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) bases_tap(1 % NST, k, tb);
+  int rd = 1 % NST, wr = 0;                        // slot of stage st + 1 (read in iteration st), slot refilled in iteration st
+
+  // one stage: multiply stage st from (ycur, xb) while (ynxt, xb) are refilled from stage st + 1 (its bases are in tb); tap k's
+  // bases are replaced by those of stage st + 2 right behind the last read that uses them
+  auto body = [&](u32x2 (&ycur)[NT][2], u32x2 (&ynxt)[NT][2]) {
+    // stage st + 1 landed (this wave's pieces), every read of stage st retired -> after the barrier: all pieces, slot `wr` free
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * LOADS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int rd2 = rd == NST - 1 ? 0 : rd + 1;
+    bf16x8 af[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4){ycur[i][0][0], ycur[i][0][1], ycur[i][1][0], ycur[i][1][1]});
+#pragma unroll
+    for (int j = 0; j < KTL; ++j) {
+      if (W0 * KTL + j < NTILES) {
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
+      }
+      if (j < LOADS) issue_piece(wr, j);
+      if (j == 0) advance();
+      if (j >= 1 && (j - 1) * 2 < NT) { read_y(rd, (j - 1) * 2, ynxt); if ((j - 1) * 2 + 1 < NT) read_y(rd, (j - 1) * 2 + 1, ynxt); }
+      read_x(tb, j, xb);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (last_j(k) == j) bases_tap(rd2, k, tb);
+      __builtin_amdgcn_sched_barrier(0);          // each column tile's MFMAs keep their own fillers
+    }
+    rd = rd2;
+    wr = wr == NST - 1 ? 0 : wr + 1;
+  };
+  for (int st = 0; st < steps; st += 2) {
+    body(yA, yB);
+    if (st + 1 < steps) body(yB, yA);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  // (the lane id is taken again here: nothing of the store addressing stays live across the stage loop, which runs at the
+  //  256-register limit)
+  int lane2;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
+  const int g = lane2 >> 4, li = lane2 & 15;
+  float* out = a.ws + (size_t)split * a.K * a.Ktot;
+#pragma unroll
+  for (int j = 0; j < KTL; ++j) {
+    const int J = W0 * KTL + j;
+    if (J >= NTILES) continue;
+    const int cin = ct * TC + (J % CT) * 16 + li;
+    const int kcol = (J / CT) * a.C + cin;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * TN + i * 16 + g * 4 + r;
+        if (n < a.K && cin < a.C) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
+      }
+  }
+  };   // run
+  if (wv == 0) run(std::integral_constant<int, 0>{});
+  else if (wv == 1) run(std::integral_constant<int, 1>{});
+  else if (wv == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 3>{});
+}
+
 // dw[k][r][s][c] (+)= sum_split ws[split][k][r][s_pad][c_pad]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splitM,
                                     int k_real, int R, int S, int c_real, int K, int S_pad,
@@ -1422,6 +1677,7 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
   a.M = d->n * d->p * d->q; a.PQ = d->p * d->q; a.HW = d->h * d->w;
   make_magic((uint32_t)a.PQ, a.pq_mul, a.pq_shift);
   make_magic((uint32_t)d->q, a.q_mul, a.q_shift);
+  a.adv_q = 32 % d->q; a.adv_p = (32 / d->q) % d->p;
   a.Ktot = d->r * d->s_pad * d->c;
   a.tilesN = p.tilesN; a.tilesK = p.tilesK; a.splitM = p.splitM; a.mchunk = p.mchunk;
   // bias partials: with the flat reduce each split's row sits behind its dW slab (padded to 4 floats) and the one reduce
@@ -1468,6 +1724,18 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
       }();   // once per process (thread-safe function-local static)
       (void)attr_w;
       const dim3 gw(a.tilesN * a.tilesK * a.splitM);
+      static const int winp = [] { const char* e = getenv("TOK_WGRAD_WINP"); return e ? atoi(e) : 1; }();   // 0: the unpipelined window kernel (A/B switch)
+      if (winp && a.x_bytes < 0x40000000u && a.dy_bytes < 0x40000000u) {
+        static const bool attr_p = [&] {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<4, 3, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (32 * 128 + 128 * 128));
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (32 * 128 + 128 * 128));
+          return true;
+        }();
+        (void)attr_p;
+        constexpr int smem_p = 3 * (32 * 128 + 128 * 128);
+        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_winp_kernel<3, 3, 7>), gw, dim3(256), smem_p, st, a);
+        else hipLaunchKernelGGL((conv_wgrad_winp_kernel<4, 3, 9>), gw, dim3(256), smem_p, st, a);
+      } else
       if (nst == 3) {
         static const int w48 = [] { const char* e = getenv("TOK_WGRAD_WIN48_WAVES"); return e ? atoi(e) : 4; }();   // 3: A/B switch
         if (p.TN == 48 && w48 == 4) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3, 7>), gw, dim3(256), smem_w, st, a);
