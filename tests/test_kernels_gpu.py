@@ -1098,6 +1098,29 @@ def test_colsum_partial(libs, m, n):
     assert torch.equal(a0, b0) and torch.equal(a1, b1)
 
 
+@pytest.mark.parametrize('rows,cols', [(1024, 7203), (256, 14406), (64, 57624), (1, 2048), (37, 2049), (1000, 4099)])
+@pytest.mark.parametrize('acc', [0, 1])
+def test_colsum_f32_wide_matrices(libs, rows, cols, acc):
+    """The fold of window attention's d(bias) partial rows (heads x 49 x 49 columns: odd for three heads) on the wide kernel
+    (cols >= 2048, csrc/transformer.hip: colsum_f32_wide_kernel): column sums in fp64 order-of-rows, accumulate, run twice
+    bit-identical, nothing written past the last column."""
+    lib, _ = libs
+    g = torch.Generator(device='cuda').manual_seed(rows + cols)
+    src = torch.randn(rows, cols, device='cuda', generator=g)
+    base = torch.randn(cols + 8, device='cuda', generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for _ in range(2):
+        out = base.clone()
+        assert lib.tok_colsum_f32(src.data_ptr(), rows, cols, out.data_ptr(), acc, st) == 0, lib.tok_last_error()
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0][cols:], base[cols:])
+    ref = src.double().sum(0) + (base[:cols].double() if acc else 0)
+    assert float((outs[0][:cols].double() - ref).abs().max()) < 2e-6 * float(src.double().abs().sum(0).max() + 1)
+
+
 @pytest.mark.parametrize('case', [(4, 16, 16, 64, 64, 3, 1, 1), (2, 14, 14, 256, 512, 1, 1, 0), (3, 9, 11, 32, 24, 3, 2, 1),
                                   (8, 28, 28, 128, 128, 3, 1, 1)])
 def test_fused_bn_finalize_equals_standalone(libs, case):

@@ -331,6 +331,50 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
   if (rl == 0 && col < cols) dst[col] = (float)red[threadIdx.x] + (accumulate ? dst[col] : 0.f);
 }
 
+// The same fold for WIDE matrices (window attention's d(bias) partials: 64 ... 1024 rows of 7 203 ... 57 624 columns, 15-30 MB
+// per launch, twelve launches per SwinV2-T step).  colsum_f32_kernel gives a block 16 columns: a wave instruction touches four
+// rows x 64 bytes, and the fold ran at ~160 GB/s (up to 360 us per launch, 1.2 ms of a step on the position-bias stream).
+// Here a block owns 256 columns and a wave instruction reads 256 contiguous bytes of ONE row (lane l: columns l, l + 64,
+// l + 128, l + 192 — no alignment condition: 49 x 49 x heads is odd for three heads); the block's sixteen waves take the rows
+// round-robin, sixteen loads in flight per lane, and are folded through LDS in wave order; fp64 accumulation in row order per
+// wave like the narrow kernel (deterministic; the order of additions differs from the narrow kernel's, which no caller mixes
+// on one tensor).
+__global__ __launch_bounds__(1024) void colsum_f32_wide_kernel(const float* __restrict__ src, int64_t rows, int cols,
+                                                               float* dst, int accumulate) {
+  __shared__ double red[16][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int col0 = blockIdx.x * 256 + lane;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  constexpr int U = 4;
+  for (int64_t r = wv; r < rows; r += 16 * U) {
+    float v[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t ru = r + 16 * u;
+      const float* s0 = src + (ru < rows ? ru : rows - 1) * cols;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = col0 + 64 * e;
+        v[u][e] = s0[c < cols ? c : cols - 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r + 16 * u < rows)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += (double)v[u][e];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wv][e][lane] = a[e];
+  __syncthreads();
+  if (wv < 4) {                      // wave e folds column slot e
+    const int c = col0 + 64 * wv;
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w][wv][lane];
+    if (c < cols) dst[c] = (float)t + (accumulate ? dst[c] : 0.f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // activations (kind 0 = ReLU, 1 = GELU erf)
 // gelu_f / gelu_d: tok_common.h (shared with the GEMM epilogues of conv_igemm.hip)
@@ -1214,6 +1258,13 @@ extern "C" int tok_layernorm_bwd(const void* dout, const void* x, const float* m
 extern "C" int tok_colsum_f32(const float* src, int64_t rows, int cols, float* dst, int accumulate, void* stream) {
   TOK_CHECK_ARG(src && dst && rows > 0 && cols > 0, "tok_colsum_f32: bad args");
   if (tok_dbg_skip(4)) return TOK_OK;
+  static const int wide = [] { const char* e = getenv("TOK_COLSUM_WIDE"); return e ? atoi(e) : 1; }();   // 0: the narrow kernel everywhere (A/B switch)
+  if (wide && cols >= 2048) {
+    hipLaunchKernelGGL(colsum_f32_wide_kernel, dim3((cols + 255) / 256), dim3(1024), 0, tok_stream(stream), src, rows, cols, dst,
+                       accumulate);
+    TOK_CHECK_LAUNCH("tok_colsum_f32(wide)");
+    return TOK_OK;
+  }
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((cols + 15) / 16), dim3(256), 0, tok_stream(stream), src, rows, cols, dst,
                      accumulate, (const float*)nullptr, (float*)nullptr, 0);
   TOK_CHECK_LAUNCH("tok_colsum_f32");
