@@ -396,10 +396,43 @@ def main():
     swin = args.backbone.startswith('swinv2') or args.backbone.startswith('davit')
     if swin and args.backbone not in ('swinv2_custom', 'davit_t'):
         raise SystemExit('bench.py: the transformer workloads are swinv2_custom (SwinV2-T geometry, window 7) and davit_t at --res')
-    task = (build_seg_task(args.backbone, args.classes, args.res, width) if seg
-            else build_swin_task(args.classes, args.res, args.backbone) if swin
-            else build_task(args.backbone, args.classes)).cuda().train()
-    opt = task.configure_optimizers()[0]['optimizer']
+    def make_task():
+        t = (build_seg_task(args.backbone, args.classes, args.res, width) if seg
+             else build_swin_task(args.classes, args.res, args.backbone) if swin
+             else build_task(args.backbone, args.classes)).cuda().train()
+        return t, t.configure_optimizers()[0]['optimizer']
+
+    # N > 1: the single-rank step of THIS run first — a throw-away replica stepped without a reducer on
+    # every rank at once (same box, same host contention, no exchange) — so that the line can state what the exchange and
+    # the shared host cost against it.  Its parameters and optimizer state are discarded: the timed replica below is built
+    # fresh and broadcast from rank 0.
+    local_probe = None
+    if dist_on:
+        from torchok_amd.engine.step import train_step as _ts
+        t0_, o0_ = make_task()
+        g0 = torch.Generator(device='cuda').manual_seed(99 + rank)
+        im0 = torch.randn(args.batch, 3, args.res, width, generator=g0, device='cuda', dtype=torch.float32).to(torch.bfloat16)
+        tg0 = torch.randint(0, args.classes, (args.batch, args.res, width) if seg else (args.batch,), generator=g0, device='cuda')
+        b0 = {'image': im0, 'target': tg0}
+        nw, ns = min(args.warmup, 5), max(3, min(args.steps, 15))
+        for i in range(nw):
+            _ts(t0_, o0_, b0, i, None)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e_ = [torch.cuda.Event(enable_timing=True) for _ in range(ns + 1)]
+        e_[0].record()
+        for i in range(ns):
+            _ts(t0_, o0_, b0, nw + i, None)
+            e_[i + 1].record()
+        torch.cuda.synchronize()
+        local_probe = statistics.median([e_[i].elapsed_time(e_[i + 1]) for i in range(ns)])
+        del t0_, o0_, b0, im0, tg0, e_
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        dist.barrier()
+
+    task, opt = make_task()
     reducer = None
     if dist_on:
         from torchok_amd.dist import GradientAllReducer
@@ -409,6 +442,7 @@ def main():
                                      find_unused_parameters=True if swin else None,
                                      # the unused set of these backbones is the same in every step: no per-step host read
                                      static_unused_pattern=True if swin else None)
+        reducer.enable_timing()
 
     g = torch.Generator(device='cuda').manual_seed(1234 + rank)
     image = torch.randn(args.batch, 3, args.res, width, generator=g, device='cuda', dtype=torch.float32).to(torch.bfloat16)
@@ -440,6 +474,7 @@ def main():
     if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
+        reducer.enable_timing()          # drop the warm-up steps' event pairs
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
@@ -459,10 +494,18 @@ def main():
     host_lead_ms = [evs[0].elapsed_time(evs[i + 1]) - (host_done[i] - t0) * 1e3 for i in range(args.steps)]
     final_loss = float(loss.detach())
     in_sync = replicas_in_sync(reducer)      # N > 1: every rank must hold bit-identical parameters after the run
+    per_rank = None
     if dist_on:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # one row per rank: [host lead min, host lead p50, step p50, single-rank step p50 of this run, exposed exchange p50 / max]
+        ex = reducer.exposed_comm_ms() or [0.0]
+        mine = torch.tensor([min(host_lead_ms), statistics.median(host_lead_ms), statistics.median(step_ms), local_probe,
+                             statistics.median(ex), max(ex)], device='cuda', dtype=torch.float64)
+        rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+        per_rank = [[round(float(v), 3) for v in r.tolist()] for r in rows]
 
     if rank == 0:
         value = args.batch * world * args.steps / dt
@@ -522,6 +565,24 @@ def main():
             #  from inside the timed process)
             roofline['mfma_util_committed_profile'] = measured_mfma_util(args.backbone, args.res, width, args.batch)
         if dist_on:
+            # self-diagnosis of a multi-rank run: who is slow (per-rank step p50), whether a launch thread starves its GPU
+            # (host_lead_ms.min <= 0 on some rank), how much of the exchange the backward did not hide, and what the step costs
+            # against the single-rank step measured in this same run on the same (shared) host
+            cols = list(zip(*per_rank))
+            single = statistics.mean(cols[3])
+            line['scaling_diagnosis'] = {
+                'per_rank': {'host_lead_ms_min': list(cols[0]), 'host_lead_ms_p50': list(cols[1]), 'step_p50_ms': list(cols[2]),
+                             'single_rank_step_p50_ms': list(cols[3]), 'exposed_exchange_ms_p50': list(cols[4]),
+                             'exposed_exchange_ms_max': list(cols[5])},
+                'slowest_rank': int(max(range(len(cols[2])), key=lambda r_: cols[2][r_])),
+                'host_bound_ranks': [r_ for r_ in range(len(cols[0])) if cols[0][r_] <= 0.0],
+                'single_rank_step_ms_same_run': round(single, 3),
+                'weak_scaling_efficiency_same_run': round(single / (dt / args.steps * 1e3), 4),
+                'note': 'single_rank_step = a throw-away replica stepped without a reducer on every rank at once before the timed '
+                        'region (same box, same host contention, no exchange); exposed_exchange = step-stream time between the end '
+                        'of backward and the join of every bucket / buffer broadcast (incl. cast / scale kernels); the driver '
+                        'computes the official efficiency from its own N=1 run',
+            }
             line['config']['rccl_ranks'] = dist.get_world_size()
             if host_pin is not None:
                 line['config']['host'] = host_pin

@@ -90,8 +90,12 @@ class GradientAllReducer:
         map of every step is compared with it ON THE DEVICE, the verdict is MAX-reduced over the ranks (one more tiny
         collective per step, issued by every rank in every step) and travels to pinned memory behind an event that the next
         `finish_step` polls.  A change on another rank that this rank could not see is therefore detected one step late —
-        by EVERY rank in the same `finish_step`, before any of them launches a collective (with a per-rank
-        verdict one rank raised while its peers sat in all_reduce until the RCCL timeout)."""
+        by EVERY rank in the same `finish_step` (with a per-rank verdict one rank raised while its peers sat in
+        all_reduce until the RCCL timeout).  What that means for the caller: the stale step's optimizer update HAS been
+        applied (with the stale rank's gradients differing on the late parameters), and the bucket all-reduces of the step
+        that raises were already launched by the backward hooks — `finish_step` waits for them before raising (every rank
+        launched the same ones, so nothing hangs and no collective is left in flight), but the reducer must be treated as
+        unusable afterwards: rebuild it (or reload a checkpoint) with static_unused_pattern=False."""
         if not dist.is_initialized():
             raise RuntimeError('torch.distributed is not initialised')
         if find_unused_parameters is None:
@@ -118,6 +122,7 @@ class GradientAllReducer:
         self.comm_stream = pick_stream(torch.device('cuda', torch.cuda.current_device())) if self.cuda else None
         self._avg = dist.ReduceOp.AVG if (self.cuda and dist.get_backend(process_group) == 'nccl') else None
         self._active = False
+        self._timing: Optional[List] = None    # enable_timing(): [(backward done, exchange joined)] HIP event pairs per step
         self._events: List = []       # hipEvents of the fork edges, reused round-robin (a step needs a handful)
         self._ev_next = 0
         self._small: Dict = {}
@@ -318,12 +323,33 @@ class GradientAllReducer:
             ev.synchronize()
         if float(verdict[0]) != 0:
             self._used_host = None
+            # the backward hooks of THIS step already launched bucket all-reduces on the comm stream (every rank the same
+            # ones): wait for them so that the error leaves no collective in flight
+            for blist in self.buckets:
+                for b in blist:
+                    if b.work is not None:
+                        b.work.wait()
+                        b.work = None
             raise RuntimeError(
                 'GradientAllReducer: the set of parameters used by some ranks changed in the previous step while the pattern '
                 'of a rank that missed them stayed the same; its cached used-map was stale for that step (every rank raises '
                 'here together).  static_unused_pattern=True (TOK_DDP_UNUSED_STATIC=1) is for models whose unused parameters '
                 'are the same in every step; leave it False otherwise: the used-map is then read on the host in every step, '
-                'as torch DDP does.')
+                'as torch DDP does.  The previous step\'s update was applied with a stale map: this reducer is unusable now.')
+
+    def enable_timing(self, on: bool = True):
+        """Diagnosis (bench.py, N > 1): from now on every `finish_step` brackets its wait for the collectives with two timing
+        events on the step stream — (a) where the backward's own kernels (and side-stream joins) are done, (b) where every
+        bucket, the buffer broadcast and the used-map have been joined.  `exposed_comm_ms()` = elapsed(a, b) per step: the
+        communication the backward did NOT hide (it includes the bf16 -> fp32 casts / scaling kernels, which exist only
+        because of the exchange).  No host synchronisation is added to the step."""
+        self._timing = [] if (on and self.cuda) else None
+
+    def exposed_comm_ms(self) -> List[float]:
+        """Per finished step since enable_timing(); call after a device synchronisation."""
+        if not self._timing:
+            return []
+        return [a.elapsed_time(b) for a, b in self._timing]
 
     def finish_step(self):
         """Call after backward, before optimizer.step(): flush stragglers, exchange the module buffers (and, with
@@ -331,6 +357,10 @@ class GradientAllReducer:
         state: with find_unused_parameters the reduced used-map is read on the host only when this rank's own pattern
         changed (see __init__)."""
         flags, changed = None, False
+        t_a = None
+        if self._timing is not None:
+            t_a = torch.cuda.Event(enable_timing=True)
+            t_a.record()
         try:
             if self.find_unused:
                 self._poll_late_check()
@@ -432,6 +462,10 @@ class GradientAllReducer:
                 if ev is not None:
                     ev.record()
                 self._late = (verdict, ev)
+        if t_a is not None:
+            t_b = torch.cuda.Event(enable_timing=True)
+            t_b.record()
+            self._timing.append((t_a, t_b))
         self._active = False
 
     def params_checksum(self) -> torch.Tensor:
