@@ -555,11 +555,6 @@ def main():
             line['config']['arena_elements'] = int(sum(a.total for a in opt._arenas if a is not None))
         except Exception:
             pass
-        try:      # in-kernel waits of the folded launches that gave up (0, or the run's results are invalid)
-            from torchok_amd.engine import functional as _EF
-            line['phase_sync_errors'] = _EF.phase_sync_errors(torch.device('cuda', torch.cuda.current_device()))
-        except Exception:
-            pass
         if roofline is not None:
             # (a constant read from the committed PMC pass of this workload, like `traffic`: counters cannot be collected
             #  from inside the timed process)

@@ -294,35 +294,7 @@ int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* mask,
                      const float* scale, const float* shift, const float* coef, int relu,
                      void* dy, void* dshortcut, int dshortcut_accumulate,
                      int64_t m, int c, void* stream);
-/* EXPERIMENT (library built with TOK_BUILD_EXPERIMENTS=1; the default library answers tok_bn_fused_apply_ok = 0): measured
- * slower than the two launches it replaces, profiles/r05_bn_fold_probe.txt.
- * The finalize folded into the apply pass (round 5; csrc/bn.hip "finalize folded into the apply pass"): ONE launch for
- * tok_bn_finalize -> tok_bn_act_fwd(_colsum) resp. tok_bn_bwd_finalize -> tok_bn_bwd_apply — F.batch_norm's statistics step
- * and its element-wise step as the reference runs them back to back (modules/bricks/convbnact.py:48-53, [timm] Bottleneck
- * bn1..bn3 via backbones/resnet.py:12-14).  The first blocks of the apply grid fold the partial rows (same order of additions
- * as the stand-alone finalize: every output is bit-identical to the two-launch form), publish scale / shift (coef) with
- * device-scope stores and signal a counter that every block polls before it consumes; all blocks request their first rows
- * before they wait.  `sync`: a scratch slot of TOK_PHASE_SLOT_BYTES bytes shared only by launches of ONE stream — int32 [0]:
- * arrival counter, never reset by a kernel: `sync_target` is the value it reaches when the producers of THIS launch have
- * signalled = its value before the launch + tok_bn_fused_producers(c) (the caller keeps the running total; wrap-safe);
- * [2] != 0 afterwards means a wait gave up (results invalid); from byte 256 on: the published vectors, one 128-byte line per
- * producer block (written once per launch by exactly one block and read only after the signal, so consumers fetch them
- * through their L2 with ordinary loads).  Not for hipGraph capture (a replay would repeat the targets).  Served: c <= 2048 (ask tok_bn_fused_apply_ok; with_colsum:
- * the grid of tok_bn_act_fwd_colsum_rows must hold the producers).  tok_bn_bwd_finalize_apply carries the completion event of
- * tok_next_launch_event like tok_bn_bwd_apply.                                                                              */
-#define TOK_PHASE_SLOT_BYTES (256 + 32768)
-int tok_bn_fused_apply_ok(int64_t m, int c, int with_colsum);
-int tok_bn_fused_producers(int c);
-int tok_bn_finalize_act_fwd(const float* stats, int rows, int64_t count, int c, int c_real, const float* gamma,
-                            const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                            float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
-                            const void* y, const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m,
-                            float* colsum_partial, int32_t* sync, int32_t sync_target, void* stream);
-int tok_bn_bwd_finalize_apply(const float* partial, int rows, int64_t m, int c, int c_real, const float* gamma,
-                              const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef,
-                              int accumulate, int dzy_form, const void* dout, const void* y, const uint8_t* mask,
-                              const float* scale, const float* shift, int relu, void* dy, void* dshortcut,
-                              int dshortcut_accumulate, int32_t* sync, int32_t sync_target, void* stream);
+
 
 /* ---- pooling ----------------------------------------------------------------------------
  * aten::max_pool2d(3, stride 2, pad 1) at resnet.py:510; adaptive avg pool + flatten at
@@ -585,8 +557,8 @@ int tok_conv_dgrad_act(const tok_conv_desc* d, const void* dy, const void* w_dgr
  * w2 = fc2 forward pack [c][hidden] (tok_pack_weight_fwd), b1 [hidden] / b2 [c] fp32.  The 4c-wide hidden tensor is never
  * read back: pre / act = NULL (inference) it is never stored; with pre / act [rows][hidden] given the bf16
  * pre-activation and activation rows are written for the backward GEMMs (tok_conv_dgrad_act, the two weight gradients)
- * while fc2 consumes them out of registers; with pre given and act = NULL (training on the recompute plan: tok_mlp_bwd_dx
- * reads pre, tok_mlp_bwd_dw recomputes everything else) only the pre-activation rows are written.  Rounding points
+ * while fc2 consumes them out of registers; with pre given and act = NULL only the pre-activation rows are written
+ * (tok_mlp_bwd_dx reads nothing else).  Rounding points
  * (pre-activation and activation to bf16) and results are those of tok_conv_fwd_act + tok_conv_fwd, bit for bit.
  * tok_mlp_serves: 1 when the geometry has a kernel (c in {96, 192, 384}, hidden = 4c), else the caller stays on the two
  * GEMM launches.                                                                                                         */
@@ -600,26 +572,6 @@ int tok_mlp_fwd(const void* x, const void* w1, const float* b1, const void* w2, 
  * those of tok_conv_dgrad_act + tok_conv_dgrad, bit for bit.                                                              */
 int tok_mlp_bwd_dx(const void* dy, const void* w2_dgrad, const void* pre, const void* w1_dgrad, void* dx, int accumulate,
                    void* dpre, int64_t rows, int c, int hidden, void* stream);
-/* All four parameter gradients of that Mlp from its INPUT x and its OUTPUT GRADIENT dy alone (csrc/mlp_dw.hip): pre, act,
- * d(act) = dy W2 and d(pre) = d(act) GELU'(pre) are recomputed 32 tokens at a time in registers (same bf16 rounding points
- * as the forward / tok_mlp_bwd_dx) and contracted with x / dy over the tokens on the spot:
- *   dW1 [hidden][c] (+)= d(pre)^T x,  db1 [hidden] (+)= colsum d(pre),  dW2 [c][hidden] (+)= dy^T act,  db2 [c] (+)= colsum dy
- * — the unfused weight-gradient GEMMs (tok_conv_wgrad_bias on (x, d(pre)) and (act, dy)) read two [rows][hidden] tensors
- * that then have to be written first; this is the reference's `grad_checkpointing` trade (models/backbones/swin.py:75-78)
- * applied inside one block.  w1 = fc1 forward pack [hidden][c], w2_dgrad = fc2 dgrad pack [hidden][c].  Token ranges
- * run as independent workgroups whose fp32 partial slabs (workspace, tok_mlp_bwd_dw_ws_bytes) are folded in a fixed
- * order: deterministic.  A NULL gradient pointer skips that parameter; acc_* != 0 adds to what the slot holds.        */
-size_t tok_mlp_bwd_dw_ws_bytes(int64_t rows, int c, int hidden);
-int tok_mlp_bwd_dw(const void* x, const void* dy, const void* w1, const float* b1, const void* w2_dgrad, float* dw1,
-                   int acc_w1, float* db1, int acc_b1, float* dw2, int acc_w2, float* db2, int acc_b2, void* workspace,
-                   size_t ws_bytes, int64_t rows, int c, int hidden, void* stream);
-/* 1 when the library was compiled with -DTOK_BUILD_EXPERIMENTS (__graft_entry__.build() under TOK_BUILD_EXPERIMENTS=1): the
- * measured-negative kernels — tok_mlp_bwd_dw (csrc/mlp_dw.hip), the 256 x 128 ring convolution (csrc/conv_ring.hip,
- * TOK_CONV_RING=1) and the fused-activation mode of the 256 x 256 tile kernel (TOK_GEMM256_ACT=1) — are then present.  The
- * default library does not contain them: tok_mlp_bwd_dw_ws_bytes answers 0 and tok_mlp_bwd_dw fails with an error string.
- * No reference counterpart (a build property).                                                                          */
-int tok_built_with_experiments(void);
-
 /* ---- DaViT (models/backbones/davit.py) --------------------------------------------------------------
  * SpatialBlock's WindowAttention (davit.py:168-207) is tok_window_attn_fwd/_bwd with logit_scale == bias == NULL:
  * softmax(q k^T / sqrt(32)) v on unshifted windows, no cosine normalisation (ds_scratch / dscale_part unused).

@@ -174,31 +174,6 @@ class FakeTok:
             _t(act, (rows, hidden), BF16).copy_(h)
         return 0
 
-    def tok_built_with_experiments(self):
-        return 1      # the stand-in implements every entry point
-
-    def tok_mlp_bwd_dw_ws_bytes(self, rows, c, hidden):
-        return 64
-
-    def tok_mlp_bwd_dw(self, x, dy, w1, b1, w2d, dw1, acc_w1, db1, acc_b1, dw2, acc_w2, db2, acc_b2, ws, ws_bytes, rows, c,
-                       hidden, st):
-        """fp32 restatement with the kernel's rounding points: pre, act, d(act), d(pre) rounded to bf16, fp32 sums."""
-        self.calls.append('mlp_bwd_dw')
-        xv, gv = _t(x, (rows, c), BF16).float(), _t(dy, (rows, c), BF16).float()
-        w1v, w2t = _t(w1, (hidden, c), BF16).float(), _t(w2d, (hidden, c), BF16).float()
-        pre = _bf(xv @ w1v.t() + _t(b1, (hidden,), torch.float32)).float()
-        act = _bf(F.gelu(pre)).float()
-        dact = _bf(gv @ w2t.t()).float()
-        d = 0.5 * (1 + torch.erf(pre * 0.7071067811865476)) + pre * 0.3989422804014327 * torch.exp(-0.5 * pre * pre)
-        dpre = _bf(dact * d).float()
-        for ptr_, acc, val, shape in ((dw1, acc_w1, dpre.t() @ xv, (hidden, c)), (db1, acc_b1, dpre.sum(0), (hidden,)),
-                                      (dw2, acc_w2, gv.t() @ act, (c, hidden)), (db2, acc_b2, gv.sum(0), (c,))):
-            if ptr_ is None:
-                continue
-            out = _t(ptr_, shape, torch.float32)
-            out.copy_(out + val if acc else val)
-        return 0
-
     def tok_mlp_bwd_dx(self, dy, w2d, pre, w1d, dx, accumulate, dpre, rows, c, hidden, st):
         self.calls.append('mlp_bwd_dx')
 
@@ -531,34 +506,6 @@ class FakeTok:
 
     def tok_bn_act_fwd_colsum_rows(self, m, c):
         return 3
-
-    def tok_bn_fused_producers(self, c):
-        return (c + 15) // 16 if c >= 512 else (c + 3) // 4
-
-    def tok_bn_fused_apply_ok(self, m, c, with_colsum):
-        return 1 if c <= 2048 else 0
-
-    def tok_bn_finalize_act_fwd(self, stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd, scale,
-                                shift, y, shortcut, relu, out, mask, m, colsum_partial, sync, sync_target, st):
-        rc = self.tok_bn_finalize(stats, rows, count, cp, c, gamma, beta, rm, rv, nbt, momentum, eps, mean, rstd, scale, shift,
-                                  st)
-        if rc:
-            return rc
-        if colsum_partial is not None:
-            rc = self.tok_bn_act_fwd_colsum(y, scale, shift, shortcut, relu, out, mask, m, cp, colsum_partial, st)
-        else:
-            rc = self.tok_bn_act_fwd(y, scale, shift, shortcut, relu, out, mask, m, cp, st)
-        self.calls[-1] = 'bn_finalize_act_fwd'
-        return rc
-
-    def tok_bn_bwd_finalize_apply(self, partial, rows, m, cp, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, dout,
-                                  y, mask, scale, shift, relu, dy, dshortcut, ds_acc, sync, sync_target, st):
-        rc = self.tok_bn_bwd_finalize(partial, rows, m, cp, c, gamma, mean, rstd, dgamma, dbeta, coef, accumulate, dzy, st)
-        if rc:
-            return rc
-        rc = self.tok_bn_bwd_apply(dout, y, mask, scale, shift, coef, relu, dy, dshortcut, ds_acc, m, cp, st)
-        self.calls[-1] = 'bn_bwd_finalize_apply'
-        return rc
 
     def tok_bn_act_fwd_colsum(self, y, scale, shift, shortcut, relu, out, mask, m, c, partial, st):
         rc = self.tok_bn_act_fwd(y, scale, shift, shortcut, relu, out, mask, m, c, st)

@@ -35,7 +35,7 @@ def _worker(case: str):
     from torchok_amd import _C
     from torchok_amd.engine import functional as EF
     from torchok_amd.models.backbones import resnet as PR
-    for k in ('TOK_CONV_WIN_MIN_TILES', 'TOK_MLP_MIN_ROWS', 'TOK_CONV_RING', 'TOK_GEMM256', 'TOK_UNIT3_MIN_ROWS'):
+    for k in ('TOK_CONV_WIN_MIN_TILES', 'TOK_MLP_MIN_ROWS', 'TOK_GEMM256', 'TOK_UNIT3_MIN_ROWS'):
         assert k not in os.environ, k
     assert EF.UNIT3_MIN_ROWS == 100000
     lib = _C.load_library()

@@ -1464,82 +1464,6 @@ def test_fused_mlp_backward_equals_the_two_dgrad_launches(libs, rows, c, acc):
     assert relerr(dx1[:n].float(), dxh.float()) < 1e-2
 
 
-@pytest.mark.parametrize('rows,c', [(1000, 96), (77, 192), (4133, 384), (70000, 96), (33000, 192), (16500, 384)])
-def test_mlp_parameter_gradients_by_recomputation(libs, rows, c):
-    """tok_mlp_bwd_dw: dW1, db1, dW2, db2 of the Mlp from x and dy alone (the hidden tensors are recomputed in registers).
-    Against the fp32 restatement on the same rounding points <= 1e-2 (north_star's bf16 bound; measured ~1e-3: a hidden
-    element whose bf16 rounding flips between two summation orders moves a whole product); against the UNFUSED device
-    launches (tok_mlp_fwd saving pre / act, tok_mlp_bwd_dx saving d(pre), tok_conv_wgrad_bias on them) <= 2e-3;
-    accumulate / overwrite / skipped slots; ragged row counts (partial last tile); bit-reproducible."""
-    lib, fake = libs
-    if not lib.tok_built_with_experiments():
-        assert lib.tok_mlp_bwd_dw_ws_bytes(rows, c, 4 * c) == 0        # the default library answers "not served"
-        pytest.skip('csrc/mlp_dw.hip is compiled only with TOK_BUILD_EXPERIMENTS=1 (measured slower on the step)')
-    st = torch.cuda.current_stream().cuda_stream
-    P = lambda t_: t_.data_ptr() if t_ is not None else None   # noqa: E731
-    h = 4 * c
-    x = rnd(rows, c).to(BF16).cuda()
-    dy = (rnd(rows, c, seed=7) * 0.5).to(BF16).cuda()
-    w1 = (rnd(h, c, seed=1) * c ** -0.5).to(BF16).cuda()            # fc1 forward pack [hidden][c]
-    w2 = (rnd(c, h, seed=2) * h ** -0.5).to(BF16).cuda()            # fc2 forward pack [c][hidden]
-    w2d = w2.t().contiguous()                                       # fc2 dgrad pack [hidden][c]
-    w1d = w1.t().contiguous()                                       # fc1 dgrad pack [c][hidden]
-    b1, b2 = (rnd(h, seed=3) * 0.3).cuda(), (rnd(c, seed=4) * 0.3).cuda()
-    ws_bytes = lib.tok_mlp_bwd_dw_ws_bytes(rows, c, h)
-    assert ws_bytes > 0 and lib.tok_mlp_bwd_dw_ws_bytes(rows, 100, 400) == 0
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device='cuda')
-    base = [rnd(h, c, seed=11).cuda(), rnd(h, seed=12).cuda(), rnd(c, h, seed=13).cuda(), rnd(c, seed=14).cuda()]
-
-    def run(acc):
-        outs = [b.clone() for b in base]
-        assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), acc, P(outs[1]), acc, P(outs[2]), acc, P(outs[3]),
-                                  acc, P(ws), ws_bytes, rows, c, h, st) == 0, lib.tok_last_error()
-        torch.cuda.synchronize()
-        return outs
-    got = run(0)
-    again = run(0)
-    for a_, b_ in zip(got, again):
-        assert torch.equal(a_, b_)                                  # fixed-order fold: deterministic
-    acc = run(1)
-    for a_, b_, base_ in zip(acc, got, base):
-        assert torch.allclose(a_, b_ + base_, rtol=1e-6, atol=1e-5)
-    # a skipped slot is not written, the others are unchanged by that
-    keep = base[1].clone()
-    outs = [b.clone() for b in base]
-    assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), 0, None, 0, P(outs[2]), 0, P(outs[3]), 0, P(ws),
-                              ws_bytes, rows, c, h, st) == 0, lib.tok_last_error()
-    torch.cuda.synchronize()
-    assert torch.equal(outs[0], got[0]) and torch.equal(outs[2], got[2]) and torch.equal(outs[3], got[3]) and torch.equal(outs[1], keep)
-    # workspace too small: refused
-    assert lib.tok_mlp_bwd_dw(P(x), P(dy), P(w1), P(b1), P(w2d), P(outs[0]), 0, None, 0, None, 0, None, 0, P(ws), 16, rows, c, h, st) != 0
-    # (a) the unfused launches on the tensors the fused forward / backward write
-    pre, act, dpre = (torch.empty(rows, h, dtype=BF16, device='cuda') for _ in range(3))
-    y, dx = (torch.empty(rows, c, dtype=BF16, device='cuda') for _ in range(2))
-    assert lib.tok_mlp_fwd(P(x), P(w1), P(b1), P(w2), P(b2), P(y), P(pre), P(act), rows, c, h, st) == 0, lib.tok_last_error()
-    assert lib.tok_mlp_bwd_dx(P(dy), P(w2d), P(pre), P(w1d), P(dx), 0, P(dpre), rows, c, h, st) == 0, lib.tok_last_error()
-    torch.cuda.synchronize()
-    want = [dpre.float().t() @ x.float(), dpre.float().sum(0), dy.float().t() @ act.float(), dy.float().sum(0)]
-    names = ('dW1', 'db1', 'dW2', 'db2')
-    for nm, a_, w_ in zip(names, got, want):
-        assert relerr(a_, w_) < 2e-3, (nm, relerr(a_, w_))
-    # (b) the fp32 restatement (host)
-    n = min(rows, 4096)
-    xs, dys = x[:n].contiguous(), dy[:n].contiguous()
-    ws_n = torch.empty(lib.tok_mlp_bwd_dw_ws_bytes(n, c, h) // 4 + 16, dtype=torch.float32, device='cuda') \
-        if lib.tok_mlp_serves(n, c, h) else None
-    if ws_n is not None:
-        sub = [torch.empty_like(b) for b in base]
-        assert lib.tok_mlp_bwd_dw(P(xs), P(dys), P(w1), P(b1), P(w2d), P(sub[0]), 0, P(sub[1]), 0, P(sub[2]), 0, P(sub[3]), 0,
-                                  P(ws_n), ws_n.numel() * 4, n, c, h, st) == 0, lib.tok_last_error()
-        torch.cuda.synchronize()
-        host = [torch.zeros_like(b, device='cpu') for b in base]
-        xc, dyc, w1c, b1c, w2c = xs.cpu(), dys.cpu(), w1.cpu(), b1.cpu(), w2d.cpu()
-        assert fake.tok_mlp_bwd_dw(P(xc), P(dyc), P(w1c), P(b1c), P(w2c), P(host[0]), 0, P(host[1]), 0, P(host[2]), 0, P(host[3]), 0,
-                                   None, 0, n, c, h, None) == 0
-        for nm, a_, w_ in zip(names, sub, host):
-            assert relerr(a_, w_) < 1e-2, (nm, relerr(a_, w_))
-
-
 @pytest.mark.parametrize('n,hs,ws,classes,hd,wd', [(2, 32, 64, 19, 128, 256), (1, 16, 24, 3, 64, 96), (2, 9, 13, 21, 36, 52),
                                                    (1, 8, 8, 8, 20, 28), (3, 128, 256, 19, 512, 1024)])
 def test_upsample_ce_equals_interpolate_then_cross_entropy(libs, n, hs, ws, classes, hd, wd):
@@ -1911,91 +1835,3 @@ def test_wgrad_256_tile_kernel_matches_the_128_tile_plan():
         m = re.search(r'dW-vs-fp32 new ([0-9.e+-]+)', l)
         if m:
             assert float(m.group(1)) < 1e-5, l
-
-
-@pytest.mark.parametrize('m,c,cr', [(1000, 64, 64), (50176, 256, 256), (300, 2048, 2048), (777, 48, 48), (12544, 1024, 1024),
-                                    (40, 512, 512), (4096, 24, 18), (200704, 128, 128)])
-@pytest.mark.parametrize('relu,with_sc', [(1, 0), (1, 1), (0, 0)])
-def test_bn_finalize_folded_into_apply_is_bit_identical(libs, m, c, cr, relu, with_sc):
-    """Round 5: tok_bn_finalize_act_fwd / tok_bn_bwd_finalize_apply (the first blocks of the apply grid fold the partial rows,
-    publish with device-scope stores, every block polls a counter) against the two-launch form: every output bit for bit —
-    statistics vectors, running statistics, out, ReLU bits, column-sum rows, dgamma / dbeta (+ accumulate), coefficients, dy,
-    dshortcut.  Several launches per case on ONE sync slot (its arrival counter only grows; the caller passes each launch its target), grids smaller than the number of
-    producer blocks (m = 40), padded channels (24 / 18), no wait may give up."""
-    lib, _ = libs
-    if not lib.tok_built_with_experiments():
-        assert lib.tok_bn_fused_apply_ok(m, c, 0) == 0
-        pytest.skip('the folded launches are compiled only with TOK_BUILD_EXPERIMENTS=1 (measured slower, profiles/r05_bn_fold_probe.txt)')
-    st = torch.cuda.current_stream().cuda_stream
-    P = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    dev = lambda t: t.to(DEV)   # noqa: E731
-    assert lib.tok_bn_fused_apply_ok(m, c, 0) == 1 and lib.tok_bn_fused_apply_ok(m, 4096, 0) == 0
-    y = dev((rnd(m, c) * 1.5 + 0.3).to(BF16))
-    rows = 37
-    stats = dev(rnd(2, rows, c, seed=5).abs() * m / rows)
-    gamma, beta = dev(rnd(cr, seed=1) * 0.5 + 1), dev(rnd(cr, seed=2) * 0.2)
-    sc = dev(rnd(m, c, seed=9).to(BF16)) if with_sc else None
-    sync = torch.zeros((256 + 32768) // 4, dtype=torch.int32, device=DEV)      # TOK_PHASE_SLOT_BYTES
-    total = [0]                   # running value of the slot's arrival counter (the kernels never reset it)
-    want_cs = bool(lib.tok_bn_fused_apply_ok(m, c, 1)) and not with_sc
-    cs_rows = lib.tok_bn_act_fwd_colsum_rows(m, c)
-
-    stats_b = dev(rnd(2, rows, c, seed=6).abs() * m / rows * 3.0)      # a second layer's statistics through the same slot
-
-    def fwd(fused, stats=stats):
-        rm, rv, nbt = dev(rnd(cr, seed=3)), dev(rnd(cr, seed=4).abs() + 0.5), dev(torch.tensor([7]))
-        vec = torch.full((4, c), 7.0, device=DEV)
-        out = torch.zeros(m, c, dtype=BF16, device=DEV)
-        mask = torch.zeros(m, c // 8, dtype=torch.uint8, device=DEV)
-        cs = torch.zeros(cs_rows, c, device=DEV) if want_cs else None
-        fin = (P(stats), rows, m, c, cr, P(gamma), P(beta), P(rm), P(rv), P(nbt), 0.1, 1e-5, P(vec[2]), P(vec[3]), P(vec[0]),
-               P(vec[1]))
-        if fused:
-            total[0] += lib.tok_bn_fused_producers(c)
-            assert lib.tok_bn_finalize_act_fwd(*fin, P(y), P(sc), relu, P(out), P(mask), m, P(cs), P(sync), total[0], st) == 0, \
-                lib.tok_last_error()
-        else:
-            assert lib.tok_bn_finalize(*fin, st) == 0
-            if want_cs:
-                assert lib.tok_bn_act_fwd_colsum(P(y), P(vec[0]), P(vec[1]), P(sc), relu, P(out), P(mask), m, c, P(cs), st) == 0
-            else:
-                assert lib.tok_bn_act_fwd(P(y), P(vec[0]), P(vec[1]), P(sc), relu, P(out), P(mask), m, c, st) == 0
-        torch.cuda.synchronize()
-        return [vec, rm, rv, nbt, out, mask] + ([cs] if want_cs else [])
-    ref, ref_b = fwd(False), fwd(False, stats_b)
-    assert not torch.equal(ref[4], ref_b[4])
-    for _ in range(3):
-        for want, st_ in ((ref, stats), (ref_b, stats_b)):      # alternating: a stale published line of the previous launch would show
-            got = fwd(True, st_)
-            for a, b in zip(got, want):
-                assert torch.equal(a, b)
-            assert sync.tolist()[:3] == [total[0], 0, 0]
-    vec = ref[0]
-    mask = ref[5] if (relu and with_sc) else None
-    dout = dev(rnd(m, c, seed=11).to(BF16))
-    rows_b = lib.tok_bn_bwd_rows(m, c)
-    part = torch.zeros(2, rows_b, c, device=DEV)
-    assert lib.tok_bn_bwd_reduce(P(dout), P(y), P(mask), P(vec[0]), P(vec[1]), P(vec[2]), P(vec[3]), relu, m, c, P(part), st) == 0
-
-    def bwd(fused, acc, dzy):
-        dg, db = torch.full((cr,), 0.5, device=DEV), torch.full((cr,), -0.25, device=DEV)
-        coef = torch.full((3, c), 3.0, device=DEV)
-        dy = torch.zeros(m, c, dtype=BF16, device=DEV)
-        ds = dev(rnd(m, c, seed=13).to(BF16)) if with_sc else None
-        fin = (P(part), rows_b, m, c, cr, P(gamma), P(vec[2]), P(vec[3]), P(dg), P(db), P(coef), acc, dzy)
-        app = (P(dout), P(y), P(mask), P(vec[0]), P(vec[1]))
-        if fused:
-            total[0] += lib.tok_bn_fused_producers(c)
-            assert lib.tok_bn_bwd_finalize_apply(*fin, *app, relu, P(dy), P(ds), acc, P(sync), total[0], st) == 0, \
-                lib.tok_last_error()
-        else:
-            assert lib.tok_bn_bwd_finalize(*fin, st) == 0
-            assert lib.tok_bn_bwd_apply(*app, P(coef), relu, P(dy), P(ds), acc, m, c, st) == 0
-        torch.cuda.synchronize()
-        return [dg, db, coef, dy] + ([ds] if with_sc else [])
-    for acc, dzy in ((0, 0), (1, 1)):
-        ref_b = bwd(False, acc, dzy)
-        for _ in range(2):
-            for a, b in zip(bwd(True, acc, dzy), ref_b):
-                assert torch.equal(a, b)
-            assert sync.tolist()[:3] == [total[0], 0, 0]

@@ -1,12 +1,12 @@
 #!/bin/bash
-# round-5 artifact set: bench line + kernel stats + timeline + main-queue gaps + PMC traffic (calibrated on the optimizer kernel) / MFMA
+# round-6 artifact set: bench line + kernel stats + timeline + main-queue gaps + PMC traffic (calibrated on the optimizer kernel) / MFMA
 # for the three workloads, the default bench line, the launch-class ablation (TOK_DBG_SKIP)
-cd $GRAFT_REPO_ROOT; o=gpurun_out/r05; mkdir -p $o
-bash tools/profile_workload.sh r05_resnet50_bs256 $o --steps 50 --warmup 10 > $o/p1.log 2>&1
-bash tools/profile_workload.sh r05_swinv2t_224_bs256 $o --backbone swinv2_custom --steps 30 --warmup 10 > $o/p2.log 2>&1
-bash tools/profile_workload.sh r05_hrnet_w48_512x1024_bs24 $o --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 10 --warmup 4 > $o/p3.log 2>&1
-python bench.py > $o/r05_bench_default_line.json 2> $o/bench_default.err
-python bench.py --backbone davit_t --steps 30 --warmup 10 --no-cpu-baseline --no-secondary > $o/r05_davit_t_224_bs256_bench.json 2> /dev/null
+cd $GRAFT_REPO_ROOT; o=gpurun_out/r06; mkdir -p $o
+bash tools/profile_workload.sh r06_resnet50_bs256 $o --steps 50 --warmup 10 > $o/p1.log 2>&1
+bash tools/profile_workload.sh r06_swinv2t_224_bs256 $o --backbone swinv2_custom --steps 30 --warmup 10 > $o/p2.log 2>&1
+bash tools/profile_workload.sh r06_hrnet_w48_512x1024_bs24 $o --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 10 --warmup 4 > $o/p3.log 2>&1
+python bench.py > $o/r06_bench_default_line.json 2> $o/bench_default.err
+python bench.py --backbone davit_t --steps 30 --warmup 10 --no-cpu-baseline --no-secondary > $o/r06_davit_t_224_bs256_bench.json 2> /dev/null
 { echo "# launch-class ablation on the ResNet-50 B=256 step (TOK_DBG_SKIP: the named launches are not issued, results garbage, ms/step = upper bound on what removing the class can buy; bench.py --steps 60 --warmup 15, same box)";
   for v in "0 base" "1 BatchNorm_finalizes(88_launches)" "2 wgrad_reduce_flat(61)" "4 fused-unit_helpers+colsum_f32(46)" "7 all_three" "8 BatchNorm_apply_passes(86)" "16 every_weight_gradient"; do set -- $v
     TOK_DBG_SKIP=$1 python bench.py --steps 60 --warmup 15 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_DBG_SKIP=$1 $2', d['ms_per_step'], 'ms/step')"; done
@@ -20,5 +20,5 @@ python bench.py --backbone davit_t --steps 30 --warmup 10 --no-cpu-baseline --no
     TOK_DBG_SKIP=$1 python bench.py --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_DBG_SKIP=$1 $2', d['ms_per_step'], 'ms/step')"; done
   TOK_BRANCH_STREAMS=0 python bench.py --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_BRANCH_STREAMS=0 (no branch streams)', d['ms_per_step'], 'ms/step')"
   TOK_STREAM_PRIO=-1 python bench.py --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_STREAM_PRIO=-1 (side / branch streams at high priority)', d['ms_per_step'], 'ms/step')"
-} > $o/r05_launch_class_ablation.txt 2>&1
+} > $o/r06_launch_class_ablation.txt 2>&1
 ls $o

@@ -82,12 +82,6 @@ PROTOTYPES = {
     'tok_bn_bwd_reduce': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int64, c_int, _P, _P]),
     'tok_bn_bwd_finalize': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     'tok_bn_bwd_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int64, c_int, _P]),
-    'tok_bn_fused_apply_ok': (c_int, [c_int64, c_int, c_int]),
-    'tok_bn_fused_producers': (c_int, [c_int]),
-    'tok_bn_finalize_act_fwd': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P,
-                                        _P, _P, c_int, _P, _P, c_int64, _P, _P, c_int, _P]),
-    'tok_bn_bwd_finalize_apply': (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, _P,
-                                          _P, _P, c_int, _P, _P, c_int, _P, c_int, _P]),
     'tok_maxpool3x3s2_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_maxpool3x3s2_bwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     'tok_avgpool2x2_fwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
@@ -170,10 +164,6 @@ PROTOTYPES = {
     'tok_mlp_serves': (c_int, [c_int64, c_int, c_int]),
     'tok_mlp_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
     'tok_mlp_bwd_dx': (c_int, [_P, _P, _P, _P, _P, c_int, _P, c_int64, c_int, c_int, _P]),
-    'tok_mlp_bwd_dw_ws_bytes': (c_size_t, [c_int64, c_int, c_int]),
-    'tok_mlp_bwd_dw': (c_int, [_P, _P, _P, _P, _P, _P, c_int, _P, c_int, _P, c_int, _P, c_int, _P, c_size_t, c_int64, c_int,
-                               c_int, _P]),
-    'tok_built_with_experiments': (c_int, []),
     'tok_chan_gram': (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, _P, _P]),
     'tok_chan_apply': (c_int, [_P, c_int, _P, c_int, c_float, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_scale_rows_add': (c_int, [_P, _P, _P, c_int, _P, c_int, c_int64, c_int, _P]),

@@ -423,284 +423,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 }
 
 
-#ifdef TOK_BUILD_EXPERIMENTS   // measured slower than two launches (profiles/r05_bn_fold_probe.txt): not in the default library
-// ---- finalize folded into the apply pass (round 5) ---------------------------------------------------------------------------
-// One launch instead of tok_bn_finalize -> tok_bn_act_fwd (and tok_bn_bwd_finalize -> tok_bn_bwd_apply): the first `nprod`
-// blocks of the apply grid fold the partial rows of CW channels each (the code of bn_finalize_kernel / bn_bwd_finalize_kernel,
-// same order of additions: same bits), publish scale / shift (coef) with device-scope stores and signal; every block
-// requests its first rows BEFORE it waits, so the fold's latency is covered by loads that are needed anyway
-// (tok_common.h: tok_phase_signal / tok_phase_wait).  C <= 2048 (one channel-group pass per thread).
-// the 8 values of vector `which` (0 scale, 1 shift) for channel group cg out of the producers' lines:
-// CW = 4: producer p = channels 4p..4p+3, line p = [4 scale][4 shift];  CW = 16: line p = [16 scale][16 shift]
-template <int CW>
-__device__ __forceinline__ void pub_load(const float* pub, int cg, int which, float (&v)[8]) {
-  if (CW == 4) {
-    const float4 a = *reinterpret_cast<const float4*>(pub + (size_t)(2 * cg) * 32 + which * 4);
-    const float4 b = *reinterpret_cast<const float4*>(pub + (size_t)(2 * cg + 1) * 32 + which * 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    load8f(pub + (size_t)(cg >> 1) * 32 + which * 16 + (cg & 1) * 8, v);
-  }
-}
-// three vectors (c1, c2, c3): CW = 4: line p = [4][4][4];  CW = 16: two lines per producer = [16][16][16]
-template <int CW>
-__device__ __forceinline__ void pub_load3(const float* pub, int cg, int which, float (&v)[8]) {
-  if (CW == 4) {
-    const float4 a = *reinterpret_cast<const float4*>(pub + (size_t)(2 * cg) * 32 + which * 4);
-    const float4 b = *reinterpret_cast<const float4*>(pub + (size_t)(2 * cg + 1) * 32 + which * 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
-    load8f(pub + (size_t)(cg >> 1) * 64 + which * 16 + (cg & 1) * 8, v);
-  }
-}
-
-struct FinFwd {
-  const float* stats; int rows; double inv_count, unbias; int C, Creal;
-  const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt; float momentum, eps;
-  float* mean; float* rstd; float* scale; float* shift;
-};
-
-template <int CW>
-__global__ __launch_bounds__(256) void bn_fin_act_fwd_kernel(FinFwd f, const bf16* __restrict__ y,
-                                                             const bf16* __restrict__ shortcut, int relu, bf16* __restrict__ out,
-                                                             uint8_t* __restrict__ mask, int64_t M, int cge, int rpb,
-                                                             float* __restrict__ csum, int32_t* sync, int nprod,
-                                                             float* pub, int32_t target) {
-  __shared__ double red[2][256];
-  __shared__ float cred[256][8];
-  const int tid = threadIdx.x;
-  const int C = f.C;
-  const int cg = tid % cge, rl = tid / cge;
-  const bool active = rl < rpb;
-  const int cg_total = C >> 3;
-  const int64_t step = (int64_t)gridDim.x * rpb;
-  int64_t m = (int64_t)blockIdx.x * rpb + rl;
-  // first rows in flight before anything else
-  bf16x8 v0 = zero8(), v1 = zero8(), s0 = zero8(), s1 = zero8();
-  if (active && m < M) {
-    v0 = ldg16(y + (size_t)m * C + cg * 8);
-    if (shortcut != nullptr) s0 = ldg16(shortcut + (size_t)m * C + cg * 8);
-  }
-  if (active && m + step < M) {
-    v1 = ldg16(y + (size_t)(m + step) * C + cg * 8);
-    if (shortcut != nullptr) s1 = ldg16(shortcut + (size_t)(m + step) * C + cg * 8);
-  }
-  if ((int)blockIdx.x < nprod) {
-    constexpr int RL = 256 / CW;
-    const int cl = tid % CW, frl = tid / CW;
-    const int c = blockIdx.x * CW + cl;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < C) fold_rows<RL>(f.stats, f.rows, C, c, frl, a1, a2);
-    red[0][tid] = a1;
-    red[1][tid] = a2;
-    __syncthreads();
-    for (int s = RL / 2; s > 0; s >>= 1) {
-      if (frl < s) {
-        red[0][tid] += red[0][tid + s * CW];
-        red[1][tid] += red[1][tid + s * CW];
-      }
-      __syncthreads();
-    }
-    // published copy: this block's CW scale + CW shift values in its OWN 128-byte line of `pub` (device-scope stores).  One
-    // writer per line, no reader before the signal, and an XCD's L2 holds no line of `pub` from an earlier launch (L2 is
-    // invalidated at kernel start): consumers may read the lines with ordinary cached loads, so the 1024 blocks of an
-    // apply pass fetch them through their L2 instead of issuing millions of uncached 4-byte loads
-    float* line = pub + (size_t)blockIdx.x * 32;
-    if (frl == 0 && c >= f.Creal && c < C) {
-      f.mean[c] = 0.f; f.rstd[c] = 0.f; f.scale[c] = 0.f; f.shift[c] = 0.f;
-      tok_st_dev(line + cl, 0.f); tok_st_dev(line + CW + cl, 0.f);
-    }
-    if (frl == 0 && c < f.Creal) {
-      float muf, rs, sc, sh;
-      double var;
-      bn_fwd_coeffs(red[0][tid], red[1][tid], f.inv_count, f.eps, f.gamma[c], f.beta[c], muf, rs, sc, sh, var);
-      f.mean[c] = muf;
-      f.rstd[c] = rs;
-      f.scale[c] = sc;
-      f.shift[c] = sh;
-      tok_st_dev(line + cl, sc);
-      tok_st_dev(line + CW + cl, sh);
-      if (f.running_mean != nullptr) bn_running_update(f.running_mean, f.running_var, c, f.momentum, muf, var, f.unbias);
-    }
-    if (f.nbt != nullptr && blockIdx.x == 0 && tid == 0) *f.nbt += 1;
-    tok_phase_signal(sync);
-  }
-  tok_phase_wait(sync, target);
-  float sc[8], sh[8], cs[8];
-  pub_load<CW>(pub, cg, 0, sc);
-  pub_load<CW>(pub, cg, 1, sh);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = 0.f;
-  if (active) {
-    for (; m < M; m += step) {
-      const bf16x8 v = v0, s = s0;
-      v0 = v1; s0 = s1;
-      const int64_t mn = m + 2 * step;
-      if (mn < M) {
-        v1 = ldg16(y + (size_t)mn * C + cg * 8);
-        if (shortcut != nullptr) s1 = ldg16(shortcut + (size_t)mn * C + cg * 8);
-      }
-      const size_t off = (size_t)m * C + cg * 8;
-      bf16x8 o;
-      if (shortcut != nullptr) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float z = fmaf(bf2f(v[e]), sc[e], sh[e]) + bf2f(s[e]);
-          if (relu) z = fmaxf(z, 0.f);
-          o[e] = f2bf(z);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float z = fmaf(bf2f(v[e]), sc[e], sh[e]);
-          if (relu) z = fmaxf(z, 0.f);
-          o[e] = f2bf(z);
-        }
-      }
-      stg16(out + off, o);
-      if (csum != nullptr) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] += bf2f(o[e]);
-      }
-      if (mask != nullptr) {
-        unsigned bits = 0;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bits |= (bf2f(o[e]) > 0.f ? 1u : 0u) << e;
-        mask[(size_t)m * cg_total + cg] = (uint8_t)bits;
-      }
-    }
-  }
-  if (csum != nullptr) {      // per-block column sums of the stored values (bn_act_fwd_kernel's layout and order)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) cred[tid][e] = cs[e];
-    __syncthreads();
-    if (rl == 0) {
-      for (int r = 1; r < rpb; ++r)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[e] += cred[r * cge + cg][e];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) csum[(size_t)blockIdx.x * C + cg * 8 + e] = cs[e];
-    }
-  }
-}
-
-struct FinBwd {
-  const float* partial; int rows; double inv_m; int C, Creal;
-  const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta; float* coef; int accumulate, dzy_form;
-};
-
-template <int CW>
-__global__ __launch_bounds__(256) void bn_fin_bwd_apply_kernel(FinBwd f, const bf16* dout, const bf16* __restrict__ y,
-                                                               const uint8_t* __restrict__ mask, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift, int relu, bf16* __restrict__ dy,
-                                                               bf16* dshortcut, int ds_acc, int64_t M, int cge, int rpb,
-                                                               int32_t* sync, int nprod, const float* pub_c, int32_t target) {
-  float* pub = const_cast<float*>(pub_c);
-  __shared__ double red[2][256];
-  const int tid = threadIdx.x;
-  const int C = f.C;
-  const int cg = tid % cge, rl = tid / cge;
-  const bool active = rl < rpb;
-  const int cg_total = C >> 3;
-  const int64_t step = (int64_t)gridDim.x * rpb;
-  int64_t m = (int64_t)blockIdx.x * rpb + rl;
-  const bool use_mask = relu && mask != nullptr;
-  bf16x8 g0 = zero8(), g1 = zero8(), v0 = zero8(), v1 = zero8();
-  unsigned b0 = 0, b1 = 0;
-  if (active && m < M) {
-    g0 = ldg16(dout + (size_t)m * C + cg * 8);
-    v0 = ldg16(y + (size_t)m * C + cg * 8);
-    if (use_mask) b0 = mask[(size_t)m * cg_total + cg];
-  }
-  if (active && m + step < M) {
-    g1 = ldg16(dout + (size_t)(m + step) * C + cg * 8);
-    v1 = ldg16(y + (size_t)(m + step) * C + cg * 8);
-    if (use_mask) b1 = mask[(size_t)(m + step) * cg_total + cg];
-  }
-  if ((int)blockIdx.x < nprod) {
-    constexpr int RL = 256 / CW;
-    const int cl = tid % CW, frl = tid / CW;
-    const int c = blockIdx.x * CW + cl;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < C) fold_rows<RL>(f.partial, f.rows, C, c, frl, a1, a2);
-    red[0][tid] = a1;
-    red[1][tid] = a2;
-    __syncthreads();
-    for (int s = RL / 2; s > 0; s >>= 1) {
-      if (frl < s) {
-        red[0][tid] += red[0][tid + s * CW];
-        red[1][tid] += red[1][tid + s * CW];
-      }
-      __syncthreads();
-    }
-    float* line = pub + (size_t)blockIdx.x * (CW == 4 ? 32 : 64);     // three vectors: CW = 16 takes two lines
-    if (frl == 0 && c >= f.Creal && c < C) {
-      f.coef[c] = 0.f; f.coef[C + c] = 0.f; f.coef[2 * C + c] = 0.f;
-      tok_st_dev(line + cl, 0.f); tok_st_dev(line + CW + cl, 0.f); tok_st_dev(line + 2 * CW + cl, 0.f);
-    }
-    if (frl == 0 && c < f.Creal) {
-      float sdz, sdzx, c1, c2, c3;
-      bn_bwd_coeffs(red[0][tid], red[1][tid], f.dzy_form, f.inv_m, f.gamma[c], f.mean[c], f.rstd[c], sdz, sdzx, c1, c2, c3);
-      if (f.dgamma != nullptr) f.dgamma[c] = f.accumulate ? f.dgamma[c] + sdzx : sdzx;
-      if (f.dbeta != nullptr) f.dbeta[c] = f.accumulate ? f.dbeta[c] + sdz : sdz;
-      f.coef[c] = c1;
-      f.coef[C + c] = c2;
-      f.coef[2 * C + c] = c3;
-      tok_st_dev(line + cl, c1);
-      tok_st_dev(line + CW + cl, c2);
-      tok_st_dev(line + 2 * CW + cl, c3);
-    }
-    tok_phase_signal(sync);
-  }
-  tok_phase_wait(sync, target);
-  if (!active) return;
-  float sc[8], sh[8], c1[8], c2[8], c3[8];
-  load8f(scale + cg * 8, sc);
-  load8f(shift + cg * 8, sh);
-  pub_load3<CW>(pub, cg, 0, c1);
-  pub_load3<CW>(pub, cg, 1, c2);
-  pub_load3<CW>(pub, cg, 2, c3);
-  for (; m < M; m += step) {
-    const bf16x8 g = g0, v = v0;
-    const unsigned bits = b0;
-    g0 = g1; v0 = v1; b0 = b1;
-    const int64_t mn = m + 2 * step;
-    if (mn < M) {
-      g1 = ldg16(dout + (size_t)mn * C + cg * 8);
-      v1 = ldg16(y + (size_t)mn * C + cg * 8);
-      if (use_mask) b1 = mask[(size_t)mn * cg_total + cg];
-    }
-    const size_t off = (size_t)m * C + cg * 8;
-    float dz[8];
-    if (use_mask) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dz[e] = ((bits >> e) & 1u) ? bf2f(g[e]) : 0.f;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        dz[e] = bf2f(g[e]);
-        if (relu && !(fmaf(bf2f(v[e]), sc[e], sh[e]) > 0.f)) dz[e] = 0.f;
-      }
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(c1[e], dz[e], fmaf(c2[e], bf2f(v[e]), c3[e])));
-    stg16(dy + off, o);
-    if (dshortcut != nullptr) {
-      bf16x8 d;
-      if (ds_acc) {
-        const bf16x8 old = ldg16(dshortcut + off);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = f2bf(dz[e] + bf2f(old[e]));
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = f2bf(dz[e]);
-      }
-      stg16(dshortcut + off, d);
-    }
-  }
-}
-#endif
 
 // ---- stem: BatchNorm + ReLU + 3x3/s2/p1 max-pool as ONE pass (forward) and pool-gather + BatchNorm backward as the
 // reduce / apply pair (backward).  The activated map z = relu(bn(y)) (ResNet stem: 112 x 112 x 64 per image, the largest
@@ -1081,96 +803,6 @@ extern "C" int tok_bn_bwd_apply(const void* dout, const void* y, const uint8_t* 
   return TOK_OK;
 }
 
-#ifdef TOK_BUILD_EXPERIMENTS
-// ---- finalize + apply in one launch (kernels above) --------------------------------------------------------------------------
-extern "C" int tok_bn_fused_producers(int c) { return c >= 512 ? (c + 15) / 16 : (c + 3) / 4; }
-
-extern "C" int tok_bn_fused_apply_ok(int64_t m, int c, int with_colsum) {
-  if (m <= 0 || c <= 0 || c % 8 != 0 || c > 2048) return 0;
-  const int nprod = c >= 512 ? (c + 15) / 16 : (c + 3) / 4;
-  // the column-sum rows are one per block of tok_bn_act_fwd_colsum_rows(m, c): the grid may not grow beyond that
-  if (with_colsum && nprod > stream_blocks(m, make_geo(c), kStreamCap)) return 0;
-  return 1;
-}
-
-extern "C" int tok_bn_finalize_act_fwd(const float* stats, int rows, int64_t count, int c, int c_real, const float* gamma,
-                                       const float* beta, float* running_mean, float* running_var, int64_t* nbt,
-                                       float momentum, float eps, float* mean, float* rstd, float* scale, float* shift,
-                                       const void* y, const void* shortcut, int relu, void* out, uint8_t* mask, int64_t m,
-                                       float* colsum_partial, int32_t* sync, int32_t sync_target, void* stream) {
-  TOK_CHECK_ARG(stats && gamma && beta && mean && rstd && scale && shift && y && out && sync, "tok_bn_finalize_act_fwd: null pointer");
-  TOK_CHECK_ARG(rows > 0 && count > 0 && c_real > 0 && c_real <= c, "tok_bn_finalize_act_fwd: bad sizes");
-  TOK_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "tok_bn_finalize_act_fwd: running stats");
-  TOK_CHECK_ARG(tok_bn_fused_apply_ok(m, c, colsum_partial != nullptr), "tok_bn_finalize_act_fwd: (m, c) not served (ask tok_bn_fused_apply_ok)");
-  if (tok_dbg_skip(1 | 8)) return TOK_OK;
-  const Geo g = make_geo(c);
-  FinFwd f;
-  f.stats = stats; f.rows = rows; f.inv_count = 1.0 / (double)count;
-  f.unbias = count > 1 ? (double)count / (double)(count - 1) : 1.0;
-  f.C = c; f.Creal = c_real; f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
-  f.nbt = nbt; f.momentum = momentum; f.eps = eps; f.mean = mean; f.rstd = rstd; f.scale = scale; f.shift = shift;
-  const int nprod = c >= 512 ? (c + 15) / 16 : (c + 3) / 4;
-  int grid = stream_blocks(m, g, kStreamCap);
-  if (grid < nprod) grid = nprod;
-  if (c >= 512)
-    hipLaunchKernelGGL(bn_fin_act_fwd_kernel<16>, dim3(grid), dim3(256), 0, tok_stream(stream), f, (const bf16*)y,
-                       (const bf16*)shortcut, relu, (bf16*)out, mask, m, g.cge, g.rpb, colsum_partial, sync, nprod,
-                       reinterpret_cast<float*>(sync + 64), sync_target);
-  else
-    hipLaunchKernelGGL(bn_fin_act_fwd_kernel<4>, dim3(grid), dim3(256), 0, tok_stream(stream), f, (const bf16*)y,
-                       (const bf16*)shortcut, relu, (bf16*)out, mask, m, g.cge, g.rpb, colsum_partial, sync, nprod,
-                       reinterpret_cast<float*>(sync + 64), sync_target);
-  TOK_CHECK_LAUNCH("tok_bn_finalize_act_fwd");
-  return TOK_OK;
-}
-
-extern "C" int tok_bn_bwd_finalize_apply(const float* partial, int rows, int64_t m, int c, int c_real, const float* gamma,
-                                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* coef,
-                                         int accumulate, int dzy_form, const void* dout, const void* y, const uint8_t* mask,
-                                         const float* scale, const float* shift, int relu, void* dy, void* dshortcut,
-                                         int dshortcut_accumulate, int32_t* sync, int32_t sync_target, void* stream) {
-  TOK_CHECK_ARG(partial && gamma && mean && rstd && coef && dout && y && scale && shift && dy && sync,
-                "tok_bn_bwd_finalize_apply: null pointer");
-  TOK_CHECK_ARG(rows > 0 && c_real > 0 && c_real <= c, "tok_bn_bwd_finalize_apply: bad sizes");
-  TOK_CHECK_ARG(tok_bn_fused_apply_ok(m, c, 0), "tok_bn_bwd_finalize_apply: (m, c) not served (ask tok_bn_fused_apply_ok)");
-  if (tok_dbg_skip(1 | 8)) { t_done_event = nullptr; return TOK_OK; }
-  const Geo g = make_geo(c);
-  FinBwd f;
-  f.partial = partial; f.rows = rows; f.inv_m = 1.0 / (double)m; f.C = c; f.Creal = c_real; f.gamma = gamma; f.mean = mean;
-  f.rstd = rstd; f.dgamma = dgamma; f.dbeta = dbeta; f.coef = coef; f.accumulate = accumulate; f.dzy_form = dzy_form;
-  const int nprod = c >= 512 ? (c + 15) / 16 : (c + 3) / 4;
-  int grid = stream_blocks(m, g, kStreamCap);
-  if (grid < nprod) grid = nprod;
-  hipEvent_t ev = t_done_event;      // completion event carried by this dispatch (see tok_bn_bwd_apply)
-  t_done_event = nullptr;
-  if (c >= 512)
-    hipExtLaunchKernelGGL(bn_fin_bwd_apply_kernel<16>, dim3(grid), dim3(256), 0, tok_stream(stream), nullptr, ev, 0, f,
-                          (const bf16*)dout, (const bf16*)y, mask, scale, shift, relu, (bf16*)dy, (bf16*)dshortcut,
-                          dshortcut_accumulate, m, g.cge, g.rpb, sync, nprod, reinterpret_cast<const float*>(sync + 64), sync_target);
-  else
-    hipExtLaunchKernelGGL(bn_fin_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, tok_stream(stream), nullptr, ev, 0, f,
-                          (const bf16*)dout, (const bf16*)y, mask, scale, shift, relu, (bf16*)dy, (bf16*)dshortcut,
-                          dshortcut_accumulate, m, g.cge, g.rpb, sync, nprod, reinterpret_cast<const float*>(sync + 64), sync_target);
-  TOK_CHECK_LAUNCH("tok_bn_bwd_finalize_apply");
-  return TOK_OK;
-}
-#else   // default build: entry points stay (C ABI), nothing is served
-extern "C" int tok_bn_fused_producers(int) { return 0; }
-extern "C" int tok_bn_fused_apply_ok(int64_t, int, int) { return 0; }
-extern "C" int tok_bn_finalize_act_fwd(const float*, int, int64_t, int, int, const float*, const float*, float*, float*, int64_t*,
-                                       float, float, float*, float*, float*, float*, const void*, const void*, int, void*,
-                                       uint8_t*, int64_t, float*, int32_t*, int32_t, void*) {
-  tok_set_error("tok_bn_finalize_act_fwd: not built (compile with TOK_BUILD_EXPERIMENTS=1)");
-  return TOK_ERR_INVALID;
-}
-extern "C" int tok_bn_bwd_finalize_apply(const float*, int, int64_t, int, int, const float*, const float*, const float*, float*,
-                                         float*, float*, int, int, const void*, const void*, const uint8_t*, const float*,
-                                         const float*, int, void*, void*, int, int32_t*, int32_t, void*) {
-  t_done_event = nullptr;
-  tok_set_error("tok_bn_bwd_finalize_apply: not built (compile with TOK_BUILD_EXPERIMENTS=1)");
-  return TOK_ERR_INVALID;
-}
-#endif
 
 // ---- completion events carried by a launch (two-stream schedule without record packets) ------------------------------------
 extern "C" void* tok_event_create(void) {

@@ -1,5 +1,5 @@
 // Argument block and fast division shared by the convolution kernels of libtok_gfx950.so (conv_igemm.hip: two-buffer
-// implicit GEMM; conv_ring.hip: 256 x 128 tiles on a three-stage DMA ring).  Not part of the C ABI.
+// implicit GEMM; conv_win.hip / conv_s2d.hip / stem.hip: shared-window kernels; gemm256.hip).  Not part of the C ABI.
 #pragma once
 #include "tok_common.h"
 
@@ -67,11 +67,6 @@ struct ConvArgs {
   FastDiv cls_fd_hw[4], cls_fd_w[4];
 };
 
-
-// conv_ring.hip
-bool conv_ring_serves(const ConvArgs& a, bool pointwise);    // geometry / mode test (pure function of the arguments)
-int conv_ring_grid(int gridM256, int gridN128);              // persistent grid (statistics rows = grid / gridN128)
-int conv_ring_launch(ConvArgs& a, hipStream_t st);           // a.gridM / a.gridN must be the 256 x 128 tile counts
 
 // conv_win.hip: 3x3 / stride 1 / padding 1 layers on a shared input window
 bool conv_win_serves(const ConvArgs& a);

@@ -961,8 +961,6 @@ extern "C" int tok_conv_fwd_stat_rows(const tok_conv_desc* d) {
       return conv_win_grid(gm, gn) / gn;
     }
     if (g256_owns(g, bn_tile)) return gemm256_rows(g);
-    if (bn_tile == 128 && conv_ring_serves(g, false))
-      return conv_ring_grid(tok_cdiv(g.M, 256), tok_cdiv(d->k, 128)) / tok_cdiv(d->k, 128);
   }
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && d->c != 4 && pw_serves(bn_tile, (long long)d->n * d->p * d->q, d->c, d->k))
     return pw_ring_grid(bn_tile, gridM, gridN) / gridN;
@@ -1054,18 +1052,9 @@ int conv_fwd_impl(const tok_conv_desc* d, const void* x, const void* w, const fl
   }
   // (a mode gemm256 does not carry that still writes statistics rows: this file's kernel on gemm256's row count — a multiple of 8)
   if (g256 && a.stats != nullptr && a.fin_mode == 0) a.force_grid = gemm256_rows(a) * tok_cdiv(d->k, ep != nullptr ? 64 : bn_pick);
-  if (!c4 && ep == nullptr && bn_pick == 128 && conv_ring_serves(a, false)) {
-    // deep-K layers: 256 x 128 tiles on the three-stage DMA ring (conv_ring.hip)
-    a.gridM = tok_cdiv(a.M, 256);
-    a.gridN = tok_cdiv(d->k, 128);
-    rc = conv_ring_launch(a, st);
-    if (rc) return rc;
-    TOK_CHECK_LAUNCH("tok_conv_fwd");
-    return TOK_OK;
-  }
   if (a.fin_mode != 0) {
     // "last workgroup finalizes" stays on this file's kernels; the caller sized `stats` with tok_conv_fwd_stat_rows, which may
-    // describe the (smaller) grid of conv_win / conv_ring: never write more rows than that
+    // describe the (smaller) grid of conv_win: never write more rows than that
     const int rows_q = tok_conv_fwd_stat_rows(d);
     const int gn = tok_cdiv(d->k, bn_pick);
     if (rows_q > 0 && rows_q * gn < plan_grid(bn_pick, a.gridM, gn)) a.force_grid = rows_q * gn;
@@ -1166,14 +1155,6 @@ int dgrad_impl(const tok_conv_desc* d, const void* dy, const void* w_dgrad, void
     TOK_CHECK_LAUNCH(who);
     return TOK_OK;
   }
-  if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false)) {
-    a.gridM = tok_cdiv(a.M, 256);
-    a.gridN = tok_cdiv(d->c, 128);
-    rc = conv_ring_launch(a, st);
-    if (rc) return rc;
-    TOK_CHECK_LAUNCH(who);
-    return TOK_OK;
-  }
   if (g256 && a.stats != nullptr && a.fin_mode == 0) a.force_grid = gemm256_rows(a) * pl.gridN;   // (see conv_fwd_impl)
   if (a.fin_mode != 0) {
     const int rows_q = tok_conv_dgrad_stat_rows(d);
@@ -1221,8 +1202,6 @@ extern "C" int tok_conv_dgrad_stat_rows(const tok_conv_desc* d) {
     return conv_s2d_grid(gm, gn) / gn;
   }
   if (d->stride == 1 && g256_owns(a, pl.bn_tile)) return gemm256_rows(a);
-  if (d->stride == 1 && pl.bn_tile == 128 && conv_ring_serves(a, false))
-    return conv_ring_grid(tok_cdiv(a.M, 256), tok_cdiv(d->c, 128)) / tok_cdiv(d->c, 128);
   if (d->r == 1 && d->s == 1 && d->stride == 1 && d->pad == 0 && pw_serves(pl.bn_tile, (long long)d->n * d->h * d->w, d->k, d->c))
     return pw_ring_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;
   return plan_grid(pl.bn_tile, pl.gridM, pl.gridN) / pl.gridN;

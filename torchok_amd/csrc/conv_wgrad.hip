@@ -865,230 +865,9 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_taps_kernel(WgradArgs a) {
 // NST = stages of the ring (NST - 1 in flight ahead of the one being read): 4 x 20 KB = 80 KB, two workgroups per CU.
 // KTL = column tiles (tap, 16 channels) per compute wave: 9 (CT = 4: 36 tiles on four waves; CT = 3: 27 tiles on three waves, the
 // fourth only stages) or 7 (CT = 3: 27 tiles on FOUR waves, 7 + 7 + 7 + 6: a quarter less MFMA / transpose-read chain per barrier).
-template <int CT, int NST, int KTLP = 9>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_win_kernel(WgradArgs a) {
-  constexpr int MS = 32, TN = 16 * CT, TC = 16 * CT, TAPS = 9;
-  constexpr int WIN = MS + 2;                    // pixels per filter-row window
-  constexpr int YT = MS * 128;                   // dy tile: 4 KB
-  constexpr int XT = 128 * 128;                  // x region: room for 4 DMA instructions (128 rows), 3 * 34 = 102 used
-  constexpr int STAGE = YT + XT;                 // 20 KB
-  constexpr int LOADS = 1 + 4;
-  constexpr int NT = CT, KTL = KTLP;
-  constexpr int NTILES = TAPS * CT;                // column tiles of the workgroup tile
-  constexpr int NCW = (NTILES + KTL - 1) / KTL;    // compute waves
-  static_assert(NCW <= 4 && KTL >= 5, "wave split");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-  const int tilesC = a.tilesK;
-  const int ntile = a.tilesN * tilesC;
-  const int id = tok_xcd_remap(blockIdx.x, ntile * a.splitM);
-  const int split = id / ntile;
-  const int t = id - split * ntile;
-  const int tn = t / tilesC;
-  const int ct = t - tn * tilesC;
-
-  const int mstart = split * a.mchunk;
-  const int mend = min(a.M, mstart + a.mchunk);
-  const int steps = (mend - mstart + MS - 1) / MS;
-
-  const int row = tid >> 3, cc = tid & 7;
-  const int clog = cc ^ ((row & 3) << 1);        // (row + 32 j) & 3 == row & 3: one logical chunk per thread
-  const int yn = tn * TN + clog * 8;
-  const bool yn_ok = yn < a.K && clog * 8 < TN;
-  const int cx = ct * TC + clog * 8;
-  const bool cx_ok = cx < a.C && clog * 8 < TC;
-  // LDS row R = row + 32 j of the x region -> window R / 34, pixel R % 34 of it
-  int xdelta[4];
-  bool xlive[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int R = row + 32 * j;
-    const int win = R / WIN;
-    xlive[j] = cx_ok && R < 3 * WIN;
-#if defined(TOK_WGWIN_PROBE) && (TOK_WGWIN_PROBE & 1)
-    xdelta[j] = -1 + (R - win * WIN);            // probe (timing only): the three filter-row windows alias the centre row
-#else
-    xdelta[j] = (win - 1) * a.W - 1 + (R - win * WIN);
-#endif
-  }
-  const int total_pix = a.M;                     // stride 1, "same" padding: input pixels == output pixels
-
-  const __amdgpu_buffer_rsrc_t ysrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  typedef __attribute__((address_space(3))) void lds_void;
-
-  int m0 = mstart;                               // first output pixel of the stage being issued (uniform)
-  auto issue = [&](int slot) {
-    char* base = smem + slot * STAGE + wv * 1024;
-    {
-      const int m = m0 + row;
-      uint32_t off = (uint32_t)(m * a.K + yn) * 2u;
-      asm volatile("" : "+v"(off));
-      off = (m < mend && yn_ok) ? off : 0xFFFFFFF0u;
-      asm volatile("" : "+v"(off));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ysrd, (lds_void*)base, 16, off, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pix = m0 + xdelta[j];
-      uint32_t off = (uint32_t)(pix * a.C + cx) * 2u;
-      asm volatile("" : "+v"(off));
-      off = (xlive[j] && m0 < mend && (unsigned)pix < (unsigned)total_pix) ? off : 0xFFFFFFF0u;
-      asm volatile("" : "+v"(off));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrd, (lds_void*)(base + YT + j * 4096), 16, off, 0, 0, 0);
-    }
-    m0 += MS;
-  };
-
-  const int g = lane >> 4, li = lane & 15;
-  const int rrow = 4 * g + (li >> 2);
-  const uint32_t ysw = (uint32_t)(((rrow & 3) << 1) << 4);
-  const uint32_t cq = (uint32_t)((li & 3) * 8);          // byte offset of this lane's 4 columns inside a 16-column tile
-  // zero line = row 127 of the stage's own x region: rows 102..127 take out-of-range DMA offsets (xlive false), i.e. zeros,
-  // with every stage; target of the transpose reads of invalid (pixel, tap) pairs
-  typedef __attribute__((address_space(3))) char lds_char;
-  const uint32_t lds_base = (uint32_t)(size_t)(lds_char*)smem;
-
-  // the whole stage loop is instantiated once per wave index (tap / tile numbers become literals); every copy executes the
-  // same barriers, so the four waves of a workgroup may sit in different copies
-  auto run = [&](auto WVC) {
-  constexpr int W0 = decltype(WVC)::value;
-  constexpr int T0 = W0 >= 0 ? (W0 * KTL) / CT : 0;       // first tap of this wave's nine column tiles (three taps at most)
-  // per tap: byte offset of LDS row (kr * 34 + ks + rrow) and the swizzle of that row (rows + 16 share it)
-  uint32_t trow[3], tsw[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int tap = T0 + k < TAPS ? T0 + k : TAPS - 1;
-    const int kr = tap / 3, ks = tap - kr * 3;
-    const int R = kr * WIN + ks + rrow;
-    trow[k] = (uint32_t)(R * 128);
-    tsw[k] = (uint32_t)(((R & 3) << 1) << 4);
-  }
-  f32x4 acc[NT][KTL];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < KTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s_ = 0; s_ < NST - 1; ++s_) issue(s_);
-  int cur = 0, nxt = NST - 1;
-  int mrd = mstart + rrow;                        // output pixel of this lane's first reduction row in the stage being read
-  for (int st = 0; st < steps; ++st) {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 2) * LOADS) : "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(nxt);
-    if constexpr (W0 < 0) {      // staging-only wave: its DMA share is issued, nothing to multiply
-      cur = cur == NST - 1 ? 0 : cur + 1;
-      nxt = nxt == NST - 1 ? 0 : nxt + 1;
-      continue;
-    } else {
-    // validity of (row, tap) for this lane's two reduction rows: bit tap of va / vb
-    uint32_t va = 0, vb = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int m = mrd + 16 * h;
-      const uint32_t mm = (uint32_t)min(m, a.M - 1);
-      const uint32_t b = magic_div(mm, a.pq_mul, a.pq_shift);
-      const uint32_t rem = mm - b * (uint32_t)a.PQ;
-      const uint32_t pp = magic_div(rem, a.q_mul, a.q_shift);
-      const uint32_t qq = rem - pp * (uint32_t)a.Q;
-      const uint32_t rowm = (pp >= 1u ? 0x007u : 0u) | 0x038u | ((int)pp <= a.H - 2 ? 0x1C0u : 0u);
-      const uint32_t colm = (qq >= 1u ? 0x049u : 0u) | 0x092u | ((int)qq <= a.W - 2 ? 0x124u : 0u);
-      const uint32_t v = (m < mend) ? (rowm & colm) : 0u;
-      if (h == 0) va = v; else vb = v;
-    }
-    mrd += MS;
-    const uint32_t Yb = lds_base + cur * STAGE + (uint32_t)(rrow * 128);
-    const uint32_t Xb = lds_base + cur * STAGE + YT;
-    const uint32_t zero_line = Xb + 127 * 128;
-    u32x2 ya[NT][2], xb[KTL][2];
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const uint32_t cb = ((uint32_t)(i * 32) + cq) ^ ysw;
-      ya[i][0] = tr_read_asm(Yb + cb);
-      ya[i][1] = tr_read_asm(Yb + 16 * 128 + cb);
-    }
-    // the wave's nine column tiles cover three taps (2 W0 .. 2 W0 + 2): one base per (tap, half) — the stage's row of that
-    // tap, or the zero line where this lane's reduction row is outside the image for it — and one add per read
-    {
-      uint32_t tb[3][2];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int tap = T0 + k;                         // (taps past 8 are never read)
-        tb[k][0] = (tap < TAPS && (va & (1u << tap))) ? Xb + trow[k] : zero_line;
-        tb[k][1] = (tap < TAPS && (vb & (1u << tap))) ? Xb + trow[k] + 16 * 128 : zero_line;
-      }
-#pragma unroll
-      for (int j = 0; j < KTL; ++j) {
-        const int J = W0 * KTL + j < NTILES ? W0 * KTL + j : NTILES - 1;     // (a ragged last wave repeats its last tile; never stored)
-        const int k = J / CT - T0;
-        const uint32_t cb = ((uint32_t)((J % CT) * 32) + cq) ^ tsw[k];       // stays inside 128 bytes: fine for the zero line too
-        xb[j][0] = tr_read_asm(tb[k][0] + cb);
-        xb[j][1] = tr_read_asm(tb[k][1] + cb);
-      }
-    }
-    bf16x8 af[NT];
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (KTL - 5)) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NT; ++i) af[i] = __builtin_bit_cast(bf16x8, (u32x4){ya[i][0][0], ya[i][0][1], ya[i][1][0], ya[i][1][1]});
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 5; j < KTL; ++j) {
-      if (W0 * KTL + j >= NTILES) continue;
-      const bf16x8 bfr = __builtin_bit_cast(bf16x8, (u32x4){xb[j][0][0], xb[j][0][1], xb[j][1][0], xb[j][1][1]});
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr, acc[i][j], 0, 0, 0);
-    }
-    cur = cur == NST - 1 ? 0 : cur + 1;
-    nxt = nxt == NST - 1 ? 0 : nxt + 1;
-    }   // compute waves
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  float* out = a.ws + (size_t)split * a.K * a.Ktot;
-  if constexpr (W0 >= 0) {
-#pragma unroll
-  for (int j = 0; j < KTL; ++j) {
-    const int J = W0 * KTL + j;
-    if (J >= NTILES) continue;
-    const int cin = ct * TC + (J % CT) * 16 + li;
-    const int kcol = (J / CT) * a.C + cin;
-#pragma unroll
-    for (int i = 0; i < NT; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = tn * TN + i * 16 + g * 4 + r;
-        if (n < a.K && cin < a.C) out[(size_t)n * a.Ktot + kcol] = acc[i][j][r];
-      }
-  }
-  }   // compute waves
-  (void)out;
-  };   // run
-  if (wv == 0) run(std::integral_constant<int, 0>{});
-  else if (wv == 1) run(std::integral_constant<int, 1>{});
-  else if (wv == 2) run(std::integral_constant<int, 2>{});
-  else if (NCW == 4) run(std::integral_constant<int, 3>{});
-  else run(std::integral_constant<int, -1>{});       // staging-only wave (48-wide tiles on three compute waves)
-}
-
-
 // ---- the window kernel, software-pipelined inside the wave (round 6) -------------------------------------------------------------
-// conv_wgrad_win_kernel runs one wave per SIMD at the step's split target (256 workgroups), and its stage is a serial chain:
+// Round 5's form of this kernel (conv_wgrad_win_kernel, in the history) ran one wave per SIMD at the step's split target (256
+// workgroups), and its stage was a serial chain:
 // barrier -> five DMA issues -> border masks -> 26 transpose reads -> lgkmcnt -> 36 MFMAs (576 of the stage's ~1700 cycles;
 // profiles/r05_layer_tables.txt: 411-644 TF/s).  Nothing overlaps the MFMA phase because the fragments it multiplies are the
 // ones it just waited for.  Here the fragments of stage st + 1 are read WHILE stage st is multiplied from registers: the x
@@ -1475,7 +1254,8 @@ Plan make_plan(const tok_conv_desc* d) {
   // (64-wide channel tiles; widths that are multiples of 48 but not of 64 — HRNet's 48 / 96 — take the 48-wide form of the
   //  window kernel on stride-1 layers and stay on the two-buffer kernel otherwise)
   const bool same3 = d->r == 3 && d->s == 3 && d->s_pad == 3 && d->stride == 1 && d->pad == 1 && taps_enabled() != 2 &&
-                     (unsigned long long)d->n * d->h * d->w * d->c * 2 < 0xFFFFFFF0ull;
+                     (unsigned long long)d->n * d->h * d->w * d->c * 2 < 0x40000000ull &&
+                     (unsigned long long)d->n * d->p * d->q * d->k * 2 < 0x40000000ull;
   const bool w64 = d->c % 64 == 0 && d->k % 64 == 0;
   const bool w48 = !w64 && d->c % 48 == 0 && d->k % 48 == 0 && same3 && taps_enabled() != 3;   // window kernel only
   if (d->c != 4 && (w64 || w48) && d->r == 3 && d->s == 3 && d->s_pad == 3 && taps_enabled()) {
@@ -1709,42 +1489,21 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
       return true;
     }();   // once per process (thread-safe function-local static)
     (void)attr_set;
-    const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W &&
-                      (unsigned long long)a.M * a.C * 2 < 0xFFFFFFF0ull && taps_enabled() != 2;
+    // stride 1 / "same" padding: the shared-window kernel (its idle DMA lanes sit at 2^31 + 2^30: tensors below 1 GiB — make_plan
+    // sends 48-wide layers elsewhere above that, 64-wide ones take the per-tap kernel below)
+    const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W && a.x_bytes < 0x40000000u && a.dy_bytes < 0x40000000u &&
+                      taps_enabled() != 2;
     if (same) {
-      static const int nst = [] { const char* e = getenv("TOK_WGRAD_WIN_NST"); return e ? atoi(e) : 3; }();   // 4: A/B switch (measured neutral)
-      const int smem_w = (nst == 3 ? 3 : 4) * (32 * 128 + 128 * 128);
-      static const bool attr_w = [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_win_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_w);
+      constexpr int smem_p = 3 * (32 * 128 + 128 * 128);
+      static const bool attr_p = [&] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<4, 3, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
         return true;
       }();   // once per process (thread-safe function-local static)
-      (void)attr_w;
+      (void)attr_p;
       const dim3 gw(a.tilesN * a.tilesK * a.splitM);
-      static const int winp = [] { const char* e = getenv("TOK_WGRAD_WINP"); return e ? atoi(e) : 1; }();   // 0: the unpipelined window kernel (A/B switch)
-      if (winp && a.x_bytes < 0x40000000u && a.dy_bytes < 0x40000000u) {
-        static const bool attr_p = [&] {
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<4, 3, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (32 * 128 + 128 * 128));
-          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (32 * 128 + 128 * 128));
-          return true;
-        }();
-        (void)attr_p;
-        constexpr int smem_p = 3 * (32 * 128 + 128 * 128);
-        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_winp_kernel<3, 3, 7>), gw, dim3(256), smem_p, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_winp_kernel<4, 3, 9>), gw, dim3(256), smem_p, st, a);
-      } else
-      if (nst == 3) {
-        static const int w48 = [] { const char* e = getenv("TOK_WGRAD_WIN48_WAVES"); return e ? atoi(e) : 4; }();   // 3: A/B switch
-        if (p.TN == 48 && w48 == 4) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3, 7>), gw, dim3(256), smem_w, st, a);
-        else if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 3>), gw, dim3(256), smem_w, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_win_kernel<4, 3>), gw, dim3(256), smem_w, st, a);
-      } else {
-        if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_win_kernel<3, 4>), gw, dim3(256), smem_w, st, a);
-        else hipLaunchKernelGGL((conv_wgrad_win_kernel<4, 4>), gw, dim3(256), smem_w, st, a);
-      }
+      if (p.TN == 48) hipLaunchKernelGGL((conv_wgrad_winp_kernel<3, 3, 7>), gw, dim3(256), smem_p, st, a);
+      else hipLaunchKernelGGL((conv_wgrad_winp_kernel<4, 3, 9>), gw, dim3(256), smem_p, st, a);
     } else {
       hipLaunchKernelGGL((conv_wgrad_taps_kernel<0>), dim3(a.tilesN * a.tilesK * a.splitM), dim3(256), smem, st, a);
     }

@@ -3,9 +3,9 @@
 //
 // What bounds the implicit-GEMM kernels on these layers is not the MFMA pipe and not HBM but the path from L2 into the CU:
 // the vector-memory front end delivers ~40 B/clk/CU (tools/ubench/dma_rate.hip: 36-43), and a 128 x 128 x 64 K step stages
-// 32 KB for 512 MFMA cycles = 64 B/clk at the matrix peak (256 x 128: 48).  conv_igemm.hip / conv_ring.hip stage the
+// 32 KB for 512 MFMA cycles = 64 B/clk at the matrix peak (256 x 128: 48).  conv_igemm.hip (and round 3's ring kernel) stage the
 // activation tile once PER TAP — nine copies of (almost) the same pixels (probe: with one of four activation DMA rows real,
-// conv_ring runs 1.2-1.3x faster; profiles/r03_ring_probe.txt).  Here a workgroup owns a 2-D patch of TH x TW = 256 output
+// the ring kernel ran 1.2-1.3x faster; profiles/r03_ring_probe.txt).  Here a workgroup owns a 2-D patch of TH x TW = 256 output
 // pixels x 128 output channels and keeps, per 32-channel chunk, the (TH + 2) x (TW + 2) input window in LDS ONCE; the nine
 // taps read their MFMA B fragments from it at shifted pixel offsets.  Staged bytes per 32-channel chunk: window ~25 KB +
 // weights 9 x 8 KB = 97 KB instead of 9 x 24 KB = 216 KB (21 B/clk at the matrix peak), DMA instructions per thread and
@@ -25,10 +25,10 @@
 //   * the window image is lane-linear (pixel p at p * 64 B, no swizzle): a ds_read_b128 of 16 consecutive pixels is 2-way
 //     bank-conflicted (8 LDS cycles instead of 4; 640 of the 1024 MFMA cycles of a stage pair per CU) — cheaper than the
 //     nine VALU instructions per read a swizzle that survives arbitrary pixel shifts would cost.  Weight rows keep
-//     conv_ring.hip's conflict-free XOR swizzle (applied to the DMA source chunk).
+//     a conflict-free XOR swizzle (applied to the DMA source chunk).
 //   * 4 waves = 2 (pixel rows) x 2 (64 channels): a wave owns 128 pixels x 64 channels (128 accumulator registers), weights
 //     are the MFMA A operand (16-byte NHWC stores), persistent XCD-aware tile walk, BatchNorm partial sums folded per tile
-//     into two registers, epilogue options as conv_ring.hip.  80 KB of LDS: two workgroups per CU.
+//     into two registers, epilogue options as conv_igemm.hip.  80 KB of LDS: two workgroups per CU.
 //     (s_setprio(1) around the MFMA clusters: measured neutral to -3 % — the two waves of a SIMD belong to different
 //     workgroups at unrelated phases; not kept.)
 #include "conv_common.h"

@@ -51,8 +51,7 @@ __device__ __forceinline__ float row16_sum_f(float v) {
 }
 
 // MODE 0: plain (bias, accumulate); 1: + batch statistics of the stored output; 2: + BatchNorm-backward sums (bn_y, bn_mask);
-// 3: dz = relu_mask ? dx : 0 is what gets stored, and sum(dz) goes to the statistics rows (tok_conv_dgrad_maskstore);
-// 4: fused activation (tok_conv_fwd_act's second output / tok_conv_dgrad_act's derivative factor), no statistics
+// 3: dz = relu_mask ? dx : 0 is what gets stored, and sum(dz) goes to the statistics rows (tok_conv_dgrad_maskstore)
 template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -213,28 +212,6 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(ConvArgs a) {
             s1[p][e] += bf2f(o[e]);
           }
         }
-        if constexpr (MODE == 4) {
-          // fused activation, conv_igemm.hip's arithmetic on the bf16-rounded GEMM result (bit-identical to the unfused launches):
-          // backward, o *= act'(act_x); forward, a second output y2 = act(o)
-          if (a.act_x != nullptr) {
-            const bf16x8 hx = ldg16(a.act_x + off);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float f = bf2f(hx[e]);
-              const float dd = a.act == 0 ? (f > 0.f ? 1.f : 0.f) : gelu_d(f);
-              o[e] = f2bf(bf2f(o[e]) * dd);
-            }
-          }
-          if (a.y2 != nullptr) {
-            bf16x8 o2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float f = bf2f(o[e]);
-              o2[e] = f2bf(a.act == 0 ? fmaxf(f, 0.f) : gelu_f(f));
-            }
-            stg16(a.y2 + off, o2);
-          }
-        }
         stg16(a.y + off, o);
         if constexpr (MODE == 1) {
           // batch statistics of the bf16 output as stored (what bn_act_fwd normalises; conv_igemm.hip's rounding point)
@@ -311,13 +288,8 @@ int g256_min_tiles() {
 bool gemm256_modes(const ConvArgs& a) {
   if (a.ep_scale != nullptr || a.sub != nullptr || a.fin_mode != 0) return false;
   if (a.mask_store && (a.bn_mask == nullptr || a.stats == nullptr)) return false;
-  if (a.y2 != nullptr || a.act_x != nullptr) {
-#ifndef TOK_BUILD_EXPERIMENTS
-    return false;      // gemm256_kernel<4> (fused activation) is an experiment: step 0.06 ms slower with it
-#endif
-    static const int act_on = [] { const char* e = getenv("TOK_GEMM256_ACT"); return (int)(e ? atoi(e) : 0); }();   // TOK_GEMM256_ACT=1: fused-activation layers too (bit-identical; per call 105 vs 122 us on SwinV2-T stage 4 fc1, but the STEP is 0.06 ms slower with it — SwinV2-T 20.41 vs 20.35, DaViT-T 21.71 vs 21.53 — so off by default)
-    if (!act_on || a.stats != nullptr || a.mask_store) return false;
-  }
+  // (fused activation — round 4's gemm256_kernel<4> — was bit-identical and 0.06 ms slower on the step: DESIGN.md "measured and rejected")
+  if (a.y2 != nullptr || a.act_x != nullptr) return false;
   return true;
 }
 bool gemm256_serves(const ConvArgs& a) { return gemm256_geometry(a) && gemm256_modes(a); }
@@ -352,9 +324,6 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-#ifdef TOK_BUILD_EXPERIMENTS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-#endif
     return true;
   }();
   (void)attr_set;
@@ -363,10 +332,6 @@ int gemm256_launch(ConvArgs& a, hipStream_t st) {
   a.stat_rows = gemm256_rows(a);
   const int tiles = a.gridM * a.gridN;
   const int grid = tiles < 256 ? tiles : 256;          // one workgroup per CU, walking tiles
-#ifdef TOK_BUILD_EXPERIMENTS
-  if (a.y2 != nullptr || a.act_x != nullptr) hipLaunchKernelGGL(gemm256_kernel<4>, dim3(grid), dim3(512), smem, st, a);
-  else
-#endif
   if (a.mask_store) hipLaunchKernelGGL(gemm256_kernel<3>, dim3(grid), dim3(512), smem, st, a);
   else if (a.stats == nullptr) hipLaunchKernelGGL(gemm256_kernel<0>, dim3(grid), dim3(512), smem, st, a);
   else if (a.bn_y == nullptr) hipLaunchKernelGGL(gemm256_kernel<1>, dim3(grid), dim3(512), smem, st, a);

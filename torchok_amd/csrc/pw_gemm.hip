@@ -429,285 +429,6 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void pw_gemm_ring_kernel(PwA
   }
 }
 
-#ifdef TOK_BUILD_EXPERIMENTS   // bit-identical to the ring kernel and slower in every mode a training step uses (profiles/r05_pw_stream_probe.txt)
-// ---- the same GEMM WITHOUT the ring, for the write-heavy streaming layers (round 5) ---------------------------------------------
-// On the 1x1 data gradients of a bottleneck's first convolution (C = 64 / 128 input channels of dy, N = 4C output channels,
-// >= 100 k pixels: layers 1-2 of ResNet-50 at batch 256) the ring kernel spends ~2.9 us per iteration whatever it moves — a
-// barrier, an LDS round trip and seven DMA instructions per thread for 16 KB of output, and an accumulating / statistics
-// launch needs three such iterations per tile (profiles/r04_pw_ring_probe.txt: 3.6 TB/s on a layer whose stores alone run
-// at 6.5).  With so short a reduction nothing needs LDS: the weights of the workgroup's fixed 64-channel tile are 32 (64)
-// registers per lane and stay resident for the whole kernel, a wave's activation fragments are 16-byte rows in exactly the
-// MFMA B layout, and every epilogue operand (previous value, producer's raw output, ReLU bits) is read in the accumulator
-// layout.  So: no ring, no barrier, no LDS in the loop; each wave streams its 32 rows x 64 channels per tile on its own, the
-// loads of the NEXT tile (two register sets, ping-pong) in flight while the current one is multiplied and stored.
-// Tile walk, statistics rows, every epilogue mode and the order of the MFMA accumulation are the ring kernel's: same bits.
-template <int KS>
-struct StreamOps {        // the operands of ONE 16-row sub-tile of a wave
-  u32x4 xf[KS];
-  u32x4 e1[2];
-  u32x4 e2[2];
-  uint32_t mk[2];
-};
-
-// E1 / E2 / MK / MS: which epilogue operands exist — compile-time, because hipcc puts an `s_waitcnt vmcnt(0)` behind every load
-// that sits in a (even kernel-uniform) branch, which would serialise the whole prefetch.
-// A wave walks its 16-row sub-tiles (two per 128-row tile of the workgroup) through a ring of FOUR register sets: three
-// sub-tiles' loads are in flight while one is multiplied and stored.  (First version: two sets of a 32-row tile, i.e. one tile in
-// flight — 3.3 TB/s, exactly 8 waves x 4 KB x 256 CUs per 2.5 us of loaded-HBM latency: the loop of a wave is a chain
-// load -> MFMA -> store, and what bounds it is how many loads it keeps outstanding, not bytes.)
-template <int KS, bool E1, bool E2, bool MK, bool MS>
-__global__ __launch_bounds__(256, (KS > 2 && E1 && E2) ? 1 : 2) void pw_stream_kernel(PwArgs a, uint32_t x_bytes, uint32_t w_bytes, uint32_t y_bytes,
-                                                           uint32_t m_bytes, uint32_t e1_bytes, PwDiv fd_hw, PwDiv fd_w) {
-  constexpr int BN = 64, WGM = 4;
-  __shared__ float red[2 * WGM * BN];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wm = tid >> 6;
-  const int sl = lane >> 4;
-  const int li = lane & 15;
-
-  const __amdgpu_buffer_rsrc_t xsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wsrd = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t e1srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e1 ? a.e1 : a.x), 0, a.e1 ? e1_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t e2srd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.e2 ? a.e2 : a.x), 0, a.e2 ? y_bytes : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t msrd =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask_in ? (const void*)a.mask_in : (const void*)a.x), 0, a.mask_in ? m_bytes : 0, 0x00020000);
-
-  // tile ownership: the ring kernel's (workgroup b on XCD b % 8, fixed channel tile, m-tiles it0, it0 + sweep, ...)
-  const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-  const int bn_fixed = jx % a.gridN, jm = jx / a.gridN;
-  const int S8 = (gridDim.x >> 3) / a.gridN;
-  const int sweep = 8 * S8;
-  const int n0 = bn_fixed * BN;
-  const int it0 = xcd * S8 + jm;
-  const int mask_cols = a.N >> 3;
-  const int nb = n0 + sl * 8;
-  const int arow0 = wm * 32 + li;
-  const int ntiles = it0 < a.gridM ? (a.gridM - it0 + sweep - 1) / sweep : 0;
-  const int nsub = 2 * ntiles;           // sub-tile j: tile it0 + (j >> 1) * sweep, rows arow0 + (j & 1) * 16
-
-  // resident weights: fragment (ks, t) = filter rows n0 + (li >> 2) * 8 + (li & 3) + (t >> 1) * 32 + (t & 1) * 4, k = 32 ks + 8 sl ..
-  u32x4 wf[KS][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int n = n0 + (li >> 2) * 8 + (li & 3) + (t >> 1) * 32 + (t & 1) * 4;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const uint32_t off = n < a.N ? (uint32_t)(n * a.C + ks * 32 + sl * 8) * 2u : 0xFFFFFFF0u;
-      wf[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(wsrd, off, 0, 0);
-    }
-  }
-  float s1[16], s2[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-
-  // byte offset of row m / channel n in the E1 operand; e1_sub: the row of the half-resolution tensor, even pixels only
-  const bool sub = a.e1_sub != 0;
-  auto e1row = [&](int m, int n, bool ok) -> uint32_t {       // branch-free: selects only
-    const uint32_t b = pwdiv((uint32_t)m, fd_hw);
-    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.sub_H * a.sub_W);
-    const uint32_t h = pwdiv(rem, fd_w);
-    const uint32_t w = rem - h * (uint32_t)a.sub_W;
-    const uint32_t ph = (uint32_t)(a.sub_H + 1) >> 1, pw = (uint32_t)(a.sub_W + 1) >> 1;
-    const uint32_t so = (((b * ph + (h >> 1)) * pw + (w >> 1)) * (uint32_t)a.N + (uint32_t)n) * 2u;
-    const uint32_t po = (uint32_t)(m * a.N + n) * 2u;
-    const bool live = ok && !(sub && ((h | w) & 1u));
-    return live ? (sub ? so : po) : 0xFFFFFFF0u;
-  };
-
-  auto row_of = [&](int j) -> int { return (it0 + (j >> 1) * sweep) * BM + arow0 + (j & 1) * 16; };
-
-  auto load_sub = [&](int j, StreamOps<KS>& o) {
-    const int m = row_of(j);
-    const bool ok = j < nsub && m < a.M;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      uint32_t off = ok ? (uint32_t)(m * a.C + ks * 32 + sl * 8) * 2u : 0xFFFFFFF0u;
-      asm volatile("" : "+v"(off));
-      o.xf[ks] = __builtin_amdgcn_raw_buffer_load_b128(xsrd, off, 0, 0);
-    }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int n = nb + half * 32;
-      const bool okn = ok && n + 8 <= a.N;
-      if constexpr (E1) {
-        uint32_t off = e1row(m, n, okn);
-        asm volatile("" : "+v"(off));
-        o.e1[half] = __builtin_amdgcn_raw_buffer_load_b128(e1srd, off, 0, 0);
-      }
-      if constexpr (E2) {
-        uint32_t off = okn ? (uint32_t)(m * a.N + n) * 2u : 0xFFFFFFF0u;
-        asm volatile("" : "+v"(off));
-        o.e2[half] = __builtin_amdgcn_raw_buffer_load_b128(e2srd, off, 0, 0);
-      }
-      if constexpr (MK) {
-        uint32_t off = okn ? (uint32_t)(m * mask_cols + (n >> 3)) : 0xFFFFFFF0u;
-        asm volatile("" : "+v"(off));
-        o.mk[half] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(msrd, off, 0, 0);
-      }
-    }
-  };
-
-  auto process = [&](int j, const StreamOps<KS>& o) {
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ks][t]), __builtin_bit_cast(bf16x8, o.xf[ks]),
-                                                         acc[t], 0, 0, 0);
-    if constexpr (E1) {       // acc += previous value (fp32 add of the bf16 tile, rounded once below)
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const bf16x8 ev = __builtin_bit_cast(bf16x8, o.e1[half]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[half * 2 + (e >> 2)][e & 3] += bf2f(ev[e]);
-      }
-    }
-    const int m = row_of(j);
-    if (m >= a.M) return;
-    bf16* yp = a.y + (size_t)m * a.N + nb;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      if (nb + half * 32 + 8 > a.N) continue;
-      bf16x8 ov;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ov[e] = f2bf(acc[half * 2 + (e >> 2)][e & 3]);
-      if constexpr (MS) {
-        const unsigned bits = o.mk[half];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (!((bits >> e) & 1u)) ov[e] = (bf16)0.f;
-          s1[half * 8 + e] += bf2f(ov[e]);
-        }
-      }
-      stg16(yp + half * 32, ov);
-      if (!MS && a.stats != nullptr) {
-        if constexpr (E2) {
-          const bf16x8 ev = __builtin_bit_cast(bf16x8, o.e2[half]);
-          const unsigned bits = MK ? o.mk[half] : 0xffu;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dz = ((bits >> e) & 1u) ? bf2f(ov[e]) : 0.f;
-            s1[half * 8 + e] += dz;
-            s2[half * 8 + e] = fmaf(dz, bf2f(ev[e]), s2[half * 8 + e]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float r = bf2f(ov[e]);
-            s1[half * 8 + e] += r;
-            s2[half * 8 + e] = fmaf(r, r, s2[half * 8 + e]);
-          }
-        }
-      }
-    }
-  };
-
-  StreamOps<KS> A = {}, B = {}, C = {}, D = {};
-  load_sub(0, A);
-  load_sub(1, B);
-  load_sub(2, C);
-  for (int j = 0; j < nsub; j += 4) {           // nsub is even; the tail sub-tiles beyond it load nothing and store nothing
-    load_sub(j + 3, D);
-    process(j, A);
-    load_sub(j + 4, A);
-    process(j + 1, B);
-    load_sub(j + 5, B);
-    if (j + 2 < nsub) process(j + 2, C);
-    load_sub(j + 6, C);
-    if (j + 3 < nsub) process(j + 3, D);
-  }
-
-  // ---- BatchNorm partial sums -> one row per workgroup (the ring kernel's butterfly and row layout) -------------------------
-  if (a.stats != nullptr) {
-#pragma unroll
-    for (int step = 0; step < 4; ++step) {
-      const int off = 8 >> step;
-      const int cnt = 8 >> step;
-      const bool up = (li & off) != 0;
-#pragma unroll
-      for (int j = 0; j < cnt; ++j) {
-        const float send1 = up ? s1[j] : s1[j + cnt];
-        const float send2 = up ? s2[j] : s2[j + cnt];
-        const float keep1 = up ? s1[j + cnt] : s1[j];
-        const float keep2 = up ? s2[j + cnt] : s2[j];
-        s1[j] = keep1 + __shfl_xor(send1, off, 64);
-        s2[j] = keep2 + __shfl_xor(send2, off, 64);
-      }
-    }
-    const int nl = (li >> 3) * 32 + sl * 8 + (li & 7);
-    red[(0 * WGM + wm) * BN + nl] = s1[0];
-    red[(1 * WGM + wm) * BN + nl] = s2[0];
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN;
-      const int c = tid - which * BN;
-      float t = 0.f;
-#pragma unroll
-      for (int w_ = 0; w_ < WGM; ++w_) t += red[(which * WGM + w_) * BN + c];
-      const int row = xcd * S8 + jm;
-      const int n = n0 + c;
-      if (n < a.N) a.stats[((size_t)which * a.stat_rows + row) * a.N + n] = t;
-    }
-  }
-}
-
-int stream_flag() {   // TOK_PW_STREAM (experiments build only; default 0 = ring): 1: C = 128 write-heavy layers, 3: all write-heavy (N >= 2C) layers, 2: every layer the kernel can run
-  static const int v = [] { const char* e = getenv("TOK_PW_STREAM"); return (int)(e ? atoi(e) : 0); }();
-  return v;
-}
-
-// Which ring launches go to the stream kernel instead (same grid, same statistics rows: the choice is free per launch).
-bool stream_serves(const PwArgs& a) {
-  const int flag = stream_flag();
-  if (!flag) return false;
-  if (a.ep_scale != nullptr || a.x2 != nullptr || a.mask_out != nullptr || a.bias != nullptr) return false;   // BatchNorm epilogue / second source / bias: ring
-  if (a.accumulate && a.e1 == nullptr) return false;
-  if (a.mask_store && (a.mask_in == nullptr || a.e2 != nullptr)) return false;
-  if (a.mask_in != nullptr && !a.mask_store && a.e2 == nullptr) return false;
-  if (!a.accumulate && a.e1 != nullptr) return false;
-  if (a.C != 64 && a.C != 128) return false;
-  if (a.N % 8 != 0) return false;
-  if (flag >= 2) return true;
-  if (flag == 3) return a.N >= 2 * a.C;
-  return a.C == 128 && a.N >= 2 * a.C;
-}
-
-template <int KS, bool E1, bool E2, bool MK, bool MS>
-int launch_stream_m(const PwArgs& a, hipStream_t st) {
-  const unsigned long long xb = (unsigned long long)a.M * a.C * 2, wb = (unsigned long long)a.N * a.C * 2,
-                           yb = (unsigned long long)a.M * a.N * 2, mb = (unsigned long long)a.M * (a.N / 8);
-  if (xb >= 0xFFFFFFF0ull || wb >= 0xFFFFFFF0ull || yb >= 0xFFFFFFF0ull) return 1;
-  unsigned long long e1b = yb;
-  PwDiv fd_hw = make_pwdiv(1), fd_w = make_pwdiv(1);
-  PwArgs b = a;
-  if (a.e1_sub) {
-    const unsigned long long hw = (unsigned long long)a.sub_H * a.sub_W;
-    e1b = (unsigned long long)(a.M / hw) * ((a.sub_H + 1) / 2) * ((a.sub_W + 1) / 2) * a.N * 2;
-    fd_hw = make_pwdiv((uint32_t)hw);
-    fd_w = make_pwdiv((uint32_t)a.sub_W);
-  } else {
-    b.sub_H = 1; b.sub_W = 1;        // the (unused) half-resolution offset arithmetic stays well-defined
-  }
-  const int grid = pw_ring_grid(64, a.gridM, a.gridN);
-  hipLaunchKernelGGL((pw_stream_kernel<KS, E1, E2, MK, MS>), dim3(grid), dim3(256), 0, st, b, (uint32_t)xb, (uint32_t)wb,
-                     (uint32_t)yb, (uint32_t)mb, (uint32_t)e1b, fd_hw, fd_w);
-  return 0;
-}
-
-template <int KS>
-int launch_stream(const PwArgs& a, hipStream_t st) {
-  const bool e1 = a.e1 != nullptr, e2 = a.e2 != nullptr, mk = a.mask_in != nullptr, ms = a.mask_store != 0;
-  if (ms) return e1 ? launch_stream_m<KS, true, false, true, true>(a, st) : launch_stream_m<KS, false, false, true, true>(a, st);
-  if (e2 && mk) return e1 ? launch_stream_m<KS, true, true, true, false>(a, st) : launch_stream_m<KS, false, true, true, false>(a, st);
-  if (e2) return e1 ? launch_stream_m<KS, true, true, false, false>(a, st) : launch_stream_m<KS, false, true, false, false>(a, st);
-  return e1 ? launch_stream_m<KS, true, false, false, false>(a, st) : launch_stream_m<KS, false, false, false, false>(a, st);
-}
-#endif
-
 int ring_flag() {   // TOK_PW_RING=0: every pointwise launch stays on conv_igemm's two-buffer loop (A/B switch)
   static const int v = [] { const char* e = getenv("TOK_PW_RING"); return (int)(e ? atoi(e) : 1); }();
   return v;
@@ -768,9 +489,6 @@ int pw_ring_launch(const PwArgs& a, int bn_tile, hipStream_t st) {
   if (a.e1_sub && (!a.accumulate || a.ep_scale != nullptr || a.sub_H <= 0 || a.sub_W <= 0 ||
                    a.M % (a.sub_H * a.sub_W) != 0)) return -1;
   const bool bnep = a.ep_scale != nullptr;
-#ifdef TOK_BUILD_EXPERIMENTS
-  if (bn_tile == 64 && stream_serves(a)) return a.C == 64 ? launch_stream<2>(a, st) : launch_stream<4>(a, st);
-#endif
   if (bn_tile == 64) return bnep ? launch_ring<64, true>(a, st) : launch_ring<64, false>(a, st);
   if (bnep) return 1;
   return launch_ring<128, false>(a, st);

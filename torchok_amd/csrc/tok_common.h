@@ -45,8 +45,16 @@ static inline hipStream_t tok_stream(void* s) { return reinterpret_cast<hipStrea
 //   1 BatchNorm finalizes (forward + backward)   2 wgrad_reduce_flat   4 fused-unit helpers (Gram finalize, prepare rows, Wb) + colsum_f32
 //   8 BatchNorm apply passes (bn_act_fwd, bn_bwd_apply)   16 every weight-gradient launch   32 optimizer + repack
 #include <stdlib.h>
-static inline int tok_dbg_skip(int bit) {
-  static const int v = [] { const char* e = getenv("TOK_DBG_SKIP"); return (int)(e ? atoi(e) : 0); }();
+// A process that runs with it set says so once on stderr: the launches it names return TOK_OK without running.
+inline int tok_dbg_skip(int bit) {   // (inline, not static: ONE instance and one warning per process)
+  static const int v = [] {
+    const char* e = getenv("TOK_DBG_SKIP");
+    const int m = (int)(e ? atoi(e) : 0);
+    if (m != 0)
+      fprintf(stderr, "libtok_gfx950: TOK_DBG_SKIP=%d — ablation mode, the named launch classes are NOT issued and every result of "
+                      "this process is garbage (timing probe only; unset it for real runs)\n", m);
+    return m;
+  }();
   return v & bit;
 }
 static inline int tok_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -170,45 +178,6 @@ __device__ __forceinline__ int tok_xcd_remap(int b, int nwg) {
   const int q = nwg >> 3, r = nwg & 7;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + slot;
-}
-
-// ---- dependent phases inside ONE launch ---------------------------------------------------------------------------------------
-// A few-microsecond launch between two dependent kernels (a BatchNorm finalize: fold some hundred partial rows per channel)
-// costs the chain its own duration plus a launch hand-over; here the blocks with the LOWEST indices of the consumer's grid
-// do that work ("producers"), publish the result with device-scope stores and bump a counter; every block polls the
-// counter before it consumes.  The hardware dispatches workgroups in index order, so a block only ever waits for blocks
-// that were dispatched before it: no deadlock whatever else occupies the chip (side-stream kernels).  While they wait the
-// consumers already have their first rows in flight.
-//   sync[0]: arrivals, NEVER reset by a kernel — the host hands every launch the value the counter reaches once all of ITS
-//            producers have signalled (launches that share a slot are on one stream, hence serialized; a per-block "passed"
-//            count for an in-kernel reset was measured: 1024 atomics on one address cost the apply pass +16 us)
-//   sync[2]: sticky error flag (a wait that gave up).
-// Published data is written with relaxed device-scope atomic stores (global_store ... sc1: written through the XCD's L2).
-__device__ __forceinline__ float tok_ld_dev(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tok_st_dev(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// every thread of a producer block, after its tok_st_dev stores
-__device__ __forceinline__ void tok_phase_signal(int32_t* sync) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores of this thread are complete at device scope
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// every thread of every block: returns once sync[0] has reached `target` (wrap-safe comparison)
-__device__ __forceinline__ void tok_phase_wait(int32_t* sync, int32_t target) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while ((int32_t)(__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 18)) {     // ~0.2 s: never reached unless the dispatch-order assumption breaks; do not hang the device
-        __hip_atomic_store(&sync[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -335,11 +335,7 @@ _anchors = {}
 _tls = threading.local()
 _side_streams = {}
 _branch_streams = {}
-# (the folded BatchNorm launches of the experiments build — TOK_FUSE_FIN_APPLY=1 — poll a per-stream arrival counter inside the kernel;
-#  with several branch streams issuing such launches concurrently the waits of one stream starve behind the pollers of another and give
-#  up: HRNet-W48 B=24 ended 2-3 of 15 steps with phase_sync_errors > 0 and non-reproducible parameters, 0 with one stream
-#  (profiles/r05_gpu_tests_experiments.txt).  The experiment therefore runs the branches on the main stream.)
-BRANCH_STREAMS = os.environ.get('TOK_BRANCH_STREAMS', '1') == '1' and os.environ.get('TOK_FUSE_FIN_APPLY', '0') != '1'
+BRANCH_STREAMS = os.environ.get('TOK_BRANCH_STREAMS', '1') == '1'
 LAZY_EVENTS = os.environ.get('TOK_LAZY_EVENTS', '1') == '1'
 
 

@@ -144,46 +144,6 @@ FUSE_BN_FINALIZE = os.environ.get('TOK_FUSE_BN_FINALIZE', '0') == '1'    # tok_c
 _ticket_rings = {}
 
 
-# TOK_FUSE_FIN_APPLY=1 (and a library built with TOK_BUILD_EXPERIMENTS=1): BatchNorm finalize + apply as ONE launch, the first
-# blocks of the apply grid fold the partial rows (csrc/bn.hip "finalize folded into the apply pass").  Bit-identical to the
-# two launches and measured SLOWER on every shape (profiles/r05_bn_fold_probe.txt: a kernel boundary costs ~2.5 us, the
-# in-kernel device-scope hand-over 6-11 us): off, and not compiled into the default library.
-FUSE_FIN_APPLY = os.environ.get('TOK_FUSE_FIN_APPLY', '0') == '1'
-
-
-_PHASE_SLOT_INTS = (256 + 32768) // 4      # include/tok.h: TOK_PHASE_SLOT_BYTES
-_phase_slots = {}                          # (device, raw stream) -> [slot tensor, running total of the arrival counter]
-
-
-def _phase_slot(device, producers: int):
-    """(slot pointer, counter target) for one folded launch on the CURRENT stream (tok_bn_finalize_act_fwd & co.).  One slot
-    per stream: launches of a stream are serialized, the arrival counter only grows, and the host knows the value it reaches
-    when the producers of this launch have signalled."""
-    key = (device, stream_ptr())
-    ent = _phase_slots.get(key)
-    if ent is None:
-        ent = _phase_slots[key] = [torch.zeros(_PHASE_SLOT_INTS, dtype=torch.int32, device=device), 0]
-    total = ent[1] + producers
-    if total >= 1 << 30:            # far from the int32 wrap: start over (in stream order behind every earlier launch)
-        ent[0][:4].zero_()
-        total = producers
-    ent[1] = total
-    return ent[0].data_ptr(), total
-
-
-def fused_launch_ok(device) -> bool:
-    """Folded launches keep a host-side running total of their arrival counter: not inside a hipGraph capture (a replay
-    would repeat the recorded targets)."""
-    return FUSE_FIN_APPLY and not (device.type == 'cuda' and torch.cuda.is_current_stream_capturing())
-
-
-def phase_sync_errors(device) -> int:
-    """Number of scratch slots whose in-kernel wait gave up (tok_common.h: tok_phase_wait) — 0 unless the dispatch-order
-    assumption behind the folded launches broke; checked by the tests and by bench.py after a run."""
-    device = device if isinstance(device, torch.device) else torch.device(device)
-    return sum(int(ent[0][2] != 0) for (dev, _), ent in _phase_slots.items() if dev == device)
-
-
 def _ticket_counters(device):
     """Pointer to 64 zeroed device ints for one fused-finalize launch.  A ring of 256 slots per device: kernels
     leave their counters zero, and no 256 such launches are ever in flight at once."""
@@ -286,16 +246,14 @@ class _ConvBnActNode(Node):
     def release(self):
         self.x = self.out = self.shortcut = None
         self.y = self.pk = self.mask = self.fused_partial = self.fused_coef = self.coef = self.pool = self.ypool = None
-        self.mean = self.rstd = self.scale = self.shift = self._keep_partial = None
+        self.mean = self.rstd = self.scale = self.shift = None
 
     def wants_fused_bwd_stats(self) -> bool:
         """Can the kernel that completes d(out) also reduce sum(dz), sum(dz*y) for this unit?"""
         return self.bn is not None and self.batch_stats and (not self.relu or self.mask is not None) and self.pool is None
 
-    def _finalize_bwd(self, lib, st, g, mask, m, kp, g_need, b_need, defer=False):
-        """sum(dz), sum(dz*xhat) -> dgamma, dbeta, apply coefficients (stand-alone reduce / finalize launches).
-        defer=True: the finalize is not launched when the apply pass can carry it (tok_bn_bwd_finalize_apply); returns
-        (arguments of the finalize half, commit callback) for the caller's apply launch, else None."""
+    def _finalize_bwd(self, lib, st, g, mask, m, kp, g_need, b_need):
+        """sum(dz), sum(dz*xhat) -> dgamma, dbeta, apply coefficients (stand-alone reduce / finalize launches)."""
         bn = self.bn
         dzy = 0
         if self.fused_partial is not None:
@@ -346,11 +304,6 @@ class _ConvBnActNode(Node):
                     commit_param_grad(bn.weight, gs, gm)
                 if b_need:
                     commit_param_grad(bn.bias, bs, bm)
-            if defer and self.pool is None and lib.tok_bn_fused_apply_ok(m, kp, 0) and fused_launch_ok(g.device):
-                self.coef = coef
-                self._keep_partial = partial      # read by the apply launch
-                return ((ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean), ptr(self.rstd), ptr(gs),
-                         ptr(bs), ptr(coef), 1 if (gm == 1 or bm == 1) else 0, dzy), commit)
             _C.check(lib.tok_bn_bwd_finalize(ptr(partial), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(self.mean),
                                              ptr(self.rstd), ptr(gs), ptr(bs), ptr(coef),
                                              1 if (gm == 1 or bm == 1) else 0, dzy, st), 'tok_bn_bwd_finalize')
@@ -366,7 +319,7 @@ class _ConvBnActNode(Node):
             r, s = conv.weight.shape[2], conv.weight.shape[3]
         side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                    (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
-                   _pointwise_wgrad_is_mfma_bound(conv.weight.shape[0], conv.weight.shape[1]))
+                   (r * s == 1 and _pointwise_wgrad_is_mfma_bound(conv.weight.shape[0], conv.weight.shape[1])))   # == launch_wgrad's side_ok
         return bool(WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
                     and not torch.cuda.is_current_stream_capturing())
 
@@ -391,14 +344,13 @@ class _ConvBnActNode(Node):
             sc_need = sc is not None and sc.requires_grad
             mask = self.mask if self.relu else None
             need_dy = w_need or x_need or bias_need
-            fin = None
             if self.batch_stats:
                 if self.fused_coef is not None:
                     # the dgrad that completed d(out) reduced AND finalized (tok_conv_dgrad_bn): dgamma / dbeta are
                     # already in their slots, only the apply coefficients are needed here
                     coef = self.fused_coef
                 else:
-                    fin = self._finalize_bwd(lib, st, g, mask, m, kp, g_need, b_need, defer=bool(need_dy or sc_need))
+                    self._finalize_bwd(lib, st, g, mask, m, kp, g_need, b_need)
                     coef = self.coef
             else:
                 # eval-mode BN: y -> out is a fixed affine map: dy = scale * dz, dgamma/dbeta unsupported
@@ -430,18 +382,9 @@ class _ConvBnActNode(Node):
                     if apply_event is not None:
                         lib.tok_next_launch_event(apply_event)
                     try:
-                        if fin is not None:
-                            # finalize + apply as one launch; dgamma / dbeta are committed behind it
-                            _C.check(lib.tok_bn_bwd_finalize_apply(*fin[0], ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
-                                                                   ptr(self.shift), int(self.relu), ptr(dy), ds_ptr, ds_acc,
-                                                                   *_phase_slot(g.device, lib.tok_bn_fused_producers(kp)), st),
-                                     'tok_bn_bwd_finalize_apply')
-                            fin[1]()
-                            fin = None
-                        else:
-                            _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
-                                                          ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
-                                                          ds_acc, m, kp, st), 'tok_bn_bwd_apply')
+                        _C.check(lib.tok_bn_bwd_apply(ptr(g), ptr(self.y), ptr(mask), ptr(self.scale),
+                                                      ptr(self.shift), ptr(coef), int(self.relu), ptr(dy), ds_ptr,
+                                                      ds_acc, m, kp, st), 'tok_bn_bwd_apply')
                     finally:
                         if apply_event is not None:
                             lib.tok_next_launch_event(None)   # never left armed for an unrelated later launch
@@ -868,21 +811,11 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             vec = torch.empty((4, kp), dtype=F32, device=dev)
             scale, shift = vec[0], vec[1]
             mean = rstd = None
-        fin_args = None
         if batch_stats and not fused_fin:
             if bn.momentum is None:
                 raise NotImplementedError('BatchNorm momentum=None (cumulative average)')
             mean, rstd = vec[2], vec[3]
             track = bn.training and bn.track_running_stats and bn.running_mean is not None
-            if not pool and lib.tok_bn_fused_apply_ok(m, kp, 0) and fused_launch_ok(dev):
-                # the finalize rides the apply pass below (one launch)
-                fin_args = (ptr(stats), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(bn.bias),
-                            ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
-                            ptr(bn.num_batches_tracked) if track else None, float(bn.momentum), float(bn.eps), ptr(mean),
-                            ptr(rstd), ptr(scale), ptr(shift))
-        if fin_args is not None:
-            pass
-        elif batch_stats and not fused_fin:
             _C.check(lib.tok_bn_finalize(ptr(stats), rows, m, kp, bn.num_features, ptr(bn.weight), ptr(bn.bias),
                                          ptr(bn.running_mean) if track else None,
                                          ptr(bn.running_var) if track else None,
@@ -914,21 +847,13 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
             if want_cs:
                 cs_rows = lib.tok_bn_act_fwd_colsum_rows(m, kp)
                 cs_part = torch.empty((cs_rows, kp), dtype=F32, device=dev)
-            if fin_args is not None and (cs_part is None or lib.tok_bn_fused_apply_ok(m, kp, 1)):
-                _C.check(lib.tok_bn_finalize_act_fwd(*fin_args, ptr(y), ptr(shortcut.data) if shortcut is not None else None,
-                                                     int(relu), ptr(out_data), ptr(mask), m, ptr(cs_part),
-                                                     *_phase_slot(dev, lib.tok_bn_fused_producers(kp)), st),
-                         'tok_bn_finalize_act_fwd')
+            if want_cs:
+                _C.check(lib.tok_bn_act_fwd_colsum(ptr(y), ptr(scale), ptr(shift), None, int(relu), ptr(out_data), ptr(mask),
+                                                   m, kp, ptr(cs_part), st), 'tok_bn_act_fwd_colsum')
             else:
-                if fin_args is not None:
-                    _C.check(lib.tok_bn_finalize(*fin_args, st), 'tok_bn_finalize')
-                if want_cs:
-                    _C.check(lib.tok_bn_act_fwd_colsum(ptr(y), ptr(scale), ptr(shift), None, int(relu), ptr(out_data), ptr(mask),
-                                                       m, kp, ptr(cs_part), st), 'tok_bn_act_fwd_colsum')
-                else:
-                    _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift),
-                                                ptr(shortcut.data) if shortcut is not None else None,
-                                                int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
+                _C.check(lib.tok_bn_act_fwd(ptr(y), ptr(scale), ptr(shift),
+                                            ptr(shortcut.data) if shortcut is not None else None,
+                                            int(relu), ptr(out_data), ptr(mask), m, kp, st), 'tok_bn_act_fwd')
         node.mask = mask
         node.mean, node.rstd, node.scale, node.shift = mean, rstd, scale, shift
     else:

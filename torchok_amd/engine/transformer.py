@@ -281,64 +281,6 @@ FUSE_MLP = os.environ.get('TOK_FUSE_MLP', '1') == '1'
 FUSE_MLP_BWD = os.environ.get('TOK_FUSE_MLP_BWD', '1') == '1'
 
 
-# Training on the RECOMPUTE plan (round 4): the forward keeps the bf16 pre-activation rows only; the backward is two launches
-# that read nothing hidden-sized besides them — tok_mlp_bwd_dx (d(pre) in registers between its two products) and, beside the
-# main chain, tok_mlp_bwd_dw, which recomputes pre / act / d(act) / d(pre) tile-wise from x and dy and contracts them into all
-# four parameter gradients (csrc/mlp_dw.hip).  Per SwinV2-T block 2 hidden-sized tensor passes instead of 6 (write pre, act;
-# read pre, write d(pre); read act, d(pre)), and two weight-gradient launches + two reduces + two activation-sized scratch
-# allocations fewer.  The reference has the same trade as `grad_checkpointing` (models/backbones/swin.py:75-78).
-# TOK_MLP_RECOMPUTE=0: the round-3 tape (fc1 / GELU / fc2 nodes over saved pre and act rows).
-MLP_RECOMPUTE = os.environ.get('TOK_MLP_RECOMPUTE', '0') == '1'
-
-
-class _MlpNode(Node):
-    """fc2(GELU(fc1(x))) as ONE tape entry (recompute plan)."""
-    needs_backward = True
-
-    def backward(self):
-        lib = _C.lib()
-        g = self.out.grad
-        if g is None:
-            return
-        x, fc1, fc2 = self.x, self.fc1, self.fc2
-        m, c = g.shape
-        hid = fc1.out_features
-        params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias)
-        need_p = any(p.requires_grad for p in params)
-        side = need_p and _use_side(self, g)
-
-        def param_grads():
-            ws_bytes = int(lib.tok_mlp_bwd_dw_ws_bytes(m, c, hid))
-            if ws_bytes == 0 and not lib.tok_built_with_experiments():
-                raise RuntimeError('TOK_MLP_RECOMPUTE=1 needs a library built with TOK_BUILD_EXPERIMENTS=1 '
-                                   '(csrc/mlp_dw.hip is not part of the default libtok_gfx950.so)')
-            ws = torch.empty(max(ws_bytes // 4, 1), dtype=F32, device=g.device)
-            tg = [param_grad_target(p) if p.requires_grad else (None, 0) for p in params]
-            a = [ptr(t[0]) if t[0] is not None else None for t in tg]
-            acc = [1 if t[1] == 1 else 0 for t in tg]
-            _C.check(lib.tok_mlp_bwd_dw(ptr(x.data), ptr(g), ptr(self.pk1.fwd), ptr(fc1.bias.detach()), ptr(self.pk2.dgrad),
-                                        a[0], acc[0], a[1], acc[1], a[2], acc[2], a[3], acc[3], ptr(ws), ws_bytes, m, c, hid,
-                                        stream_ptr()), 'tok_mlp_bwd_dw')
-            for p, (slot, mode) in zip(params, tg):
-                if slot is not None:
-                    commit_param_grad(p, slot, mode)
-            return ws
-        if need_p:
-            if side:
-                with self.region.fork_side((x.data, g)):
-                    self.region.keep_until_join(param_grads())
-            else:
-                param_grads()
-        if x.requires_grad:
-            tgt_x, acc_x = grad_target(x)
-            _C.check(lib.tok_mlp_bwd_dx(ptr(g), ptr(self.pk2.dgrad), ptr(self.pre), ptr(self.pk1.dgrad), ptr(tgt_x), acc_x, None,
-                                        m, c, hid, stream_ptr()), 'tok_mlp_bwd_dx')
-        self.out.grad = None
-
-    def release(self):
-        self.x = self.out = self.pk1 = self.pk2 = self.pre = self.fc1 = self.fc2 = None
-
-
 def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TTensor:
     """fc2(GELU(fc1(x))) — [timm 0.6.13] models/layers/mlp.py: Mlp.forward with drop = 0."""
     lib = _C.lib()
@@ -352,7 +294,6 @@ def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TT
     st = stream_ptr()
     params = (fc1.weight, fc1.bias, fc2.weight, fc2.bias)
     train = region.grad_mode and (x.requires_grad or any(p.requires_grad for p in params))
-    recompute = train and MLP_RECOMPUTE and FUSE_MLP_BWD
     pk1 = get_packs(fc1.weight, None, hid, 1, cp, want_dgrad=region.grad_mode and x.requires_grad, refresh=True)
     pk2 = get_packs(fc2.weight, None, c, 1, hid, want_dgrad=train, refresh=True)
     dev = x.data.device
@@ -360,21 +301,11 @@ def mlp_module(region: Region, x: TTensor, fc1: nn.Linear, fc2: nn.Linear) -> TT
     pre = act = None
     if train:
         pre = torch.empty((n, hid), dtype=BF16, device=dev)
-        if not recompute:
-            act = torch.empty_like(pre)
+        act = torch.empty_like(pre)
     _C.check(lib.tok_mlp_fwd(ptr(x.data), ptr(pk1.fwd), ptr(fc1.bias.detach()), ptr(pk2.fwd), ptr(fc2.bias.detach()), ptr(y),
                              ptr(pre), ptr(act), n, c, hid, st), 'tok_mlp_fwd')
     if not train:
         return TTensor(y, c, requires_grad=False)
-    if recompute:
-        out = TTensor(y, c, requires_grad=True)
-        node = _MlpNode()
-        node.x, node.out, node.fc1, node.fc2, node.pk1, node.pk2, node.pre = x, out, fc1, fc2, pk1, pk2, pre
-        out.node = node
-        if x.requires_grad:
-            x.uses += 1
-        region.add(node)
-        return out
     d1 = _C.ConvDesc(n, 1, 1, cp, hid, 1, 1, 1, 1, 1, 0, 1)
     d2 = _C.ConvDesc(n, 1, 1, hid, c, 1, 1, 1, 1, 1, 0, 1)
     h_pre = _record_linear(region, x, fc1.weight, [(fc1.bias, 0)], pre, d1, pk1)

@@ -115,9 +115,12 @@ class UpsampledLogits(torch.Tensor):
     # a contiguous NCHW tensor while the real one is channels-last with a padded pitch.
     _META = {'dim', 'size', 'numel', 'is_floating_point', '__len__', 'ndimension', 'nelement', 'element_size', 'is_complex',
              'get_device', '__repr__', '__str__', '__format__'}
-    _META_PROPS = {'shape', 'dtype', 'device', 'ndim', 'requires_grad', 'is_cuda', 'is_cpu', 'layout', 'names', 'is_leaf',
-                   'grad_fn', 'is_sparse', 'is_quantized', 'is_meta', 'is_mkldnn', 'is_nested', 'is_sparse_csr', 'is_xpu',
-                   'is_mps', 'is_xla', 'is_vulkan', 'is_ipu', 'is_maia', 'is_mtia', 'output_nr', '_version', 'name'}
+    # (the autograd properties — requires_grad, grad_fn, is_leaf, output_nr, _version — are NOT answered here: the wrapper is a
+    #  leaf that requires no gradient, the materialised tensor hangs on the head's graph; a user loss that tests
+    #  `input.requires_grad` or hands the input to its own autograd.Function must see the real tensor's answers)
+    _META_PROPS = {'shape', 'dtype', 'device', 'ndim', 'is_cuda', 'is_cpu', 'layout', 'names',
+                   'is_sparse', 'is_quantized', 'is_meta', 'is_mkldnn', 'is_nested', 'is_sparse_csr', 'is_xpu',
+                   'is_mps', 'is_xla', 'is_vulkan', 'is_ipu', 'is_maia', 'is_mtia', 'name'}
 
     def __repr__(self, *, tensor_contents=None):
         return f'UpsampledLogits(low={tuple(self._low.shape)}, size={self._size}, materialized={self._full is not None})'
