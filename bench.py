@@ -38,11 +38,11 @@ HBM_PEAK = 8.0e12
 # PMC-measured HBM bytes of ONE step (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command,
 # summarised by tools/pmc_traffic.py; corrections per MI355X_MICROARCH.md).  One file per workload, newest round first.
 PMC_FILES = {
-    ('resnet50', 224, 224, 256): ['r05_resnet50_bs256_pmc_traffic.json', 'r04_resnet50_bs256_pmc_traffic.json', 'r03_resnet50_bs256_pmc_traffic.json', 'r02_resnet50_bs256_pmc_traffic.json',
+    ('resnet50', 224, 224, 256): ['r06_resnet50_bs256_pmc_traffic.json', 'r05_resnet50_bs256_pmc_traffic.json', 'r04_resnet50_bs256_pmc_traffic.json', 'r03_resnet50_bs256_pmc_traffic.json', 'r02_resnet50_bs256_pmc_traffic.json',
                                  'r01_resnet50_bs256_pmc_traffic.json'],
-    ('swinv2_custom', 224, 224, 256): ['r05_swinv2t_224_bs256_pmc_traffic.json', 'r04_swinv2t_224_bs256_pmc_traffic.json', 'r03_swinv2t_224_bs256_pmc_traffic.json', 'r02_swinv2t_224_bs256_pmc_traffic.json'],
+    ('swinv2_custom', 224, 224, 256): ['r06_swinv2t_224_bs256_pmc_traffic.json', 'r05_swinv2t_224_bs256_pmc_traffic.json', 'r04_swinv2t_224_bs256_pmc_traffic.json', 'r03_swinv2t_224_bs256_pmc_traffic.json', 'r02_swinv2t_224_bs256_pmc_traffic.json'],
     ('davit_t', 224, 224, 256): ['r02_davit_t_224_bs256_pmc_traffic.json'],
-    ('hrnet_w48', 512, 1024, 24): ['r05_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r04_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r03_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r02_hrnet_w48_512x1024_bs24_pmc_traffic.json'],
+    ('hrnet_w48', 512, 1024, 24): ['r06_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r05_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r04_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r03_hrnet_w48_512x1024_bs24_pmc_traffic.json', 'r02_hrnet_w48_512x1024_bs24_pmc_traffic.json'],
     ('hrnet_w48', 512, 1024, 8): ['r02_hrnet_w48_512x1024_bs8_pmc_traffic.json'],
 }
 
