@@ -1494,9 +1494,10 @@ int wgrad_impl(const tok_conv_desc* d, const void* x, const void* dy, float* dw,
     const bool same = a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W && a.x_bytes < 0x40000000u && a.dy_bytes < 0x40000000u &&
                       taps_enabled() != 2;
     if (same) {
-      // TOK_WGRAD_WINP_LDS=<bytes> (probe): ask for more LDS than the ring needs — 81920: one workgroup of this kernel + at most 80 KB of
-      // others per CU; 163840: no LDS-using workgroup of another kernel beside it
-      static const int smem_p = [] { const char* e = getenv("TOK_WGRAD_WINP_LDS"); const int v = e ? atoi(e) : 0; const int need = 3 * (32 * 128 + 128 * 128); return v > need ? (v > 163840 ? 163840 : v) : need; }();
+      // (probe, round 6: asking for 160 KB of LDS — no LDS-using workgroup of another kernel beside this one — costs HRNet-W48 +1.2 ms and
+      //  ResNet-50 +0.13 ms per step: the co-residency of the main stream's kernels is worth more than an undisturbed CU;
+      //  profiles/r06_wgrad_winp_ab.txt)
+      constexpr int smem_p = 3 * (32 * 128 + 128 * 128);
       static const bool attr_p = [&] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<4, 3, 9>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_winp_kernel<3, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_p);
