@@ -913,6 +913,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winp_kernel(WgradArgs a) {
   const int mend = min(a.M, mstart + a.mchunk);
   const int steps = (mend - mstart + MS - 1) / MS;
 
+  // (everything lane-dependent lives INSIDE the per-wave instantiation: nothing of one copy stays live across another's stage loop)
+  auto run = [&](auto WVC) {
   const int row = tid >> 3, cc = tid & 7;
   const int clog = cc ^ ((row & 3) << 1);
   const int yn = tn * TN + clog * 8;
@@ -969,7 +971,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_winp_kernel(WgradArgs a) {
   }
   const int mend16 = mend - 16;
 
-  auto run = [&](auto WVC) {
   constexpr int W0 = decltype(WVC)::value;
   constexpr int T0 = (W0 * KTL) / CT;
   // tap index (0..2, relative to T0) of the wave's column tile j, and the last tile that reads tap k's bases
