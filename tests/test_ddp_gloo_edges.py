@@ -73,6 +73,8 @@ def _worker(rank, world, port, tmp):
     assert all(int(b) == 1 for b in nbt)
     sd = task.state_dict()
     assert any(k.endswith('running_mean') for k in sd)
+    red.enable_timing()                       # bench.py's N > 1 diagnosis needs HIP events: a no-op on the CPU backend
+    assert red.exposed_comm_ms() == []
 
     # steady state of find_unused_parameters: this rank's pattern of missing gradients does not change, so the reduced used-map
     # is not read on the host again (one blocking copy per step under torch DDP) and the per-parameter scan does not run;

@@ -142,6 +142,7 @@ def _worker(rank, world, port, tmp):
                 real_finish()
             sync_calls.append(list(c.calls))
         red.finish_step = spied_finish
+        red.enable_timing()          # bench.py's N > 1 diagnosis: two timing events per finish_step, no host synchronisation
         for i in range(3):
             train_step(task, opt, batch, i, red)
         red.finish_step = real_finish
@@ -149,6 +150,10 @@ def _worker(rank, world, port, tmp):
         if not find_unused:
             assert sync_calls[0] == [], (backbone, sync_calls)
         torch.cuda.synchronize()
+        exposed = red.exposed_comm_ms()      # step-stream time between "backward done" and "exchange joined", per step
+        assert len(exposed) == 3 and all(0.0 <= v < 5e3 for v in exposed), (backbone, exposed)
+        red.enable_timing(False)
+        assert red.exposed_comm_ms() == []
         flat = torch.cat([p.detach().flatten() for p in task.parameters()] +
                          [b.detach().float().flatten() for b in task.buffers()])
         every = [torch.zeros_like(flat) for _ in range(world)]
