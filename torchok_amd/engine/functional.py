@@ -959,7 +959,9 @@ class _Subsample2Node(Node):
 # gradient on the streaming kernels; the unit-3 fusion applies to the projection + BatchNorm).  Measured on ResNet-50 B=256:
 # see DESIGN.md section 8.
 SUBSAMPLE_S2 = os.environ.get('TOK_SUBSAMPLE_S2', '1') != '0'
-SUBSAMPLE_MIN_ROWS = int(os.environ.get('TOK_SUBSAMPLE_MIN_ROWS', '100000'))   # rows of the full-resolution input
+# rows of the full-resolution input (round 6: 100 000 -> 40 000 puts ResNet-50's layer4.0 projection at batch 256 — 50 176 rows, the
+# last stride-2 1x1 data gradient on the parity-class kernel — on the subsampled plan too: 17.42 vs 17.50 ms/step, two same-box rounds)
+SUBSAMPLE_MIN_ROWS = int(os.environ.get('TOK_SUBSAMPLE_MIN_ROWS', '40000'))
 
 
 def subsample2(region: Region, x: TTensor) -> TTensor:
