@@ -11,6 +11,7 @@ all-to-all fuse ``relu(sum_j fuse_ij(x_j))`` is ONE summation kernel per output 
 low-resolution BN outputs at their native size (the nearest ``nn.Upsample`` is an index shift in that kernel,
 the upsampled maps never exist in HBM); the whole backbone is a single autograd node.
 """
+import os
 from typing import Any, Dict, List
 
 import torch
@@ -22,6 +23,10 @@ from ...engine import functional as EF
 from ...engine import resample as ER
 from ..base import BaseBackbone
 from .resnet import BasicBlock, Bottleneck
+
+_BRANCH0_FIRST = os.environ.get('TOK_HRNET_BRANCH0_FIRST', '0') == '1'     # A/B switch: the enqueue order of rounds 1-5
+_FUSE_STREAMS = os.environ.get('TOK_HRNET_FUSE_STREAMS', '1') != '0'       # A/B switch: fuse rows on the branch streams (forward)
+_FUSE_BWD_MAIN = os.environ.get('TOK_HRNET_FUSE_STREAMS', '1') != '2'      # =2: their backward on the branch streams too
 
 _BN_MOMENTUM = 0.1
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
@@ -126,28 +131,59 @@ class HighResolutionModule(nn.Module):
         if self.num_branches == 1:
             return [self.branches[0](x[0])]
         # the branches are independent until the fuse: branch 0 on the main stream, the low-resolution ones (few
-        # tiles, long reductions: they cannot fill the GPU alone) each on its own branch stream beside it
-        outs = []
-        for i, (branch, xi) in enumerate(zip(self.branches, x)):
+        # tiles, long reductions: they cannot fill the GPU alone) each on its own branch stream beside it.
+        # LOW-RESOLUTION BRANCHES FIRST (round 6): entering a branch stream records its fork event on the main stream at that
+        # moment — recorded after branch 0's two dozen launches it made branches 1..3 START when branch 0 had FINISHED (per-queue
+        # dump of a step: the forward of every module ran [branch 0] then [branches 1-3]; TOK_HRNET_BRANCH0_FIRST=1 restores it)
+        order = range(self.num_branches) if _BRANCH0_FIRST else reversed(range(self.num_branches))
+        outs = [None] * self.num_branches
+        nodes = getattr(r, 'nodes', None)
+        start, spans = (len(nodes) if nodes is not None else 0), {}
+        for i in order:
+            a = len(nodes) if nodes is not None else 0
             with r.branch(i) as br:
-                outs.append(br.publish(branch(xi)))
+                outs[i] = br.publish(self.branches[i](x[i]))
+            spans[i] = (a, len(nodes) if nodes is not None else 0)
+        if nodes is not None and not _BRANCH0_FIRST:
+            # ... but the TAPE keeps the order branch 0, 1, 2, 3 (the branches are independent blocks of it): the backward walks
+            # it in reverse and starts with the low-resolution branches, as before — enqueued the other way round it was 2.5 ms
+            # slower (same box: forward 23.9 vs 24.2 ms, backward 48.6 vs 46.1)
+            nodes[start:] = [n for i in range(self.num_branches) for n in nodes[spans[i][0]:spans[i][1]]]
         x = outs
-        fused = []
-        for i, row in enumerate(self.fuse_layers):
-            terms = []
-            for j in range(self.num_branches):
-                if j == i:
-                    terms.append((x[j], 0))
-                elif j > i:      # 1x1 conv + BN at the low resolution; the nearest upsample is folded into the sum
-                    terms.append((EF.conv_bn_act(r, x[j], row[j][0], row[j][1], relu=False), j - i))
-                else:
-                    t = x[j]
-                    for step in row[j]:
-                        t = _run_conv_bn(r, t, step)
-                    terms.append((t, 0))
-            # output-resolution term first: it fixes the shape
-            terms.sort(key=lambda ts: ts[1])
-            fused.append(ER.fuse_sum_relu(r, terms, relu=True))
+        # the fuse: output row i = relu(sum_j fuse_ij(x_j)) is independent of the other rows, and its result is the input of
+        # branch i of the next module — so row i runs on branch stream i (round 6; it was a chain of ~24 small kernels per module
+        # on the main queue, 0.6 ms forward and 1.8 ms backward with the other queues idle; TOK_HRNET_FUSE_STREAMS=0 restores that).
+        # Low-resolution rows are entered first for the same reason as the branches above; the tape keeps row 0 first.
+        fused = [None] * len(self.fuse_layers)
+        start, spans = (len(nodes) if nodes is not None else 0), {}
+        rows = range(len(self.fuse_layers))
+        for i in (reversed(rows) if _FUSE_STREAMS else rows):
+            row = self.fuse_layers[i]
+            a = len(nodes) if nodes is not None else 0
+            with r.branch(i if _FUSE_STREAMS else 0) as br:
+                terms = []
+                for j in range(self.num_branches):
+                    if j == i:
+                        terms.append((x[j], 0))
+                    elif j > i:      # 1x1 conv + BN at the low resolution; the nearest upsample is folded into the sum
+                        terms.append((EF.conv_bn_act(r, x[j], row[j][0], row[j][1], relu=False), j - i))
+                    else:
+                        t = x[j]
+                        for step in row[j]:
+                            t = _run_conv_bn(r, t, step)
+                        terms.append((t, 0))
+                # output-resolution term first: it fixes the shape
+                terms.sort(key=lambda ts: ts[1])
+                fused[i] = br.publish(ER.fuse_sum_relu(r, terms, relu=True))
+            spans[i] = (a, len(nodes) if nodes is not None else 0)
+        if nodes is not None and _FUSE_STREAMS:
+            nodes[start:] = [n for i in rows for n in nodes[spans[i][0]:spans[i][1]]]
+            if _FUSE_BWD_MAIN:
+                # ... and the BACKWARD of the fuse rows stays on the main stream: their gradient contributions fan into the
+                # branches' outputs from every row, and ordering those accumulations across four queues cost more events and
+                # waits than the rows' concurrency returned
+                for n in nodes[start:]:
+                    n.stream_tag = 0
         return fused
 
 
