@@ -140,6 +140,19 @@ def _pointwise_wgrad_is_mfma_bound(k, c) -> bool:
     return (k * c) / float(k + c) >= WGRAD_SIDE_MIN_INTENSITY
 
 
+# Only units of the MAIN stream fork their weight gradients to the side stream (round 6).  A unit recorded on a branch stream
+# (HRNet's low-resolution branches, SwinV2's position-bias chain) keeps them on its own stream: with three branch streams + the
+# side stream there are more streams than hardware queues (two share one), and the side queue — every weight gradient of every
+# branch in one FIFO — was 33 ms busy beside a 46-ms HRNet-W48 backward.  HRNet-W48 B=24: 67.1 -> 66.1 ms/step (nobody forks:
+# 66.1 as well; only the branches fork: 67.9).  TOK_WGRAD_SIDE_TAGS=<comma-separated stream tags that fork> overrides ("0,1,2,3":
+# rounds 1-5).
+_SIDE_TAGS = {int(v) for v in os.environ.get('TOK_WGRAD_SIDE_TAGS', '0').split(',') if v != ''}
+
+
+def _side_for_tag(tag) -> bool:
+    return int(tag or 0) in _SIDE_TAGS
+
+
 FUSE_BN_FINALIZE = os.environ.get('TOK_FUSE_BN_FINALIZE', '0') == '1'    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
 _ticket_rings = {}
 
@@ -320,7 +333,7 @@ class _ConvBnActNode(Node):
         side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                    (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
                    (r * s == 1 and _pointwise_wgrad_is_mfma_bound(conv.weight.shape[0], conv.weight.shape[1])))   # == launch_wgrad's side_ok
-        return bool(WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
+        return bool(WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag) and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
                     and not torch.cuda.is_current_stream_capturing())
 
     def backward(self):
@@ -436,7 +449,7 @@ class _ConvBnActNode(Node):
             side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                        (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
                        (r * s == 1 and _pointwise_wgrad_is_mfma_bound(k, c)))
-            if WGRAD_SIDE_STREAM and side_ok and g.is_cuda and self.region is not None \
+            if WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag) and g.is_cuda and self.region is not None \
                     and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region

@@ -25,8 +25,9 @@ from ..base import BaseBackbone
 from .resnet import BasicBlock, Bottleneck
 
 _BRANCH0_FIRST = os.environ.get('TOK_HRNET_BRANCH0_FIRST', '0') == '1'     # A/B switch: the enqueue order of rounds 1-5
-_FUSE_STREAMS = os.environ.get('TOK_HRNET_FUSE_STREAMS', '1') != '0'       # A/B switch: fuse rows on the branch streams (forward)
-_FUSE_BWD_MAIN = os.environ.get('TOK_HRNET_FUSE_STREAMS', '1') != '2'      # =2: their backward on the branch streams too
+_FUSE_STREAMS = os.environ.get('TOK_HRNET_FUSE_STREAMS', '3') != '0'       # A/B switch: fuse rows on the branch streams (forward)
+_FUSE_BWD_MAIN = os.environ.get('TOK_HRNET_FUSE_STREAMS', '3') != '2'      # =2: their backward on the branch streams too
+_FUSE_BWD_SRC = os.environ.get('TOK_HRNET_FUSE_STREAMS', '3') == '3'       # =3 (probe): path j -> i backward on stream j, the sum's on stream i
 
 _BN_MOMENTUM = 0.1
 blocks_dict = {'BASIC': BasicBlock, 'BOTTLENECK': Bottleneck}
@@ -155,6 +156,7 @@ class HighResolutionModule(nn.Module):
         # on the main queue, 0.6 ms forward and 1.8 ms backward with the other queues idle; TOK_HRNET_FUSE_STREAMS=0 restores that).
         # Low-resolution rows are entered first for the same reason as the branches above; the tape keeps row 0 first.
         fused = [None] * len(self.fuse_layers)
+        path_spans = []
         start, spans = (len(nodes) if nodes is not None else 0), {}
         rows = range(len(self.fuse_layers))
         for i in (reversed(rows) if _FUSE_STREAMS else rows):
@@ -166,19 +168,28 @@ class HighResolutionModule(nn.Module):
                     if j == i:
                         terms.append((x[j], 0))
                     elif j > i:      # 1x1 conv + BN at the low resolution; the nearest upsample is folded into the sum
+                        p0 = len(nodes) if nodes is not None else 0
                         terms.append((EF.conv_bn_act(r, x[j], row[j][0], row[j][1], relu=False), j - i))
+                        path_spans.append((p0, len(nodes) if nodes is not None else 0, j))
                     else:
+                        p0 = len(nodes) if nodes is not None else 0
                         t = x[j]
                         for step in row[j]:
                             t = _run_conv_bn(r, t, step)
                         terms.append((t, 0))
+                        path_spans.append((p0, len(nodes) if nodes is not None else 0, j))
                 # output-resolution term first: it fixes the shape
                 terms.sort(key=lambda ts: ts[1])
                 fused[i] = br.publish(ER.fuse_sum_relu(r, terms, relu=True))
             spans[i] = (a, len(nodes) if nodes is not None else 0)
+        if nodes is not None and _FUSE_STREAMS and _FUSE_BWD_SRC:
+            # probe: the backward of path j -> i on the SOURCE branch's stream j (every write into d(x_j) then comes from one stream)
+            for p0, p1, j in path_spans:
+                for n in nodes[p0:p1]:
+                    n.stream_tag = j
         if nodes is not None and _FUSE_STREAMS:
             nodes[start:] = [n for i in rows for n in nodes[spans[i][0]:spans[i][1]]]
-            if _FUSE_BWD_MAIN:
+            if _FUSE_BWD_MAIN and not _FUSE_BWD_SRC:
                 # ... and the BACKWARD of the fuse rows stays on the main stream: their gradient contributions fan into the
                 # branches' outputs from every row, and ordering those accumulations across four queues cost more events and
                 # waits than the rows' concurrency returned
