@@ -147,10 +147,15 @@ def _pointwise_wgrad_is_mfma_bound(k, c) -> bool:
 # 66.1 as well; only the branches fork: 67.9).  TOK_WGRAD_SIDE_TAGS=<comma-separated stream tags that fork> overrides ("0,1,2,3":
 # rounds 1-5).
 _SIDE_TAGS = {int(v) for v in os.environ.get('TOK_WGRAD_SIDE_TAGS', '0').split(',') if v != ''}
+_SIDE_TAGS_FORCED = 'TOK_WGRAD_SIDE_TAGS' in os.environ
 
 
-def _side_for_tag(tag) -> bool:
-    return int(tag or 0) in _SIDE_TAGS
+def _side_for_tag(tag, region=None) -> bool:
+    # ... and nobody forks in a region whose main stream and branch streams alone fill the four hardware queues (HRNet-W48: main +
+    # three branches; a fifth stream shares a queue with one of them: 65.4 vs 65.9 ms/step without the side stream, same box)
+    if int(tag or 0) not in _SIDE_TAGS:
+        return False
+    return _SIDE_TAGS_FORCED or region is None or len(getattr(region, '_streams', ())) < 3
 
 
 FUSE_BN_FINALIZE = os.environ.get('TOK_FUSE_BN_FINALIZE', '0') == '1'    # tok_conv_*_bn ("last workgroup finalizes") measured slower than the stand-alone finalize launches, see DESIGN.md §4
@@ -333,7 +338,7 @@ class _ConvBnActNode(Node):
         side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                    (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
                    (r * s == 1 and _pointwise_wgrad_is_mfma_bound(conv.weight.shape[0], conv.weight.shape[1])))   # == launch_wgrad's side_ok
-        return bool(WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag) and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
+        return bool(WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag, self.region) and g.is_cuda and self.region is not None and not WGRAD_AFTER_DGRAD
                     and not torch.cuda.is_current_stream_capturing())
 
     def backward(self):
@@ -449,7 +454,7 @@ class _ConvBnActNode(Node):
             side_ok = (WGRAD_SIDE_WHICH == 'all' or (r * s > 1 and WGRAD_SIDE_WHICH != '1x1') or
                        (m < WGRAD_SIDE_MAX_ROWS and (r * s == 1 or WGRAD_SIDE_WHICH != '1x1')) or
                        (r * s == 1 and _pointwise_wgrad_is_mfma_bound(k, c)))
-            if WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag) and g.is_cuda and self.region is not None \
+            if WGRAD_SIDE_STREAM and side_ok and _side_for_tag(self.stream_tag, self.region) and g.is_cuda and self.region is not None \
                     and (SIDE_IN_GRAPH or not torch.cuda.is_current_stream_capturing()):
                 # nothing on the main chain waits for dW: the weight gradient (LDS/MFMA-bound) runs on the side stream
                 # beside the HBM-bound BatchNorm passes and the dgrad of the units below; joined at the end of the region
