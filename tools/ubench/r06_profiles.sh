@@ -21,4 +21,15 @@ python bench.py --backbone davit_t --steps 30 --warmup 10 --no-cpu-baseline --no
   TOK_BRANCH_STREAMS=0 python bench.py --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_BRANCH_STREAMS=0 (no branch streams)', d['ms_per_step'], 'ms/step')"
   TOK_STREAM_PRIO=-1 python bench.py --backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('TOK_STREAM_PRIO=-1 (side / branch streams at high priority)', d['ms_per_step'], 'ms/step')"
 } > $o/r06_launch_class_ablation.txt 2>&1
+# HRNet-W48 scheduling switches of round 6, each turned back to its round-5 behaviour alone (same box, two interleaved rounds)
+H="--backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 15 --warmup 4 --no-cpu-baseline --no-secondary"
+{ echo "# HRNet-W48 512x1024 B=24, ms/step, same box, two interleaved rounds; each line turns ONE round-6 scheduling change back";
+  for rep in 1 2; do
+  for e in "X=0(round-6_defaults)" "TOK_HRNET_BRANCH0_FIRST=1(branch_0_enqueued_first:_forks_recorded_behind_it)" "TOK_HRNET_FUSE_STREAMS=0(fuse_rows_on_the_main_stream)" \
+           "TOK_HRNET_FUSE_STREAMS=1(fuse_rows_on_streams,_their_backward_on_main)" "TOK_HRNET_FUSE_STREAMS=2(fuse_backward_on_the_row_streams)" \
+           "TOK_WGRAD_SIDE_TAGS=0(main_stream_forks_its_weight_gradients_to_a_fifth_stream)" "TOK_WGRAD_SIDE_TAGS=0,1,2,3(every_stream_forks:_round_5)" \
+           "TOK_WGRAD_TAPS_WGS=192(192-way_split_of_the_3x3_weight_gradients)" "TOK_BRANCH_STREAMS=0(no_branch_streams)"; do
+    env ${e%%(*} python bench.py $H 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$e', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
+  done; done
+} > $o/r06_hrnet_scheduling_ab.txt 2>&1
 ls $o

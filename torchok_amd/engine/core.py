@@ -381,8 +381,12 @@ def _shares_queue(a: 'torch.cuda.Stream', b: 'torch.cuda.Stream') -> bool:
 _STREAM_PRIO = int(os.environ.get('TOK_STREAM_PRIO', '0'))
 
 
-def pick_stream(device, main: Optional['torch.cuda.Stream'] = None) -> 'torch.cuda.Stream':
-    """A new stream for work that is meant to run BESIDE the calling (main) stream and beside the streams picked before."""
+def pick_stream(device, main: Optional['torch.cuda.Stream'] = None, share_cost: Optional[int] = None) -> 'torch.cuda.Stream':
+    """A new stream for work that is meant to run BESIDE the calling (main) stream and beside the streams picked before.
+    `share_cost`: what it costs a LATER pick to land on this stream's hardware queue (default: 2 + how long ago it was handed
+    out — HRNet's branches are handed out busiest first).  The weight-gradient side stream passes 1: in a process that ran a
+    ResNet first (bench.py's secondary workloads) HRNet-W48's third branch stream otherwise shared a queue with the second one
+    and left the side stream, which only its neck / head region uses, a queue of its own (67.2 vs 65.6 ms/step)."""
     if (not PICK_STREAMS or torch.cuda.is_current_stream_capturing()):
         return torch.cuda.Stream(device=device, priority=_STREAM_PRIO)
     with torch.cuda.device(device):
@@ -392,16 +396,17 @@ def pick_stream(device, main: Optional['torch.cuda.Stream'] = None) -> 'torch.cu
         best, best_cost = None, None
         for _ in range(8):
             c = torch.cuda.Stream(device=device, priority=_STREAM_PRIO)
-            cost = 100 * int(_shares_queue(main, c))
-            if cost < 100:
+            cost = 1000 * int(_shares_queue(main, c))
+            if cost < 1000:
                 # when sharing cannot be avoided (five streams on four queues: HRNet's three branch streams + the side
-                # stream), share with the stream picked last — the HRNet branches are handed out busiest first
-                cost += sum((len(others) - i) * int(_shares_queue(o, c)) for i, o in enumerate(others))
+                # stream), share with the cheapest one
+                cost += sum((w if w is not None else 2 + len(others) - i) * int(_shares_queue(o, c))
+                            for i, (o, w) in enumerate(others))
             if best is None or cost < best_cost:
                 best, best_cost = c, cost
             if cost == 0:
                 break
-        others.append(best)
+        others.append((best, share_cost))
     return best
 
 
@@ -465,7 +470,7 @@ class _Branch:
 def _side_stream(device) -> 'torch.cuda.Stream':
     s = _side_streams.get(device)
     if s is None:
-        s = pick_stream(device)
+        s = pick_stream(device, share_cost=1)
         if PICK_STREAMS and torch.cuda.is_current_stream_capturing():
             return s     # see _branch_stream
         _side_streams[device] = s
