@@ -452,6 +452,17 @@ int tok_bilinear_fwd(const void* src, int n, int hs, int ws, int c, int ld_src, 
                      int wd, int ld_dst, int ch_off, void* stream);
 int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_dst, int ch_off, void* dsrc,
                      int hs, int ws, int c, int ld_src, int accumulate, void* stream);
+/* y = y0 + sum_j bilinear(t_j -> h x w) (align_corners=False as above; t_j NULL = absent), every map [..][c] bf16 with row
+ * pitch c, summed in fp32 and rounded once; y may be y0.  stats (nullable): float[2][tok_bilinear_sum_stats_rows(n*h*w, c)][c]
+ * per-channel partial (sum, sum of squares) of the rounded y, the rows tok_bn_finalize folds.
+ * HRNetSegmentationNeck (necks/segmentation/hrnet.py:36-45) is ConvBnRelu1x1(cat_j interpolate(x_j)): a 1x1 convolution
+ * commutes with the interpolation, conv(cat_j up(x_j)) = sum_j up(conv_j(x_j)) with conv_j = the filter columns of source j,
+ * so the product runs at every source's own resolution and this entry point adds the results up (and leaves the BatchNorm
+ * statistics of the sum); the concat tensor is never built.                                              */
+int tok_bilinear_sum_stats_rows(int64_t m, int c);
+int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, int w1, const void* t2, int h2, int w2,
+                           const void* t3, int h3, int w3, int n, int h, int w, int c, void* y, float* stats,
+                           void* stream);
 
 /* ---- token-major transformer units (SwinV2) -------------------------------------------------------
  * swin.py:71-256 over [timm 0.6.13] swin_transformer_v2.  Tokens are rows of a bf16 [rows][ld] matrix

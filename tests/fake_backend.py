@@ -1297,6 +1297,28 @@ class FakeTok:
             d[..., :c] = _bf(gx)
         return 0
 
+    def tok_bilinear_sum_stats_rows(self, m, c):
+        return self.tok_bn_stats_rows(m, c)
+
+    def tok_bilinear_sum_stats(self, y0, t1, h1, w1, t2, h2, w2, t3, h3, w3, n, h, w, c, y, stats, st):
+        self.calls.append('bilinear_sum_stats')
+        acc = _t(y0, (n, h, w, c), BF16).float()
+        for t, hs, ws in ((t1, h1, w1), (t2, h2, w2), (t3, h3, w3)):
+            if t is None:
+                continue
+            x = _t(t, (n, hs, ws, c), BF16).float().permute(0, 3, 1, 2)
+            acc = acc + F.interpolate(x, size=(h, w), mode='bilinear', align_corners=False).permute(0, 2, 3, 1)
+        out = _bf(acc)
+        _t(y, (n, h, w, c), BF16).copy_(out)
+        if stats is not None:
+            rows = self.tok_bn_stats_rows(n * h * w, c)
+            s_ = _t(stats, (2, rows, c), torch.float32)
+            s_.zero_()
+            f = out.float().reshape(-1, c)
+            s_[0, 0] = f.sum(0)
+            s_[1, 0] = (f * f).sum(0)
+        return 0
+
     # ---- token-major transformer units (SwinV2) ----------------------------------------------------------
     def tok_layernorm_fwd(self, x, shortcut, row_scale, rps, gamma, beta, out, mean, rstd, rows, c, ld, eps, st):
         self.calls.append('layernorm_fwd')

@@ -177,6 +177,41 @@ def test_reference_neck_test_w18(dev):
     assert tuple(input_image.shape) == (2, 3, 224, 224)
 
 
+def test_segmentation_neck_commuted_vs_direct(dev, monkeypatch):
+    """engine/neck.py: conv1x1(cat_j up(x_j)) evaluated as sum_j up(conv1x1_j(x_j)) — against the direct order (interpolate
+    into the concat buffer, one product) on the same inputs and parameters: output, input gradients, parameter gradients and
+    the BatchNorm running statistics agree to bf16 rounding; state_dict names are those of the reference either way."""
+    from torchok_amd.engine import neck as EN
+    chans = (16, 32, 64, 128)
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(3, c, 32 >> i, 48 >> i, generator=g) for i, c in enumerate(chans)]
+    img = torch.zeros(3, 3, 128, 192)
+    gout = torch.randn(3, sum(chans), 32, 48, generator=g)
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(EN, 'NECK_COMMUTE', mode)
+        neck = T.NECKS.get('HRNetSegmentationNeck')(chans)
+        neck.load_state_dict(deterministic_state(neck.state_dict(), 11))
+        neck.to(dev).train()
+        assert set(neck.state_dict()) == {'convbnact.conv.weight', 'convbnact.bn.weight', 'convbnact.bn.bias',
+                                          'convbnact.bn.running_mean', 'convbnact.bn.running_var',
+                                          'convbnact.bn.num_batches_tracked'}
+        xd = [t.to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last).requires_grad_(True) for t in xs]
+        out = neck([img.to(dev)] + xd)[1]
+        out.backward(gout.to(dev).to(out.dtype))
+        res[mode] = ([out.detach().float().cpu()] + [t.grad.float().cpu() for t in xd]
+                     + [p.grad.float().cpu() for p in neck.parameters()]
+                     + [neck.convbnact.bn.running_mean.float().cpu(), neck.convbnact.bn.running_var.float().cpu()])
+        assert int(neck.convbnact.bn.num_batches_tracked) == 1
+    names = ['out'] + [f'd(x{i})' for i in range(4)] + ['d(conv.weight)', 'd(bn.weight)', 'd(bn.bias)', 'running_mean',
+                                                      'running_var']
+    for nm, a, b in zip(names, res[True], res[False]):
+        assert a.shape == b.shape
+        # gradients behind a ReLU on a bf16-rounded pre-activation: the two orders round y differently (5e-3 apart), ~0.3 % of the
+        # ReLU decisions flip, 2-4 % of a gradient's norm between ANY two bf16 evaluations (tests/test_units_gpu.py, gate 2)
+        assert rel_err(a, b) < (6e-2 if nm.startswith('d(') else 2e-2), (nm, rel_err(a, b))
+
+
 def test_classification_neck(dev):
     """HRNetClassificationNeck: reference shape test (necks/test_hrnet.py:15-19, hrnet_w18 -> (2, 2048, 7, 7)) and values /
     gradients / BatchNorm side effects vs the oracle restatement (the loop overwrites y, as in the reference)."""

@@ -812,6 +812,44 @@ def test_bilinear(libs, n, hs, ws, c, hd, wd, ld, off):
         assert relerr(dv[id(ds)].float(), ds.float()) < 6e-3
 
 
+@pytest.mark.parametrize('n,h,w,c,lows', [(2, 16, 16, 16, [(8, 8), (4, 4), (2, 2)]), (1, 32, 64, 720, [(16, 32), (8, 16), (4, 8)]),
+                                         (2, 13, 20, 24, [(5, 7)]), (1, 8, 8, 2056, [(4, 4), (2, 2)]), (3, 8, 8, 8, [])])
+def test_bilinear_sum_stats(libs, n, h, w, c, lows):
+    """y = y0 + sum_j up(t_j), in place, + the BatchNorm partial rows of the rounded sum (the commuted HRNet neck)."""
+    lib, fake = libs
+    y0 = rnd(n, h, w, c).to(BF16)
+    ts = [rnd(n, hs, ws, c, seed=3 + j).to(BF16) for j, (hs, ws) in enumerate(lows)]
+    rows = lib.tok_bilinear_sum_stats_rows(n * h * w, c)
+    assert rows == lib.tok_bn_stats_rows(n * h * w, c) and rows >= 1
+    st_dev = torch.zeros(2, rows, c, device=DEV)
+    st_host = torch.zeros(2, fake.tok_bilinear_sum_stats_rows(n * h * w, c), c)
+    yd = y0.to(DEV)
+    td = [t.to(DEV) for t in ts]
+
+    def args(y, tt, stats):
+        a = [y.data_ptr()]
+        for j in range(3):
+            a += [tt[j].data_ptr(), lows[j][0], lows[j][1]] if j < len(tt) else [None, 1, 1]
+        return a + [n, h, w, c, y.data_ptr(), stats.data_ptr()]
+    assert lib.tok_bilinear_sum_stats(*args(yd, td, st_dev), torch.cuda.current_stream().cuda_stream) == 0, lib.tok_last_error()
+    torch.cuda.synchronize()
+    yh = y0.clone()
+    assert fake.tok_bilinear_sum_stats(*args(yh, ts, st_host), None) == 0
+    assert relerr(yd.float(), yh.float()) < 4e-3
+    # the statistics are those of the ROUNDED values the kernel stored, folded over its partial rows
+    f = yd.float().reshape(-1, c).double()
+    got = st_dev.double().sum(1).cpu()
+    assert torch.allclose(got[0], f.sum(0).cpu(), rtol=1e-4, atol=1e-3 * (n * h * w) ** 0.5)
+    assert relerr(got[1], (f * f).sum(0).cpu()) < 1e-5
+    # stats = NULL: the sum alone, same bits
+    y2 = y0.to(DEV)
+    a = args(y2, td, st_dev)
+    a[-1] = None
+    assert lib.tok_bilinear_sum_stats(*a, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y2, yd)
+
+
 def test_bilinear_adjoint_property(libs):
     """<up(x), g> == <x, up^T(g)> at a size no oracle run is needed for (size-independent property)."""
     lib, _ = libs

@@ -427,7 +427,11 @@ def test_hr_neck_and_head_units(dev, hrnet_capture):
     out.backward(gneck.to(dev).to(out.dtype))
     ours = ([out.detach().float().cpu()], [t.grad.float().cpu() for t in xs],
             {'neck.' + n: p.grad.detach().float().cpu() for n, p in ours_neck.named_parameters()})
-    _check('hr seg neck', ours, r32, rac)
+    # composite: the neck runs in the commuted order (engine/neck.py: the pointwise product at every source's own resolution,
+    # THEN interpolate and sum) — the same fp32 function as interpolate -> concat -> product with other bf16 rounding points
+    # (four partial products instead of four interpolated inputs), so its gradients are held to the fp32 yardstick, its
+    # output to both gates
+    _check('hr seg neck', ours, r32, rac, composite=True)
 
     # head + loss: logits and the loss value and d(features)
     class HeadLoss(nn.Module):

@@ -211,6 +211,87 @@ __global__ __launch_bounds__(256) void bilinear_fwd_generic_kernel(const bf16* _
   }
 }
 
+// y = y0 + sum_j bilinear(t_j -> h x w), all maps [..][c] bf16 (row pitch c), rounded once; y may be y0 (in place).
+// partial[2][gridDim.x][c] = per-channel (sum, sum of squares) of the ROUNDED y: the rows tok_bn_finalize folds.
+// The HRNet segmentation neck is conv1x1(cat_j(bilinear(x_j))) — and a 1x1 convolution (a linear map across channels at one
+// pixel) commutes with the interpolation (a linear map across pixels of one channel): conv1x1(cat_j up(x_j)) =
+// sum_j up(conv1x1_j(x_j)) with conv1x1_j = the filter's columns of source j.  So the 720 -> 720 product runs at each
+// source's OWN resolution (48 + 96/4 + 192/16 + 384/64 = 90 input channels' worth of MACs per output pixel instead of 720)
+// and this kernel adds the results up: the 720-channel concat tensor (1.1 GB at 512x1024 B=24) and its gradient are never
+// built.  Block geometry of the bn.hip streaming kernels (c / 8 channel groups across the block, 256 / that rows).
+struct UpSumArgs {
+  const bf16* t[3];
+  int hs[3], ws[3];
+  float sh[3], sw[3];
+  int nt, n, h, w, c;
+};
+
+__global__ __launch_bounds__(256) void bilinear_sum_stats_kernel(const bf16* y0, bf16* y, UpSumArgs a, int cge, int rpb,
+                                                                 float* __restrict__ partial) {
+  __shared__ float red[2][256][8];
+  const int tid = threadIdx.x;
+  const int cgl = tid % cge, rl = tid / cge;
+  const int cg_total = a.c >> 3;
+  const int M = a.n * a.h * a.w;
+  for (int cg = cgl; cg < cg_total; cg += cge) {
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (rl < rpb) {
+      for (int m = blockIdx.x * rpb + rl; m < M; m += gridDim.x * rpb) {
+        const int x = m % a.w;
+        const int t2 = m / a.w;
+        const int yy = t2 % a.h;
+        const int b = t2 / a.h;
+        const bf16x8 v0 = ldg16(y0 + (size_t)m * a.c + cg * 8);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bf2f(v0[e]);
+        for (int j = 0; j < a.nt; ++j) {
+          int r0, r1, c0, c1;
+          float ly, lx;
+          src_index(a.sh[j], yy, a.hs[j], r0, r1, ly);
+          src_index(a.sw[j], x, a.ws[j], c0, c1, lx);
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const bf16* base = a.t[j] + (size_t)b * a.hs[j] * a.ws[j] * a.c + cg * 8;
+          const bf16x8 v00 = ldg16(base + ((size_t)r0 * a.ws[j] + c0) * a.c);
+          const bf16x8 v01 = ldg16(base + ((size_t)r0 * a.ws[j] + c1) * a.c);
+          const bf16x8 v10 = ldg16(base + ((size_t)r1 * a.ws[j] + c0) * a.c);
+          const bf16x8 v11 = ldg16(base + ((size_t)r1 * a.ws[j] + c1) * a.c);
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            acc[e] += hy * (hx * bf2f(v00[e]) + lx * bf2f(v01[e])) + ly * (hx * bf2f(v10[e]) + lx * bf2f(v11[e]));
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = f2bf(acc[e]);
+          const float f = bf2f(o[e]);
+          s1[e] += f;
+          s2[e] += f * f;
+        }
+        stg16(y + (size_t)m * a.c + cg * 8, o);
+      }
+    }
+    if (partial != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+      __syncthreads();
+      if (rl == 0) {
+        for (int r = 1; r < rpb; ++r)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] += red[0][r * cge + cgl][e]; s2[e] += red[1][r * cge + cgl][e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          partial[((size_t)0 * gridDim.x + blockIdx.x) * a.c + cg * 8 + e] = s1[e];
+          partial[((size_t)1 * gridDim.x + blockIdx.x) * a.c + cg * 8 + e] = s2[e];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void bilinear_bwd_generic_kernel(const bf16* __restrict__ ddst, bf16* dsrc, BilArgs a,
                                                                    int accumulate) {
   const size_t total = (size_t)a.n * a.hs * a.ws * a.c;
@@ -325,5 +406,38 @@ extern "C" int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_
     hipLaunchKernelGGL(bilinear_bwd_generic_kernel, dim3(blocks_for((size_t)n * hs * ws * c)), dim3(256), 0,
                        tok_stream(stream), (const bf16*)ddst, (bf16*)dsrc, a, accumulate);
   TOK_CHECK_LAUNCH("tok_bilinear_bwd");
+  return TOK_OK;
+}
+
+extern "C" int tok_bilinear_sum_stats_rows(int64_t m, int c) { return tok_bn_stats_rows(m, c); }
+
+extern "C" int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, int w1, const void* t2, int h2, int w2,
+                                      const void* t3, int h3, int w3, int n, int h, int w, int c, void* y, float* stats,
+                                      void* stream) {
+  UpSumArgs a;
+  const void* ts[3] = {t1, t2, t3};
+  const int hs[3] = {h1, h2, h3}, ws[3] = {w1, w2, w3};
+  TOK_CHECK_ARG(y0 && y && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0 && (int64_t)n * h * w < (int64_t)1 << 31,
+                "tok_bilinear_sum_stats: bad args");
+  a.nt = 0;
+  for (int j = 0; j < 3; ++j) {
+    a.t[j] = nullptr; a.hs[j] = a.ws[j] = 1; a.sh[j] = a.sw[j] = 1.f;
+  }
+  for (int j = 0; j < 3; ++j) {
+    if (ts[j] == nullptr) continue;
+    TOK_CHECK_ARG(hs[j] > 0 && ws[j] > 0, "tok_bilinear_sum_stats: term %d: bad size", j + 1);
+    a.t[a.nt] = (const bf16*)ts[j];
+    a.hs[a.nt] = hs[j]; a.ws[a.nt] = ws[j];
+    a.sh[a.nt] = (float)hs[j] / (float)h;
+    a.sw[a.nt] = (float)ws[j] / (float)w;
+    ++a.nt;
+  }
+  a.n = n; a.h = h; a.w = w; a.c = c;
+  const int64_t m = (int64_t)n * h * w;
+  const int rows = tok_bn_stats_rows(m, c);
+  const int cg_total = c / 8, cge = cg_total < 256 ? cg_total : 256, rpb = 256 / cge;
+  hipLaunchKernelGGL(bilinear_sum_stats_kernel, dim3(rows), dim3(256), 0, tok_stream(stream), (const bf16*)y0, (bf16*)y, a,
+                     cge, rpb, stats);
+  TOK_CHECK_LAUNCH("tok_bilinear_sum_stats");
   return TOK_OK;
 }

@@ -505,7 +505,8 @@ class Node:
     """One fused unit on the tape."""
     needs_backward = False
     region = None      # set by Region.add
-    stream_tag = 0     # branch stream the unit was recorded on (0 = main)
+    stream_tag = 0     # branch stream the unit's BACKWARD runs on (0 = main): the stream it was recorded on unless re-tagged
+    fwd_tag = 0        # branch stream the unit was recorded on: its saved tensors come from THAT stream's allocator pool
 
     def backward(self):
         raise NotImplementedError
@@ -579,7 +580,7 @@ class Region:
 
     def add(self, node: Node):
         node.region = self
-        node.stream_tag = self._tag
+        node.stream_tag = node.fwd_tag = self._tag
         self.nodes.append(node)
 
     # -- branch streams ----------------------------------------------------------------------------
@@ -683,7 +684,11 @@ class Region:
                         if t.gevents is None:
                             t.gevents = []
                         t.gevents.append((s, seq))
-                if s is main:
+                # a unit's saved tensors go back to the allocator pool of the stream that RECORDED it; released here, with the
+                # backward kernel that reads them still queued on another stream, that stream's next allocation may hand the
+                # memory out again (round 6: HRNet's fuse paths recorded on a row's stream with their backward re-tagged to the
+                # main stream — parameters differed run to run in the last bits).  Only main-recorded, main-run units go now.
+                if s is main and not node.fwd_tag:
                     node.release()
                 else:
                     held.append(node)

@@ -1,7 +1,9 @@
 """HRNetSegmentationNeck (reference ``torchok/models/necks/segmentation/hrnet.py:16-43``): bilinear
 (align_corners=False) upsample of the three low-resolution branches to branch-0 size, channel concat,
-1x1 ConvBnReLU.  Here the four sources are interpolated straight into their channel slices of ONE buffer
-(no separate upsampled maps, no torch.cat pass), then one fused conv-BN-ReLU unit."""
+1x1 ConvBnReLU.  Here as ONE engine unit in the commuted order (engine/neck.py): the pointwise product runs at every
+source's own resolution and the four results are interpolated and summed — the concat tensor is never built.  Where
+that form is not served (BatchNorm in eval mode, widths that are not multiples of 8; TOK_NECK_COMMUTE=0) the four sources are
+interpolated straight into their channel slices of ONE buffer, then one fused conv-BN-ReLU unit."""
 from functools import partial
 from typing import List, Tuple, Union
 
@@ -10,7 +12,7 @@ from torch import Tensor
 
 from ... import engine
 from ...constructor import NECKS
-from ...engine import resample as ER
+from ...engine import neck as EN
 from ..base import BaseModel
 from ..modules import ConvBnAct
 
@@ -28,6 +30,8 @@ class HRNetSegmentationNeck(BaseModel):
         input_image, x0, x1, x2, x3 = features
         with engine.region() as r:
             srcs = [r.input(t) for t in (x0, x1, x2, x3)]
-            feats = ER.bilinear_concat(r, srcs, (x0.size(2), x0.size(3)))
-            feats = r.output(self.convbnact.run(r, feats))
+            cba = self.convbnact
+            bn = cba.bn if isinstance(cba.bn, nn.BatchNorm2d) else None
+            feats = r.output(EN.upsample_concat_conv_bn_relu(r, srcs, (x0.size(2), x0.size(3)), cba.conv, bn,
+                                                             relu=isinstance(cba.act, nn.ReLU)))
         return [input_image, feats]
