@@ -453,13 +453,18 @@ int tok_bilinear_fwd(const void* src, int n, int hs, int ws, int c, int ld_src, 
 int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_dst, int ch_off, void* dsrc,
                      int hs, int ws, int c, int ld_src, int accumulate, void* stream);
 /* y = y0 + sum_j bilinear(t_j -> h x w) (align_corners=False as above; t_j NULL = absent), every map [..][c] bf16 with row
- * pitch c, summed in fp32 and rounded once; y may be y0.  stats (nullable): float[2][tok_bilinear_sum_stats_rows(n*h*w, c)][c]
+ * pitch c, summed in fp32 and rounded once; y may be y0.  stats (nullable): float[2][tok_bilinear_sum_stats_rows(n, h, w, c)][c]
  * per-channel partial (sum, sum of squares) of the rounded y, the rows tok_bn_finalize folds.
  * HRNetSegmentationNeck (necks/segmentation/hrnet.py:36-45) is ConvBnRelu1x1(cat_j interpolate(x_j)): a 1x1 convolution
  * commutes with the interpolation, conv(cat_j up(x_j)) = sum_j up(conv_j(x_j)) with conv_j = the filter columns of source j,
  * so the product runs at every source's own resolution and this entry point adds the results up (and leaves the BatchNorm
  * statistics of the sum); the concat tensor is never built.                                              */
-int tok_bilinear_sum_stats_rows(int64_t m, int c);
+/* The transposes of up to three interpolations of ONE map: d_j [n][h_j][w_j][c] = up_j^T ddst, ddst [n][hd][wd][c] (row pitch c
+ * everywhere; d_j NULL = absent) — tok_bilinear_bwd (ch_off 0, no accumulate) once per source, as ONE pass over ddst where
+ * every factor hd / h_j is 2, 4 or 8 and hd, wd are multiples of 16 (the commuted neck's d(y_j) = up_j^T d(y)).           */
+int tok_bilinear_bwd_multi(const void* ddst, int n, int hd, int wd, int c, void* d1, int h1, int w1, void* d2, int h2,
+                           int w2, void* d3, int h3, int w3, void* stream);
+int tok_bilinear_sum_stats_rows(int n, int h, int w, int c);
 int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, int w1, const void* t2, int h2, int w2,
                            const void* t3, int h3, int w3, int n, int h, int w, int c, void* y, float* stats,
                            void* stream);

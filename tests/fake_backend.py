@@ -1297,8 +1297,14 @@ class FakeTok:
             d[..., :c] = _bf(gx)
         return 0
 
-    def tok_bilinear_sum_stats_rows(self, m, c):
-        return self.tok_bn_stats_rows(m, c)
+    def tok_bilinear_bwd_multi(self, ddst, n, hd, wd, c, d1, h1, w1, d2, h2, w2, d3, h3, w3, st):
+        for d, hs, ws in ((d1, h1, w1), (d2, h2, w2), (d3, h3, w3)):
+            if d is not None:
+                self.tok_bilinear_bwd(ddst, n, hd, wd, c, 0, d, hs, ws, c, c, 0, st)
+        return 0
+
+    def tok_bilinear_sum_stats_rows(self, n, h, w, c):
+        return 1
 
     def tok_bilinear_sum_stats(self, y0, t1, h1, w1, t2, h2, w2, t3, h3, w3, n, h, w, c, y, stats, st):
         self.calls.append('bilinear_sum_stats')
@@ -1311,8 +1317,7 @@ class FakeTok:
         out = _bf(acc)
         _t(y, (n, h, w, c), BF16).copy_(out)
         if stats is not None:
-            rows = self.tok_bn_stats_rows(n * h * w, c)
-            s_ = _t(stats, (2, rows, c), torch.float32)
+            s_ = _t(stats, (2, 1, c), torch.float32)
             s_.zero_()
             f = out.float().reshape(-1, c)
             s_[0, 0] = f.sum(0)

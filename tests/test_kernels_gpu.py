@@ -813,16 +813,18 @@ def test_bilinear(libs, n, hs, ws, c, hd, wd, ld, off):
 
 
 @pytest.mark.parametrize('n,h,w,c,lows', [(2, 16, 16, 16, [(8, 8), (4, 4), (2, 2)]), (1, 32, 64, 720, [(16, 32), (8, 16), (4, 8)]),
-                                         (2, 13, 20, 24, [(5, 7)]), (1, 8, 8, 2056, [(4, 4), (2, 2)]), (3, 8, 8, 8, [])])
+                                         (2, 13, 20, 24, [(5, 7)]), (1, 8, 8, 2056, [(4, 4), (2, 2)]), (3, 8, 8, 8, []),
+                                         (2, 48, 32, 40, [(6, 4), (24, 16)]), (1, 32, 32, 24, [(8, 8)]), (1, 16, 32, 8, []),
+                                         (1, 32, 32, 16, [(16, 16), (16, 16)]), (1, 32, 32, 16, [(11, 11)])])
 def test_bilinear_sum_stats(libs, n, h, w, c, lows):
     """y = y0 + sum_j up(t_j), in place, + the BatchNorm partial rows of the rounded sum (the commuted HRNet neck)."""
     lib, fake = libs
     y0 = rnd(n, h, w, c).to(BF16)
     ts = [rnd(n, hs, ws, c, seed=3 + j).to(BF16) for j, (hs, ws) in enumerate(lows)]
-    rows = lib.tok_bilinear_sum_stats_rows(n * h * w, c)
-    assert rows == lib.tok_bn_stats_rows(n * h * w, c) and rows >= 1
+    rows = lib.tok_bilinear_sum_stats_rows(n, h, w, c)
+    assert rows >= 1
     st_dev = torch.zeros(2, rows, c, device=DEV)
-    st_host = torch.zeros(2, fake.tok_bilinear_sum_stats_rows(n * h * w, c), c)
+    st_host = torch.zeros(2, fake.tok_bilinear_sum_stats_rows(n, h, w, c), c)
     yd = y0.to(DEV)
     td = [t.to(DEV) for t in ts]
 
@@ -848,6 +850,32 @@ def test_bilinear_sum_stats(libs, n, h, w, c, lows):
     assert lib.tok_bilinear_sum_stats(*a, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(y2, yd)
+
+
+@pytest.mark.parametrize('n,hd,wd,c,lows', [(2, 32, 48, 16, [(16, 24), (8, 12), (4, 6)]), (1, 16, 16, 720, [(8, 8), (4, 4), (2, 2)]),
+                                           (2, 32, 32, 24, [(8, 8)]), (1, 64, 32, 72, [(8, 4), (32, 16)]),
+                                           (1, 20, 20, 8, [(10, 10), (5, 5)]), (1, 32, 32, 8, [(11, 11)])])
+def test_bilinear_bwd_multi(libs, n, hd, wd, c, lows):
+    """up_j^T g for several sources in one pass over g == tok_bilinear_bwd once per source (tiled LDS form where every factor
+    is 2 / 4 / 8 and the map is a multiple of 16, the gather launches otherwise) — and TOK-independent of which form ran."""
+    lib, fake = libs
+    g = rnd(n, hd, wd, c, seed=7).to(BF16)
+    gd = g.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = [torch.full((n, hs, ws, c), 7.0, dtype=BF16, device=DEV) for hs, ws in lows]
+    a = [gd.data_ptr(), n, hd, wd, c]
+    for j in range(3):
+        a += [outs[j].data_ptr(), lows[j][0], lows[j][1]] if j < len(lows) else [None, 1, 1]
+    assert lib.tok_bilinear_bwd_multi(*a, st) == 0, lib.tok_last_error()
+    for (hs, ws), o in zip(lows, outs):
+        ref = torch.empty((n, hs, ws, c), dtype=BF16, device=DEV)
+        assert lib.tok_bilinear_bwd(gd.data_ptr(), n, hd, wd, c, 0, ref.data_ptr(), hs, ws, c, c, 0, st) == 0
+        torch.cuda.synchronize()
+        # same taps and weights, another fp32 summation order: equal to bf16 rounding of the result
+        assert relerr(o.float(), ref.float()) < 3e-3, (hs, ws)
+        host = torch.zeros(n, hs, ws, c, dtype=BF16)
+        assert fake.tok_bilinear_bwd(g.data_ptr(), n, hd, wd, c, 0, host.data_ptr(), hs, ws, c, c, 0, None) == 0
+        assert relerr(o.float(), host.float()) < 6e-3, (hs, ws)
 
 
 def test_bilinear_adjoint_property(libs):

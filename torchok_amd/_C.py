@@ -135,7 +135,8 @@ PROTOTYPES = {
     'tok_fuse_sum_relu_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_bilinear_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_bilinear_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),
-    'tok_bilinear_sum_stats_rows': (c_int, [c_int64, c_int]),
+    'tok_bilinear_bwd_multi': (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, _P]),
+    'tok_bilinear_sum_stats_rows': (c_int, [c_int, c_int, c_int, c_int]),
     'tok_bilinear_sum_stats': (c_int, [_P, _P, c_int, c_int, _P, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'tok_layernorm_fwd': (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, _P]),
     'tok_layernorm_bwd_rows': (c_int, [c_int64, c_int]),

@@ -6,6 +6,7 @@
 //                           concat buffer, :41) and SegmentationHead (heads/segmentation/base.py:37)
 // All four are HBM streaming kernels; the backward passes are gathers (deterministic, no atomics).
 #include "tok_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -211,6 +212,159 @@ __global__ __launch_bounds__(256) void bilinear_fwd_generic_kernel(const bf16* _
   }
 }
 
+// The transposes of up to three interpolations of ONE map in one pass (the commuted HRNet neck: d(y_j) = up_j^T d(y) for the
+// factor-2 / 4 / 8 sources, all over the same 720-channel d(y)).  The gather kernel above reads every element of d(y) four
+// times per scale through L2 (each destination pixel lies in the 2 x 2 footprints of four source pixels): 12 x 1.13 GB at
+// 512x1024 B=24, 1.7 ms.  Here a workgroup stages a 16 x 16 destination tile with a 4-pixel halo (24 x 24 pixels x 4
+// channel groups = 36 KB of LDS) ONCE and every source pixel whose footprint lies inside it — 8 x 8 at factor 2 (4 x 4
+// taps), 4 x 4 at factor 4 (8 x 8 taps), 2 x 2 at factor 8 (16 x 16 taps) — takes its taps from LDS; d(y) crosses L2 -> CU
+// 2.25 times instead of 12.  One work unit of 16 taps per thread and scale; the units of one source pixel sit in lanes
+// 4 / 8 (/ 16 / 32) apart and are folded with fixed-order shuffles.  Weights through src_index, as forward, once per
+// workgroup.  The next chunk's window is in flight (nine 16-byte loads per thread, held in registers) while this one is
+// consumed: with the loads, the LDS fill and the taps as three serial phases the kernel ran at 2.4 TB/s of staged bytes.
+constexpr int ADJ_T = 16, ADJ_HALO = 4, ADJ_W = ADJ_T + 2 * ADJ_HALO, ADJ_G = 4;
+constexpr int ADJ_SMEM = ADJ_W * ADJ_W * ADJ_G * 16;
+constexpr int ADJ_LD = ADJ_W * ADJ_W * ADJ_G / 256;     // staged 16-byte items per thread: 9
+
+struct Adj3Args {
+  const bf16* dy;
+  bf16 *d2, *d4, *d8;    // the factor-2 / 4 / 8 sources (NULL = absent)
+  int n, h, w, c;
+};
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// Weights of one work unit: ROWS footprint rows x 2F columns of source pixel (gsy, gsx).  They depend on the tile and the thread
+// only — computed once per workgroup, kept in registers across the channel-group chunks (plain local arrays of the kernel: as
+// members of a struct they stayed in scratch memory).
+template <int F, int ROWS>
+__device__ __forceinline__ void adj_weights(float (&wx)[2 * F], float (&wy)[ROWS], int sy, int sx, int row0, int gsy, int gsx,
+                                            int ty, int tx, int hs, int ws) {
+  // footprint of source pixel (gsy, gsx): destination rows [F gsy - F/2, F gsy + 3F/2), columns alike
+  const float scale = 1.f / (float)F;
+#pragma unroll
+  for (int j = 0; j < 2 * F; ++j) {
+    int x0, x1; float lx;
+    src_index(scale, tx * ADJ_T + F * sx - F / 2 + j, ws, x0, x1, lx);
+    wx[j] = (x0 == gsx ? 1.f - lx : 0.f) + (x1 == gsx ? lx : 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    int y0, y1; float ly;
+    src_index(scale, ty * ADJ_T + F * sy - F / 2 + row0 + i, hs, y0, y1, ly);
+    wy[i] = (y0 == gsy ? 1.f - ly : 0.f) + (y1 == gsy ? ly : 0.f);
+  }
+}
+
+// acc += sum_i wy[i] * (sum_j wx[j] * window[row i][col j]) — the row sums first (one packed fma per channel pair and tap)
+template <int F, int ROWS>
+__device__ __forceinline__ void adj_unit(const uint4* __restrict__ win, int cgl, int sy, int sx, int row0,
+                                         const float (&wx)[2 * F], const float (&wy)[ROWS], f32x2 (&acc)[4]) {
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int wr = F * sy + ADJ_HALO - F / 2 + row0 + i;
+    const uint4* rowp = win + ((size_t)wr * ADJ_W + (F * sx + ADJ_HALO - F / 2)) * ADJ_G + cgl;
+    f32x2 r[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int j = 0; j < 2 * F; ++j) {
+      const uint4 v = rowp[j * ADJ_G];
+      const f32x2 wj = {wx[j], wx[j]};
+      r[0] += wj * (f32x2){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+      r[1] += wj * (f32x2){__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+      r[2] += wj * (f32x2){__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u)};
+      r[3] += wj * (f32x2){__uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+    }
+    const f32x2 wi = {wy[i], wy[i]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += wi * r[q];
+  }
+}
+
+__device__ __forceinline__ void adj_store(bf16* dst, size_t pix, int c, int cg, const f32x2 (&acc)[4]) {
+  bf16x8 o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { o[2 * q] = f2bf(acc[q].x); o[2 * q + 1] = f2bf(acc[q].y); }
+  stg16(dst + pix * c + cg * 8, o);
+}
+
+template <int MASKS>
+__device__ __forceinline__ void adj_fold(f32x2 (&acc)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int m = 0; m < MASKS; ++m) {
+      acc[q].x += __shfl_xor(acc[q].x, ADJ_G << m);
+      acc[q].y += __shfl_xor(acc[q].y, ADJ_G << m);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_adj3_kernel(Adj3Args a) {
+  extern __shared__ __attribute__((aligned(16))) char adj_smem[];
+  uint4* win = reinterpret_cast<uint4*>(adj_smem);
+  const int tid = threadIdx.x;
+  const int tiles_x = a.w / ADJ_T, tiles_y = a.h / ADJ_T;
+  const int tx = blockIdx.x % tiles_x;
+  const int ty = (blockIdx.x / tiles_x) % tiles_y;
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const int cg_total = a.c >> 3;
+  const int cgl = tid % ADJ_G;
+  // factor 2: source pixel tid / 4 of the tile's 8 x 8, 4 x 4 taps
+  // factor 4: source pixel tid / 16 of 4 x 4, part (tid / 4) % 4 = two of the eight footprint rows
+  // factor 8: source pixel tid / 64 of 2 x 2, part (tid / 4) % 16 = one of the sixteen rows
+  const int s2 = tid / ADJ_G, s4 = tid / (ADJ_G * 4), s8 = tid / (ADJ_G * 16);
+  const int p4 = (tid / ADJ_G) % 4, p8 = (tid / ADJ_G) % 16;
+  float w2x[4], w2y[4], w4x[8], w4y[2], w8x[16], w8y[1];
+  adj_weights<2, 4>(w2x, w2y, s2 / 8, s2 % 8, 0, ty * 8 + s2 / 8, tx * 8 + s2 % 8, ty, tx, a.h / 2, a.w / 2);
+  adj_weights<4, 2>(w4x, w4y, s4 / 4, s4 % 4, 2 * p4, ty * 4 + s4 / 4, tx * 4 + s4 % 4, ty, tx, a.h / 4, a.w / 4);
+  adj_weights<8, 1>(w8x, w8y, s8 / 2, s8 % 2, p8, ty * 2 + s8 / 2, tx * 2 + s8 % 2, ty, tx, a.h / 8, a.w / 8);
+  // this thread's nine window items: pixel (tid + 256 i) / 4 of the 24 x 24 window, channel group cgl
+  const bf16* src[ADJ_LD];
+#pragma unroll
+  for (int i = 0; i < ADJ_LD; ++i) {
+    const int px = (tid + 256 * i) / ADJ_G;
+    const int yd = ty * ADJ_T - ADJ_HALO + px / ADJ_W, xd = tx * ADJ_T - ADJ_HALO + px % ADJ_W;
+    src[i] = (yd >= 0 && yd < a.h && xd >= 0 && xd < a.w) ? a.dy + (((size_t)b * a.h + yd) * a.w + xd) * a.c + cgl * 8 : nullptr;
+  }
+  uint4 nxt[ADJ_LD];
+  auto fetch = [&](int cg0) {
+#pragma unroll
+    for (int i = 0; i < ADJ_LD; ++i) {
+      nxt[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (src[i] != nullptr && cg0 + cgl < cg_total) nxt[i] = *reinterpret_cast<const uint4*>(src[i] + cg0 * 8);
+    }
+  };
+  fetch(0);
+  for (int cg0 = 0; cg0 < cg_total; cg0 += ADJ_G) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ADJ_LD; ++i) win[tid + 256 * i] = nxt[i];
+    __syncthreads();
+    if (cg0 + ADJ_G < cg_total) fetch(cg0 + ADJ_G);
+    const bool live = cg0 + cgl < cg_total;
+    if (a.d2 != nullptr) {
+      const int hs = a.h / 2, ws = a.w / 2;
+      f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      adj_unit<2, 4>(win, cgl, s2 / 8, s2 % 8, 0, w2x, w2y, acc);
+      if (live) adj_store(a.d2, ((size_t)b * hs + ty * 8 + s2 / 8) * ws + tx * 8 + s2 % 8, a.c, cg0 + cgl, acc);
+    }
+    if (a.d4 != nullptr) {
+      const int hs = a.h / 4, ws = a.w / 4;
+      f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      adj_unit<4, 2>(win, cgl, s4 / 4, s4 % 4, 2 * p4, w4x, w4y, acc);
+      adj_fold<2>(acc);
+      if (live && p4 == 0) adj_store(a.d4, ((size_t)b * hs + ty * 4 + s4 / 4) * ws + tx * 4 + s4 % 4, a.c, cg0 + cgl, acc);
+    }
+    if (a.d8 != nullptr) {
+      const int hs = a.h / 8, ws = a.w / 8;
+      f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      adj_unit<8, 1>(win, cgl, s8 / 2, s8 % 2, p8, w8x, w8y, acc);
+      adj_fold<4>(acc);
+      if (live && p8 == 0) adj_store(a.d8, ((size_t)b * hs + ty * 2 + s8 / 2) * ws + tx * 2 + s8 % 2, a.c, cg0 + cgl, acc);
+    }
+  }
+}
+
 // y = y0 + sum_j bilinear(t_j -> h x w), all maps [..][c] bf16 (row pitch c), rounded once; y may be y0 (in place).
 // partial[2][gridDim.x][c] = per-channel (sum, sum of squares) of the ROUNDED y: the rows tok_bn_finalize folds.
 // The HRNet segmentation neck is conv1x1(cat_j(bilinear(x_j))) — and a 1x1 convolution (a linear map across channels at one
@@ -344,6 +498,192 @@ bool fill_bil(BilArgs& a, int n, int hs, int ws, int c, int ld_src, int hd, int 
 
 inline bool vec_ok(const BilArgs& a) { return !((a.c | a.ld_src | a.ld_dst | a.ch_off) & 7); }
 
+// The tiled form of the kernel above for the commuted neck's geometry (factors 2 / 4 / 8, map a multiple of 16): the generic
+// kernel re-derives indices and weights and unpacks 12 taps for every (pixel, channel group) — ~330 VALU instructions per 16
+// output bytes, 1.5 ms at 512x1024 B=24 where HBM needs 0.45.  Here a workgroup owns a 16 x 16 output tile; per chunk of 4
+// channel groups the source windows (10 x 10, 6 x 6, 4 x 4 pixels) sit in LDS and a thread owns one column x FOUR CONSECUTIVE
+// rows x one channel group: those rows read 4 / 3 / 2 source rows, so the horizontal interpolation runs 9 times per thread
+// instead of 24, rows and weights are per-thread constants (computed once per workgroup through src_index, as everywhere),
+// and the next chunk's y0 and windows are in flight while this one is summed.  Statistics: per chunk, lanes of one channel
+// group are folded with shuffles inside the wave, the four waves through LDS in wave order; one partial row per workgroup.
+constexpr int UPS_T = 16, UPS_G = 4;
+constexpr int UPS_N2 = UPS_T / 2 + 2, UPS_N4 = UPS_T / 4 + 2, UPS_N8 = UPS_T / 8 + 2;      // window edge: 10, 6, 4 pixels
+constexpr int UPS_O2 = 0, UPS_O4 = UPS_N2 * UPS_N2, UPS_O8 = UPS_O4 + UPS_N4 * UPS_N4, UPS_PX = UPS_O8 + UPS_N8 * UPS_N8;   // 152
+constexpr int UPS_WLD = (UPS_PX * UPS_G + 255) / 256;     // window items per thread: 3
+
+struct UpsTArgs {
+  const bf16* y0;
+  bf16* y;
+  const bf16 *t2, *t4, *t8;     // the factor-2 / 4 / 8 sources (NULL = absent)
+  float* partial;               // [2][gridDim.x][c] or NULL
+  int n, h, w, c;
+};
+
+__device__ __forceinline__ void ups_unpack(const uint4 v, f32x2 (&o)[4]) {
+  o[0] = (f32x2){__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+  o[1] = (f32x2){__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+  o[2] = (f32x2){__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u)};
+  o[3] = (f32x2){__uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)};
+}
+
+// hoisted constants of one factor: window columns + weights of the thread's column, the window row of its first source row,
+// and for each of its four output rows the weights of the two source rows the row pattern assigns to it
+template <int F>
+struct UpsRowPat;
+template <> struct UpsRowPat<2> { static constexpr int NR = 4; static constexpr int A[4] = {0, 1, 1, 2}; };
+template <> struct UpsRowPat<4> { static constexpr int NR = 3; static constexpr int A[4] = {0, 0, 1, 1}; };
+template <> struct UpsRowPat<8> { static constexpr int NR = 2; static constexpr int A[4] = {0, 0, 0, 0}; };
+
+template <int F>
+__device__ __forceinline__ void ups_consts(int ty, int tx, int rb, int col, int hs, int ws, int& cA, int& cB, float& hx, float& lx,
+                                           int& wrow, float (&wa)[4], float (&wb)[4]) {
+  const float scale = 1.f / (float)F;
+  int x0, x1;
+  src_index(scale, tx * UPS_T + col, ws, x0, x1, lx);
+  hx = 1.f - lx;
+  const int oc = tx * (UPS_T / F) - 1;                       // source column of window column 0
+  cA = x0 - oc;  cB = x1 - oc;
+  const int d0 = ty * UPS_T + 4 * rb;
+  // first source row of the thread's four output rows: rows d0 .. d0 + 3 read source rows base .. base + NR - 1
+  const int base = F == 8 ? d0 / 8 - 1 + ((d0 % 8) >= 4 ? 1 : 0) : d0 / F - 1;
+  wrow = base - (ty * (UPS_T / F) - 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int y0, y1; float ly;
+    src_index(scale, d0 + k, hs, y0, y1, ly);
+    const int ra = base + UpsRowPat<F>::A[k], rbb = ra + 1;
+    wa[k] = (ra >= 0 && ra < hs) ? (y0 == ra ? 1.f - ly : 0.f) + (y1 == ra ? ly : 0.f) : 0.f;
+    wb[k] = (rbb >= 0 && rbb < hs) ? (y0 == rbb ? 1.f - ly : 0.f) + (y1 == rbb ? ly : 0.f) : 0.f;
+  }
+}
+
+template <int F, int OFF, int N>
+__device__ __forceinline__ void ups_add(const uint4* __restrict__ lw, int cgl, int cA, int cB, float hx, float lx, int wrow,
+                                        const float (&wa)[4], const float (&wb)[4], f32x2 (&acc)[4][4]) {
+  constexpr int NR = UpsRowPat<F>::NR;
+  f32x2 X[NR][4];
+  const f32x2 hx2 = {hx, hx}, lx2 = {lx, lx};
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const uint4* rowp = lw + (size_t)(OFF + (wrow + r) * N) * UPS_G + cgl;
+    f32x2 a[4], b[4];
+    ups_unpack(rowp[cA * UPS_G], a);
+    ups_unpack(rowp[cB * UPS_G], b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) X[r][q] = hx2 * a[q] + lx2 * b[q];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f32x2 wa2 = {wa[k], wa[k]}, wb2 = {wb[k], wb[k]};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[k][q] += wa2 * X[UpsRowPat<F>::A[k]][q] + wb2 * X[UpsRowPat<F>::A[k] + 1][q];
+  }
+}
+
+__global__ __launch_bounds__(256) void bilinear_sum_tiled_kernel(UpsTArgs a) {
+  __shared__ uint4 lw[UPS_PX * UPS_G];
+  __shared__ float sred[4][UPS_G][16];
+  const int tid = threadIdx.x;
+  const int tiles_x = a.w / UPS_T, tiles_y = a.h / UPS_T;
+  const int tx = blockIdx.x % tiles_x;
+  const int ty = (blockIdx.x / tiles_x) % tiles_y;
+  const int b = blockIdx.x / (tiles_x * tiles_y);
+  const int cg_total = a.c >> 3;
+  const int cgl = tid % UPS_G, col = (tid / UPS_G) % UPS_T, rb = tid / (UPS_G * UPS_T);     // rb = wave index
+  int cA2, cB2, cA4, cB4, cA8, cB8, wr2, wr4, wr8;
+  float hx2, lx2, hx4, lx4, hx8, lx8, wa2[4], wb2[4], wa4[4], wb4[4], wa8[4], wb8[4];
+  ups_consts<2>(ty, tx, rb, col, a.h / 2, a.w / 2, cA2, cB2, hx2, lx2, wr2, wa2, wb2);
+  ups_consts<4>(ty, tx, rb, col, a.h / 4, a.w / 4, cA4, cB4, hx4, lx4, wr4, wa4, wb4);
+  ups_consts<8>(ty, tx, rb, col, a.h / 8, a.w / 8, cA8, cB8, hx8, lx8, wr8, wa8, wb8);
+  // the thread's window items (pixel (tid + 256 i) / 4 of the three windows) and its four y0 rows
+  const bf16* wsrc[UPS_WLD];
+#pragma unroll
+  for (int i = 0; i < UPS_WLD; ++i) {
+    const int px = (tid + 256 * i) / UPS_G;
+    wsrc[i] = nullptr;
+    if (px < UPS_PX) {
+      const int f = px < UPS_O4 ? 2 : (px < UPS_O8 ? 4 : 8);
+      const int nn = f == 2 ? UPS_N2 : (f == 4 ? UPS_N4 : UPS_N8);
+      const int p = px - (f == 2 ? UPS_O2 : (f == 4 ? UPS_O4 : UPS_O8));
+      const int hs = a.h / f, ws = a.w / f;
+      const int r = ty * (UPS_T / f) - 1 + p / nn, cc = tx * (UPS_T / f) - 1 + p % nn;
+      const bf16* t = f == 2 ? a.t2 : (f == 4 ? a.t4 : a.t8);
+      if (t != nullptr && r >= 0 && r < hs && cc >= 0 && cc < ws) wsrc[i] = t + (((size_t)b * hs + r) * ws + cc) * a.c + cgl * 8;
+    }
+  }
+  const size_t pix0 = ((size_t)b * a.h + ty * UPS_T + 4 * rb) * a.w + tx * UPS_T + col;
+  uint4 nw[UPS_WLD], ny[4];
+  auto fetch = [&](int cg0) {
+    const bool ok = cg0 + cgl < cg_total;
+#pragma unroll
+    for (int i = 0; i < UPS_WLD; ++i) {
+      nw[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok && wsrc[i] != nullptr) nw[i] = *reinterpret_cast<const uint4*>(wsrc[i] + cg0 * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ny[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (ok) ny[k] = *reinterpret_cast<const uint4*>(a.y0 + (pix0 + (size_t)k * a.w) * a.c + (cg0 + cgl) * 8);
+    }
+  };
+  fetch(0);
+  for (int cg0 = 0; cg0 < cg_total; cg0 += UPS_G) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < UPS_WLD; ++i)
+      if (tid + 256 * i < UPS_PX * UPS_G) lw[tid + 256 * i] = nw[i];
+    f32x2 acc[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ups_unpack(ny[k], acc[k]);
+    __syncthreads();
+    if (cg0 + UPS_G < cg_total) fetch(cg0 + UPS_G);
+    if (a.t2 != nullptr) ups_add<2, UPS_O2, UPS_N2>(lw, cgl, cA2, cB2, hx2, lx2, wr2, wa2, wb2, acc);
+    if (a.t4 != nullptr) ups_add<4, UPS_O4, UPS_N4>(lw, cgl, cA4, cB4, hx4, lx4, wr4, wa4, wb4, acc);
+    if (a.t8 != nullptr) ups_add<8, UPS_O8, UPS_N8>(lw, cgl, cA8, cB8, hx8, lx8, wr8, wa8, wb8, acc);
+    const bool live = cg0 + cgl < cg_total;
+    f32x2 s1[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[2 * q] = f2bf(acc[k][q].x);
+        o[2 * q + 1] = f2bf(acc[k][q].y);
+        const f32x2 f = {bf2f(o[2 * q]), bf2f(o[2 * q + 1])};
+        s1[q] += f;
+        s2[q] += f * f;
+      }
+      if (live) stg16(a.y + (pix0 + (size_t)k * a.w) * a.c + (cg0 + cgl) * 8, o);
+    }
+    if (a.partial != nullptr) {
+      // lanes cgl, cgl + 4, ... of the wave hold the same channel group (16 columns): fold, then the four waves in order
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int m = UPS_G; m < 64; m <<= 1) {
+          s1[q].x += __shfl_xor(s1[q].x, m);  s1[q].y += __shfl_xor(s1[q].y, m);
+          s2[q].x += __shfl_xor(s2[q].x, m);  s2[q].y += __shfl_xor(s2[q].y, m);
+        }
+      }
+      if ((tid & 63) < UPS_G) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sred[rb][cgl][2 * q] = s1[q].x;      sred[rb][cgl][2 * q + 1] = s1[q].y;
+          sred[rb][cgl][8 + 2 * q] = s2[q].x;  sred[rb][cgl][8 + 2 * q + 1] = s2[q].y;
+        }
+      }
+      __syncthreads();
+      if (tid < UPS_G * 16) {
+        const int g = tid / 16, e = tid % 16;
+        if (cg0 + g < cg_total) {
+          const float v = ((sred[0][g][e] + sred[1][g][e]) + sred[2][g][e]) + sred[3][g][e];
+          a.partial[((size_t)(e >> 3) * gridDim.x + blockIdx.x) * a.c + (cg0 + g) * 8 + (e & 7)] = v;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tok_fuse_sum_relu_fwd(const void* t0, int s0, const void* t1, int s1, const void* t2, int s2,
@@ -409,7 +749,15 @@ extern "C" int tok_bilinear_bwd(const void* ddst, int n, int hd, int wd, int ld_
   return TOK_OK;
 }
 
-extern "C" int tok_bilinear_sum_stats_rows(int64_t m, int c) { return tok_bn_stats_rows(m, c); }
+static bool ups_tiled_shape(int n, int h, int w, int c) {
+  return c % 8 == 0 && h % UPS_T == 0 && w % UPS_T == 0 && (long long)n * (h / UPS_T) * (w / UPS_T) <= 65536;
+}
+
+extern "C" int tok_bilinear_sum_stats_rows(int n, int h, int w, int c) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || c % 8) return TOK_ERR_INVALID;
+  if (ups_tiled_shape(n, h, w, c)) return n * (h / UPS_T) * (w / UPS_T);      // one row per 16 x 16 tile
+  return tok_bn_stats_rows((int64_t)n * h * w, c);
+}
 
 extern "C" int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, int w1, const void* t2, int h2, int w2,
                                       const void* t3, int h3, int w3, int n, int h, int w, int c, void* y, float* stats,
@@ -423,6 +771,10 @@ extern "C" int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, in
   for (int j = 0; j < 3; ++j) {
     a.t[j] = nullptr; a.hs[j] = a.ws[j] = 1; a.sh[j] = a.sw[j] = 1.f;
   }
+  UpsTArgs u;
+  u.y0 = (const bf16*)y0; u.y = (bf16*)y; u.t2 = u.t4 = u.t8 = nullptr; u.partial = stats;
+  u.n = n; u.h = h; u.w = w; u.c = c;
+  bool tiled = ups_tiled_shape(n, h, w, c);
   for (int j = 0; j < 3; ++j) {
     if (ts[j] == nullptr) continue;
     TOK_CHECK_ARG(hs[j] > 0 && ws[j] > 0, "tok_bilinear_sum_stats: term %d: bad size", j + 1);
@@ -431,13 +783,60 @@ extern "C" int tok_bilinear_sum_stats(const void* y0, const void* t1, int h1, in
     a.sh[a.nt] = (float)hs[j] / (float)h;
     a.sw[a.nt] = (float)ws[j] / (float)w;
     ++a.nt;
+    const int f = h / hs[j];
+    const bf16** slot = f == 2 ? &u.t2 : (f == 4 ? &u.t4 : (f == 8 ? &u.t8 : nullptr));
+    if (hs[j] * f == h && ws[j] * f == w && slot != nullptr && *slot == nullptr) *slot = (const bf16*)ts[j];   // one source per factor
+    else tiled = false;
   }
   a.n = n; a.h = h; a.w = w; a.c = c;
-  const int64_t m = (int64_t)n * h * w;
-  const int rows = tok_bn_stats_rows(m, c);
-  const int cg_total = c / 8, cge = cg_total < 256 ? cg_total : 256, rpb = 256 / cge;
-  hipLaunchKernelGGL(bilinear_sum_stats_kernel, dim3(rows), dim3(256), 0, tok_stream(stream), (const bf16*)y0, (bf16*)y, a,
-                     cge, rpb, stats);
+  const int rows = tok_bilinear_sum_stats_rows(n, h, w, c);
+  static const int off = [] { const char* e = getenv("TOK_BILINEAR_SUM_TILED"); return (int)(e ? atoi(e) == 0 : 0); }();   // A/B switch
+  if (tiled && !off) {
+    hipLaunchKernelGGL(bilinear_sum_tiled_kernel, dim3(rows), dim3(256), 0, tok_stream(stream), u);
+  } else {
+    // (any grid works for the generic kernel: blocks beyond the rows write zero partials)
+    const int cg_total = c / 8, cge = cg_total < 256 ? cg_total : 256, rpb = 256 / cge;
+    hipLaunchKernelGGL(bilinear_sum_stats_kernel, dim3(rows), dim3(256), 0, tok_stream(stream), (const bf16*)y0, (bf16*)y, a,
+                       cge, rpb, stats);
+  }
   TOK_CHECK_LAUNCH("tok_bilinear_sum_stats");
+  return TOK_OK;
+}
+
+extern "C" int tok_bilinear_bwd_multi(const void* ddst, int n, int hd, int wd, int c, void* d1, int h1, int w1, void* d2, int h2,
+                                      int w2, void* d3, int h3, int w3, void* stream) {
+  void* ds[3] = {d1, d2, d3};
+  const int hs[3] = {h1, h2, h3}, ws[3] = {w1, w2, w3};
+  TOK_CHECK_ARG(ddst && n > 0 && hd > 0 && wd > 0 && c > 0, "tok_bilinear_bwd_multi: bad args");
+  Adj3Args a;
+  a.dy = (const bf16*)ddst; a.n = n; a.h = hd; a.w = wd; a.c = c;
+  bool fast = c % 8 == 0 && hd % ADJ_T == 0 && wd % ADJ_T == 0 && (long long)n * (hd / ADJ_T) * (wd / ADJ_T) < (1ll << 31);
+  int present = 0;
+  a.d2 = a.d4 = a.d8 = nullptr;
+  for (int j = 0; j < 3; ++j) {
+    if (ds[j] == nullptr) continue;
+    TOK_CHECK_ARG(hs[j] > 0 && ws[j] > 0, "tok_bilinear_bwd_multi: source %d: bad size", j + 1);
+    ++present;
+    const int f = hd / hs[j];
+    bf16** slot = f == 2 ? &a.d2 : (f == 4 ? &a.d4 : (f == 8 ? &a.d8 : nullptr));
+    if (hs[j] * f == hd && ws[j] * f == wd && slot != nullptr && *slot == nullptr) *slot = (bf16*)ds[j];   // one source per factor
+    else fast = false;
+  }
+  static const int off = [] { const char* e = getenv("TOK_BILINEAR_ADJ3"); return (int)(e ? atoi(e) == 0 : 0); }();   // A/B switch
+  if (present == 0) return TOK_OK;
+  if (fast && !off) {
+    static const bool attr_set = [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bilinear_adj3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ADJ_SMEM);
+      return true;
+    }();
+    (void)attr_set;
+    hipLaunchKernelGGL(bilinear_adj3_kernel, dim3(n * (hd / ADJ_T) * (wd / ADJ_T)), dim3(256), ADJ_SMEM, tok_stream(stream), a);
+    TOK_CHECK_LAUNCH("tok_bilinear_bwd_multi");
+    return TOK_OK;
+  }
+  for (int j = 0; j < 3; ++j)        // any other geometry: one gather launch per source
+    if (ds[j] != nullptr)
+      if (int e = tok_bilinear_bwd(ddst, n, hd, wd, c, 0, ds[j], hs[j], ws[j], c, c, 0, stream)) return e;
   return TOK_OK;
 }

@@ -32,7 +32,7 @@ from .core import (BF16, Region, TTensor, await_ready, commit_param_grad, grad_t
                    stream_ptr)
 
 F32 = torch.float32
-NECK_COMMUTE = os.environ.get('TOK_NECK_COMMUTE', '0') != '0'
+NECK_COMMUTE = os.environ.get('TOK_NECK_COMMUTE', '1') != '0'
 NECK_WGRAD_SIDE = os.environ.get('TOK_NECK_WGRAD_SIDE', '1') != '0'
 
 
@@ -71,19 +71,18 @@ class _CommutedNeckNode(EF._ConvBnActNode):
         out.grad = None
         ctot = sum(t.cp for t in srcs)
         wd = self.pk.dgrad.view(ctot, kp) if self.pk.dgrad is not None else None
-        dys = []
+        # d(y_j) = up_j^T d(y): the transposes of the interpolations over ALL kp channels of d(y) — one pass for the three
+        # low-resolution sources (source 0: identity)
+        dys = [dy] + [torch.empty((n, d.h, d.w, kp), dtype=BF16, device=dy.device) for d in self.descs[1:]]
+        low = []
+        for j in range(1, 4):
+            low += [ptr(dys[j]), self.descs[j].h, self.descs[j].w] if j < len(dys) else [None, 1, 1]
+        _C.check(lib.tok_bilinear_bwd_multi(ptr(dy), n, h, w, kp, *low, st), 'tok_bilinear_bwd_multi')
         for j, (t, d) in enumerate(zip(srcs, self.descs)):
-            # d(y_j) = up_j^T d(y): the transpose of the interpolation over ALL kp channels of d(y) (source 0: identity)
-            if j == 0:
-                dyj = dy
-            else:
-                dyj = torch.empty((n, d.h, d.w, kp), dtype=BF16, device=dy.device)
-                _C.check(lib.tok_bilinear_bwd(ptr(dy), n, h, w, kp, 0, ptr(dyj), d.h, d.w, kp, kp, 0, st), 'tok_bilinear_bwd')
-            dys.append(dyj)
             if t.requires_grad:
                 tgt, acc = grad_target(t)
                 off = self.offs[j]
-                _C.check(lib.tok_conv_dgrad(d, ptr(dyj), ptr(wd[off:off + t.cp]), ptr(tgt), acc, st), 'tok_conv_dgrad')
+                _C.check(lib.tok_conv_dgrad(d, ptr(dys[j]), ptr(wd[off:off + t.cp]), ptr(tgt), acc, st), 'tok_conv_dgrad')
         if not w_need:
             return
         k_real = conv.weight.shape[0]
@@ -164,7 +163,7 @@ def upsample_concat_conv_bn_relu(region: Region, srcs: List[TTensor], size: Tupl
         descs.append(d)
         offs.append(off)
         off += t.cp
-    rows = lib.tok_bilinear_sum_stats_rows(m, kp)
+    rows = lib.tok_bilinear_sum_stats_rows(n, h, w, kp)
     stats = torch.empty((2, rows, kp), dtype=F32, device=dev)
     low = []
     for j in range(1, 4):
