@@ -33,3 +33,18 @@ H="--backbone hrnet_w48 --res 512 --width 1024 --batch 24 --classes 19 --steps 1
   done; done
 } > $o/r06_hrnet_scheduling_ab.txt 2>&1
 ls $o
+# HRNet segmentation neck alone, commuted vs direct order (tools/ubench/neck_time.py) + kernel stats of both
+{ echo "# HRNet-W48 segmentation neck alone at 512x1024 B=24 (tools/ubench/neck_time.py): forward + backward, commuted order (engine/neck.py) vs direct order";
+  python tools/ubench/neck_time.py 2>/dev/null
+  for m in commuted direct; do
+    cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+    timeout 300 rocprofv3 --kernel-trace --stats -d $o/raw/neck_$m -o kt -- python tools/ubench/neck_time.py --only $m --iters 5 > $o/raw/neck_$m.log 2>&1
+    db=$(ls $o/raw/neck_$m/*results.db | head -1)
+    echo "## rocprofv3 --kernel-trace --stats, $m order (5 timed + 5 warm-up / check calls)"; python tools/prof_summary.py $db 10 | head -16; rm -rf $o/raw/neck_$m
+  done
+  echo "## HRNet-W48 step, same box, two interleaved rounds"
+  for rep in 1 2; do for e in "X=0(commuted)" "TOK_NECK_COMMUTE=0(direct)"; do
+    env ${e%%(*} python bench.py $H 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print('$e', d['ms_per_step'], 'ms/step', d['roofline']['frac'])"
+  done; done
+} > $o/r06_hrnet_neck_commuted_ab.txt 2>&1
+ls $o
