@@ -37,6 +37,32 @@ from ..engine.arena import ParamArena
 from ..engine.core import cur_stream, pick_stream, ptr, stream_ptr
 
 
+# Collectives on the PICKED comm stream (round 6).  torch's ProcessGroupNCCL runs an `async_op=True` collective on an internal
+# stream of its own, and HIP maps that stream onto one of the four hardware queues in creation order — in `bench.py` and in
+# tools/ubench/nccl_stream_probe.py it landed on the MAIN stream's queue (kernel trace: oneRankReduce on queue 2 / stream 9, the
+# step's kernels on queue 2 / stream 0), where two streams run strictly one after the other: every bucket's all-reduce then
+# sits IN the backward's kernel order instead of beside it.  A sync collective (`async_op=False`) is enqueued on the CURRENT
+# stream (torch >= 2.8; same probe: queue 3 / stream 2 = the comm stream), without blocking the host — so on RCCL the reducer
+# issues sync collectives with the comm stream current and orders consumers behind an event on that stream.  Correct under
+# either torch behaviour (a sync collective is ordered with the stream it was called on in both); TOK_DDP_SYNC_COLLECTIVES=0
+# restores the work handles.
+SYNC_COLLECTIVES = os.environ.get('TOK_DDP_SYNC_COLLECTIVES', '1') != '0'
+
+
+class _StreamWork:
+    """`work.wait()` of a collective issued synchronously on `stream`: the calling stream waits for an event recorded on
+    `stream` right behind it (no host synchronisation)."""
+    __slots__ = ('event',)
+
+    def __init__(self, stream):
+        self.event = torch.cuda.Event()
+        self.event.record(stream)
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
 class _Bucket:
     __slots__ = ('lo', 'hi', 'first', 'last', 'pending', 'work', 'streams', 'narrow')
 
@@ -239,10 +265,23 @@ class GradientAllReducer:
         if b.pending == 0:
             self._launch(ai, b)
 
-    def _reduce(self, buf: torch.Tensor):
-        if self._avg is not None:
-            return dist.all_reduce(buf, op=self._avg, group=self.group, async_op=True)
-        return dist.all_reduce(buf, group=self.group, async_op=True)
+    def _on_comm(self) -> bool:
+        """Called with the comm stream current on RCCL: collectives go out synchronously on it (see SYNC_COLLECTIVES)."""
+        return bool(self._avg is not None and SYNC_COLLECTIVES and torch.cuda.current_stream() == self.comm_stream)   # (_avg: CUDA + RCCL)
+
+    def _reduce(self, buf: torch.Tensor, op=None):
+        op = op if op is not None else self._avg
+        kw = {} if op is None else {'op': op}
+        if self._on_comm():
+            dist.all_reduce(buf, group=self.group, async_op=False, **kw)
+            return _StreamWork(self.comm_stream)
+        return dist.all_reduce(buf, group=self.group, async_op=True, **kw)
+
+    def _broadcast(self, buf: torch.Tensor):
+        if self._on_comm():
+            dist.broadcast(buf, src=0, group=self.group, async_op=False)
+            return _StreamWork(self.comm_stream)
+        return dist.broadcast(buf, src=0, group=self.group, async_op=True)
 
     def _launch(self, ai: int, b: _Bucket):
         arena = self.arenas[ai]
@@ -282,9 +321,9 @@ class GradientAllReducer:
             if self.cuda:
                 self._fork_to_comm()
                 with torch.cuda.stream(self.comm_stream):
-                    self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
+                    self._buffer_work.append(self._broadcast(ba.flat))
             else:
-                self._buffer_work.append(dist.broadcast(ba.flat, src=0, group=self.group, async_op=True))
+                self._buffer_work.append(self._broadcast(ba.flat))
 
     def _local_flags(self):
         """(flags, changed): one float per parameter, 1 where THIS rank produced a gradient in the step that just ran.
@@ -398,9 +437,9 @@ class GradientAllReducer:
             if self.cuda:
                 self._fork_to_comm()
                 with torch.cuda.stream(self.comm_stream):
-                    used_work = dist.all_reduce(self._used, group=self.group, async_op=True)
+                    used_work = self._reduce(self._used, op=dist.ReduceOp.SUM)
             else:
-                used_work = dist.all_reduce(self._used, group=self.group, async_op=True)
+                used_work = self._reduce(self._used, op=dist.ReduceOp.SUM)
         if self._buffer_arenas:
             self.sync_buffers()
         lib = _C.lib()
