@@ -89,6 +89,8 @@ CONV_CASES = [
     (5, 13, 15, 40, 136, 3, 1, 1),     # C = 40: second chunk a quarter full; K = 136: second channel tile ragged
     (2, 56, 56, 64, 64, 3, 1, 1),      # 64-channel form of the window kernel (4 x 1 waves): ResNet stage 1
     (1, 40, 72, 48, 48, 3, 1, 1),      # HRNet-W48's high-resolution branch: 48 of 64 channels, C = 32 + 16
+    (8, 128, 128, 48, 48, 3, 1, 1),    # ... at a size the register-resident form serves (conv_winr_kernel: 8 x 32 tiles, >= 512 of them)
+    (4, 64, 512, 48, 48, 3, 1, 1),     # ... sixteen x-tiles per row group, images of 8 row groups
 ]
 
 
@@ -227,7 +229,8 @@ def test_conv_dgrad_stride2_on_the_shared_window(libs, case, mode):
 
 
 @pytest.mark.parametrize('case', S2D_CASES + [(2, 20, 36, 48, 48, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
-                                              (2, 16, 32, 192, 192, 3, 1, 1), (2, 16, 32, 64, 64, 3, 1, 1)])
+                                              (2, 16, 32, 192, 192, 3, 1, 1), (2, 16, 32, 64, 64, 3, 1, 1),
+                                              (8, 128, 128, 48, 48, 3, 1, 1)])
 @pytest.mark.parametrize('mode', ['maskstore', 'bias_sums'])
 def test_conv_dgrad_window_kernels_mask_store_and_bias(libs, case, mode):
     """The remaining epilogues of the window kernels (conv_win.hip / conv_s2d.hip) on every channel-tile form (48 = half +
@@ -567,7 +570,7 @@ def test_optimizers_match_torch(libs):
                                   (3, 14, 14, 64, 256, 1, 2, 0), (2, 17, 19, 64, 128, 3, 2, 1),
                                   (1, 7, 7, 512, 512, 3, 1, 1), (1, 24, 40, 96, 96, 3, 1, 1),
                                   (2, 16, 32, 192, 192, 3, 1, 1), (2, 20, 36, 48, 48, 3, 1, 1),
-                                  (1, 16, 32, 384, 384, 3, 1, 1)])
+                                  (1, 16, 32, 384, 384, 3, 1, 1), (8, 128, 128, 48, 48, 3, 1, 1)])
 @pytest.mark.parametrize('with_mask', [0, 1])
 def test_conv_dgrad_bnstats(libs, case, with_mask):
     """dgrad whose epilogue also reduces sum(dz), sum(dz*y) of the unit that produced x."""
