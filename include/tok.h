@@ -442,6 +442,13 @@ int tok_embed_reg_bwd(const void* e, const float* row_reg, const float* gscale, 
 int tok_fuse_sum_relu_fwd(const void* t0, int s0, const void* t1, int s1, const void* t2, int s2,
                           const void* t3, int s3, int n, int h, int w, int c, int relu, void* out,
                           uint8_t* mask, void* stream);
+/* ... with per-term BatchNorm coefficients: a term j given with sc_j / sf_j [c] (fp32) is the RAW convolution output of a unit
+ * without activation (the last Conv2d + BatchNorm2d of a fuse path, hrnet.py:122-140) and enters the sum as t * sc + sf — the
+ * unit's apply pass (tok_bn_act_fwd: a write and a read of the term) is folded into this kernel; sc_j NULL: as above.       */
+int tok_fuse_sum_affine_relu_fwd(const void* t0, int s0, const float* sc0, const float* sf0, const void* t1, int s1,
+                                 const float* sc1, const float* sf1, const void* t2, int s2, const float* sc2,
+                                 const float* sf2, const void* t3, int s3, const float* sc3, const float* sf3, int n, int h,
+                                 int w, int c, int relu, void* out, uint8_t* mask, void* stream);
 int tok_fuse_sum_relu_bwd(const void* dout, const uint8_t* mask, int n, int h, int w, int c, int shift,
                           void* dterm, int accumulate, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) (necks/segmentation/hrnet.py:36-39,

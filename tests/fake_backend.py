@@ -1246,12 +1246,19 @@ class FakeTok:
 
     # ---- multi-resolution glue (HRNet) ----------------------------------------------------------------
     def tok_fuse_sum_relu_fwd(self, t0, s0, t1, s1, t2, s2, t3, s3, n, h, w, c, relu, out, mask, st):
+        return self.tok_fuse_sum_affine_relu_fwd(t0, s0, None, None, t1, s1, None, None, t2, s2, None, None, t3, s3, None, None,
+                                                 n, h, w, c, relu, out, mask, st)
+
+    def tok_fuse_sum_affine_relu_fwd(self, t0, s0, sc0, sf0, t1, s1, sc1, sf1, t2, s2, sc2, sf2, t3, s3, sc3, sf3, n, h, w, c, relu,
+                                     out, mask, st):
         self.calls.append('fuse_sum_relu_fwd')
         acc = torch.zeros(n, h, w, c)
-        for tp, sh in ((t0, s0), (t1, s1), (t2, s2), (t3, s3)):
+        for tp, sh, sc, sf in ((t0, s0, sc0, sf0), (t1, s1, sc1, sf1), (t2, s2, sc2, sf2), (t3, s3, sc3, sf3)):
             if tp is None:
                 continue
             v = _t(tp, (n, h >> sh, w >> sh, c), BF16).float()
+            if sc is not None:
+                v = v * _t(sc, (c,), torch.float32) + _t(sf, (c,), torch.float32)
             if sh:
                 v = v.repeat_interleave(1 << sh, dim=1).repeat_interleave(1 << sh, dim=2)
             acc = acc + v

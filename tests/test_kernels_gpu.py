@@ -795,6 +795,40 @@ def test_fuse_sum_relu(libs, n, h, w, c, shifts, relu):
             assert relerr(dv[id(dt)].float(), dt.float()) < 6e-3
 
 
+@pytest.mark.parametrize('n,h,w,c,shifts,affine,relu', [(2, 16, 16, 16, (0, 1, 2, 3), (0, 1, 1, 1), 1), (2, 8, 24, 48, (0, 0, 1), (1, 0, 1), 1),
+                                                      (1, 32, 32, 32, (0, 0), (1, 1), 1), (3, 8, 8, 64, (0, 2), (0, 0), 0)])
+def test_fuse_sum_affine_relu(libs, n, h, w, c, shifts, affine, relu):
+    """relu(sum_j (t_j * sc_j + sf_j | t_j)): terms handed over as raw conv outputs with their BatchNorm coefficients (the
+    apply pass of a unit without activation folded into the HRNet fuse sum) beside terms taken as stored."""
+    terms = [rnd(n, h >> s, w >> s, c, seed=7 + i).to(BF16) for i, s in enumerate(shifts)]
+    scs = [rnd(c, seed=20 + i).abs() + 0.5 for i in range(len(shifts))]
+    sfs = [rnd(c, seed=30 + i) for i in range(len(shifts))]
+    out = torch.empty(n, h, w, c, dtype=BF16)
+    mask = torch.empty(n * h * w, c // 8, dtype=torch.uint8)
+
+    def args(d):
+        a = []
+        for i in range(4):
+            if i < len(terms):
+                a += [d(terms[i]), shifts[i]] + ([d(scs[i]), d(sfs[i])] if affine[i] else [None, None])
+            else:
+                a += [None, 0, None, None]
+        return a + [n, h, w, c, relu, d(out), d(mask), None]
+    dv = both(libs, 'tok_fuse_sum_affine_relu_fwd', args)
+    assert relerr(dv[id(out)].float(), out.float()) < 4e-3
+    assert (dv[id(mask)].cpu() != mask).float().mean() < 2e-3
+    # against the definition, computed here
+    acc = torch.zeros(n, h, w, c)
+    for i, s_ in enumerate(shifts):
+        v = terms[i].float()
+        if affine[i]:
+            v = v * scs[i] + sfs[i]
+        if s_:
+            v = v.repeat_interleave(1 << s_, dim=1).repeat_interleave(1 << s_, dim=2)
+        acc = acc + v
+    assert relerr(dv[id(out)].float(), acc.clamp_min(0) if relu else acc) < 4e-3
+
+
 @pytest.mark.parametrize('n,hs,ws,c,hd,wd,ld,off', [(2, 8, 8, 16, 16, 16, 16, 0), (2, 4, 8, 32, 32, 64, 96, 32),
                                                     (1, 16, 16, 24, 64, 64, 24, 0), (2, 16, 16, 16, 16, 16, 48, 16),
                                                     (1, 5, 7, 8, 13, 20, 8, 0), (1, 9, 9, 8, 4, 5, 8, 0),

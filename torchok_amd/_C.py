@@ -132,6 +132,7 @@ PROTOTYPES = {
     'tok_contrastive_fwd': (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P]),
     'tok_contrastive_bwd': (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, c_int, _P]),
     'tok_fuse_sum_relu_fwd': (c_int, [_P, c_int, _P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    'tok_fuse_sum_affine_relu_fwd': (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     'tok_fuse_sum_relu_bwd': (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     'tok_bilinear_fwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, _P]),
     'tok_bilinear_bwd': (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P]),

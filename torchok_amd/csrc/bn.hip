@@ -735,6 +735,7 @@ extern "C" int tok_bn_act_fwd(const void* y, const float* scale, const float* sh
                               void* stream) {
   TOK_CHECK_ARG(y && scale && shift && out && m > 0 && c > 0 && c % 8 == 0, "tok_bn_act_fwd: bad args");
   if (tok_dbg_skip(8)) return TOK_OK;
+  if (tok_dbg_skip(32) && !relu && shortcut == nullptr) return TOK_OK;     // ablation: the apply passes of units WITHOUT activation (HRNet's fuse-path terms, projection shortcuts)
   const Geo g = make_geo(c);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_blocks(m, g, kStreamCap)), dim3(256), 0,
                      tok_stream(stream), (const bf16*)y, scale, shift, (const bf16*)shortcut, relu,

@@ -12,6 +12,8 @@ namespace {
 
 struct FuseArgs {
   const bf16* t[4];
+  const float* sc[4];      // per-term BatchNorm scale / shift (NULL: the term is taken as stored).  A term whose unit has no
+  const float* sf[4];      // activation is passed as its RAW convolution output: the apply pass (a write + a read of the term) is this fma
   int sh[4];
   int nt, n, h, w, c;
 };
@@ -35,8 +37,16 @@ __global__ __launch_bounds__(256) void fuse_sum_relu_fwd_kernel(FuseArgs a, int 
       const int hs = a.h >> s, ws = a.w >> s;
       const size_t off = (((size_t)b * hs + (y >> s)) * ws + (x >> s)) * a.c + cg * 8;
       const bf16x8 v = ldg16(a.t[j] + off);
+      if (a.sc[j] != nullptr) {
+        const float4 s0 = *reinterpret_cast<const float4*>(a.sc[j] + cg * 8), s1 = *reinterpret_cast<const float4*>(a.sc[j] + cg * 8 + 4);
+        const float4 f0 = *reinterpret_cast<const float4*>(a.sf[j] + cg * 8), f1 = *reinterpret_cast<const float4*>(a.sf[j] + cg * 8 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sf[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+        for (int e = 0; e < 8; ++e) acc[e] += fmaf(bf2f(v[e]), sc[e], sf[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+      }
     }
     bf16x8 o;
     unsigned bits = 0;
@@ -686,28 +696,41 @@ __global__ __launch_bounds__(256) void bilinear_sum_tiled_kernel(UpsTArgs a) {
 
 }  // namespace
 
-extern "C" int tok_fuse_sum_relu_fwd(const void* t0, int s0, const void* t1, int s1, const void* t2, int s2,
-                                     const void* t3, int s3, int n, int h, int w, int c, int relu, void* out,
-                                     uint8_t* mask, void* stream) {
+extern "C" int tok_fuse_sum_affine_relu_fwd(const void* t0, int s0, const float* sc0, const float* sf0, const void* t1, int s1,
+                                            const float* sc1, const float* sf1, const void* t2, int s2, const float* sc2,
+                                            const float* sf2, const void* t3, int s3, const float* sc3, const float* sf3, int n,
+                                            int h, int w, int c, int relu, void* out, uint8_t* mask, void* stream) {
   FuseArgs a;
   const void* ts[4] = {t0, t1, t2, t3};
   const int ss[4] = {s0, s1, s2, s3};
+  const float* scs[4] = {sc0, sc1, sc2, sc3};
+  const float* sfs[4] = {sf0, sf1, sf2, sf3};
   a.nt = 0;
   for (int j = 0; j < 4; ++j) {
     if (ts[j] == nullptr) continue;
     TOK_CHECK_ARG(ss[j] >= 0 && ss[j] < 8 && (h >> ss[j]) << ss[j] == h && (w >> ss[j]) << ss[j] == w,
                   "tok_fuse_sum_relu_fwd: term %d: %dx%d is not a multiple of 2^%d", j, h, w, ss[j]);
+    TOK_CHECK_ARG((scs[j] == nullptr) == (sfs[j] == nullptr), "tok_fuse_sum_relu_fwd: term %d: scale without shift", j);
     a.t[a.nt] = (const bf16*)ts[j];
     a.sh[a.nt] = ss[j];
+    a.sc[a.nt] = scs[j];
+    a.sf[a.nt] = sfs[j];
     ++a.nt;
   }
-  for (int j = a.nt; j < 4; ++j) { a.t[j] = nullptr; a.sh[j] = 0; }
+  for (int j = a.nt; j < 4; ++j) { a.t[j] = nullptr; a.sh[j] = 0; a.sc[j] = a.sf[j] = nullptr; }
   TOK_CHECK_ARG(a.nt > 0 && out && n > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "tok_fuse_sum_relu_fwd: bad args");
   a.n = n; a.h = h; a.w = w; a.c = c;
   hipLaunchKernelGGL(fuse_sum_relu_fwd_kernel, dim3(blocks_for((size_t)n * h * w * (c >> 3))), dim3(256), 0,
                      tok_stream(stream), a, relu, (bf16*)out, mask);
   TOK_CHECK_LAUNCH("tok_fuse_sum_relu_fwd");
   return TOK_OK;
+}
+
+extern "C" int tok_fuse_sum_relu_fwd(const void* t0, int s0, const void* t1, int s1, const void* t2, int s2,
+                                     const void* t3, int s3, int n, int h, int w, int c, int relu, void* out,
+                                     uint8_t* mask, void* stream) {
+  return tok_fuse_sum_affine_relu_fwd(t0, s0, nullptr, nullptr, t1, s1, nullptr, nullptr, t2, s2, nullptr, nullptr, t3, s3, nullptr,
+                                      nullptr, n, h, w, c, relu, out, mask, stream);
 }
 
 extern "C" int tok_fuse_sum_relu_bwd(const void* dout, const uint8_t* mask, int n, int h, int w, int c, int shift,

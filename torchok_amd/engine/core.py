@@ -110,7 +110,7 @@ class TTensor:
 
     data: (N, H, W, Cp) or (N, Cp);  c: logical channel count (<= Cp)."""
     __slots__ = ('data', 'c', 'node', 'grad', 'grad_owned', 'requires_grad', 'uses', 'arrived', 'ready', 'gevents',
-                 'sub_closers', 'grad_sub', 'colsum_part', '__weakref__')
+                 'sub_closers', 'grad_sub', 'colsum_part', 'affine', '__weakref__')
 
     def __init__(self, data: torch.Tensor, c: int, requires_grad: bool = False, node=None):
         self.data = data
@@ -126,6 +126,7 @@ class TTensor:
         self.sub_closers = 0  # consumers whose data gradient can absorb a pending half-resolution contribution (forward)
         self.grad_sub = None  # pending contribution: gradient of the stride-2 pixel subsample of this tensor (backward)
         self.colsum_part = None  # (partial [rows][C] fp32, rows): per-block column sums left by the pass that produced `data`
+        self.affine = None  # (scale, shift) fp32 [Cp]: `data` is a RAW conv output whose BatchNorm apply is left to the consumer (conv_bn_act defer_apply)
 
     @property
     def cp(self) -> int:

@@ -758,11 +758,15 @@ STEM_POOLED_STATS = os.environ.get('TOK_STEM_POOLED_STATS', '1') != '0'   # Batc
 
 
 def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.BatchNorm2d] = None,
-                relu: bool = False, shortcut: Optional[TTensor] = None, pool: bool = False) -> TTensor:
+                relu: bool = False, shortcut: Optional[TTensor] = None, pool: bool = False, defer_apply: bool = False) -> TTensor:
     """out = act(bn(conv(x)) (+ shortcut)).  `conv` is an nn.Conv2d or nn.Linear used purely as
     the parameter container (state_dict names stay those of the reference).
     pool=True (BatchNorm + ReLU, no shortcut): out = maxpool3x3/s2/p1(act(bn(conv(x)))) with the activated map never
-    stored (the ResNet stem when only the pooled map is consumed)."""
+    stored (the ResNet stem when only the pooled map is consumed).
+    defer_apply=True (BatchNorm, no activation, no shortcut — the last unit of an HRNet fuse path): the apply pass is NOT run;
+    the returned tensor holds the RAW convolution output and carries `.affine = (scale, shift)` for a consumer that applies
+    them itself (resample.fuse_sum_relu: the write and the read of the normalised term are one fma there).  Its backward is
+    the unit's usual one (it never reads the normalised values of a unit without activation)."""
     if pool and (bn is None or not relu or shortcut is not None or x.data.dim() != 4):
         raise ValueError('conv_bn_act(pool=True): BatchNorm + ReLU on a 4-D input, no shortcut')
     await_ready(x, shortcut)
@@ -845,7 +849,11 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
                                             ptr(bn.running_var), float(bn.eps), kp, bn.num_features, ptr(scale), ptr(shift), st),
                      'tok_bn_eval_coeffs')
         mask = None
-        if pool:
+        deferred = bool(defer_apply and not relu and shortcut is None and not pool and x.data.dim() == 4 and not fused_fin)
+        if deferred:
+            out_data = y
+            cs_part = None
+        elif pool:
             p2, q2 = (d.p + 2 - 3) // 2 + 1, (d.q + 2 - 3) // 2 + 1
             out_data = torch.empty((d.n, p2, q2, kp), dtype=BF16, device=dev)
             node.pool = torch.empty((d.n, p2, q2, kp), dtype=torch.uint8, device=dev)
@@ -884,6 +892,8 @@ def conv_bn_act(region: Region, x: TTensor, conv: nn.Module, bn: Optional[nn.Bat
 
     req = bool(training or (shortcut is not None and shortcut.requires_grad and region.grad_mode))
     out = TTensor(out_data, k_real, requires_grad=req)
+    if bn is not None and deferred:
+        out.affine = (scale, shift)
     if bn is not None and not pool and cs_part is not None:
         out.colsum_part = (cs_part, cs_rows)
     if req:

@@ -53,18 +53,27 @@ def fuse_sum_relu(region: Region, terms: Sequence[Tuple[TTensor, int]], relu: bo
             # the reference fails here as well: nn.Upsample(2^k) of a ceil-halved map does not match (y + ...)
             raise ValueError(f'HRNet fuse: branch map {t.shape} x{1 << sh} does not match {(n, h, w, cp)}; '
                              f'input height/width must be divisible by 32')
+    # a term that carries `.affine` is the raw output of a unit without activation: its BatchNorm apply is one fma here
+    affine = any(t.affine is not None for t, _ in terms)
     args = []
     for i in range(4):
         if i < len(terms):
-            args += [ptr(terms[i][0].data), terms[i][1]]
+            t = terms[i][0]
+            args += [ptr(t.data), terms[i][1]]
+            if affine:
+                args += [ptr(t.affine[0]), ptr(t.affine[1])] if t.affine is not None else [None, None]
         else:
-            args += [None, 0]
+            args += [None, 0] + ([None, None] if affine else [])
     dev = ref.data.device
     out_data = torch.empty((n, h, w, cp), dtype=BF16, device=dev)
     req = region.grad_mode and any(t.requires_grad for t, _ in terms)
     mask = torch.empty((n * h * w, cp // 8), dtype=torch.uint8, device=dev) if (req and relu) else None
-    _C.check(_C.lib().tok_fuse_sum_relu_fwd(*args, n, h, w, cp, int(relu), ptr(out_data), ptr(mask), stream_ptr()),
-             'tok_fuse_sum_relu_fwd')
+    if affine:
+        _C.check(_C.lib().tok_fuse_sum_affine_relu_fwd(*args, n, h, w, cp, int(relu), ptr(out_data), ptr(mask), stream_ptr()),
+                 'tok_fuse_sum_affine_relu_fwd')
+    else:
+        _C.check(_C.lib().tok_fuse_sum_relu_fwd(*args, n, h, w, cp, int(relu), ptr(out_data), ptr(mask), stream_ptr()),
+                 'tok_fuse_sum_relu_fwd')
     out = TTensor(out_data, ref.c, requires_grad=req)
     if req:
         node = _FuseSumNode()

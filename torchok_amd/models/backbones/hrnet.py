@@ -67,9 +67,16 @@ def _conv_bn(cin, cout, k, stride, pad, relu):
     return nn.Sequential(*layers)
 
 
-def _run_conv_bn(r, x, seq: nn.Sequential):
+# the last unit of a fuse path (Conv2d + BatchNorm2d, no activation) hands its RAW output + BatchNorm coefficients to the row's
+# summation kernel instead of running its own apply pass (round 6: by ablation those passes cost 1.3 ms of a 64.3-ms HRNet-W48
+# step; TOK_HRNET_DEFER_TERM_BN=0 restores them)
+_DEFER_TERM_BN = os.environ.get('TOK_HRNET_DEFER_TERM_BN', '1') != '0'
+
+
+def _run_conv_bn(r, x, seq: nn.Sequential, defer_apply: bool = False):
     """One `Conv2d, BatchNorm2d[, ReLU]` Sequential (transition / fuse building block) as one engine unit."""
-    return EF.conv_bn_act(r, x, seq[0], seq[1], relu=len(seq) > 2 and isinstance(seq[2], nn.ReLU))
+    relu = len(seq) > 2 and isinstance(seq[2], nn.ReLU)
+    return EF.conv_bn_act(r, x, seq[0], seq[1], relu=relu, defer_apply=defer_apply and not relu and _DEFER_TERM_BN)
 
 
 class HighResolutionModule(nn.Module):
@@ -169,13 +176,13 @@ class HighResolutionModule(nn.Module):
                         terms.append((x[j], 0))
                     elif j > i:      # 1x1 conv + BN at the low resolution; the nearest upsample is folded into the sum
                         p0 = len(nodes) if nodes is not None else 0
-                        terms.append((EF.conv_bn_act(r, x[j], row[j][0], row[j][1], relu=False), j - i))
+                        terms.append((EF.conv_bn_act(r, x[j], row[j][0], row[j][1], relu=False, defer_apply=_DEFER_TERM_BN), j - i))
                         path_spans.append((p0, len(nodes) if nodes is not None else 0, j))
                     else:
                         p0 = len(nodes) if nodes is not None else 0
                         t = x[j]
-                        for step in row[j]:
-                            t = _run_conv_bn(r, t, step)
+                        for si, step in enumerate(row[j]):
+                            t = _run_conv_bn(r, t, step, defer_apply=si == len(row[j]) - 1)
                         terms.append((t, 0))
                         path_spans.append((p0, len(nodes) if nodes is not None else 0, j))
                 # output-resolution term first: it fixes the shape
