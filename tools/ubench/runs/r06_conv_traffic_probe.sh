@@ -10,8 +10,6 @@ run() { tag=$1; shift
     rm -rf $o/$tag-$c
   done; }
 run fwd48 python tools/ubench/one_conv.py 12 256 48 48 3 1 fwd 5
-TOK_CONV_WIN_WIDE_TW=32 run fwd48_tw32 python tools/ubench/one_conv.py 12 256 48 48 3 1 fwd 5
-TOK_CONV_WIN_WIDE_TW=16 run fwd48_tw16 python tools/ubench/one_conv.py 12 256 48 48 3 1 fwd 5
 run fwd64 python tools/ubench/one_conv.py 12 256 64 64 3 1 fwd 5
 run fwd96 python tools/ubench/one_conv.py 12 128 96 96 3 1 fwd 5
 run wgrad48 python tools/ubench/one_conv.py 12 256 48 48 3 1 wgrad 5
